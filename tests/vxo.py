@@ -1,0 +1,261 @@
+"""ctypes binding for oracle/vxo_api.h — the C interface shared by the two CPU checkers
+(oracle/_ref/libvoxels_ref.so = the unmodified reference, oracle/libvoxels_port.so = this repo's
+restatement).  TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package."""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvoxels_ref.so")
+PORT_SO = os.path.join(ROOT, "oracle", "libvoxels_port.so")
+
+VERTEX_DTYPE = np.dtype([("pos", "<f4", 3), ("sec", "<f4", 4), ("nrm", "<f4", 3), ("tex", "u1", 8)])
+assert VERTEX_DTYPE.itemsize == 48
+
+BLOCK_INFO_DTYPE = np.dtype([
+    ("id", "<u4"), ("n_verts", "<u4"), ("n_idx", "<u4"),
+    ("n_tverts", "<u4", 6), ("n_tidx", "<u4", 6),
+    ("min_corner", "<f4", 3), ("max_corner", "<f4", 3)])
+assert BLOCK_INFO_DTYPE.itemsize == 84
+
+
+def _ptr(a, ty=C.c_void_p):
+    if a is None:
+        return None
+    return a.ctypes.data_as(ty)
+
+
+class Level:
+    """One LOD level of a polygonized surface, concatenated in block order."""
+
+    def __init__(self, infos, verts, idx, tverts, tidx):
+        self.infos, self.verts, self.idx, self.tverts, self.tidx = infos, verts, idx, tverts, tidx
+
+    def totals(self):
+        return (len(self.infos), len(self.verts), len(self.idx), len(self.tverts), len(self.tidx))
+
+
+class Surface:
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        self.destroy()
+
+    def destroy(self):
+        if self._h:
+            self._lib.vxo_surface_destroy(self._h)
+            self._h = None
+
+    @property
+    def levels_count(self):
+        return self._lib.vxo_surface_levels(self._h)
+
+    def extents(self):
+        out = np.zeros(3, np.float32)
+        self._lib.vxo_surface_extents(self._h, _ptr(out))
+        return out
+
+    def stats(self):
+        out = np.zeros(20, np.uint32)
+        self._lib.vxo_surface_stats(self._h, _ptr(out))
+        return out
+
+    def cache_bytes(self):
+        return self._lib.vxo_surface_cache_bytes(self._h)
+
+    def polygon_bytes(self):
+        return self._lib.vxo_surface_polygon_bytes(self._h)
+
+    def level(self, lvl):
+        nb = self._lib.vxo_surface_blocks(self._h, lvl)
+        tot = np.zeros(4, np.uint64)
+        self._lib.vxo_surface_level_totals(self._h, lvl, _ptr(tot))
+        infos = np.zeros(nb, BLOCK_INFO_DTYPE)
+        verts = np.zeros(int(tot[0]), VERTEX_DTYPE)
+        idx = np.zeros(int(tot[1]), np.uint32)
+        tverts = np.zeros(int(tot[2]), VERTEX_DTYPE)
+        tidx = np.zeros(int(tot[3]), np.uint32)
+        self._lib.vxo_surface_dump_level(self._h, lvl, _ptr(infos), _ptr(verts), _ptr(idx), _ptr(tverts), _ptr(tidx))
+        return Level(infos, verts, idx, tverts, tidx)
+
+    def all_levels(self):
+        return [self.level(l) for l in range(self.levels_count)]
+
+
+class Grid:
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+        self.n = lib.vxo_grid_size(handle)
+
+    def __del__(self):
+        if self._h:
+            self._lib.vxo_grid_destroy(self._h)
+            self._h = None
+
+    def read_dense(self):
+        n = self.n
+        d = np.zeros((n, n, n), np.int8)
+        m = np.zeros((n, n, n), np.uint8)
+        b = np.zeros((n, n, n), np.uint8)
+        self._lib.vxo_grid_read_dense(self._h, _ptr(d), _ptr(m), _ptr(b))
+        return d, m, b
+
+    def block_flags(self):
+        nb = self.n // 16
+        out = np.zeros(nb ** 3, np.uint8)
+        self._lib.vxo_grid_block_flags(self._h, _ptr(out))
+        return out
+
+    def memory_size(self):
+        return self._lib.vxo_grid_memory_size(self._h)
+
+    def inject_ball(self, pos, ext, radius, inj_type):
+        pos = np.asarray(pos, np.float32)
+        ext = np.asarray(ext, np.float32)
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._lib.vxo_grid_inject_ball(self._h, _ptr(pos), _ptr(ext), C.c_float(radius), int(inj_type), _ptr(mn), _ptr(mx))
+        return mn, mx
+
+    def inject_material(self, pos, ext, material, add):
+        pos = np.asarray(pos, np.float32)
+        ext = np.asarray(ext, np.float32)
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._lib.vxo_grid_inject_material(self._h, _ptr(pos), _ptr(ext), int(material), int(bool(add)), _ptr(mn), _ptr(mx))
+        return mn, mx
+
+    def pack(self):
+        sz = self._lib.vxo_grid_pack(self._h, None, 0)
+        buf = np.zeros(sz, np.uint8)
+        self._lib.vxo_grid_pack(self._h, _ptr(buf), sz)
+        return buf
+
+
+def default_lut():
+    """MaterialMap used by the fixtures: material m -> Ids0 = (6m, 6m+1, 6m+2), Ids1 = (6m+3..6m+5) mod 256."""
+    lut = (np.arange(256 * 6, dtype=np.uint32) % 251).astype(np.uint8).reshape(256, 6)
+    return lut
+
+
+class Oracle:
+    """Either checker behind the same interface."""
+
+    def __init__(self, path):
+        lib = C.CDLL(path)
+        self.lib = lib
+        vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+        lib.vxo_kind.restype = C.c_char_p
+        lib.vxo_grid_from_dense.restype = vp
+        lib.vxo_grid_from_dense.argtypes = [u32, vp, vp, vp]
+        lib.vxo_grid_from_float.restype = vp
+        lib.vxo_grid_from_float.argtypes = [u32, vp, vp, vp]
+        lib.vxo_grid_destroy.argtypes = [vp]
+        lib.vxo_grid_size.restype = u32
+        lib.vxo_grid_size.argtypes = [vp]
+        lib.vxo_grid_read_dense.argtypes = [vp, vp, vp, vp]
+        lib.vxo_grid_block_flags.argtypes = [vp, vp]
+        lib.vxo_grid_memory_size.restype = u32
+        lib.vxo_grid_memory_size.argtypes = [vp]
+        lib.vxo_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
+        lib.vxo_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
+        lib.vxo_grid_pack.restype = sz
+        lib.vxo_grid_pack.argtypes = [vp, vp, sz]
+        lib.vxo_grid_load.restype = vp
+        lib.vxo_grid_load.argtypes = [vp, sz]
+        lib.vxo_execute.restype = vp
+        lib.vxo_execute.argtypes = [vp, vp, vp, C.c_int]
+        lib.vxo_execute_modify.restype = u32
+        lib.vxo_execute_modify.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, u32]
+        lib.vxo_surface_destroy.argtypes = [vp]
+        lib.vxo_surface_levels.restype = u32
+        lib.vxo_surface_levels.argtypes = [vp]
+        lib.vxo_surface_extents.argtypes = [vp, vp]
+        lib.vxo_surface_blocks.restype = u32
+        lib.vxo_surface_blocks.argtypes = [vp, u32]
+        lib.vxo_surface_level_totals.argtypes = [vp, u32, vp]
+        lib.vxo_surface_dump_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        lib.vxo_surface_stats.argtypes = [vp, vp]
+        lib.vxo_surface_cache_bytes.restype = u32
+        lib.vxo_surface_cache_bytes.argtypes = [vp]
+        lib.vxo_surface_polygon_bytes.restype = u32
+        lib.vxo_surface_polygon_bytes.argtypes = [vp]
+        lib.vxo_log_errors.restype = u32
+        self.kind = lib.vxo_kind().decode()
+
+    def grid_from_dense(self, dist, mat=None, blend=None):
+        n = dist.shape[0]
+        assert dist.shape == (n, n, n) and dist.dtype == np.int8 and dist.flags.c_contiguous
+        for a in (mat, blend):
+            assert a is None or (a.shape == (n, n, n) and a.dtype == np.uint8 and a.flags.c_contiguous)
+        h = self.lib.vxo_grid_from_dense(n, _ptr(dist), _ptr(mat), _ptr(blend))
+        return Grid(self.lib, h)
+
+    def grid_from_float(self, values, mat=None, blend=None):
+        n = values.shape[0]
+        assert values.shape == (n, n, n) and values.dtype == np.float32 and values.flags.c_contiguous
+        h = self.lib.vxo_grid_from_float(n, _ptr(values), _ptr(mat), _ptr(blend))
+        return Grid(self.lib, h)
+
+    def grid_load(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        h = self.lib.vxo_grid_load(_ptr(blob), blob.size)
+        return Grid(self.lib, h) if h else None
+
+    def execute(self, grid, lut=None, valid=None, threads=0):
+        lut = default_lut() if lut is None else np.ascontiguousarray(lut, np.uint8)
+        valid = np.ones(256, np.uint8) if valid is None else np.ascontiguousarray(valid, np.uint8)
+        h = self.lib.vxo_execute(grid._h, _ptr(lut), _ptr(valid), int(threads))
+        return Surface(self.lib, h)
+
+    def execute_modify(self, grid, surface, min_corner, max_corner, lut=None, valid=None, threads=0):
+        lut = default_lut() if lut is None else np.ascontiguousarray(lut, np.uint8)
+        valid = np.ones(256, np.uint8) if valid is None else np.ascontiguousarray(valid, np.uint8)
+        mn = np.asarray(min_corner, np.float32)
+        mx = np.asarray(max_corner, np.float32)
+        cap = 1 << 20
+        ids = np.zeros(cap, np.uint32)
+        cnt = self.lib.vxo_execute_modify(grid._h, _ptr(lut), _ptr(valid), int(threads), surface._h,
+                                          _ptr(mn), _ptr(mx), _ptr(ids), cap)
+        return ids[:cnt].copy()
+
+    def log_errors(self):
+        return self.lib.vxo_log_errors()
+
+
+def load_ref():
+    return Oracle(REF_SO) if os.path.exists(REF_SO) else None
+
+
+def load_port():
+    return Oracle(PORT_SO) if os.path.exists(PORT_SO) else None
+
+
+def index_hash(levels):
+    """64-bit FNV-style hash over index values as defined in SURVEY.md §8(c): level ascending, block
+    order ascending, regular indices then transition indices of faces 0..5."""
+    h = 1469598103934665603
+    mask = (1 << 64) - 1
+    for lv in levels:
+        oi = oti = 0
+        for info in lv.infos:
+            ni = int(info["n_idx"])
+            for v in lv.idx[oi:oi + ni].tolist():
+                h = ((h ^ v) * 1099511628211) & mask
+            oi += ni
+            for f in range(6):
+                nt = int(info["n_tidx"][f])
+                for v in lv.tidx[oti:oti + nt].tolist():
+                    h = ((h ^ v) * 1099511628211) & mask
+                oti += nt
+    return h
+
+
+def sphere_field(n, r_frac=0.35):
+    """fp32 ball distance used by the survey's known-answer table: d = sqrtf(dx^2+dy^2+dz^2) - r."""
+    c = np.float32(n / 2)
+    r = np.float32(r_frac * n)
+    ax = np.arange(n, dtype=np.float32) - c
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    d2 = (x * x + y * y) + z * z
+    return (np.sqrt(d2.astype(np.float32)) - r).astype(np.float32)
