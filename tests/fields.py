@@ -1,0 +1,93 @@
+"""Seeded synthetic voxel fields used by the parity tests (numpy; small sizes).  Big grids for the bench
+come from the product's own generator (vx_synth_terrain, voxels_amd/csrc/vx_synth.cpp)."""
+import numpy as np
+
+
+def smooth_noise(n, seed, scale=8, amp=6.0, octaves=2):
+    """Band-limited random field (trilinear upsampling of coarse random lattices), float32, Z-up [z,y,x]."""
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, n, n), np.float32)
+    a = amp
+    s = scale
+    for _ in range(octaves):
+        m = max(2, n // s + 2)
+        lat = rng.uniform(-1, 1, (m, m, m)).astype(np.float32)
+        c = np.arange(n, dtype=np.float32) / np.float32(s)
+        i0 = np.floor(c).astype(np.int32)
+        f = (c - i0).astype(np.float32)
+        f = f * f * (3 - 2 * f)
+
+        def lerp_axis(v, axis):
+            lo = np.take(v, i0, axis=axis)
+            hi = np.take(v, i0 + 1, axis=axis)
+            shape = [1, 1, 1]
+            shape[axis] = n
+            w = f.reshape(shape)
+            return lo + (hi - lo) * w
+
+        v = lerp_axis(lerp_axis(lerp_axis(lat, 0), 1), 2)
+        out += a * v
+        a *= 0.5
+        s = max(2, s // 2)
+    return out.astype(np.float32)
+
+
+def terrain_field(n, seed, caves=True):
+    """Height-field terrain (+ optional 3-D noise for overhangs): d = z - h(x,y) - cave(x,y,z), clamped +-100."""
+    rng = np.random.RandomState(seed)
+    base = smooth_noise(n, seed, scale=max(4, n // 4), amp=0.25 * n, octaves=3)[0]  # 2-D slice as heightmap
+    h = np.float32(n / 2) + base
+    z = np.arange(n, dtype=np.float32).reshape(n, 1, 1)
+    d = z - h.reshape(1, n, n)
+    if caves:
+        d = d - smooth_noise(n, seed + 17, scale=max(4, n // 8), amp=5.0, octaves=2)
+    return np.clip(d, -100, 100).astype(np.float32)
+
+
+def materials_for(n, seed, nmat=3):
+    """Material ids by dithered height band + smooth blend; exercises M0 != M1 and reuse-by-material failures."""
+    rng = np.random.RandomState(seed + 101)
+    z = np.arange(n, dtype=np.float32).reshape(n, 1, 1)
+    jitter = rng.uniform(-4, 4, (n, n, n)).astype(np.float32)
+    band = np.clip(((z + jitter) * nmat / n), 0, nmat - 1e-3)
+    mat = band.astype(np.uint8)
+    blend = (255 * (band - np.floor(band))).astype(np.uint8)
+    return np.ascontiguousarray(mat), np.ascontiguousarray(blend)
+
+
+def quantize_full_range(f, scale=12.0):
+    """int8 distances using the whole range (bypasses the +-4 clamp of Grid::Create), so t takes many values."""
+    q = np.clip(np.round(f * scale), -127, 127)
+    return q.astype(np.int8)
+
+
+def surface_equal(a_levels, b_levels, nrm_tol=0.0):
+    """Compare two lists of vxo.Level. Returns (ok, message)."""
+    if len(a_levels) != len(b_levels):
+        return False, "level count %d vs %d" % (len(a_levels), len(b_levels))
+    for li, (a, b) in enumerate(zip(a_levels, b_levels)):
+        if a.totals() != b.totals():
+            return False, "L%d totals %s vs %s" % (li, a.totals(), b.totals())
+        for name in a.infos.dtype.names:
+            if not np.array_equal(a.infos[name], b.infos[name]):
+                return False, "L%d block info field %s differs" % (li, name)
+        if not np.array_equal(a.idx, b.idx):
+            return False, "L%d indices differ" % li
+        if not np.array_equal(a.tidx, b.tidx):
+            return False, "L%d transition indices differ" % li
+        for kind, va, vb in (("verts", a.verts, b.verts), ("tverts", a.tverts, b.tverts)):
+            for fld in ("pos", "sec", "tex"):
+                xa = va[fld].view(np.uint32) if fld != "tex" else va[fld]
+                xb = vb[fld].view(np.uint32) if fld != "tex" else vb[fld]
+                if not np.array_equal(xa, xb):
+                    bad = np.argwhere(xa != xb)[0]
+                    return False, "L%d %s.%s differs at %s: %s vs %s" % (li, kind, fld, bad, va[fld][bad[0]], vb[fld][bad[0]])
+            if nrm_tol == 0.0:
+                if not np.array_equal(va["nrm"].view(np.uint32), vb["nrm"].view(np.uint32)):
+                    bad = np.argwhere(va["nrm"].view(np.uint32) != vb["nrm"].view(np.uint32))[0]
+                    return False, "L%d %s.nrm differs bitwise at %s: %s vs %s" % (li, kind, bad, va["nrm"][bad[0]], vb["nrm"][bad[0]])
+            elif len(va):
+                err = np.abs(va["nrm"] - vb["nrm"]).max()
+                if err > nrm_tol:
+                    return False, "L%d %s.nrm max err %g" % (li, kind, err)
+    return True, "ok"
