@@ -1,0 +1,137 @@
+"""CPU tests of the checker itself: oracle/port.cpp (the restatement) against
+  (a) the committed fixtures generated from the unmodified reference (tests/golden/), and
+  (b) the unmodified reference run live (oracle/_ref), when it was built in this container.
+Everything is compared bit-for-bit (the reference build and the port are both strict IEEE fp32)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fields
+import vxo
+from golden_io import Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def port():
+    if not os.path.exists(vxo.PORT_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"])
+    return vxo.load_port()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    r = vxo.load_ref()
+    if r is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    return r
+
+
+def assert_same(a, b):
+    ok, msg = fields.surface_equal(a, b)
+    assert ok, msg
+
+
+def test_known_answer_hash_sphere64(port):
+    """64^3 ball r=0.35N -> index hash 473e8b8c4d4f3c9d, counts and stats."""
+    g = port.grid_from_float(vxo.sphere_field(64))
+    s = port.execute(g)
+    lv = s.all_levels()
+    assert [l.totals() for l in lv] == [(32, 12024, 56904, 0, 0), (8, 2952, 14424, 1680, 4896), (1, 582, 3480, 0, 0)]
+    assert list(s.stats()[:4]) == [73, 286528, 12480, 0]
+    assert "%016x" % vxo.index_hash(lv) == "473e8b8c4d4f3c9d"
+
+
+@pytest.mark.parametrize("name", ["sphere64", "terrain32_mat", "noise64_fullrange_mat"])
+def test_port_matches_golden(port, name):
+    gold = Golden(name)
+    g = port.grid_from_dense(gold.dist, gold.mat, gold.blend)
+    assert np.array_equal(g.block_flags(), gold.flags)
+    assert g.memory_size() == int(gold["memory_size"][0])
+    s = port.execute(g, threads=4)
+    assert_same(s.all_levels(), gold.levels)
+    assert np.array_equal(s.stats(), gold.stats)
+    assert s.cache_bytes() == int(gold["cache_bytes"][0])
+
+
+def test_port_quantisation_golden(port):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "quantize16.npz"))
+    g = port.grid_from_float(np.ascontiguousarray(z["values"]))
+    assert np.array_equal(g.read_dense()[0], z["dist"])
+
+
+def test_port_carve_modify_golden(port):
+    gold = Golden("terrain64_carve_modify")
+    g = port.grid_from_dense(gold["pre_dist"], gold["pre_mat"], gold["pre_blend"])
+    s = port.execute(g)
+    mn, mx = g.inject_ball(gold["inject_pos"], gold["inject_ext"], float(gold["inject_radius"][0]), 2)
+    assert np.array_equal(mn, gold["box_min"]) and np.array_equal(mx, gold["box_max"])
+    d, m, b = g.read_dense()
+    assert np.array_equal(d, gold.dist) and np.array_equal(m, gold.mat) and np.array_equal(b, gold.blend)
+    assert np.array_equal(g.block_flags(), gold.flags)
+    ids = port.execute_modify(g, s, mn, mx)
+    assert np.array_equal(ids, gold["modified_ids"])
+    assert_same(s.all_levels(), gold.levels)
+    assert np.array_equal(s.stats(), gold.stats)
+
+
+def test_port_thread_count_independent(port):
+    gold = Golden("terrain32_mat")
+    g = port.grid_from_dense(gold.dist, gold.mat, gold.blend)
+    assert_same(port.execute(g, threads=1).all_levels(), port.execute(g, threads=8).all_levels())
+
+
+def test_rle_empty_flag_edge_cases(port):
+    """BF_Empty (VoxelGrid.cpp:622-667): uniform strict sign AND compressible; an all-zero block is NOT empty
+    (the 255-run split multiplies 0*0), nor is a same-sign block whose run count overflows the codec."""
+    n = 32
+    d = np.full((n, n, n), 4, np.int8)
+    d[:16, :16, :16] = 0            # block 0: all zero
+    d[:16, :16, 16:] = -3           # block 1: uniform negative -> empty
+    blk = np.tile(np.array([1, 2], np.int8), 2048).reshape(16, 16, 16)
+    d[:16, 16:, :16] = blk          # block 2: same sign but 4096 runs -> stored raw -> not empty
+    g = port.grid_from_dense(np.ascontiguousarray(d))
+    fl = g.block_flags()
+    assert fl[0] == 0 and fl[1] == 1 and fl[2] == 0 and fl[3] == 1
+
+
+# ---- live comparison with the unmodified reference (only where oracle/_ref exists) -------------------
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_port_vs_reference_live(port, ref, seed):
+    n = 32 if seed != 23 else 64
+    f = fields.terrain_field(n, seed)
+    m, b = fields.materials_for(n, seed)
+    gr, gp = ref.grid_from_float(f, m, b), port.grid_from_float(f, m, b)
+    assert np.array_equal(gr.block_flags(), gp.block_flags())
+    sr, sp = ref.execute(gr), port.execute(gp)
+    assert_same(sr.all_levels(), sp.all_levels())
+    assert np.array_equal(sr.stats(), sp.stats())
+    q = fields.quantize_full_range(fields.smooth_noise(n, seed, scale=8, amp=3.0))
+    gr, gp = ref.grid_from_dense(q, m, b), port.grid_from_dense(q, m, b)
+    sr, sp = ref.execute(gr), port.execute(gp)
+    assert_same(sr.all_levels(), sp.all_levels())
+    assert np.array_equal(sr.stats(), sp.stats())
+
+
+def test_port_vs_reference_edit_and_pack(port, ref):
+    n = 48 if False else 64
+    f = fields.terrain_field(n, 31)
+    m, b = fields.materials_for(n, 31)
+    gr, gp = ref.grid_from_float(f, m, b), port.grid_from_float(f, m, b)
+    sr, sp = ref.execute(gr), port.execute(gp)
+    for t, pos, ext, r in ((2, (30.0, 33.5, 31.25), (20, 20, 20), 7.0), (0, (40, 20, 25), (16, 16, 16), 6.0), (1, (12, 40, 30), (10, 14, 12), 5.0)):
+        br, bp = gr.inject_ball(pos, ext, r, t), gp.inject_ball(pos, ext, r, t)
+        assert np.array_equal(br[0], bp[0]) and np.array_equal(br[1], bp[1])
+        ir, ip = ref.execute_modify(gr, sr, *br), port.execute_modify(gp, sp, *bp)
+        assert np.array_equal(ir, ip)
+        assert_same(sr.all_levels(), sp.all_levels())
+    gr.inject_material((20, 20, 30), (12, 12, 12), 5, True)
+    gp.inject_material((20, 20, 30), (12, 12, 12), 5, True)
+    for a, c in zip(gr.read_dense(), gp.read_dense()):
+        assert np.array_equal(a, c)
+    assert np.array_equal(gr.pack(), gp.pack())
+    assert_same(ref.execute(gr).all_levels(), port.execute(gp).all_levels())
