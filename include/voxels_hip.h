@@ -1,0 +1,114 @@
+/* voxels_hip.h — C ABI of libvoxels_hip.so, the MI355X (gfx950) TransVoxel polygonizer.
+ *
+ * This is the drop-in boundary for the reference's polygonization path.  The reference has no C interface
+ * below Polygonizer::Execute (include/Polygonizer.h:230-232 -> src/TransVoxelImpl.cpp:74-79, :2153-2169,
+ * TransVoxelRun::Execute :468-538); the entry points below are what a host binding of that call needs:
+ * the C++ host layer of this repo (include/Voxels.h, voxels_amd/csrc/vx_api_cpp.cpp) implements
+ * Voxels::Polygonizer::Execute on top of them, and INTEGRATION.md shows the equivalent patch to the
+ * reference's own TransVoxelImpl::Execute.
+ *
+ * Conventions: plain pointers and sizes only; every function returns VX_OK (0) or a negative VX_ERR_* code and
+ * never throws; vx_last_error() gives a message.  Grids are cubes of edge n (multiple of 16), Z-up, dense,
+ * x fastest: index (z*n + y)*n + x (reference: src/VoxelGrid.h:31-35).  Output is Y-up, exactly the bytes of
+ * Voxels::PolygonVertex / BlockPolygons (include/Polygonizer.h:14-106).  One polygonization at a time per
+ * context (the reference has the same restriction, src/TransVoxelImpl.cpp:2144).
+ */
+#ifndef VOXELS_HIP_H
+#define VOXELS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_ERR_INVALID (-1)   /* bad argument or call order */
+#define VX_ERR_DEVICE (-2)    /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define VX_ERR_OVERFLOW (-3)  /* output pools could not be grown */
+
+typedef struct vx_ctx vx_ctx;
+
+/* 48 bytes, bit-identical to Voxels::PolygonVertex (include/Polygonizer.h:14-48) */
+typedef struct vx_vertex {
+	float pos[3];
+	float sec[4];     /* sec[3]: transition-face adjacency mask as raw integer bits */
+	float nrm[3];
+	uint8_t tex[8];   /* Reserved, Blend, Uxz, Txz, Uny, Upy, Tny, Tpy */
+} vx_vertex;
+
+/* One emitted block = one Voxels::BlockPolygons (include/Polygonizer.h:52-106) */
+typedef struct vx_block_info {
+	uint32_t id;            /* BlockPolygons::GetId */
+	uint32_t n_verts;       /* GetVertices count */
+	uint32_t n_idx;         /* GetIndices count */
+	uint32_t n_tverts[6];   /* GetTransitionVertices count per TransitionFaceId */
+	uint32_t n_tidx[6];     /* GetTransitionIndices count per TransitionFaceId */
+	float min_corner[3];    /* GetMinimalCorner */
+	float max_corner[3];    /* GetMaximalCorner */
+} vx_block_info;
+
+typedef struct vx_exec_info {
+	uint32_t levels;            /* LOD levels produced (PolygonSurface::GetLevelsCount) */
+	uint32_t retries;           /* re-runs after growing the output pools */
+	float device_ms;            /* device time of the last run, HIP events on the context's stream */
+	uint64_t total_verts;       /* vertices in the pools (regular + transition, incl. blocks dropped as empty) */
+	uint64_t total_indices;
+	uint32_t active_blocks[8];  /* surface-bearing blocks per level */
+	uint64_t algorithmic_bytes; /* n^3 + 2*4096*surface blocks + 48*V + 4*I */
+} vx_exec_info;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int vx_ctx_create(int device_index, vx_ctx** out);
+void vx_ctx_destroy(vx_ctx* ctx);
+const char* vx_last_error(const vx_ctx* ctx);
+/* Run on a caller-provided hipStream_t (e.g. PyTorch's current stream); NULL = the context's own stream. */
+int vx_set_stream(vx_ctx* ctx, void* hip_stream);
+
+/* ---- grid residency (what TransVoxelRun reads through VoxelGrid::GetBlockData / GetMaterialBlockData /
+ *      IsBlockEmpty, src/VoxelGrid.cpp:586-608) ------------------------------------------------------------ */
+/* Copy a whole host grid to the device. empty_flags[(n/16)^3] = BF_Empty of every block in block-id order
+ * (src/VoxelGrid.h:139-144); mat/blend may be NULL (all zero). */
+int vx_grid_upload(vx_ctx* ctx, uint32_t n, const int8_t* dist, const uint8_t* mat, const uint8_t* blend,
+                   const uint8_t* empty_flags);
+/* Use caller-owned DEVICE memory (multi-GPU slabs, PyTorch tensors).  This rank polygonizes the z-range
+ * [z_begin, z_end) of the global n^3 grid.  d_dist holds the z-planes [dist_z0, ...) and must cover
+ * [z_begin-1, z_end+1] clamped to the grid; d_mat/d_blend hold planes [mat_z0, ...) covering [z_begin, z_end]
+ * clamped.  d_empty_flags is the FULL (n/16)^3 flag array (neighbour layers of other ranks included). */
+int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
+                   const void* d_dist, int32_t dist_z0, const void* d_mat, const void* d_blend, int32_t mat_z0,
+                   const void* d_empty_flags);
+/* Re-upload `count` edited 16^3 blocks (block ids, x-fastest 4096-byte blocks) + the full flag array. */
+int vx_grid_update_blocks(vx_ctx* ctx, uint32_t count, const uint32_t* block_ids, const int8_t* dist,
+                          const uint8_t* mat, const uint8_t* blend, const uint8_t* empty_flags);
+/* MaterialMap::GetMaterial resolved on the host (include/MaterialMap.h:19-30): lut[id] = {DiffuseIds0[3],
+ * DiffuseIds1[3]}, valid[id] == 0 means GetMaterial returned NULL (texture bytes stay 0). */
+int vx_material_lut(vx_ctx* ctx, const uint8_t* lut /*256*6*/, const uint8_t* valid /*256*/);
+
+/* ---- polygonization = TransVoxelRun::Execute (src/TransVoxelImpl.cpp:468-538) ------------------------ */
+/* num_levels = 0: all log2(n/16)+1 levels like the reference; otherwise only levels 0..num_levels-1 (the
+ * "last level has no transitions" rule still uses the reference's level count). */
+int vx_polygonize(vx_ctx* ctx, uint32_t num_levels, vx_exec_info* info);
+/* Incremental re-polygonization of a dirty box (src/TransVoxelImpl.cpp:429-465); corners in OUTPUT (Y-up)
+ * coordinates as Grid::InjectSurface returns them.  Returns the new block ids. */
+int vx_polygonize_dirty(vx_ctx* ctx, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
+                        uint32_t* modified_ids, uint32_t cap, uint32_t* count);
+
+/* ---- results (PolygonSurface accessors, include/Polygonizer.h:136-178) ------------------------------- */
+int vx_level_counts(vx_ctx* ctx, uint32_t level, uint32_t* n_blocks, uint64_t totals[4] /* verts, idx, tverts, tidx */);
+/* Blocks of one level in GetBlockForLevel order, concatenated: regular vertices/indices, then per block the
+ * transition vertices/indices of faces 0..5.  Any output pointer may be NULL. */
+int vx_download_level(vx_ctx* ctx, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx,
+                      vx_vertex* tverts, uint32_t* tidx);
+/* stats[0..3] = BlocksCalculated, TrivialCells, NonTrivialCells, DegenerateTrianglesRemoved; stats[4..19] =
+ * PerCaseCellsCount (include/Polygonizer.h:110-132) */
+int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
+
+/* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */
+const char* vx_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

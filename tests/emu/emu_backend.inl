@@ -1,0 +1,154 @@
+// tests/emu/emu_backend.inl — the CPU "backend" for vx_host.inl (tests only).
+namespace {
+
+struct ExecParamsView; // ExecParams is defined by vx_host.inl; stages are templates so they see it late
+
+struct Backend {
+	std::string lastError;
+
+	bool init(int, std::string&) { return true; }
+	void shutdown() {}
+	void set_stream(void*) {}
+	std::string error() const { return lastError; }
+	void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+	void free(void* p) { ::free(p); }
+	bool fill(void* p, int v, size_t bytes) { memset(p, v, bytes); return true; }
+	bool h2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	bool d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	void sync() {}
+	void begin_timing() {}
+	float end_timing_ms() { return 0.f; }
+
+	template <typename P>
+	void run_classify(const P& p)
+	{
+		const LevelDesc& L = p.levels[0];
+		std::vector<i8> samp(SAMPLES + 7);
+		for (u32 bz = L.zb0; bz < L.zb1; ++bz)
+		for (u32 by = 0; by < L.cnt; ++by)
+		for (u32 bx = 0; bx < L.cnt; ++bx) {
+			const bool skipped = block_skipped_by_emptiness(p.G.emptyFlags, L.cnt, bx, by, bz);
+			if (!skipped) ++p.G.stats[2];
+			stage_samples(p.G.grid, bx, by, bz, 1, samp.data(), 0, 1);
+			u32 bits[128];
+			memset(bits, 0, sizeof(bits));
+			bool any = false;
+			for (int c = 0; c < BLOCK_CELLS; ++c) {
+				i8 V[8];
+				cell_values(samp.data(), c & 15, (c >> 4) & 15, c >> 8, V);
+				const u32 code = reg_case_code(V);
+				if (code != 0 && code != 255) { bits[c >> 5] |= 1u << (c & 31); any = true; }
+			}
+			if (!any) continue;
+			const u32 slot = (*L.nActive)++;
+			const u32 id = block_coord_id(bx, by, bz, L.cnt);
+			L.slotOf[id] = (int)slot;
+			L.slotCoord[slot] = id;
+			L.skip[slot] = skipped ? 1 : 0;
+			memcpy(L.ntBits + (size_t)slot * 128, bits, sizeof(bits));
+		}
+	}
+
+	template <typename P>
+	void run_hierarchy(const P& p, u32 levels)
+	{
+		const LevelDesc& L0 = p.levels[0];
+		for (u32 s = 0; s < *L0.nActive; ++s) {
+			u32 bx, by, bz;
+			block_coords(L0.slotCoord[s], L0.cnt, bx, by, bz);
+			for (u32 l = 1; l < levels; ++l) {
+				const LevelDesc& L = p.levels[l];
+				const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+				if (px >= L.cnt || py >= L.cnt || pz >= L.cnt) break;
+				const u32 id = block_coord_id(px, py, pz, L.cnt);
+				if (L.slotOf[id] >= 0) break;
+				const u32 slot = (*L.nActive)++;
+				L.slotOf[id] = (int)slot;
+				L.slotCoord[slot] = id;
+			}
+		}
+	}
+
+	template <typename P>
+	void run_material(const P& p, u32 level)
+	{
+		const LevelDesc& L = p.levels[level];
+		MatState* st = new MatState;
+		for (u32 slot = 0; slot < *L.nActive; ++slot) {
+			u32 bx, by, bz;
+			block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
+			stage_samples(p.G.grid, bx, by, bz, L.mult, st->samp, 0, 1);
+			memset(st->ntBits, 0, sizeof(st->ntBits));
+			mat_phase_classify(*st, 0, 1);
+			mat_phase_vote(*st, p.G, p.levels, level, slot, bx, by, bz, 0, 1);
+		}
+		delete st;
+	}
+
+	template <typename P>
+	void run_regular(const P& p, u32 levels)
+	{
+		Tables T{ p.tables };
+		RegState* st = new RegState;
+		for (u32 level = 0; level < levels; ++level) {
+			const LevelDesc& L = p.levels[level];
+			for (u32 slot = 0; slot < *L.nActive; ++slot) {
+				RegBlockCtx b;
+				b.level = level; b.slot = slot; b.mult = L.mult;
+				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
+				if (level == 0 && L.skip[slot]) {
+					BlockRecord& r = L.records[slot];
+					memset(&r, 0, sizeof(r));
+					r.coordId = L.slotCoord[slot];
+					continue;
+				}
+				reg_phase_load_bits(*st, L, slot, 0, 1);
+				stage_samples(p.G.grid, b.bx, b.by, b.bz, b.mult, st->samp, 0, 1);
+				for (int w = 0; w < 128; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
+				st->wordPrefix[128] = (u16)exclusive_scan(st->wordPrefix, 128);
+				reg_phase_list(*st, T, p.G, L, b, 0, 1);
+				reg_phase_count(*st, T, b, 0, 1);
+				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[128]);
+				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[0], st->vTotal);
+				reg_phase_emit_vertices(*st, T, p.G, p.P, b, 0, 1);
+				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[128]);
+				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
+				reg_phase_emit_indices(*st, T, p.P, b, 0, 1);
+				reg_phase_record(*st, p.G, L, b, p.P, 0);
+			}
+		}
+		delete st;
+	}
+
+	template <typename P>
+	void run_transition(const P& p, u32 levels)
+	{
+		Tables T{ p.tables };
+		TrState* st = new TrState;
+		for (u32 level = 1; level < levels; ++level) {
+			const LevelDesc& L = p.levels[level];
+			if (!L.hasTransitions) continue;
+			for (u32 slot = 0; slot < *L.nActive; ++slot) {
+				RegBlockCtx b;
+				b.level = level; b.slot = slot; b.mult = L.mult;
+				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
+				tr_phase_load(*st, p.G, L, b, 0, 1);
+				tr_phase_classify(*st, 0, 1);
+				for (int w = 0; w < 48; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
+				st->wordPrefix[48] = (u16)exclusive_scan(st->wordPrefix, 48);
+				if (!st->wordPrefix[48]) continue;
+				tr_phase_list(*st, T, L, b, 0, 1);
+				tr_phase_count(*st, T, 0, 1);
+				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);
+				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[48]);
+				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[0], st->vTotal);
+				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
+				tr_phase_emit(*st, T, p.G, p.P, b, 0, 1);
+				tr_phase_record(*st, L, b, p.P, 0);
+			}
+		}
+		delete st;
+	}
+};
+
+} // namespace

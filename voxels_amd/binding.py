@@ -1,0 +1,169 @@
+"""ctypes binding of include/voxels_hip.h (libvoxels_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+VERTEX_DTYPE = np.dtype([("pos", "<f4", 3), ("sec", "<f4", 4), ("nrm", "<f4", 3), ("tex", "u1", 8)])
+BLOCK_INFO_DTYPE = np.dtype([
+    ("id", "<u4"), ("n_verts", "<u4"), ("n_idx", "<u4"),
+    ("n_tverts", "<u4", 6), ("n_tidx", "<u4", 6),
+    ("min_corner", "<f4", 3), ("max_corner", "<f4", 3)])
+assert VERTEX_DTYPE.itemsize == 48 and BLOCK_INFO_DTYPE.itemsize == 84
+
+
+class VoxelsHipError(RuntimeError):
+    pass
+
+
+class ExecInfo(C.Structure):
+    _fields_ = [("levels", C.c_uint32), ("retries", C.c_uint32), ("device_ms", C.c_float),
+                ("total_verts", C.c_uint64), ("total_indices", C.c_uint64),
+                ("active_blocks", C.c_uint32 * 8), ("algorithmic_bytes", C.c_uint64)]
+
+
+def hip_library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvoxels_hip.so")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipLibrary:
+    """Loads the C-ABI library.  The default is the in-tree HIP build; a missing library is an error."""
+
+    def __init__(self, path=None):
+        path = path or hip_library_path()
+        if not os.path.exists(path):
+            raise VoxelsHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        lib = C.CDLL(path)
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+        lib.vx_backend.restype = C.c_char_p
+        lib.vx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.vx_ctx_destroy.argtypes = [vp]
+        lib.vx_last_error.restype = C.c_char_p
+        lib.vx_last_error.argtypes = [vp]
+        lib.vx_set_stream.argtypes = [vp, vp]
+        lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
+        lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
+        lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        lib.vx_material_lut.argtypes = [vp, vp, vp]
+        lib.vx_polygonize.argtypes = [vp, u32, C.POINTER(ExecInfo)]
+        lib.vx_polygonize_dirty.argtypes = [vp, vp, vp, C.POINTER(ExecInfo), vp, u32, C.POINTER(u32)]
+        lib.vx_level_counts.argtypes = [vp, u32, C.POINTER(u32), vp]
+        lib.vx_download_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        lib.vx_stats.argtypes = [vp, vp]
+        self.lib = lib
+        self.path = path
+        self.backend = lib.vx_backend().decode()
+
+
+class Level:
+    """One LOD level: blocks in PolygonSurface::GetBlockForLevel order, arrays concatenated."""
+
+    def __init__(self, infos, verts, idx, tverts, tidx):
+        self.infos, self.verts, self.idx, self.tverts, self.tidx = infos, verts, idx, tverts, tidx
+
+    def totals(self):
+        return (len(self.infos), len(self.verts), len(self.idx), len(self.tverts), len(self.tidx))
+
+
+class Polygonizer:
+    """Host-side mirror of Voxels::Polygonizer for the device path.
+
+    upload(dist, mat, blend, empty_flags)  ~ the Grid the reference's Execute reads
+    execute(num_levels=0)                   ~ Polygonizer::Execute (full run); returns exec info
+    level(l) / stats()                      ~ PolygonSurface accessors
+    """
+
+    def __init__(self, device=0, library=None):
+        self._L = library or HipLibrary()
+        self._lib = self._L.lib
+        h = C.c_void_p()
+        rc = self._lib.vx_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise VoxelsHipError("vx_ctx_create failed (%d): no usable HIP device?" % rc)
+        self._h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VoxelsHipError("%s failed (%d): %s" % (what, rc, self._lib.vx_last_error(self._h).decode()))
+
+    @property
+    def backend(self):
+        return self._L.backend
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.vx_set_stream(self._h, C.c_void_p(stream_handle)), "vx_set_stream")
+
+    def upload(self, dist, mat, blend, empty_flags):
+        n = dist.shape[0]
+        assert dist.shape == (n, n, n) and dist.dtype == np.int8 and dist.flags.c_contiguous
+        for a in (mat, blend):
+            assert a is None or (a.shape == (n, n, n) and a.dtype == np.uint8 and a.flags.c_contiguous)
+        empty_flags = np.ascontiguousarray(empty_flags, np.uint8)
+        assert empty_flags.size == (n // 16) ** 3
+        self._keep = (dist, mat, blend, empty_flags)
+        self._check(self._lib.vx_grid_upload(self._h, n, _ptr(dist), _ptr(mat), _ptr(blend), _ptr(empty_flags)), "vx_grid_upload")
+        self.n = n
+
+    def attach(self, n, z_begin, z_end, d_dist, dist_z0, d_mat, d_blend, mat_z0, d_flags):
+        """Device pointers (ints), e.g. torch tensors' data_ptr()."""
+        self._check(self._lib.vx_grid_attach(self._h, n, z_begin, z_end, C.c_void_p(d_dist), dist_z0,
+                                             C.c_void_p(d_mat), C.c_void_p(d_blend), mat_z0, C.c_void_p(d_flags)),
+                    "vx_grid_attach")
+        self.n = n
+
+    def update_blocks(self, block_ids, dist, mat, blend, empty_flags):
+        block_ids = np.ascontiguousarray(block_ids, np.uint32)
+        self._check(self._lib.vx_grid_update_blocks(self._h, block_ids.size, _ptr(block_ids), _ptr(dist), _ptr(mat),
+                                                    _ptr(blend), _ptr(np.ascontiguousarray(empty_flags, np.uint8))),
+                    "vx_grid_update_blocks")
+
+    def set_materials(self, lut, valid=None):
+        lut = np.ascontiguousarray(lut, np.uint8)
+        assert lut.shape == (256, 6)
+        valid = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self._check(self._lib.vx_material_lut(self._h, _ptr(lut), _ptr(valid)), "vx_material_lut")
+
+    def execute(self, num_levels=0):
+        info = ExecInfo()
+        self._check(self._lib.vx_polygonize(self._h, int(num_levels), C.byref(info)), "vx_polygonize")
+        self.info = info
+        return info
+
+    def level(self, lvl, with_data=True):
+        nb = C.c_uint32()
+        tot = np.zeros(4, np.uint64)
+        self._check(self._lib.vx_level_counts(self._h, lvl, C.byref(nb), _ptr(tot)), "vx_level_counts")
+        infos = np.zeros(nb.value, BLOCK_INFO_DTYPE)
+        if not with_data:
+            self._check(self._lib.vx_download_level(self._h, lvl, _ptr(infos), None, None, None, None), "vx_download_level")
+            return Level(infos, np.zeros(0, VERTEX_DTYPE), np.zeros(0, np.uint32), np.zeros(0, VERTEX_DTYPE), np.zeros(0, np.uint32))
+        verts = np.zeros(int(tot[0]), VERTEX_DTYPE)
+        idx = np.zeros(int(tot[1]), np.uint32)
+        tverts = np.zeros(int(tot[2]), VERTEX_DTYPE)
+        tidx = np.zeros(int(tot[3]), np.uint32)
+        self._check(self._lib.vx_download_level(self._h, lvl, _ptr(infos), _ptr(verts), _ptr(idx), _ptr(tverts), _ptr(tidx)),
+                    "vx_download_level")
+        return Level(infos, verts, idx, tverts, tidx)
+
+    def all_levels(self):
+        return [self.level(l) for l in range(self.info.levels)]
+
+    def stats(self):
+        out = np.zeros(20, np.uint32)
+        self._check(self._lib.vx_stats(self._h, _ptr(out)), "vx_stats")
+        return out

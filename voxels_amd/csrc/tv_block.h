@@ -1,0 +1,611 @@
+// tv_block.h — per-block phases of the polygonizer, written as "for (i = tid; i < count; i += nthreads)" loops
+// over workgroup-shared state.  On the GPU the state lives in LDS, tid = threadIdx.x and the kernels in
+// tv_kernels.hip put __syncthreads() + wavefront scans between the phases; tests/emu runs the same phases with
+// tid = 0, nthreads = 1 on a CPU to check the parallel formulation against the oracle.
+//
+// Pipeline (one polygonization):
+//   classify (stream, all level-0 blocks)  -> non-trivial bitmaps + active block slots per level
+//   material (levels 1..Lmax, serial)      -> per-cell material cache (vote over children), level bitmaps
+//   regular  (all levels at once)          -> vertices + indices of regular cells
+//   transition (levels 1..last-1)          -> vertices + indices of the 6 transition faces
+#pragma once
+
+#include "tv_core.h"
+
+#if defined(__HIPCC__)
+#define TV_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define TV_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define TV_POPC(x) __popc(x)
+#else
+namespace tv {
+template <typename T> inline T host_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+}
+#define TV_ATOMIC_ADD(p, v) tv::host_atomic_add((p), (v))
+#define TV_ATOMIC_OR(p, v) tv::host_atomic_or((p), (v))
+#define TV_POPC(x) __builtin_popcount(x)
+#endif
+
+namespace tv {
+
+enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
+
+// One emitted block (regular mesh + 6 transition meshes) inside the shared vertex/index pools
+struct BlockRecord {
+	u32 coordId;
+	u32 vOff, vCount, iOff, iCount;
+	u32 tvOff[6], tvCount[6], tiOff[6], tiCount[6];
+	u32 degenerate;
+	u32 ntCells;
+	u32 pad;
+};
+
+// Per-LOD-level device tables
+struct LevelDesc {
+	u32 cnt;            // blocks per axis of this level (global)
+	u32 mult;           // cell size in voxels
+	u32 zb0, zb1;       // block layers [zb0, zb1) owned by this rank
+	int* slotOf;        // [cnt^3] block coordinate id -> active slot, -1 = none
+	u32* slotCoord;     // [cap] slot -> coordinate id
+	u32* nActive;       // number of slots in use
+	u32* ntBits;        // [cap][128] non-trivial cell bitmap of the block
+	u16* cache;         // [cap][4096] per-cell material cache (levels >= 1)
+	u8* skip;           // [cap] level 0: block skipped by the emptiness rule
+	BlockRecord* records; // [cap]
+	u32 cap;
+	u32 hasTransitions; // 0 < level < levelsCount - 1
+};
+
+struct Pools {
+	PolyVertex* verts;
+	u32* idx;
+	u32* cursors;       // [0] vertices used, [1] indices used, [2] overflow flag
+	u32 vertCap, idxCap;
+};
+
+// stats[0] = non-trivial cells, [1] = degenerate triangles removed, [2] = level-0 blocks processed,
+// stats[4..19] = per-class cell counts
+struct Globals {
+	GridView grid;
+	const u8* emptyFlags;   // [cnt0^3] BF_Empty of every level-0 block (host-computed property of the Grid)
+	const u8* lut;          // 256 x 8 material LUT
+	u32* stats;
+	u32 levels;             // number of levels being polygonized (0..levels-1)
+	u32 refLevels;          // the reference's levelsCount = log2(N/16)+1 (decides which levels get transitions)
+};
+
+TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
+
+TV_HD void block_coords(u32 id, u32 cnt, u32& bx, u32& by, u32& bz) { bx = id % cnt; by = (id / cnt) % cnt; bz = id / (cnt * cnt); }
+
+// ---------------------------------------------------------------------------------------------------------
+// shared helpers
+// ---------------------------------------------------------------------------------------------------------
+// corner samples of a block: sample (i,j,k), 0..16, at global position (block*16 + ijk) * mult
+TV_HD void stage_samples(const GridView& g, u32 bx, u32 by, u32 bz, u32 mult, i8* samp, int tid, int nth)
+{
+	for (int s = tid; s < SAMPLES; s += nth) {
+		const int i = s % 17, j = (s / 17) % 17, k = s / 289;
+		samp[s] = (i8)dist_at(g, (int)((bx * 16 + i) * mult), (int)((by * 16 + j) * mult), (int)((bz * 16 + k) * mult));
+	}
+}
+
+TV_HD void cell_values(const i8* samp, int cx, int cy, int cz, i8 V[8])
+{
+	const int o = (cz * 17 + cy) * 17 + cx;
+	V[0] = samp[o]; V[1] = samp[o + 1]; V[2] = samp[o + 17]; V[3] = samp[o + 18];
+	V[4] = samp[o + 289]; V[5] = samp[o + 290]; V[6] = samp[o + 306]; V[7] = samp[o + 307];
+}
+
+TV_HD u32 bit_get(const u32* bits, u32 i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
+
+// rank of set bit i in a bitmap with exclusive per-word popcount prefix
+TV_HD u32 bit_rank(const u32* bits, const u16* prefix, u32 i)
+{
+	return prefix[i >> 5] + TV_POPC(bits[i >> 5] & ((1u << (i & 31)) - 1u));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Classification of level-0 blocks (portable form; the GPU kernel uses a bit-parallel streaming version)
+// ---------------------------------------------------------------------------------------------------------
+TV_HD bool block_skipped_by_emptiness(const u8* emptyFlags, u32 cnt, u32 bx, u32 by, u32 bz)
+{
+	for (int z = -1; z < 2; ++z)
+	for (int y = -1; y < 2; ++y)
+	for (int x = -1; x < 2; ++x) {
+		const u32 cx = (u32)clampi((int)bx + x, 0, (int)cnt - 1), cy = (u32)clampi((int)by + y, 0, (int)cnt - 1), cz = (u32)clampi((int)bz + z, 0, (int)cnt - 1);
+		if (!emptyFlags[block_coord_id(cx, cy, cz, cnt)]) return false;
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Material pass state (levels >= 1)
+// ---------------------------------------------------------------------------------------------------------
+struct MatState {
+	i8 samp[SAMPLES + 7];
+	u32 ntBits[128];
+};
+
+TV_HD void mat_phase_classify(MatState& st, int tid, int nth)
+{
+	for (int c = tid; c < BLOCK_CELLS; c += nth) {
+		i8 V[8];
+		cell_values(st.samp, c & 15, (c >> 4) & 15, c >> 8, V);
+		const u32 code = reg_case_code(V);
+		if (code != 0 && code != 255) TV_ATOMIC_OR(&st.ntBits[c >> 5], 1u << (c & 31));
+	}
+}
+
+// entry of the level-(L-1) cache / level-0 consistency for one child cell, id 255 = none
+TV_HD u32 child_entry(const Globals& G, const LevelDesc* levels, u32 childLevel, u32 ccx, u32 ccy, u32 ccz)
+{
+	const LevelDesc& C = levels[childLevel];
+	const u32 bx = ccx >> 4, by = ccy >> 4, bz = ccz >> 4;
+	if (bx >= C.cnt || by >= C.cnt || bz >= C.cnt) return EMPTY_MATINFO;
+	const int slot = C.slotOf[block_coord_id(bx, by, bz, C.cnt)];
+	if (slot < 0) return EMPTY_MATINFO;
+	const u32 local = ((ccz & 15) << 8) | ((ccy & 15) << 4) | (ccx & 15);
+	if (childLevel == 0) {
+		if (C.skip[slot]) return EMPTY_MATINFO;
+		if (!bit_get(C.ntBits + (size_t)slot * 128, local)) return EMPTY_MATINFO;
+		return mat_at(G.grid, (int)ccx, (int)ccy, (int)ccz);
+	}
+	return C.cache[(size_t)slot * BLOCK_CELLS + local];
+}
+
+// does the transition pass of this block visit cell (lx,ly,lz)?  (boundary cell on a face with a neighbour block)
+TV_HD bool cell_on_transition_face(const LevelDesc& L, u32 bx, u32 by, u32 bz, int lx, int ly, int lz)
+{
+	if (!L.hasTransitions) return false;
+	return (lz == 0 && bz > 0) || (ly == 0 && by > 0) || (lx == 0 && bx > 0)
+	    || (lz == 15 && bz + 1 < L.cnt) || (ly == 15 && by + 1 < L.cnt) || (lx == 15 && bx + 1 < L.cnt);
+}
+
+TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc* levels, u32 level, u32 slot,
+                          u32 bx, u32 by, u32 bz, int tid, int nth)
+{
+	const LevelDesc& L = levels[level];
+	u16* out = L.cache + (size_t)slot * BLOCK_CELLS;
+	for (int c = tid; c < BLOCK_CELLS; c += nth) {
+		const int lx = c & 15, ly = (c >> 4) & 15, lz = c >> 8;
+		u32 entry = EMPTY_MATINFO;
+		if (bit_get(st.ntBits, (u32)c) || cell_on_transition_face(L, bx, by, bz, lx, ly, lz)) {
+			const u32 gx = (bx * 16 + lx) * 2, gy = (by * 16 + ly) * 2, gz = (bz * 16 + lz) * 2;
+			entry = vote_material([&](u32 i) { return child_entry(G, levels, level - 1, gx + (i & 1), gy + ((i >> 1) & 1), gz + (i >> 2)); });
+		}
+		out[c] = (u16)entry;
+	}
+	u32* bitsOut = L.ntBits + (size_t)slot * 128;
+	for (int w = tid; w < 128; w += nth) bitsOut[w] = st.ntBits[w];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Regular-cell pass state
+// ---------------------------------------------------------------------------------------------------------
+struct RegState {
+	i8 samp[SAMPLES + 7];
+	u32 ntBits[128];
+	u16 wordPrefix[130];      // exclusive popcount prefix, [128] = number of non-trivial cells
+	u16 cellOf[BLOCK_CELLS];  // compact index -> cell id
+	u16 cellMat[BLOCK_CELLS]; // compact: id | blend << 8
+	u32 info[BLOCK_CELLS];    // compact: bits 0-15 slot ordinals (4 x 4), 16-19 slot valid, 20-23 new vertex count
+	u16 vbase[BLOCK_CELLS];   // compact: exclusive scan of new vertex counts
+	u16 ibase[BLOCK_CELLS];   // compact: exclusive scan of kept index counts
+	u8 keep[BLOCK_CELLS];     // compact: kept-triangle mask
+	u32 perCase[16];
+	u32 vOff, iOff, vTotal, iTotal, degenerate;
+};
+
+struct RegBlockCtx {
+	u32 level, slot, bx, by, bz, mult;
+};
+
+TV_HD void reg_phase_load_bits(RegState& st, const LevelDesc& L, u32 slot, int tid, int nth)
+{
+	const u32* src = L.ntBits + (size_t)slot * 128;
+	for (int w = tid; w < 128; w += nth) st.ntBits[w] = src[w];
+	for (int i = tid; i < 16; i += nth) st.perCase[i] = 0;
+	if (tid == 0) st.degenerate = 0;
+}
+
+// after wordPrefix is known: compact list, cell material, slot-valid mask
+TV_HD void reg_phase_list(RegState& st, const Tables& T, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+{
+	for (int c = tid; c < BLOCK_CELLS; c += nth) {
+		if (!bit_get(st.ntBits, (u32)c)) continue;
+		const u32 k = bit_rank(st.ntBits, st.wordPrefix, (u32)c);
+		const int cx = c & 15, cy = (c >> 4) & 15, cz = c >> 8;
+		i8 V[8];
+		cell_values(st.samp, cx, cy, cz, V);
+		const u32 code = reg_case_code(V);
+		st.cellOf[k] = (u16)c;
+		st.info[k] = reg_slot_valid(T, V, code) << 16;
+		u32 m;
+		if (b.level == 0) m = mat_at(G.grid, (int)(b.bx * 16 + cx), (int)(b.by * 16 + cy), (int)(b.bz * 16 + cz));
+		else m = L.cache[(size_t)b.slot * BLOCK_CELLS + c];
+		st.cellMat[k] = (u16)m;
+		TV_ATOMIC_ADD(&st.perCase[T.regClass(code)], 1u);
+	}
+}
+
+struct RegNeighbour {
+	const RegState* st;
+	int cx, cy, cz;
+	TV_HD void operator()(int dx, int dy, int dz, u32 slot, bool& valid, u32& mat) const
+	{
+		const u32 c = (u32)(((cz - dz) << 8) | ((cy - dy) << 4) | (cx - dx));
+		valid = false; mat = 0;
+		if (!bit_get(st->ntBits, c)) return;
+		const u32 k = bit_rank(st->ntBits, st->wordPrefix, c);
+		valid = ((st->info[k] >> (16 + slot)) & 1u) != 0;
+		mat = st->cellMat[k] & 0xFFu;
+	}
+};
+
+// reuseValidityMask of cell c from the bitmap: x-bit, y-bit, z-bit
+TV_HD u32 reg_mask3(const RegState& st, int cx, int cy, int cz)
+{
+	const u32 row = (u32)((cz << 4) | cy);              // 16 cells = half a word
+	const u32 word = st.ntBits[row >> 1];
+	const u32 rowBits = (word >> ((row & 1) * 16)) & 0xFFFFu;
+	u32 m = (rowBits & ((1u << cx) - 1u)) ? 1u : 0u;
+	// cells of this slice before row cy
+	const u32 sliceStart = (u32)cz * 256, before = (u32)cz * 256 + (u32)cy * 16;
+	const u32 nBeforeRow = bit_rank(st.ntBits, st.wordPrefix, before) - st.wordPrefix[sliceStart >> 5];
+	if (nBeforeRow) m |= 2u;
+	if (st.wordPrefix[sliceStart >> 5]) m |= 4u;
+	return m;
+}
+
+TV_HD void reg_cell_setup(const RegState& st, const RegBlockCtx& b, u32 k, int& cx, int& cy, int& cz, i8 V[8], CellGeom& geo)
+{
+	const u32 c = st.cellOf[k];
+	cx = c & 15; cy = (c >> 4) & 15; cz = c >> 8;
+	cell_values(st.samp, cx, cy, cz, V);
+	geo.mult = (int)b.mult; geo.level = (int)b.level;
+	geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
+	geo.base[0] = (int)((b.bx * 16 + cx) * b.mult); geo.base[1] = (int)((b.by * 16 + cy) * b.mult); geo.base[2] = (int)((b.bz * 16 + cz) * b.mult);
+}
+
+// new-vertex count and slot ordinals of every non-trivial cell
+TV_HD void reg_phase_count(RegState& st, const Tables& T, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[128];
+	for (int k = tid; k < nt; k += nth) {
+		int cx, cy, cz; i8 V[8]; CellGeom geo;
+		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
+		const u32 code = reg_case_code(V);
+		const u32 nv = (u32)T.regCell(T.regClass(code))[0] >> 4;
+		const u32 mask3 = reg_mask3(st, cx, cy, cz);
+		const u32 myMat = st.cellMat[k] & 0xFFu;
+		RegNeighbour nb{ &st, cx, cy, cz };
+		u32 count = 0, ords = 0;
+		for (u32 vi = 0; vi < nv; ++vi) {
+			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, myMat, nb);
+			if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
+				if (r.store != NO_SLOT) ords = (ords & ~(0xFu << (r.store * 4))) | (count << (r.store * 4));
+				++count;
+			}
+		}
+		st.info[k] = (st.info[k] & 0x000F0000u) | (count << 20) | ords;
+		st.vbase[k] = (u16)count;
+	}
+}
+
+// vertices out + kept-triangle mask; requires vbase scanned and st.vOff set
+TV_HD void reg_phase_emit_vertices(RegState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[128];
+	const bool room = st.vOff + st.vTotal <= P.vertCap;
+	for (int k = tid; k < nt; k += nth) {
+		int cx, cy, cz; i8 V[8]; CellGeom geo;
+		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
+		const u32 code = reg_case_code(V);
+		const u8* cd = T.regCell(T.regClass(code));
+		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
+		const u32 mask3 = reg_mask3(st, cx, cy, cz);
+		const u32 cellMat = st.cellMat[k];
+		RegNeighbour nb{ &st, cx, cy, cz };
+		float pos[12][3];
+		bool invalid[12];
+		u32 ord = 0;
+		for (u32 vi = 0; vi < nv; ++vi) {
+			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, cellMat & 0xFFu, nb);
+			invalid[vi] = r.kind == RK_INVALID;
+			if (r.kind == RK_NEW_EDGE) {
+				RawVertex rv;
+				reg_edge_vertex(G.grid, geo, r.a, r.b, r.t, cellMat, rv);
+				pos[vi][0] = rv.p[0]; pos[vi][1] = rv.p[1]; pos[vi][2] = rv.p[2];
+				if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
+				++ord;
+			} else if (r.kind == RK_NEW_CORNER) {
+				RawVertex rv;
+				reg_corner_vertex(G.grid, geo, r.a, cellMat, rv);
+				pos[vi][0] = rv.p[0]; pos[vi][1] = rv.p[1]; pos[vi][2] = rv.p[2];
+				if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
+				++ord;
+			} else if (r.kind == RK_REUSE) {
+				// same physical vertex as the owner's: recompute its position from this cell's own data
+				const u32 w = T.regVert(code, vi);
+				const int v0 = (w >> 4) & 15, v1 = w & 15;
+				if ((r.t & 0xFF) == 0) reg_corner_position(geo, (r.t == 0) ? v1 : v0, pos[vi]);
+				else { int P0[3], P1[3], t; reg_edge_position(G.grid, geo, v0, v1, r.t, P0, P1, t, pos[vi]); }
+			} else {
+				pos[vi][0] = pos[vi][1] = pos[vi][2] = 0.f;
+			}
+		}
+		u32 keepMask = 0, kept = 0;
+		for (u32 tr = 0; tr < ntri; ++tr) {
+			const u32 a = cd[1 + tr * 3], bb = cd[2 + tr * 3], c = cd[3 + tr * 3];
+			bool keepIt = true;
+			if (!(invalid[a] || invalid[bb] || invalid[c])) keepIt = !triangle_degenerate(pos[a], pos[bb], pos[c]);
+			if (keepIt) { keepMask |= 1u << tr; ++kept; }
+		}
+		st.keep[k] = (u8)keepMask;
+		st.ibase[k] = (u16)(kept * 3);
+		if (kept != ntri) TV_ATOMIC_ADD(&st.degenerate, ntri - kept);
+	}
+}
+
+// indices out; requires ibase scanned and st.iOff set
+TV_HD void reg_phase_emit_indices(RegState& st, const Tables& T, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[128];
+	if (st.iOff + st.iTotal > P.idxCap) return;
+	for (int k = tid; k < nt; k += nth) {
+		int cx, cy, cz; i8 V[8]; CellGeom geo;
+		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
+		const u32 code = reg_case_code(V);
+		const u8* cd = T.regCell(T.regClass(code));
+		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
+		const u32 mask3 = reg_mask3(st, cx, cy, cz);
+		RegNeighbour nb{ &st, cx, cy, cz };
+		u32 vidx[12];
+		u32 ord = 0;
+		for (u32 vi = 0; vi < nv; ++vi) {
+			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, st.cellMat[k] & 0xFFu, nb);
+			if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
+				vidx[vi] = (u32)st.vbase[k] + ord; ++ord;
+			} else if (r.kind == RK_REUSE) {
+				const u32 c2 = (u32)(((cz - ((r.a >> 2) & 1)) << 8) | ((cy - ((r.a >> 1) & 1)) << 4) | (cx - (r.a & 1)));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				vidx[vi] = (u32)st.vbase[k2] + ((st.info[k2] >> (r.b * 4)) & 0xFu);
+			} else {
+				vidx[vi] = INVALID_INDEX;
+			}
+		}
+		u32* out = P.idx + st.iOff + st.ibase[k];
+		const u32 keepMask = st.keep[k];
+		for (u32 tr = 0; tr < ntri; ++tr) {
+			if (!((keepMask >> tr) & 1u)) continue;
+			out[0] = vidx[cd[1 + tr * 3]]; out[1] = vidx[cd[2 + tr * 3]]; out[2] = vidx[cd[3 + tr * 3]];
+			out += 3;
+		}
+	}
+}
+
+TV_HD void reg_phase_record(const RegState& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
+{
+	if (tid != 0) return;
+	BlockRecord& r = L.records[b.slot];
+	r.coordId = L.slotCoord[b.slot];
+	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
+	r.vOff = st.vOff; r.vCount = ok ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = ok ? st.iTotal : 0;
+	for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
+	r.degenerate = st.degenerate;
+	r.ntCells = st.wordPrefix[128];
+	r.pad = 0;
+	if (!ok) TV_ATOMIC_OR(&P.cursors[2], 1u);
+	TV_ATOMIC_ADD(&G.stats[0], (u32)st.wordPrefix[128]);
+	if (st.vTotal) TV_ATOMIC_ADD(&G.stats[1], st.degenerate);
+	for (int i = 0; i < 16; ++i) if (st.perCase[i]) TV_ATOMIC_ADD(&G.stats[4 + i], st.perCase[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Transition pass state: all 6 faces of a block at once; cell id = f * 256 + row * 16 + col
+// ---------------------------------------------------------------------------------------------------------
+enum { TR_CELLS = 6 * 256 };
+
+struct TrState {
+	i8 plane[6][PLANE + 7];   // 33 x 33 full-resolution samples of each boundary plane, index v * 33 + u
+	u32 ntBits[48];
+	u16 wordPrefix[50];       // [48] = number of non-trivial transition cells
+	u16 cellOf[TR_CELLS];     // compact -> cell id
+	u16 cellMat[TR_CELLS];    // compact: low-res cell material
+	u16 valid[TR_CELLS];      // compact: slot valid mask (10 bits)
+	u8 ords[TR_CELLS][10];    // compact: ordinal of the vertex stored in each slot
+	u16 vbase[TR_CELLS];      // compact: exclusive scan of new vertex counts (flat over faces)
+	u16 ibase[TR_CELLS];      // compact: exclusive scan of index counts (flat over faces)
+	u32 faceOn;               // bit f = face has a neighbour block
+	u32 vOff, iOff, vTotal, iTotal;
+};
+
+TV_HD void tr_phase_load(TrState& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+{
+	u32 on = 0;
+	const u32 bc[3] = { b.bx, b.by, b.bz };
+	for (int f = 0; f < 6; ++f) {
+		const FaceGeom fg = face_geom(f);
+		if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
+	}
+	if (tid == 0) st.faceOn = on;
+	for (int w = tid; w < 48; w += nth) st.ntBits[w] = 0;
+	const int half = (int)b.mult >> 1;
+	for (int s = tid; s < 6 * PLANE; s += nth) {
+		const int f = s / PLANE, r = s % PLANE;
+		if (!((on >> f) & 1u)) continue;
+		const FaceGeom fg = face_geom(f);
+		int p[3];
+		p[fg.ua] = (int)(bc[fg.ua] * 16 * b.mult) + (r % 33) * half;
+		p[fg.va] = (int)(bc[fg.va] * 16 * b.mult) + (r / 33) * half;
+		p[fg.axis] = (int)((bc[fg.axis] * 16 + (fg.positive ? 16 : 0)) * b.mult);
+		st.plane[f][r] = (i8)dist_at(G.grid, p[0], p[1], p[2]);
+	}
+}
+
+TV_HD void tr_cell_values(const TrState& st, int f, int row, int col, i8 v9[9])
+{
+	const i8* p = st.plane[f] + (row * 2) * 33 + col * 2;
+#pragma unroll
+	for (int j = 0; j < 3; ++j)
+#pragma unroll
+		for (int i = 0; i < 3; ++i) v9[j * 3 + i] = p[j * 33 + i];
+}
+
+TV_HD void tr_phase_classify(TrState& st, int tid, int nth)
+{
+	for (int c = tid; c < TR_CELLS; c += nth) {
+		const int f = c >> 8;
+		if (!((st.faceOn >> f) & 1u)) continue;
+		i8 v9[9];
+		tr_cell_values(st, f, (c >> 4) & 15, c & 15, v9);
+		const u32 code = tr_case_code(v9);
+		if (code != 0 && code != 511) TV_ATOMIC_OR(&st.ntBits[c >> 5], 1u << (c & 31));
+	}
+}
+
+// local (x,y,z) of the low-res cell behind transition cell (f,row,col)
+TV_HD void tr_low_local(const FaceGeom& fg, int row, int col, int local[3])
+{
+	local[fg.ua] = col; local[fg.va] = row; local[fg.axis] = fg.positive ? 15 : 0;
+}
+
+TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+{
+	for (int c = tid; c < TR_CELLS; c += nth) {
+		if (!bit_get(st.ntBits, (u32)c)) continue;
+		const u32 k = bit_rank(st.ntBits, st.wordPrefix, (u32)c);
+		const int f = c >> 8, row = (c >> 4) & 15, col = c & 15;
+		i8 v9[9], v[13];
+		tr_cell_values(st, f, row, col, v9);
+		tr_expand_values(v9, v);
+		st.cellOf[k] = (u16)c;
+		st.valid[k] = (u16)tr_slot_valid(T, v, tr_case_code(v9));
+		int local[3];
+		tr_low_local(face_geom(f), row, col, local);
+		st.cellMat[k] = L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])];
+	}
+}
+
+struct TrNeighbour {
+	const TrState* st;
+	int f, row, col;
+	TV_HD void operator()(int dcol, int drow, u32 slot, bool& valid, u32& mat) const
+	{
+		const u32 c = (u32)((f << 8) | ((row - drow) << 4) | (col - dcol));
+		valid = false; mat = 0;
+		if (!bit_get(st->ntBits, c)) return;
+		const u32 k = bit_rank(st->ntBits, st->wordPrefix, c);
+		valid = ((st->valid[k] >> slot) & 1u) != 0;
+		mat = st->cellMat[k] & 0xFFu;
+	}
+};
+
+TV_HD u32 tr_mask2(const TrState& st, int f, int row, int col)
+{
+	const u32 r = (u32)((f << 4) | row);
+	const u32 rowBits = (st.ntBits[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+	u32 m = (rowBits & ((1u << col) - 1u)) ? 1u : 0u;
+	if (row > 0) m |= 2u;
+	return m;
+}
+
+TV_HD void tr_phase_count(TrState& st, const Tables& T, int tid, int nth)
+{
+	const int nt = st.wordPrefix[48];
+	for (int k = tid; k < nt; k += nth) {
+		const u32 c = st.cellOf[k];
+		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
+		i8 v9[9], v[13];
+		tr_cell_values(st, f, row, col, v9);
+		tr_expand_values(v9, v);
+		const u32 code = tr_case_code(v9);
+		const u8* cd = T.trCell(T.trClass(code) & 0x7F);
+		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
+		const u32 mask2 = tr_mask2(st, f, row, col);
+		TrNeighbour nb{ &st, f, row, col };
+		u32 count = 0;
+		for (u32 vi = 0; vi < nv; ++vi) {
+			const TrResolution r = tr_resolve(T, v, T.trVert(code, vi), mask2, st.cellMat[k] & 0xFFu, nb);
+			if (r.kind == RK_NEW_EDGE) {
+				if (r.store != NO_SLOT) st.ords[k][r.store] = (u8)count;
+				++count;
+			}
+		}
+		st.vbase[k] = (u16)count;
+		st.ibase[k] = (u16)(ntri * 3);
+	}
+}
+
+// vertices and indices of all transition cells; requires vbase/ibase scanned, vOff/iOff set
+TV_HD void tr_phase_emit(TrState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[48];
+	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
+	for (int k = tid; k < nt; k += nth) {
+		const u32 c = st.cellOf[k];
+		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
+		const FaceGeom fg = face_geom(f);
+		i8 v9[9], v[13];
+		tr_cell_values(st, f, row, col, v9);
+		tr_expand_values(v9, v);
+		const u32 code = tr_case_code(v9);
+		const u32 cls = T.trClass(code);
+		const u8* cd = T.trCell(cls & 0x7F);
+		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
+		const u32 mask2 = tr_mask2(st, f, row, col);
+		const u32 lowMat = st.cellMat[k];
+		TrNeighbour nb{ &st, f, row, col };
+		TrCellGeom geo;
+		tr_low_local(fg, row, col, geo.local);
+		geo.mult = (int)b.mult; geo.level = (int)b.level;
+		geo.lowBase[0] = (int)((b.bx * 16 + geo.local[0]) * b.mult);
+		geo.lowBase[1] = (int)((b.by * 16 + geo.local[1]) * b.mult);
+		geo.lowBase[2] = (int)((b.bz * 16 + geo.local[2]) * b.mult);
+		const u32 faceFirst = st.wordPrefix[f * 8];           // compact index of the face's first cell
+		const u32 faceVBase = st.vbase[faceFirst];            // valid: this face has at least cell k
+		u32 vidx[12];
+		u32 ord = 0;
+		for (u32 vi = 0; vi < nv; ++vi) {
+			const u32 w = T.trVert(code, vi);
+			const TrResolution r = tr_resolve(T, v, w, mask2, lowMat & 0xFFu, nb);
+			if (r.kind == RK_REUSE) {
+				const u32 c2 = (u32)((f << 8) | ((row - ((r.dir >> 1) & 1)) << 4) | (col - (r.dir & 1)));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				vidx[vi] = (u32)st.vbase[k2] - faceVBase + st.ords[k2][r.slot];
+			} else {
+				RawVertex rv;
+				tr_new_vertex(G.grid, fg, geo, v, w, r, lowMat, rv);
+				pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
+				vidx[vi] = (u32)st.vbase[k] - faceVBase + ord;
+				++ord;
+			}
+		}
+		u32* out = P.idx + st.iOff + st.ibase[k];
+		const bool flip = ((cls >> 7) ^ (u32)(f & 1)) != 0; // reverseWinding = {0,1,0,1,0,1}
+		for (u32 tr = 0; tr < ntri; ++tr) {
+			const u32 a = vidx[cd[1 + tr * 3]], bb = vidx[cd[2 + tr * 3]], cc = vidx[cd[3 + tr * 3]];
+			out[0] = a; out[1] = flip ? cc : bb; out[2] = flip ? bb : cc;
+			out += 3;
+		}
+	}
+}
+
+TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
+{
+	if (tid != 0) return;
+	BlockRecord& r = L.records[b.slot];
+	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
+	if (!ok) { TV_ATOMIC_OR(&P.cursors[2], 1u); return; }
+	const u32 nt = st.wordPrefix[48];
+	for (int f = 0; f < 6; ++f) {
+		const u32 k0 = st.wordPrefix[f * 8], k1 = st.wordPrefix[f * 8 + 8];
+		const u32 v0 = (k0 < nt) ? st.vbase[k0] : st.vTotal, v1 = (k1 < nt) ? st.vbase[k1] : st.vTotal;
+		const u32 i0 = (k0 < nt) ? st.ibase[k0] : st.iTotal, i1 = (k1 < nt) ? st.ibase[k1] : st.iTotal;
+		r.tvOff[f] = st.vOff + v0; r.tvCount[f] = v1 - v0;
+		r.tiOff[f] = st.iOff + i0; r.tiCount[f] = i1 - i0;
+	}
+}
+
+} // namespace tv

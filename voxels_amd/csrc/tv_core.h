@@ -1,0 +1,579 @@
+// tv_core.h — per-cell TransVoxel logic of the MI355X polygonizer, in closed (order-free) form.
+//
+// Everything here is a pure function of grid samples, Lengyel's tables and per-cell facts of the SAME block,
+// so thousands of cells can be evaluated concurrently and still reproduce the reference's strictly sequential
+// vertex numbering.  The functions are __host__ __device__: the HIP kernels (tv_kernels.hip) call them from
+// LDS-resident state, and tests/emu compiles the very same code with g++ to check the formulation on a CPU.
+//
+// Reference behaviour restated (all file:line into /root/reference/src/TransVoxelImpl.cpp):
+//   sampling / clamping            :1140-1151, :1194-1201
+//   normals                        :93-103, :1239-1246
+//   LOD surface-shift correction   :1484-1509, :1666-1678
+//   regular cell vertex rules      :1579-1718 (reuse, endpoint handling, material test)
+//   boundary flags + secondary pos :593-645, :683-708, :1473-1482, :1729-1738
+//   transition cells               :1754-2131
+//   material vote                  :753-838
+//   result packing                 :1248-1264, :1300-1369
+//
+// Why the closed form is exact (derivation in DESIGN.md §3):
+//   * a reuse slot of a cell is only ever written by a vertex that cell creates unconditionally (owned edge,
+//     direction 8, or the corner-7 endpoint), so "slot valid" and "ordinal of the slot's vertex" are functions
+//     of that cell alone;
+//   * every vertex a cell creates carries that cell's material id, so the reuse-by-material test compares the
+//     two cells' material ids;
+//   * the reference's data-dependent reuseValidityMask equals OR-scans of the block's non-trivial bitmap.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TV_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define TV_HD inline
+#endif
+
+namespace tv {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef int8_t i8;
+
+enum : u32 { INVALID_INDEX = 0xFFFFFFFFu };
+enum : u32 { EMPTY_MATERIAL = 255u };   // VoxelGrid.h:16 — material id 255 is reserved by the reference
+enum : u16 { EMPTY_MATINFO = 0x00FFu }; // id = 255, blend = 0 (TransVoxelImpl.cpp:424)
+
+// 48-byte output vertex, bit-compatible with Voxels::PolygonVertex (include/Polygonizer.h:14-48)
+struct PolyVertex {
+	float pos[3];
+	float sec[3];
+	u32 secW;     // adjacency bit mask, raw integer bits (never touched by float ops: values 1..63 are denormals)
+	float nrm[3];
+	u8 tex[8];    // Reserved, Blend, Uxz, Txz, Uny, Upy, Tny, Tpy
+};
+
+// Offsets of the table image (tv_tables.inc) when staged as one byte array (LDS on the GPU)
+enum : u32 {
+	TAB_REG_CLASS = 0,       // 256 B
+	TAB_REG_CELL = 256,      // 16 x 16 B
+	TAB_TR_CLASS = 512,      // 512 B
+	TAB_TR_CORNER = 1024,    // 16 B
+	TAB_TR_CELL = 1040,      // 56 x 40 B = 2240 -> 3280
+	TAB_REG_VERT = 3280,     // 256 x 12 u16 = 6144 -> 9424
+	TAB_TR_VERT = 9424,      // 512 x 12 u16 = 12288 -> 21712
+	TAB_BYTES = 21712
+};
+
+struct Tables {
+	const u8* base; // TAB_BYTES image, 16-byte aligned
+	TV_HD u32 regClass(u32 code) const { return base[TAB_REG_CLASS + code]; }
+	TV_HD const u8* regCell(u32 cls) const { return base + TAB_REG_CELL + cls * 16; }
+	TV_HD u32 regVert(u32 code, u32 i) const { return ((const u16*)(base + TAB_REG_VERT))[code * 12 + i]; }
+	TV_HD u32 trClass(u32 code) const { return base[TAB_TR_CLASS + code]; }
+	TV_HD const u8* trCell(u32 cls) const { return base + TAB_TR_CELL + cls * 40; }
+	TV_HD u32 trCorner(u32 c) const { return base[TAB_TR_CORNER + c]; }
+	TV_HD u32 trVert(u32 code, u32 i) const { return ((const u16*)(base + TAB_TR_VERT))[code * 12 + i]; }
+};
+
+// Dense voxel field resident in HBM: x fastest, then y, then z.  A rank of a multi-GPU run holds the z-planes
+// [zOrigin, zOrigin + planes) of the global grid (its slab plus halo); coordinates are always global and are
+// clamped to the GLOBAL extent [0, n-1] exactly like the reference clamps every fetch.
+struct GridView {
+	const i8* dist;
+	const u8* mat;
+	const u8* blend;
+	int n;          // global grid edge
+	int zOrigin;    // global z of plane 0 of dist[]
+	int zOriginMat; // global z of plane 0 of mat[] / blend[]
+};
+
+TV_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+TV_HD int dist_at(const GridView& g, int x, int y, int z)
+{
+	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1) - g.zOrigin;
+	return g.dist[((size_t)z * g.n + y) * g.n + x];
+}
+
+// material info packed as id | blend << 8
+TV_HD u32 mat_at(const GridView& g, int x, int y, int z)
+{
+	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1) - g.zOriginMat;
+	const size_t i = ((size_t)z * g.n + y) * g.n + x;
+	return (u32)g.mat[i] | ((u32)g.blend[i] << 8);
+}
+
+TV_HD void normalize_fix_zero(float v[3])
+{
+	const float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+	if (len <= 1.1920929e-07f) { v[0] = v[1] = v[2] = 0.f; return; }
+	v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len;
+}
+
+// level-0 central differences; components come out ordered (x, z, y) — the output is Y-up
+TV_HD void normal_at(const GridView& g, int x, int y, int z, float out[3])
+{
+	out[0] = (float)(dist_at(g, x + 1, y, z) - dist_at(g, x - 1, y, z)) * 0.5f;
+	out[1] = (float)(dist_at(g, x, y, z + 1) - dist_at(g, x, y, z - 1)) * 0.5f;
+	out[2] = (float)(dist_at(g, x, y + 1, z) - dist_at(g, x, y - 1, z)) * 0.5f;
+	normalize_fix_zero(out);
+}
+
+// `level` bisection steps toward the level-0 edge that holds the crossing
+TV_HD void lod_chain(const GridView& g, int level, int P0[3], int P1[3])
+{
+	for (int lev = level; lev > 0; --lev) {
+		const int mx = P0[0] + (P1[0] - P0[0]) / 2, my = P0[1] + (P1[1] - P0[1]) / 2, mz = P0[2] + (P1[2] - P0[2]) / 2;
+		const int midV = dist_at(g, mx, my, mz);
+		const int p0V = dist_at(g, P0[0], P0[1], P0[2]);
+		if (p0V * midV <= 0) { P1[0] = mx; P1[1] = my; P1[2] = mz; }
+		else { P0[0] = mx; P0[1] = my; P0[2] = mz; }
+	}
+}
+
+TV_HD int edge_t(int v0, int v1) { return (v1 * 256) / (v1 - v0); } // C truncating division, v0 != v1
+
+TV_HD u32 lerp_blend(int t, int u, u32 b0, u32 b1)
+{
+	const float v = ((float)t * (float)b0 + (float)u * (float)b1) / 256.f;
+	return (u32)(int)v & 0xFFu;
+}
+
+// 6-bit boundary mask (bit order ZPos,YPos,XPos,ZNeg,YNeg,XNeg) of the edge c0-c1 (corner when c0 == c1) of the
+// cell at local coordinates (lx,ly,lz); zero at level 0 and for interior cells.
+TV_HD u32 boundary_mask(int lx, int ly, int lz, int mult, int c0, int c1)
+{
+	if (mult == 1) return 0;
+	const int both = c0 & c1, none = ~(c0 | c1);
+	u32 r = 0;
+	if (lx == 0 && (none & 1)) r |= 1u << 5;
+	if (lx == 15 && (both & 1)) r |= 1u << 2;
+	if (ly == 0 && (none & 2)) r |= 1u << 4;
+	if (ly == 15 && (both & 2)) r |= 1u << 1;
+	if (lz == 0 && (none & 4)) r |= 1u << 3;
+	if (lz == 15 && (both & 4)) r |= 1u << 0;
+	return r;
+}
+
+// sum over flagged faces of 0.25 * cell size along the face's inward normal (internal Z-up axes)
+TV_HD void transition_delta(u32 faces, int mult, float out[3])
+{
+	const float q = (float)mult * 0.25f;
+	out[0] = out[1] = out[2] = 0.f;
+	if (faces & 1u) out[2] += -q;
+	if (faces & 2u) out[1] += -q;
+	if (faces & 4u) out[0] += -q;
+	if (faces & 8u) out[2] += q;
+	if (faces & 16u) out[1] += q;
+	if (faces & 32u) out[0] += q;
+}
+
+// Vertex before packing: coordinates are x256 (internal Z-up axes)
+struct RawVertex {
+	float p[3];
+	float s[3];
+	u32 flags;
+	float n[3];
+	u32 mat; // id | blend << 8
+};
+
+// PushBlocksToResult packing: x(1/256), y<->z swap, flag swizzle, texture ids from the material LUT
+// lut = 256 x 8 bytes: {Ids0[0..2], Ids1[0..2], valid, pad}
+TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out)
+{
+	const float k = 1.f / 256.f;
+	PolyVertex o;
+	o.pos[0] = r.p[0] * k; o.pos[1] = r.p[2] * k; o.pos[2] = r.p[1] * k;
+	o.sec[0] = r.s[0] * k; o.sec[1] = r.s[2] * k; o.sec[2] = r.s[1] * k;
+	u32 f = r.flags;
+	if (f) f = (f >> 3) | ((f & 7u) << 3);
+	o.secW = f;
+	o.nrm[0] = r.n[0]; o.nrm[1] = r.n[1]; o.nrm[2] = r.n[2];
+	const u8* e = lut + (r.mat & 0xFFu) * 8;
+	const bool ok = e[6] != 0;
+	o.tex[0] = 0;
+	o.tex[1] = ok ? (u8)(r.mat >> 8) : 0;
+	o.tex[2] = ok ? e[4] : 0; // Uxz = Ids1[1]
+	o.tex[3] = ok ? e[1] : 0; // Txz = Ids0[1]
+	o.tex[4] = ok ? e[5] : 0; // Uny = Ids1[2]
+	o.tex[5] = ok ? e[3] : 0; // Upy = Ids1[0]
+	o.tex[6] = ok ? e[2] : 0; // Tny = Ids0[2]
+	o.tex[7] = ok ? e[0] : 0; // Tpy = Ids0[0]
+	*out = o;
+}
+
+// degenerate-triangle test of PushBlocksToResult on x256 positions, plain fp32 (no fused multiply-add)
+TV_HD bool triangle_degenerate(const float* v0, const float* v1, const float* v2)
+{
+	const float ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2];
+	const float bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
+	const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+	const float len2 = (cx * cx + cy * cy) + cz * cz;
+	return !(len2 >= 1.1920929e-07f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Regular cells
+// ---------------------------------------------------------------------------------------------------------
+TV_HD u32 reg_case_code(const i8 V[8])
+{
+	u32 c = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) c |= ((u32)(V[i] >> 7) & 1u) << i;
+	return c;
+}
+
+// bit s set <=> this cell itself creates and stores a vertex in reuse slot s (s = 0: the corner-7 vertex)
+TV_HD u32 reg_slot_valid(const Tables& T, const i8 V[8], u32 code)
+{
+	const u32 nv = T.regCell(T.regClass(code))[0] >> 4;
+	u32 m = 0;
+	for (u32 vi = 0; vi < nv; ++vi) {
+		const u32 w = T.regVert(code, vi);
+		const int v0 = (w >> 4) & 15, v1 = w & 15;
+		const int t = edge_t(V[v0], V[v1]);
+		if ((t & 0xFF) == 0) { if (t == 0 && v1 == 7) m |= 1u; }
+		else if ((w >> 12) == 8u) m |= 1u << ((w >> 8) & 15);
+	}
+	return m;
+}
+
+enum { RK_NEW_EDGE = 0, RK_NEW_CORNER = 1, RK_REUSE = 2, RK_INVALID = 3 };
+enum { NO_SLOT = 0xFF };
+
+struct Resolution {
+	u8 kind;
+	u8 a;      // NEW_EDGE: v0 | NEW_CORNER: corner | REUSE: direction
+	u8 b;      // NEW_EDGE: v1 |                     | REUSE: slot
+	u8 store;  // slot this new vertex is stored in, or NO_SLOT
+	int t;     // NEW_EDGE: interpolation parameter from the cell's own corner values
+};
+
+// How vertex `w` (table word) of the non-trivial cell (cx,cy,cz) gets its index.
+//   mask3  : bit0 = a non-trivial cell exists earlier in this row, bit1 = in an earlier row of this slice,
+//            bit2 = in an earlier slice (the reference's reuseValidityMask)
+//   nb(dx,dy,dz, slot, &valid, &mat): reuse slot of the neighbour cell at (cx-dx, cy-dy, cz-dz)
+template <typename NB>
+TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const NB& nb)
+{
+	Resolution r;
+	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	u32 dir = w >> 12, slot = (w >> 8) & 15;
+	const int t = edge_t(V[v0], V[v1]);
+	const bool endpoint = (t & 0xFF) == 0;
+	bool check = true;
+	if (endpoint) {
+		if (t == 0 && v1 == 7) check = false;
+		else dir = (u32)((t == 0) ? v1 : v0) ^ 7u;
+		slot = 0;
+	}
+	r.t = t;
+	if (check && (dir & mask3) == dir) {
+		bool valid; u32 nmat;
+		nb((int)(dir & 1), (int)((dir >> 1) & 1), (int)((dir >> 2) & 1), slot, valid, nmat);
+		if (!valid) {
+			// empty slot counts as "same material": endpoint -> a fresh, unstored vertex at v0 (sic), else INVALID
+			r.kind = endpoint ? RK_NEW_CORNER : RK_INVALID; r.a = (u8)v0; r.b = 0; r.store = NO_SLOT;
+			return r;
+		}
+		if (nmat == myMatId) { r.kind = RK_REUSE; r.a = (u8)dir; r.b = (u8)slot; r.store = NO_SLOT; return r; }
+	}
+	if (endpoint) {
+		r.kind = RK_NEW_CORNER; r.a = (u8)((t == 0) ? v1 : v0); r.b = 0;
+		r.store = (t == 0 && v1 == 7) ? 0 : NO_SLOT;
+	} else {
+		r.kind = RK_NEW_EDGE; r.a = (u8)v0; r.b = (u8)v1;
+		r.store = ((w >> 12) == 8u) ? (u8)slot : (u8)NO_SLOT;
+	}
+	return r;
+}
+
+struct CellGeom {
+	int base[3];  // global voxel coordinates of corner 0
+	int local[3]; // cell coordinates inside the block
+	int mult;     // cell size in voxels = 1 << level
+	int level;
+};
+
+TV_HD void corner_pos(const CellGeom& c, int corner, int P[3])
+{
+	P[0] = c.base[0] + ((corner & 1) ? c.mult : 0);
+	P[1] = c.base[1] + ((corner & 2) ? c.mult : 0);
+	P[2] = c.base[2] + ((corner & 4) ? c.mult : 0);
+}
+
+TV_HD void finish_secondary(RawVertex& o, int mult)
+{
+	if ((int)o.flags > 0) {
+		float d[3];
+		transition_delta(o.flags, mult, d);
+		o.s[0] = o.p[0] + d[0] * 256.f; o.s[1] = o.p[1] + d[1] * 256.f; o.s[2] = o.p[2] + d[2] * 256.f;
+	} else {
+		o.s[0] = o.p[0]; o.s[1] = o.p[1]; o.s[2] = o.p[2];
+	}
+}
+
+// x256 position of an edge vertex (after the LOD chain); also returns the final t and endpoints
+TV_HD void reg_edge_position(const GridView& g, const CellGeom& c, int v0, int v1, int t0,
+                             int P0[3], int P1[3], int& t, float pos[3])
+{
+	corner_pos(c, v0, P0);
+	corner_pos(c, v1, P1);
+	t = t0;
+	if (c.level > 0) {
+		lod_chain(g, c.level, P0, P1);
+		const int p0 = dist_at(g, P0[0], P0[1], P0[2]), p1 = dist_at(g, P1[0], P1[1], P1[2]);
+		t = (p0 != p1) ? (p1 * 256) / (p1 - p0) : 0;
+	}
+	const float ft = (float)t, fu = (float)(256 - t);
+	pos[0] = ft * (float)P0[0] + fu * (float)P1[0];
+	pos[1] = ft * (float)P0[1] + fu * (float)P1[1];
+	pos[2] = ft * (float)P0[2] + fu * (float)P1[2];
+}
+
+TV_HD void reg_edge_vertex(const GridView& g, const CellGeom& c, int v0, int v1, int t0, u32 cellMat, RawVertex& o)
+{
+	int P0[3], P1[3], t;
+	reg_edge_position(g, c, v0, v1, t0, P0, P1, t, o.p);
+	const int u = 256 - t;
+	float N0[3], N1[3];
+	normal_at(g, P0[0], P0[1], P0[2], N0);
+	normal_at(g, P1[0], P1[1], P1[2], N1);
+	const u32 M0 = mat_at(g, P0[0], P0[1], P0[2]), M1 = mat_at(g, P1[0], P1[1], P1[2]);
+	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, v0, v1);
+	if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (cellMat & 0xFF)) o.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
+	else o.mat = cellMat;
+	const float wt = (float)t / 256.f, wu = (float)u / 256.f;
+	o.n[0] = N0[0] * wt + N1[0] * wu; o.n[1] = N0[1] * wt + N1[1] * wu; o.n[2] = N0[2] * wt + N1[2] * wu;
+	normalize_fix_zero(o.n);
+	finish_secondary(o, c.mult);
+}
+
+TV_HD void reg_corner_position(const CellGeom& c, int corner, float pos[3])
+{
+	int P[3];
+	corner_pos(c, corner, P);
+	pos[0] = (float)P[0] * 256.f; pos[1] = (float)P[1] * 256.f; pos[2] = (float)P[2] * 256.f;
+}
+
+TV_HD void reg_corner_vertex(const GridView& g, const CellGeom& c, int corner, u32 cellMat, RawVertex& o)
+{
+	int P[3];
+	corner_pos(c, corner, P);
+	o.p[0] = (float)P[0] * 256.f; o.p[1] = (float)P[1] * 256.f; o.p[2] = (float)P[2] * 256.f;
+	normal_at(g, P[0], P[1], P[2], o.n);
+	const u32 mine = mat_at(g, P[0], P[1], P[2]);
+	o.mat = ((cellMat & 0xFF) != (mine & 0xFF)) ? cellMat : mine;
+	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, corner, corner);
+	finish_secondary(o, c.mult);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Material vote of a level >= 1 cell over its 8 children (child(i) -> id | blend << 8, id 255 = no entry)
+// ---------------------------------------------------------------------------------------------------------
+template <typename ChildFn>
+TV_HD u32 vote_material(const ChildFn& child)
+{
+	u32 ids[8], cnt[8], bl[8];
+	u32 count = 0;
+	for (u32 i = 0; i < 8; ++i) { // children in x-fastest order
+		const u32 c = child(i);
+		const u32 id = c & 0xFF;
+		if (id == EMPTY_MATERIAL) continue;
+		bool found = false;
+		for (u32 k = 0; k < count; ++k) {
+			if (ids[k] == id) { ++cnt[k]; bl[k] += c >> 8; found = true; break; }
+		}
+		if (!found) { ids[count] = id; cnt[count] = 1; bl[count] = c >> 8; ++count; }
+	}
+	if (!count) return EMPTY_MATINFO;
+	u32 best = 0;
+	for (u32 k = 1; k < count; ++k) if (cnt[k] > cnt[best]) best = k; // first maximum wins
+	return ids[best] | (((bl[best] / cnt[best]) & 0xFF) << 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Transition cells.  Face f = 0..5: ZNeg, YNeg, XNeg, ZPos, YPos, XPos (internal axes) = output faces
+// YNeg, ZNeg, XNeg, YPos, ZPos, XPos.  In-plane axes (u = column, v = row): z-faces (x,y), y-faces (x,z),
+// x-faces (y,z).  Sample k = i + 3j is the full-resolution sample at (u,v) = (i,j) * mult/2 on the block's
+// boundary plane; samples 9..12 are the low-res corners (0,0) (2,0) (0,2) (2,2).
+// ---------------------------------------------------------------------------------------------------------
+struct FaceGeom {
+	int axis, ua, va; // normal axis and in-plane axes (0 = x, 1 = y, 2 = z)
+	bool positive;
+	u32 lowFaceBit;   // 1 << faceId of the low-res cell's face lying on the boundary
+	int lowFace;      // that face id (bit order ZPos,YPos,XPos,ZNeg,YNeg,XNeg)
+};
+
+TV_HD FaceGeom face_geom(int f)
+{
+	FaceGeom g;
+	const int m = f % 3;
+	g.axis = (m == 0) ? 2 : ((m == 1) ? 1 : 0);
+	g.ua = (g.axis == 0) ? 1 : 0;
+	g.va = (g.axis == 2) ? 1 : 2;
+	g.positive = f >= 3;
+	g.lowFace = g.positive ? m : m + 3; // f0 -> ZNeg(3), f1 -> YNeg(4), f2 -> XNeg(5), f3 -> ZPos(0), ...
+	g.lowFaceBit = 1u << g.lowFace;
+	return g;
+}
+
+// corner ids (0..7) of the low-res cell for samples 9..12
+TV_HD int low_corner_id(const FaceGeom& fg, int k)
+{
+	const int i = k & 1, j = k >> 1;
+	int c = (i << fg.ua) | (j << fg.va);
+	if (fg.positive) c |= 1 << fg.axis;
+	return c;
+}
+
+TV_HD u32 tr_case_code(const i8 v[9])
+{
+	// weights 1,2,4,0x80,0x100,8,0x40,0x20,0x10 for samples 0..8
+	return ((u32)(v[0] >> 7) & 1u) | (((u32)(v[1] >> 7) & 1u) << 1) | (((u32)(v[2] >> 7) & 1u) << 2)
+	     | (((u32)(v[3] >> 7) & 1u) << 7) | (((u32)(v[4] >> 7) & 1u) << 8) | (((u32)(v[5] >> 7) & 1u) << 3)
+	     | (((u32)(v[6] >> 7) & 1u) << 6) | (((u32)(v[7] >> 7) & 1u) << 5) | (((u32)(v[8] >> 7) & 1u) << 4);
+}
+
+// 13 sample values from the 9 plane samples
+TV_HD void tr_expand_values(const i8 v9[9], i8 v13[13])
+{
+#pragma unroll
+	for (int i = 0; i < 9; ++i) v13[i] = v9[i];
+	v13[9] = v9[0]; v13[10] = v9[2]; v13[11] = v9[6]; v13[12] = v9[8];
+}
+
+TV_HD void tr_vertex_dir_slot(const Tables& T, const i8 v[13], u32 w, int& t, u32& dir, u32& slot, bool& endpoint, int& corner)
+{
+	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	dir = w >> 12; slot = (w >> 8) & 15;
+	t = edge_t(v[v0], v[v1]);
+	corner = (t == 0) ? v1 : v0;
+	endpoint = (t & 0xFF) == 0;
+	if (endpoint) { const u32 cd = T.trCorner(corner); dir = cd >> 4; slot = cd & 15; }
+}
+
+// bit s set <=> the cell creates and stores a vertex in reuse slot s (0..9)
+TV_HD u32 tr_slot_valid(const Tables& T, const i8 v[13], u32 code)
+{
+	const u32 nv = (u32)(T.trCell(T.trClass(code) & 0x7F)[0]) >> 4;
+	u32 m = 0;
+	for (u32 vi = 0; vi < nv; ++vi) {
+		int t, corner; u32 dir, slot; bool endpoint;
+		tr_vertex_dir_slot(T, v, T.trVert(code, vi), t, dir, slot, endpoint, corner);
+		if (dir == 8u) m |= 1u << slot;
+	}
+	return m;
+}
+
+struct TrResolution {
+	u8 kind;   // RK_REUSE or RK_NEW_EDGE (all new transition vertices use the edge form)
+	u8 dir, slot;
+	u8 store;  // slot or NO_SLOT
+	u8 endpoint;
+	int t;
+};
+
+//   mask2 : bit0 = a non-trivial transition cell exists earlier in this row, bit1 = row > 0
+//   nb(dcol, drow, slot, &valid, &mat): reuse slot of the cell at (col - dcol, row - drow) of this face
+template <typename NB>
+TV_HD TrResolution tr_resolve(const Tables& T, const i8 v[13], u32 w, u32 mask2, u32 myMatId, const NB& nb)
+{
+	TrResolution r;
+	int t, corner; u32 dir, slot; bool endpoint;
+	tr_vertex_dir_slot(T, v, w, t, dir, slot, endpoint, corner);
+	r.t = t; r.dir = (u8)dir; r.slot = (u8)slot; r.endpoint = endpoint ? 1 : 0;
+	bool addForReuse = true;
+	if ((dir & mask2) == dir) {
+		addForReuse = false;
+		bool valid; u32 nmat;
+		nb((int)(dir & 1), (int)((dir >> 1) & 1), slot, valid, nmat);
+		if (valid && nmat == myMatId) { r.kind = RK_REUSE; r.store = NO_SLOT; return r; }
+	}
+	r.kind = RK_NEW_EDGE;
+	r.store = (addForReuse && dir == 8u) ? (u8)slot : (u8)NO_SLOT;
+	return r;
+}
+
+struct TrCellGeom {
+	int lowBase[3];  // global coordinates of the low-res cell's corner 0
+	int local[3];    // low-res cell coordinates in the block
+	int mult, level;
+};
+
+// global coordinates of transition sample k (0..12)
+TV_HD void tr_sample_pos(const FaceGeom& fg, const TrCellGeom& c, int k, int P[3])
+{
+	int i, j;
+	if (k < 9) { i = k % 3; j = k / 3; }
+	else { i = ((k - 9) & 1) * 2; j = ((k - 9) >> 1) * 2; }
+	const int half = c.mult >> 1;
+	P[fg.ua] = c.lowBase[fg.ua] + i * half;
+	P[fg.va] = c.lowBase[fg.va] + j * half;
+	P[fg.axis] = c.lowBase[fg.axis] + (fg.positive ? c.mult : 0);
+}
+
+TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom& c, const i8 v[13], u32 w,
+                         const TrResolution& r, u32 lowMat, RawVertex& o)
+{
+	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	int I0[3], I1[3];
+	tr_sample_pos(fg, c, v0, I0);
+	tr_sample_pos(fg, c, v1, I1);
+	float N0[3] = { 0.f, 0.f, 0.f }, N1[3] = { 0.f, 0.f, 0.f };
+	int t = r.t, u = 0;
+	u32 adjacency = 0;
+	if (r.endpoint) {
+		if (t == 0) {
+			u = 256;
+			normal_at(g, I1[0], I1[1], I1[2], N1);
+			if (v1 >= 9) { const int cid = low_corner_id(fg, v1 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
+		} else {
+			u = 0; t = 256;
+			normal_at(g, I0[0], I0[1], I0[2], N0);
+			if (v0 >= 9) { const int cid = low_corner_id(fg, v0 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
+		}
+	} else {
+		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
+		if (lodOfEdge > 0) {
+			lod_chain(g, lodOfEdge, I0, I1);
+			const int p0 = dist_at(g, I0[0], I0[1], I0[2]), p1 = dist_at(g, I1[0], I1[1], I1[2]);
+			t = (p0 != p1) ? (p1 * 256) / (p1 - p0) : 0;
+		}
+		u = 256 - t;
+		normal_at(g, I0[0], I0[1], I0[2], N0);
+		normal_at(g, I1[0], I1[1], I1[2], N1);
+		if (v0 >= 9 && v1 >= 9) adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, low_corner_id(fg, v0 - 9), low_corner_id(fg, v1 - 9));
+	}
+	const u32 M0 = mat_at(g, I0[0], I0[1], I0[2]), M1 = mat_at(g, I1[0], I1[1], I1[2]);
+	float P0[3] = { (float)I0[0], (float)I0[1], (float)I0[2] }, P1[3] = { (float)I1[0], (float)I1[1], (float)I1[2] };
+	float S0[3] = { P0[0], P0[1], P0[2] }, S1[3] = { P1[0], P1[1], P1[2] };
+	if (v0 >= 9 || v1 >= 9) {
+		float delta[3], move[3];
+		transition_delta(adjacency, c.mult, delta);
+		transition_delta(fg.lowFaceBit, c.mult, move); // 0.25 * inward direction of the low-res face
+		const bool simple = adjacency == fg.lowFaceBit;
+		if (v0 >= 9) {
+			S0[0] += delta[0]; S0[1] += delta[1]; S0[2] += delta[2];
+			if (simple) { P0[0] += move[0]; P0[1] += move[1]; P0[2] += move[2]; }
+		}
+		if (v1 >= 9) {
+			S1[0] += delta[0]; S1[1] += delta[1]; S1[2] += delta[2];
+			if (simple) { P1[0] += move[0]; P1[1] += move[1]; P1[2] += move[2]; }
+		}
+	}
+	const float ft = (float)t, fu = (float)u;
+	o.p[0] = ft * P0[0] + fu * P1[0]; o.p[1] = ft * P0[1] + fu * P1[1]; o.p[2] = ft * P0[2] + fu * P1[2];
+	o.s[0] = ft * S0[0] + fu * S1[0]; o.s[1] = ft * S0[1] + fu * S1[1]; o.s[2] = ft * S0[2] + fu * S1[2];
+	o.flags = adjacency;
+	const float wt = ft / 256.f, wu = fu / 256.f;
+	o.n[0] = N0[0] * wt + N1[0] * wu; o.n[1] = N0[1] * wt + N1[1] * wu; o.n[2] = N0[2] * wt + N1[2] * wu;
+	normalize_fix_zero(o.n);
+	if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (lowMat & 0xFF)) o.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
+	else o.mat = lowMat;
+}
+
+} // namespace tv

@@ -1,0 +1,464 @@
+// vx_host.inl — host orchestration behind include/voxels_hip.h, written against a small backend interface
+// (memory + the five pipeline stages).  voxels_amd/csrc/vx_hip.hip instantiates it with the HIP backend (the
+// product, gfx950 kernels); tests/emu/emu.cpp instantiates it with a CPU emulation of the same phases to test
+// the formulation and this host logic without a GPU.  There is NO runtime switch between the two: each shared
+// library is compiled with exactly one backend.
+//
+// The including file must define, before including this file:
+//   struct Backend { init/alloc/free/fill/h2d/d2h/sync/begin_timing/end_timing_ms + run_* stages }  (see below)
+//   VX_BACKEND_NAME
+#include "../../include/voxels_hip.h"
+#include "tv_block.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+#include "tv_tables.inc"
+
+using namespace tv;
+
+struct ExecParams {
+	Globals G;
+	LevelDesc levels[MAX_LEVELS];
+	Pools P;
+	const u8* tables; // TAB_BYTES image in device memory
+};
+
+struct EmittedBlock {
+	BlockRecord rec;
+	u32 id;
+	float minc[3], maxc[3];
+};
+
+} // namespace
+
+struct vx_ctx {
+	Backend be;
+	std::string err;
+	// grid
+	u32 n = 0, zBegin = 0, zEnd = 0;
+	bool ownsGrid = false;
+	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
+	int distZ0 = 0, matZ0 = 0;
+	// constant device data
+	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header: nActive[8] | cursors[4] | stats[20]
+	// level tables
+	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0;
+	u32 refLevels = 0;
+	LevelDesc lv[MAX_LEVELS];
+	std::vector<void*> levelAllocs;
+	// pools
+	void *dVerts = nullptr, *dIdx = nullptr;
+	u32 vertCap = 0, idxCap = 0;
+	// results
+	u32 levelsRun = 0;
+	bool haveSurface = false;
+	u32 nextId = 0;
+	std::vector<EmittedBlock> blocks[MAX_LEVELS];
+	std::vector<PolyVertex> hVerts;
+	std::vector<u32> hIdx;
+	bool poolsOnHost = false;
+	u32 poolVerts = 0, poolIdx = 0;
+	u32 stats[20];
+	u32 hdr[32];
+};
+
+namespace {
+
+int fail(vx_ctx* c, int code, const std::string& msg)
+{
+	if (c) c->err = msg;
+	return code;
+}
+
+u32 ref_levels(u32 n)
+{
+	u32 l = 0;
+	for (u32 v = n >> 4; v >>= 1;) ++l;
+	return l + 1; // TransVoxelImpl.cpp:490
+}
+
+void free_level_tables(vx_ctx* c)
+{
+	for (void* p : c->levelAllocs) c->be.free(p);
+	c->levelAllocs.clear();
+	c->tablesN = 0;
+}
+
+void release_grid(vx_ctx* c)
+{
+	if (c->ownsGrid) {
+		c->be.free(c->dDist); c->be.free(c->dMat); c->be.free(c->dBlend); c->be.free(c->dFlags);
+	}
+	c->dDist = c->dMat = c->dBlend = c->dFlags = nullptr;
+	c->ownsGrid = false;
+}
+
+bool ensure_level_tables(vx_ctx* c)
+{
+	const u32 zb0 = c->zBegin / 16, zb1 = c->zEnd / 16;
+	if (c->tablesN == c->n && c->tablesZb0 == zb0 && c->tablesZb1 == zb1) return true;
+	free_level_tables(c);
+	c->refLevels = ref_levels(c->n);
+	auto alloc = [&](size_t bytes) -> void* {
+		void* p = c->be.alloc(bytes ? bytes : 16);
+		if (p) c->levelAllocs.push_back(p);
+		return p;
+	};
+	for (u32 L = 0; L < MAX_LEVELS; ++L) memset(&c->lv[L], 0, sizeof(LevelDesc));
+	for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) {
+		LevelDesc& d = c->lv[L];
+		d.mult = 1u << L;
+		d.cnt = (c->n >> 4) / d.mult;
+		d.zb0 = zb0 >> L;
+		d.zb1 = (zb1 + d.mult - 1) >> L;
+		if (d.zb1 > d.cnt) d.zb1 = d.cnt;
+		d.hasTransitions = (L > 0 && L != c->refLevels - 1) ? 1 : 0;
+		const size_t total = (size_t)d.cnt * d.cnt * d.cnt;
+		const size_t cap = (size_t)d.cnt * d.cnt * (d.zb1 > d.zb0 ? d.zb1 - d.zb0 : 0);
+		d.cap = (u32)cap;
+		d.slotOf = (int*)alloc(total * 4);
+		d.slotCoord = (u32*)alloc(cap * 4);
+		d.ntBits = (u32*)alloc(cap * 512);
+		d.cache = L ? (u16*)alloc(cap * BLOCK_CELLS * 2) : nullptr;
+		d.skip = L ? nullptr : (u8*)alloc(cap);
+		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
+		d.nActive = (u32*)c->dHeader + L;
+		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || (L && !d.cache) || (!L && !d.skip)) return false;
+	}
+	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1;
+	return true;
+}
+
+bool ensure_pools(vx_ctx* c, u32 needVerts, u32 needIdx)
+{
+	if (needVerts > c->vertCap) {
+		c->be.free(c->dVerts);
+		c->dVerts = c->be.alloc((size_t)needVerts * sizeof(PolyVertex));
+		c->vertCap = c->dVerts ? needVerts : 0;
+	}
+	if (needIdx > c->idxCap) {
+		c->be.free(c->dIdx);
+		c->dIdx = c->be.alloc((size_t)needIdx * 4);
+		c->idxCap = c->dIdx ? needIdx : 0;
+	}
+	return c->dVerts && c->dIdx;
+}
+
+void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
+{
+	memset(&p, 0, sizeof(p));
+	p.G.grid.dist = (const i8*)c->dDist;
+	p.G.grid.mat = (const u8*)c->dMat;
+	p.G.grid.blend = (const u8*)c->dBlend;
+	p.G.grid.n = (int)c->n;
+	p.G.grid.zOrigin = c->distZ0;
+	p.G.grid.zOriginMat = c->matZ0;
+	p.G.emptyFlags = (const u8*)c->dFlags;
+	p.G.lut = (const u8*)c->dLut;
+	p.G.stats = (u32*)c->dHeader + 12;
+	p.G.levels = levels;
+	p.G.refLevels = c->refLevels;
+	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
+	p.P.verts = (PolyVertex*)c->dVerts;
+	p.P.idx = (u32*)c->dIdx;
+	p.P.cursors = (u32*)c->dHeader + 8;
+	p.P.vertCap = c->vertCap;
+	p.P.idxCap = c->idxCap;
+	p.tables = (const u8*)c->dTables;
+}
+
+void build_table_image(std::vector<u8>& img)
+{
+	img.assign(TAB_BYTES, 0);
+	memcpy(&img[TAB_REG_CLASS], TVT_REG_CLASS, 256);
+	memcpy(&img[TAB_REG_CELL], TVT_REG_CELL, 256);
+	memcpy(&img[TAB_TR_CLASS], TVT_TR_CLASS, 512);
+	memcpy(&img[TAB_TR_CORNER], TVT_TR_CORNER, 16);
+	memcpy(&img[TAB_TR_CELL], TVT_TR_CELL, 56 * 40);
+	memcpy(&img[TAB_REG_VERT], TVT_REG_VERT, 256 * 12 * 2);
+	memcpy(&img[TAB_TR_VERT], TVT_TR_VERT, 512 * 12 * 2);
+}
+
+// one pass of the device pipeline over the blocks listed in the level tables
+void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
+{
+	c->be.run_classify(p);
+	c->be.run_hierarchy(p, levels);
+	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
+	c->be.run_regular(p, levels);
+	c->be.run_transition(p, levels);
+}
+
+void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
+{
+	u32 bx, by, bz;
+	block_coords(coordId, d.cnt, bx, by, bz);
+	const float ext = (float)(d.mult * 16);
+	mn[0] = (float)bx * ext; mn[1] = (float)bz * ext; mn[2] = (float)by * ext; // output is Y-up
+	mx[0] = mn[0] + ext; mx[1] = mn[1] + ext; mx[2] = mn[2] + ext;
+}
+
+bool fetch_pools(vx_ctx* c)
+{
+	if (c->poolsOnHost) return true;
+	c->hVerts.resize(c->poolVerts);
+	c->hIdx.resize(c->poolIdx);
+	if (c->poolVerts && !c->be.d2h(c->hVerts.data(), c->dVerts, (size_t)c->poolVerts * sizeof(PolyVertex))) return false;
+	if (c->poolIdx && !c->be.d2h(c->hIdx.data(), c->dIdx, (size_t)c->poolIdx * 4)) return false;
+	c->poolsOnHost = true;
+	return true;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* vx_backend(void) { return VX_BACKEND_NAME; }
+
+int vx_ctx_create(int device_index, vx_ctx** out)
+{
+	if (!out) return VX_ERR_INVALID;
+	*out = nullptr;
+	vx_ctx* c = new vx_ctx;
+	memset(c->stats, 0, sizeof(c->stats));
+	std::string e;
+	if (!c->be.init(device_index, e)) { delete c; return VX_ERR_DEVICE; }
+	std::vector<u8> img;
+	build_table_image(img);
+	c->dTables = c->be.alloc(TAB_BYTES);
+	c->dLut = c->be.alloc(256 * 8);
+	c->dHeader = c->be.alloc(32 * 4);
+	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_BYTES)) {
+		vx_ctx_destroy(c);
+		return VX_ERR_DEVICE;
+	}
+	// default material map: every id valid, all texture ids 0
+	std::vector<u8> lut(256 * 8, 0);
+	for (int i = 0; i < 256; ++i) lut[i * 8 + 6] = 1;
+	c->be.h2d(c->dLut, lut.data(), lut.size());
+	*out = c;
+	return VX_OK;
+}
+
+void vx_ctx_destroy(vx_ctx* c)
+{
+	if (!c) return;
+	c->be.sync();
+	release_grid(c);
+	free_level_tables(c);
+	c->be.free(c->dVerts); c->be.free(c->dIdx);
+	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
+	c->be.shutdown();
+	delete c;
+}
+
+const char* vx_last_error(const vx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int vx_set_stream(vx_ctx* c, void* stream)
+{
+	if (!c) return VX_ERR_INVALID;
+	c->be.set_stream(stream);
+	return VX_OK;
+}
+
+int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat, const uint8_t* blend, const uint8_t* flags)
+{
+	if (!c || !dist || !flags || n < 16 || (n & 15)) return fail(c, VX_ERR_INVALID, "vx_grid_upload: n must be a multiple of 16, dist and empty_flags non-null");
+	const size_t tot = (size_t)n * n * n, nb = (size_t)(n / 16) * (n / 16) * (n / 16);
+	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n)) {
+		release_grid(c);
+		c->dDist = c->be.alloc(tot); c->dMat = c->be.alloc(tot); c->dBlend = c->be.alloc(tot); c->dFlags = c->be.alloc(nb);
+		c->ownsGrid = true;
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload: device allocation failed: " + c->be.error()); }
+	}
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	bool ok = c->be.h2d(c->dDist, dist, tot) && c->be.h2d(c->dFlags, flags, nb);
+	ok = ok && (mat ? c->be.h2d(c->dMat, mat, tot) : c->be.fill(c->dMat, 0, tot));
+	ok = ok && (blend ? c->be.h2d(c->dBlend, blend, tot) : c->be.fill(c->dBlend, 0, tot));
+	c->haveSurface = false;
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload: copy failed: " + c->be.error());
+}
+
+int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, const void* d_dist, int32_t dist_z0,
+                   const void* d_mat, const void* d_blend, int32_t mat_z0, const void* d_flags)
+{
+	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || z_begin >= z_end || z_end > n || (z_begin & 15) || (z_end & 15))
+		return fail(c, VX_ERR_INVALID, "vx_grid_attach: bad arguments (slab bounds must be multiples of 16)");
+	release_grid(c);
+	c->n = n; c->zBegin = z_begin; c->zEnd = z_end;
+	c->dDist = (void*)d_dist; c->dMat = (void*)d_mat; c->dBlend = (void*)d_blend; c->dFlags = (void*)d_flags;
+	c->distZ0 = dist_z0; c->matZ0 = mat_z0;
+	c->haveSurface = false;
+	return VX_OK;
+}
+
+int vx_grid_update_blocks(vx_ctx* c, uint32_t count, const uint32_t* ids, const int8_t* dist, const uint8_t* mat,
+                          const uint8_t* blend, const uint8_t* flags)
+{
+	if (!c || !c->ownsGrid || !c->n) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: needs a grid uploaded with vx_grid_upload");
+	const u32 n = c->n, nb = n / 16;
+	bool ok = true;
+	for (u32 i = 0; i < count && ok; ++i) {
+		const u32 id = ids[i];
+		if (id >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: block id out of range");
+		const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+		for (u32 z = 0; z < 16 && ok; ++z)
+		for (u32 y = 0; y < 16 && ok; ++y) {
+			const size_t dst = ((size_t)(bz * 16 + z) * n + (by * 16 + y)) * n + bx * 16;
+			const size_t src = (size_t)i * 4096 + z * 256 + y * 16;
+			if (dist) ok = ok && c->be.h2d((u8*)c->dDist + dst, dist + src, 16);
+			if (mat) ok = ok && c->be.h2d((u8*)c->dMat + dst, mat + src, 16);
+			if (blend) ok = ok && c->be.h2d((u8*)c->dBlend + dst, blend + src, 16);
+		}
+	}
+	if (flags) ok = ok && c->be.h2d(c->dFlags, flags, (size_t)nb * nb * nb);
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_update_blocks: copy failed: " + c->be.error());
+}
+
+int vx_material_lut(vx_ctx* c, const uint8_t* lut, const uint8_t* valid)
+{
+	if (!c || !lut) return fail(c, VX_ERR_INVALID, "vx_material_lut: null argument");
+	std::vector<u8> img(256 * 8, 0);
+	for (int i = 0; i < 256; ++i) {
+		memcpy(&img[i * 8], lut + i * 6, 6);
+		img[i * 8 + 6] = valid ? (valid[i] ? 1 : 0) : 1;
+	}
+	return c->be.h2d(c->dLut, img.data(), img.size()) ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_material_lut: copy failed");
+}
+
+int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
+{
+	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
+	if (!ensure_level_tables(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: level table allocation failed: " + c->be.error());
+	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
+	const u32 slabPlanes = c->zEnd - c->zBegin;
+	if (levels > 1 && (slabPlanes % (16u << (levels - 1))) && (c->zBegin != 0 || c->zEnd != c->n))
+		return fail(c, VX_ERR_INVALID, "vx_polygonize: slab thickness must be a multiple of the coarsest block size");
+	if (!c->vertCap) {
+		// first guess: ~3 vertices and ~12 indices per surface voxel column; grown on demand (exact need is known after a run)
+		const u32 area = c->n * c->n;
+		if (!ensure_pools(c, std::max(1u << 16, area * 6), std::max(1u << 18, area * 24))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
+	}
+	u32 retries = 0;
+	float ms = 0.f;
+	for (;;) {
+		ExecParams p;
+		fill_params(c, p, levels);
+		c->be.begin_timing();
+		c->be.fill(c->dHeader, 0, 32 * 4);
+		for (u32 L = 0; L < levels; ++L) c->be.fill(c->lv[L].slotOf, 0xFF, (size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt * 4);
+		run_pipeline(c, p, levels);
+		ms = c->be.end_timing_ms();
+		if (!c->be.d2h(c->hdr, c->dHeader, 32 * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
+		const u32 usedV = c->hdr[8], usedI = c->hdr[9], overflow = c->hdr[10];
+		if (!overflow) break;
+		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
+		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
+	}
+	c->levelsRun = levels;
+	c->poolVerts = c->hdr[8]; c->poolIdx = c->hdr[9];
+	c->poolsOnHost = false;
+	c->haveSurface = true;
+	// block lists: every surface-bearing block with at least one regular vertex, in coordinate order; ids number
+	// ALL blocks of all levels in level-major order (TransVoxelImpl.cpp:395-401)
+	u32 idBase = 0;
+	u32 blocksCalculated = 0, trivial = 0;
+	for (u32 L = 0; L < levels; ++L) {
+		const LevelDesc& d = c->lv[L];
+		const u32 nAct = c->hdr[L];
+		std::vector<BlockRecord> recs(nAct);
+		if (nAct && !c->be.d2h(recs.data(), d.records, (size_t)nAct * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: record download failed");
+		std::sort(recs.begin(), recs.end(), [](const BlockRecord& a, const BlockRecord& b) { return a.coordId < b.coordId; });
+		c->blocks[L].clear();
+		for (const BlockRecord& r : recs) {
+			if (!r.vCount) continue;
+			EmittedBlock e;
+			e.rec = r;
+			e.id = idBase + r.coordId;
+			block_corners(d, r.coordId, e.minc, e.maxc);
+			c->blocks[L].push_back(e);
+		}
+		const u32 owned = d.cnt * d.cnt * (d.zb1 - d.zb0);
+		idBase += d.cnt * d.cnt * d.cnt;
+		blocksCalculated += owned;
+		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[12 + 2] : owned);
+	}
+	c->nextId = idBase;
+	c->stats[0] = blocksCalculated;
+	c->stats[2] = c->hdr[12 + 0];
+	c->stats[1] = trivial - c->stats[2];
+	c->stats[3] = c->hdr[12 + 1];
+	for (int i = 0; i < 16; ++i) c->stats[4 + i] = c->hdr[12 + 4 + i];
+	if (info) {
+		memset(info, 0, sizeof(*info));
+		info->levels = levels;
+		info->retries = retries;
+		info->device_ms = ms;
+		info->total_verts = c->poolVerts;
+		info->total_indices = c->poolIdx;
+		for (u32 L = 0; L < levels && L < 8; ++L) info->active_blocks[L] = c->hdr[L];
+		info->algorithmic_bytes = (uint64_t)c->n * c->n * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
+	}
+	return VX_OK;
+}
+
+int vx_polygonize_dirty(vx_ctx* c, const float*, const float*, vx_exec_info*, uint32_t*, uint32_t, uint32_t*)
+{
+	return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not implemented in this build");
+}
+
+int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t totals[4])
+{
+	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_level_counts: no such level");
+	uint64_t t[4] = { 0, 0, 0, 0 };
+	for (const EmittedBlock& e : c->blocks[level]) {
+		t[0] += e.rec.vCount; t[1] += e.rec.iCount;
+		for (int f = 0; f < 6; ++f) { t[2] += e.rec.tvCount[f]; t[3] += e.rec.tiCount[f]; }
+	}
+	if (n_blocks) *n_blocks = (u32)c->blocks[level].size();
+	if (totals) memcpy(totals, t, sizeof(t));
+	return VX_OK;
+}
+
+int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx, vx_vertex* tverts, uint32_t* tidx)
+{
+	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
+	if ((verts || idx || tverts || tidx) && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
+	size_t ov = 0, oi = 0, otv = 0, oti = 0, k = 0;
+	for (const EmittedBlock& e : c->blocks[level]) {
+		const BlockRecord& r = e.rec;
+		if (infos) {
+			vx_block_info& b = infos[k];
+			b.id = e.id; b.n_verts = r.vCount; b.n_idx = r.iCount;
+			for (int f = 0; f < 6; ++f) { b.n_tverts[f] = r.tvCount[f]; b.n_tidx[f] = r.tiCount[f]; }
+			memcpy(b.min_corner, e.minc, 12); memcpy(b.max_corner, e.maxc, 12);
+		}
+		++k;
+		if (verts) memcpy(verts + ov, c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
+		ov += r.vCount;
+		if (idx) memcpy(idx + oi, c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
+		oi += r.iCount;
+		for (int f = 0; f < 6; ++f) {
+			if (tverts && r.tvCount[f]) memcpy(tverts + otv, c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
+			otv += r.tvCount[f];
+			if (tidx && r.tiCount[f]) memcpy(tidx + oti, c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
+			oti += r.tiCount[f];
+		}
+	}
+	return VX_OK;
+}
+
+int vx_stats(vx_ctx* c, uint32_t stats[20])
+{
+	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_stats: nothing polygonized yet");
+	memcpy(stats, c->stats, 80);
+	return VX_OK;
+}
+
+} // extern "C"
