@@ -1,0 +1,52 @@
+"""Build helpers: compile the HIP library for gfx950 in-tree (the .so travels with the repo snapshot)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=True):
+    """hipcc --offload-arch=gfx950 ... -o voxels_amd/csrc/libvoxels_hip.so (cross-compiles without a GPU)."""
+    out = os.path.join(CSRC, "libvoxels_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_tables.inc")]
+    srcs.append(os.path.join(ROOT, "include", "voxels_hip.h"))
+    if not force and not _newer(out, srcs):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIP_FLAGS + ["-o", out, os.path.join(CSRC, "vx_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
+def build_emu(force=False):
+    """CPU emulation of the device phases — tests only (tests/emu)."""
+    d = os.path.join(ROOT, "tests", "emu")
+    out = os.path.join(d, "libvoxels_emu.so")
+    srcs = [os.path.join(d, "emu.cpp"), os.path.join(d, "emu_backend.inl")] + \
+           [os.path.join(CSRC, f) for f in ("vx_host.inl", "tv_block.h", "tv_core.h", "tv_tables.inc")]
+    if not force and not _newer(out, srcs):
+        return out
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-Wno-subobject-linkage", "-o", out, os.path.join(d, "emu.cpp")], cwd=d)
+    return out
+
+
+def build_oracle(with_reference=True):
+    """The CPU checkers (test infrastructure): the port always, the unmodified reference when /root/reference exists."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"])
+    if with_reference and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])

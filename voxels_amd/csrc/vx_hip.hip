@@ -1,0 +1,510 @@
+// vx_hip.hip — gfx950 (MI355X / CDNA4) kernels and HIP backend of libvoxels_hip.so.
+//
+// Five kernels per polygonization, all on one stream, no host round trip in between (work lists and output
+// offsets live in device memory):
+//   k_classify    HBM-bound stream over the whole density field: 16-byte coalesced loads, sign bits packed to
+//                 bit-masks in LDS, cell classification done bit-parallel (128 cells per lane-op); emits the
+//                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block.
+//   k_hierarchy   marks the ancestors of active blocks on the coarser LOD levels.
+//   k_material    (per level >= 1, serial) per-cell material vote over the 8 children -> material cache.
+//   k_regular     persistent workgroups, one surface-bearing block at a time: 17^3 corner samples + Transvoxel
+//                 tables staged in LDS, reuse resolution, wavefront prefix sums for vertex/index offsets, one
+//                 atomicAdd per block to reserve its range of the output pools (per-block stream compaction).
+//   k_transition  same for the 6 x 16 x 16 transition cells of the blocks of levels 1..last-1.
+// The per-cell logic is tv_core.h / tv_block.h (shared with the CPU emulation used by the tests).
+//
+// No MFMA: this is table-driven integer/byte work bound by HBM bandwidth and latency.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tv_block.h"
+
+#define VX_BACKEND_NAME "hip:gfx950"
+
+namespace {
+using namespace tv;
+
+struct ExecParamsDev {
+	Globals G;
+	LevelDesc levels[MAX_LEVELS];
+	Pools P;
+	const u8* tables;
+};
+
+constexpr int WG = 256;
+
+// ------------------------------------------------------------------------------------------------------
+// workgroup helpers
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
+{
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const u32 t = __shfl_up(v, off, 64);
+		if (lane >= off) v += t;
+	}
+	return v;
+}
+
+// in-place exclusive scan of a[0..n) (LDS), all 256 threads must call; returns the total
+__device__ u32 block_exclusive_scan_u16(u16* a, u32 n, u32* scratch)
+{
+	const u32 tid = threadIdx.x;
+	const u32 per = (n + WG - 1) / WG;
+	u32 beg = tid * per, end = beg + per;
+	if (beg > n) beg = n;
+	if (end > n) end = n;
+	u32 sum = 0;
+	for (u32 i = beg; i < end; ++i) sum += a[i];
+	const u32 incl = wave_inclusive_scan(sum);
+	if ((tid & 63) == 63) scratch[tid >> 6] = incl;
+	__syncthreads();
+	u32 waveBase = 0, total = 0;
+#pragma unroll
+	for (u32 w = 0; w < WG / 64; ++w) {
+		const u32 s = scratch[w];
+		if (w < (tid >> 6)) waveBase += s;
+		total += s;
+	}
+	u32 run = waveBase + incl - sum;
+	for (u32 i = beg; i < end; ++i) { const u32 v = a[i]; a[i] = (u16)run; run += v; }
+	__syncthreads();
+	return total;
+}
+
+__device__ __forceinline__ void stage_tables(u8* dst, const u8* src)
+{
+	const uint4* s = (const uint4*)src;
+	uint4* d = (uint4*)dst;
+	for (u32 i = threadIdx.x; i < TAB_BYTES / 16; i += WG) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_classify
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >> 7) * 0x01020408u) >> 24; }
+
+__global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
+{
+	__shared__ __attribute__((aligned(16))) u16 sgn[289 * 8];   // sign masks: row r = rz*17+ry, 8 x 16 voxels
+	__shared__ u8 halo[292];                                     // sign of the voxel right of the tile, per row
+	__shared__ __attribute__((aligned(16))) u16 blockBits[8 * 256];
+	__shared__ u32 blockAny[8];
+	__shared__ int blockSlot[8];
+
+	const LevelDesc& L = p.levels[0];
+	const GridView& g = p.G.grid;
+	const int n = g.n;
+	const u32 tilesX = (L.cnt + 7) / 8;
+	const u32 tile = blockIdx.x;
+	const u32 tx = tile % tilesX, by = (tile / tilesX) % L.cnt, bz = L.zb0 + tile / (tilesX * L.cnt);
+	const int x0 = (int)tx * 128;
+	const int validCells = (n - x0) < 128 ? (n - x0) : 128; // multiple of 16
+	const int tid = threadIdx.x;
+
+	if (tid < 8) { blockAny[tid] = 0; blockSlot[tid] = -1; }
+
+	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line) ----------
+	for (int q = tid; q < 289 * 8; q += WG) {
+		const int r = q >> 3, seg = q & 7;
+		const int ry = r % 17, rz = r / 17;
+		u32 m = 0;
+		if (seg * 16 < validCells) {
+			const int y = clampi((int)by * 16 + ry, 0, n - 1);
+			const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
+			const uint4 d = *(const uint4*)(g.dist + ((size_t)z * n + y) * n + x0 + seg * 16);
+			m = sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12);
+		}
+		sgn[q] = (u16)m;
+	}
+	for (int r = tid; r < 289; r += WG) {
+		const int ry = r % 17, rz = r / 17;
+		const int y = clampi((int)by * 16 + ry, 0, n - 1);
+		const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
+		const int x = clampi(x0 + validCells, 0, n - 1);
+		halo[r] = (u8)((u32)(g.dist[((size_t)z * n + y) * n + x] >> 7) & 1u);
+	}
+	__syncthreads();
+
+	// ---- classify 128 cells of one (y,z) row per thread, bit-parallel ---------------------------------
+	{
+		const int y = tid & 15, z = tid >> 4;
+		const int r00 = z * 17 + y, r01 = r00 + 1, r10 = r00 + 17, r11 = r00 + 18;
+		const uint4 a0 = *(const uint4*)(sgn + r00 * 8), a1 = *(const uint4*)(sgn + r01 * 8);
+		const uint4 a2 = *(const uint4*)(sgn + r10 * 8), a3 = *(const uint4*)(sgn + r11 * 8);
+		u32 A[5] = { a0.x & a1.x & a2.x & a3.x, a0.y & a1.y & a2.y & a3.y, a0.z & a1.z & a2.z & a3.z, a0.w & a1.w & a2.w & a3.w, 0 };
+		u32 O[5] = { a0.x | a1.x | a2.x | a3.x, a0.y | a1.y | a2.y | a3.y, a0.z | a1.z | a2.z | a3.z, a0.w | a1.w | a2.w | a3.w, 0 };
+		const u32 hAnd = halo[r00] & halo[r01] & halo[r10] & halo[r11];
+		const u32 hOr = halo[r00] | halo[r01] | halo[r10] | halo[r11];
+		// the sample right of the last valid cell sits at bit `validCells` of the 160-bit row
+		A[validCells >> 5] |= hAnd << (validCells & 31);
+		O[validCells >> 5] |= hOr << (validCells & 31);
+		u32 nt[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const u32 sA = (A[i] >> 1) | (A[i + 1] << 31), sO = (O[i] >> 1) | (O[i + 1] << 31);
+			nt[i] = (O[i] | sO) & ~(A[i] & sA);
+		}
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			u32 bits = (nt[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+			if (j * 16 >= validCells) bits = 0;
+			blockBits[j * 256 + tid] = (u16)bits;
+			if (bits) blockAny[j] = 1; // benign race: every writer stores 1
+		}
+	}
+	__syncthreads();
+
+	// ---- one lane per block: emptiness rule, slot allocation ------------------------------------------
+	if (tid < 8 && tid * 16 < validCells) {
+		const u32 bx = tx * 8 + tid;
+		const bool skipped = block_skipped_by_emptiness(p.G.emptyFlags, L.cnt, bx, by, bz);
+		if (!skipped) atomicAdd(&p.G.stats[2], 1u);
+		if (blockAny[tid]) {
+			const u32 slot = atomicAdd(L.nActive, 1u);
+			const u32 id = block_coord_id(bx, by, bz, L.cnt);
+			L.slotOf[id] = (int)slot;
+			L.slotCoord[slot] = id;
+			L.skip[slot] = skipped ? 1 : 0;
+			blockSlot[tid] = (int)slot;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int slot = blockSlot[j];
+		if (slot >= 0) ((u16*)(L.ntBits + (size_t)slot * 128))[tid] = blockBits[j * 256 + tid];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_hierarchy: ancestors of active level-0 blocks become active on levels 1..levels-1
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_hierarchy(ExecParamsDev p, u32 levels)
+{
+	const LevelDesc& L0 = p.levels[0];
+	const u32 s = blockIdx.x * WG + threadIdx.x;
+	if (s >= *L0.nActive) return;
+	u32 bx, by, bz;
+	block_coords(L0.slotCoord[s], L0.cnt, bx, by, bz);
+	for (u32 l = 1; l < levels; ++l) {
+		const LevelDesc& L = p.levels[l];
+		const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+		if (px >= L.cnt || py >= L.cnt || pz >= L.cnt) break;
+		const u32 id = block_coord_id(px, py, pz, L.cnt);
+		const int old = atomicCAS(&L.slotOf[id], -1, -2);
+		if (old != -1) break; // somebody else owns this ancestor chain
+		const u32 slot = atomicAdd(L.nActive, 1u);
+		L.slotCoord[slot] = id;
+		L.slotOf[id] = (int)slot; // visible to the next kernel
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_material
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
+{
+	__shared__ MatState st;
+	const LevelDesc& L = p.levels[level];
+	const u32 nAct = *L.nActive;
+	for (u32 slot = blockIdx.x; slot < nAct; slot += gridDim.x) {
+		u32 bx, by, bz;
+		block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
+		stage_samples(p.G.grid, bx, by, bz, L.mult, st.samp, threadIdx.x, WG);
+		for (int w = threadIdx.x; w < 128; w += WG) st.ntBits[w] = 0;
+		__syncthreads();
+		mat_phase_classify(st, threadIdx.x, WG);
+		__syncthreads();
+		mat_phase_vote(st, p.G, p.levels, level, slot, bx, by, bz, threadIdx.x, WG);
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_regular / k_transition: persistent workgroups over (level, slot) work items
+// ------------------------------------------------------------------------------------------------------
+struct WorkList {
+	u32 start[MAX_LEVELS + 1];
+};
+
+__device__ __forceinline__ void decode_item(const WorkList& wl, u32 levels, u32 item, u32& level, u32& slot)
+{
+	level = 0;
+	for (u32 l = 1; l < levels; ++l) if (item >= wl.start[l]) level = l;
+	slot = item - wl.start[level];
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+constexpr size_t TAB_LDS = (TAB_BYTES + 15) & ~size_t(15);
+
+__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
+{
+	u8* tab = smem;
+	RegState& st = *(RegState*)(smem + TAB_LDS);
+	__shared__ WorkList wl;
+	__shared__ u32 scanScratch[8];
+
+	stage_tables(tab, p.tables);
+	if (threadIdx.x == 0) {
+		u32 run = 0;
+		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; run += *p.levels[l].nActive; }
+		for (u32 l = levels; l <= MAX_LEVELS; ++l) wl.start[l] = run;
+	}
+	__syncthreads();
+	const Tables T{ tab };
+	const u32 total = wl.start[MAX_LEVELS];
+	const int tid = threadIdx.x;
+
+	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+		RegBlockCtx b;
+		decode_item(wl, levels, item, b.level, b.slot);
+		const LevelDesc& L = p.levels[b.level];
+		b.mult = L.mult;
+		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
+		if (b.level == 0 && L.skip[b.slot]) {
+			if (tid == 0) {
+				BlockRecord& r = L.records[b.slot];
+				r.coordId = L.slotCoord[b.slot];
+				r.vOff = r.vCount = r.iOff = r.iCount = 0;
+				for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
+				r.degenerate = 0; r.ntCells = 0; r.pad = 0;
+			}
+			continue;
+		}
+		reg_phase_load_bits(st, L, b.slot, tid, WG);
+		stage_samples(p.G.grid, b.bx, b.by, b.bz, b.mult, st.samp, tid, WG);
+		__syncthreads();
+		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
+		__syncthreads();
+		{
+			const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 128, scanScratch);
+			if (tid == 0) st.wordPrefix[128] = (u16)nt;
+		}
+		__syncthreads();
+		reg_phase_list(st, T, p.G, L, b, tid, WG);
+		__syncthreads();
+		reg_phase_count(st, T, b, tid, WG);
+		__syncthreads();
+		{
+			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[128], scanScratch);
+			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[0], vt); }
+		}
+		__syncthreads();
+		reg_phase_emit_vertices(st, T, p.G, p.P, b, tid, WG);
+		__syncthreads();
+		{
+			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
+			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[1], it); }
+		}
+		__syncthreads();
+		reg_phase_emit_indices(st, T, p.P, b, tid, WG);
+		reg_phase_record(st, p.G, L, b, p.P, tid);
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
+{
+	u8* tab = smem;
+	TrState& st = *(TrState*)(smem + TAB_LDS);
+	__shared__ WorkList wl;
+	__shared__ u32 scanScratch[8];
+
+	stage_tables(tab, p.tables);
+	if (threadIdx.x == 0) {
+		u32 run = 0;
+		for (u32 l = 0; l < MAX_LEVELS; ++l) {
+			wl.start[l] = run;
+			if (l < levels && p.levels[l].hasTransitions) run += *p.levels[l].nActive;
+		}
+		wl.start[MAX_LEVELS] = run;
+	}
+	__syncthreads();
+	const Tables T{ tab };
+	const u32 total = wl.start[MAX_LEVELS];
+	const int tid = threadIdx.x;
+
+	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+		RegBlockCtx b;
+		b.level = 0;
+		for (u32 l = 1; l < MAX_LEVELS; ++l) if (item >= wl.start[l] && wl.start[l + 1] > wl.start[l]) b.level = l;
+		b.slot = item - wl.start[b.level];
+		const LevelDesc& L = p.levels[b.level];
+		b.mult = L.mult;
+		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
+
+		tr_phase_load(st, p.G, L, b, tid, WG);
+		__syncthreads();
+		tr_phase_classify(st, tid, WG);
+		__syncthreads();
+		for (int w = tid; w < 48; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
+		__syncthreads();
+		{
+			const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
+			if (tid == 0) st.wordPrefix[48] = (u16)nt;
+		}
+		__syncthreads();
+		if (st.wordPrefix[48] == 0) { __syncthreads(); continue; }
+		tr_phase_list(st, T, L, b, tid, WG);
+		__syncthreads();
+		tr_phase_count(st, T, tid, WG);
+		__syncthreads();
+		{
+			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
+			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
+			if (tid == 0) {
+				st.vTotal = vt; st.iTotal = it;
+				st.vOff = atomicAdd(&p.P.cursors[0], vt);
+				st.iOff = atomicAdd(&p.P.cursors[1], it);
+			}
+		}
+		__syncthreads();
+		tr_phase_emit(st, T, p.G, p.P, b, tid, WG);
+		tr_phase_record(st, L, b, p.P, tid);
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// HIP backend
+// ------------------------------------------------------------------------------------------------------
+struct Backend {
+	hipStream_t ownStream = nullptr, stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::string lastError;
+	int cus = 256;
+	bool ok = true;
+
+	bool check(hipError_t e, const char* what)
+	{
+		if (e == hipSuccess) return true;
+		lastError = std::string(what) + ": " + hipGetErrorString(e);
+		ok = false;
+		return false;
+	}
+
+	bool init(int device, std::string& err)
+	{
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { err = "no HIP device"; return false; }
+		if (!check(hipSetDevice(device), "hipSetDevice")) { err = lastError; return false; }
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
+		stream = ownStream;
+		hipEventCreate(&ev0);
+		hipEventCreate(&ev1);
+		const int regLds = (int)(TAB_LDS + sizeof(RegState)), trLds = (int)(TAB_LDS + sizeof(TrState));
+		if (!check(hipFuncSetAttribute((const void*)k_regular, hipFuncAttributeMaxDynamicSharedMemorySize, regLds), "hipFuncSetAttribute(k_regular)")
+		    || !check(hipFuncSetAttribute((const void*)k_transition, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")) {
+			err = lastError;
+			return false;
+		}
+		return true;
+	}
+	void shutdown()
+	{
+		if (ev0) hipEventDestroy(ev0);
+		if (ev1) hipEventDestroy(ev1);
+		if (ownStream) hipStreamDestroy(ownStream);
+	}
+	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
+	std::string error() const { return lastError; }
+	void* alloc(size_t bytes)
+	{
+		void* p = nullptr;
+		if (!check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
+		return p;
+	}
+	void free(void* p) { if (p) hipFree(p); }
+	bool fill(void* p, int v, size_t bytes) { return check(hipMemsetAsync(p, v, bytes, stream), "hipMemsetAsync"); }
+	bool h2d(void* d, const void* s, size_t bytes)
+	{
+		return check(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)")
+		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	bool d2h(void* d, const void* s, size_t bytes)
+	{
+		return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")
+		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	void sync() { hipStreamSynchronize(stream); }
+	void begin_timing() { hipEventRecord(ev0, stream); }
+	float end_timing_ms()
+	{
+		hipEventRecord(ev1, stream);
+		if (hipEventSynchronize(ev1) != hipSuccess) return -1.f;
+		float ms = 0.f;
+		hipEventElapsedTime(&ms, ev0, ev1);
+		return ms;
+	}
+
+	template <typename P>
+	static ExecParamsDev dev(const P& p)
+	{
+		static_assert(sizeof(P) == sizeof(ExecParamsDev), "ExecParams layout");
+		ExecParamsDev d;
+		memcpy(&d, &p, sizeof(d));
+		return d;
+	}
+
+	template <typename P>
+	void run_classify(const P& p)
+	{
+		const LevelDesc& L = p.levels[0];
+		const u32 tilesX = (L.cnt + 7) / 8;
+		const u32 grid = tilesX * L.cnt * (L.zb1 - L.zb0);
+		if (!grid) return;
+		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p));
+		check(hipGetLastError(), "k_classify launch");
+	}
+	template <typename P>
+	void run_hierarchy(const P& p, u32 levels)
+	{
+		if (levels < 2) return;
+		const u32 grid = (p.levels[0].cap + WG - 1) / WG;
+		hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(WG), 0, stream, dev(p), levels);
+		check(hipGetLastError(), "k_hierarchy launch");
+	}
+	template <typename P>
+	void run_material(const P& p, u32 level)
+	{
+		const u32 cap = p.levels[level].cap;
+		if (!cap) return;
+		const u32 grid = std::min<u32>(cap, (u32)cus * 8);
+		hipLaunchKernelGGL(k_material, dim3(grid), dim3(WG), 0, stream, dev(p), level);
+		check(hipGetLastError(), "k_material launch");
+	}
+	template <typename P>
+	void run_regular(const P& p, u32 levels)
+	{
+		u32 cap = 0;
+		for (u32 l = 0; l < levels; ++l) cap += p.levels[l].cap;
+		const u32 grid = std::min<u32>(cap, (u32)cus * 2);
+		hipLaunchKernelGGL(k_regular, dim3(grid), dim3(WG), TAB_LDS + sizeof(RegState), stream, dev(p), levels);
+		check(hipGetLastError(), "k_regular launch");
+	}
+	template <typename P>
+	void run_transition(const P& p, u32 levels)
+	{
+		u32 cap = 0;
+		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
+		if (!cap) return;
+		const u32 grid = std::min<u32>(cap, (u32)cus * 2);
+		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TAB_LDS + sizeof(TrState), stream, dev(p), levels);
+		check(hipGetLastError(), "k_transition launch");
+	}
+};
+
+} // namespace
+
+#include "vx_host.inl"
