@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — Mvoxels/s of one full polygonization (Polygonizer::Execute equivalent) of the 1024^3 procedural
+terrain, LOD levels 0..3 with transition cells and materials, on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one vx_polygonize over the resident grid (classify -> hierarchy -> material -> regular -> transition
+kernels + the small header read-back that tells the host the counts).  With N > 1 the grid is sharded in z-slabs
+(strong scaling: the 1024^3 grid is fixed), and every step also re-exchanges the slab halo (1 distance plane
+down, 2 distance + 1 material + 1 blend plane up) over RCCL, as the path does after an edit.  Inputs are generated
+on the host (voxels_synth) and are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("VOXELS_BENCH_N", "1024")))
+    ap.add_argument("--levels", type=int, default=int(os.environ.get("VOXELS_BENCH_LEVELS", "4")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_n, seed):
+    """The unmodified reference (oracle/_ref) — or the port when _ref is absent — on a bounded sample of the same
+    terrain, all host cores.  Reported baseline only; never part of the product path."""
+    import vxo
+    from voxels_amd import synth
+    oracle = vxo.load_ref() or vxo.load_port()
+    if oracle is None:
+        return None
+    d, m, b = synth.terrain(sample_n, 0, sample_n, seed)
+    g = oracle.grid_from_dense(d, m, b)
+    cores = os.cpu_count() or 1
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        s = oracle.execute(g, threads=cores)
+        dt = time.perf_counter() - t
+        s.destroy()
+        best = dt if best is None else min(best, dt)
+    return {"value": round(sample_n ** 3 / best / 1e6, 3), "unit": "Mvoxels/s", "cores": cores,
+            "kind": oracle.kind,
+            "sample": "%d^3 sub-world of the same seeded terrain, all %d reference LOD levels (the reference cannot "
+                      "limit levels), Polygonizer::Execute only, best of 2, %.2f s per run" % (sample_n, int(np.log2(sample_n // 16)) + 1, best)}
+
+
+def main():
+    args = parse()
+    import torch
+    from voxels_amd import Polygonizer, synth
+    import vxo
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_pkg = None
+    if world > 1:
+        import torch.distributed as dist_pkg
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_pkg.init_process_group("nccl", device_id=dev)
+
+    n, levels, seed = args.n, args.levels, 1337
+    coarse = 16 << (levels - 1)
+    assert n % (coarse * world) == 0, "slabs must hold whole blocks of the coarsest level"
+    planes = n // world
+    z0, z1 = rank * planes, (rank + 1) * planes
+
+    # ---- host generation of this rank's slab + residency ----------------------------------------------
+    t_gen = time.perf_counter()
+    d, m, b = synth.terrain(n, z0, z1, seed)
+    flags_own = synth.block_empty_flags(d)
+    t_gen = time.perf_counter() - t_gen
+    dist_t = torch.zeros((planes + 3, n, n), dtype=torch.int8, device=dev)     # plane 0 <-> global z0 - 1
+    mat_t = torch.zeros((planes + 1, n, n), dtype=torch.uint8, device=dev)     # plane 0 <-> global z0
+    blend_t = torch.zeros((planes + 1, n, n), dtype=torch.uint8, device=dev)
+    dist_t[1:planes + 1].copy_(torch.from_numpy(d))
+    mat_t[:planes].copy_(torch.from_numpy(m))
+    blend_t[:planes].copy_(torch.from_numpy(b))
+    flags_t = torch.zeros(((n // 16) ** 3,), dtype=torch.uint8, device=dev)
+    per = flags_own.size
+    flags_t[rank * per:(rank + 1) * per].copy_(torch.from_numpy(flags_own))
+    del d, m, b
+    if world > 1:
+        chunks = [torch.empty(per, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist_pkg.all_gather(chunks, flags_t[rank * per:(rank + 1) * per].clone())
+        flags_t.copy_(torch.cat(chunks))
+
+    def halo_exchange():
+        """1 distance plane from the slab below; 2 distance planes + 1 material + 1 blend plane from the slab above."""
+        if world == 1:
+            return
+        ops = []
+        if rank > 0:
+            ops.append(dist_pkg.P2POp(dist_pkg.isend, dist_t[1:3], rank - 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.isend, mat_t[0:1], rank - 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.isend, blend_t[0:1], rank - 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.irecv, dist_t[0:1], rank - 1))
+        if rank < world - 1:
+            ops.append(dist_pkg.P2POp(dist_pkg.irecv, dist_t[planes + 1:planes + 3], rank + 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.irecv, mat_t[planes:planes + 1], rank + 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.irecv, blend_t[planes:planes + 1], rank + 1))
+            ops.append(dist_pkg.P2POp(dist_pkg.isend, dist_t[planes:planes + 1], rank + 1))
+        for w in dist_pkg.batch_isend_irecv(ops):
+            w.wait()
+
+    halo_exchange()
+    torch.cuda.synchronize()
+
+    poly = Polygonizer(device=local_rank)
+    assert poly.backend == "hip:gfx950"
+    poly.set_stream(torch.cuda.current_stream().cuda_stream)
+    poly.set_materials(vxo.default_lut())
+    poly.attach(n, z0, z1, dist_t.data_ptr(), z0 - 1, mat_t.data_ptr(), blend_t.data_ptr(), z0, flags_t.data_ptr())
+
+    def step():
+        halo_exchange()
+        return poly.execute(levels)
+
+    def barrier():
+        if world > 1:
+            dist_pkg.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        info = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist_pkg.all_reduce(te, op=dist_pkg.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- per-kernel device timing of the dominant kernel (HIP events on the stream the kernels run on) ----
+    poly.set_stage_timing(True)
+    stage = np.zeros(6, np.float64)
+    reps = 5
+    dev_ms = 0.0
+    for _ in range(reps):
+        info = poly.execute(levels)
+        stage += poly.stage_times()
+        dev_ms += info.device_ms
+    stage /= reps
+    dev_ms /= reps
+    poly.set_stage_timing(False)
+    totals = np.zeros(4, np.uint64)
+    for l in range(info.levels):
+        lv = poly.level(l, with_data=False)
+        totals += np.array([lv.infos["n_verts"].sum(), lv.infos["n_idx"].sum(), lv.infos["n_tverts"].sum(), lv.infos["n_tidx"].sum()], np.uint64)
+    slab_bytes = n * n * planes
+    alg = {"k_classify": float(slab_bytes),
+           "k_regular": float(2 * 4096 * info.active_blocks[0] + 48 * int(totals[0]) + 4 * int(totals[1])),
+           "k_transition": float(48 * int(totals[2]) + 4 * int(totals[3]))}
+    stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular", "k_transition"]
+    stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
+    dominant = max(alg.keys(), key=lambda k: stage_ms[k])
+    achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
+    # HBM bytes per launch from rocprofv3 PMC passes of this same command, when a summary was committed
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            if pm.get("n") == n and pm.get("levels") == levels and pm.get("gpus") == world:
+                traffic = pm.get("hbm_bytes_per_launch", {}).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": stage_ms[dominant]}
+    whole = {"algorithmic_bytes": int(info.algorithmic_bytes), "device_ms": round(dev_ms, 4),
+             "achieved_GBps": round(info.algorithmic_bytes / (dev_ms * 1e-3) / 1e9, 2),
+             "frac_of_8TBps": round(info.algorithmic_bytes / (dev_ms * 1e-3) / 8e12, 5)}
+
+    if rank == 0:
+        out = {
+            "metric": "Mvoxels/s polygonized (1024^3 grid, 4 LOD levels)" if (n == 1024 and levels == 4) else "Mvoxels/s polygonized (%d^3 grid, %d LOD levels)" % (n, levels),
+            "value": round(n ** 3 / (elapsed / args.steps) / 1e6, 2),
+            "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 procedural noise terrain (seed %d), materials, LOD levels 0..%d with transition cells, "
+                                   "z-slab sharded over %d GPU(s)" % (n, seed, levels - 1, world),
+                       "grid": n, "levels": levels, "parallelism": "zslab%d" % world,
+                       "active_blocks": [int(x) for x in info.active_blocks[:levels]],
+                       "verts": int(totals[0]), "indices": int(totals[1]), "tverts": int(totals[2]), "tindices": int(totals[3]),
+                       "stage_ms": stage_ms, "whole_execute": whole, "host_gen_s": round(t_gen, 2),
+                       "halo_exchange_in_step": world > 1},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(512 if (os.cpu_count() or 1) >= 16 else 256, seed)
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist_pkg.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,11 @@ int vx_download_level(vx_ctx* ctx, uint32_t level, vx_block_info* infos, vx_vert
  * PerCaseCellsCount (include/Polygonizer.h:110-132) */
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
 
+/* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
+ * ms[0..5] = reset, classify, hierarchy, material (all levels), regular, transition of the LAST run. */
+int vx_set_stage_timing(vx_ctx* ctx, int enable);
+int vx_stage_times(vx_ctx* ctx, float ms[6]);
+
 /* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */
 const char* vx_backend(void);
 

@@ -18,6 +18,9 @@ struct Backend {
 	void sync() {}
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
+	void stage_enable(bool) {}
+	void stage_mark(int) {}
+	bool stage_ms(float*) { return false; }
 
 	template <typename P>
 	void run_classify(const P& p)

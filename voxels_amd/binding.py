@@ -56,6 +56,8 @@ class HipLibrary:
         lib.vx_level_counts.argtypes = [vp, u32, C.POINTER(u32), vp]
         lib.vx_download_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         lib.vx_stats.argtypes = [vp, vp]
+        lib.vx_set_stage_timing.argtypes = [vp, C.c_int]
+        lib.vx_stage_times.argtypes = [vp, vp]
         self.lib = lib
         self.path = path
         self.backend = lib.vx_backend().decode()
@@ -162,6 +164,15 @@ class Polygonizer:
 
     def all_levels(self):
         return [self.level(l) for l in range(self.info.levels)]
+
+    def set_stage_timing(self, enable):
+        self._check(self._lib.vx_set_stage_timing(self._h, int(bool(enable))), "vx_set_stage_timing")
+
+    def stage_times(self):
+        """ms of (reset, classify, hierarchy, material, regular, transition) of the last run."""
+        out = np.zeros(6, np.float32)
+        self._check(self._lib.vx_stage_times(self._h, _ptr(out)), "vx_stage_times")
+        return out
 
     def stats(self):
         out = np.zeros(20, np.uint32)

@@ -32,6 +32,17 @@ def build_hip(force=False, verbose=True):
     return out
 
 
+def build_synth(force=False):
+    """Host-side synthetic input generator (include/voxels_synth.h)."""
+    out = os.path.join(CSRC, "libvoxels_synth.so")
+    srcs = [os.path.join(CSRC, "vx_synth.cpp"), os.path.join(ROOT, "include", "voxels_synth.h")]
+    if not force and not _newer(out, srcs):
+        return out
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", out,
+                           os.path.join(CSRC, "vx_synth.cpp")], cwd=CSRC)
+    return out
+
+
 def build_emu(force=False):
     """CPU emulation of the device phases — tests only (tests/emu)."""
     d = os.path.join(ROOT, "tests", "emu")

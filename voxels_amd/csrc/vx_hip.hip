@@ -380,6 +380,8 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 struct Backend {
 	hipStream_t ownStream = nullptr, stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t stageEv[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	bool stageOn = false, stageValid = false;
 	std::string lastError;
 	int cus = 256;
 	bool ok = true;
@@ -415,6 +417,7 @@ struct Backend {
 	{
 		if (ev0) hipEventDestroy(ev0);
 		if (ev1) hipEventDestroy(ev1);
+		for (int i = 0; i < 7; ++i) if (stageEv[i]) hipEventDestroy(stageEv[i]);
 		if (ownStream) hipStreamDestroy(ownStream);
 	}
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
@@ -438,6 +441,25 @@ struct Backend {
 		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	void sync() { hipStreamSynchronize(stream); }
+	void stage_enable(bool on)
+	{
+		stageOn = on;
+		stageValid = false;
+		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i]) hipEventCreate(&stageEv[i]);
+	}
+	void stage_mark(int i)
+	{
+		if (!stageOn) return;
+		hipEventRecord(stageEv[i], stream);
+		if (i == 6) stageValid = true;
+	}
+	bool stage_ms(float* ms)
+	{
+		if (!stageOn || !stageValid) return false;
+		if (hipEventSynchronize(stageEv[6]) != hipSuccess) return false;
+		for (int i = 0; i < 6; ++i) { ms[i] = 0.f; hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
+		return true;
+	}
 	void begin_timing() { hipEventRecord(ev0, stream); }
 	float end_timing_ms()
 	{

@@ -188,11 +188,17 @@ void build_table_image(std::vector<u8>& img)
 // one pass of the device pipeline over the blocks listed in the level tables
 void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 {
+	c->be.stage_mark(1);
 	c->be.run_classify(p);
+	c->be.stage_mark(2);
 	c->be.run_hierarchy(p, levels);
+	c->be.stage_mark(3);
 	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
+	c->be.stage_mark(4);
 	c->be.run_regular(p, levels);
+	c->be.stage_mark(5);
 	c->be.run_transition(p, levels);
+	c->be.stage_mark(6);
 }
 
 void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
@@ -351,6 +357,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		ExecParams p;
 		fill_params(c, p, levels);
 		c->be.begin_timing();
+		c->be.stage_mark(0);
 		c->be.fill(c->dHeader, 0, 32 * 4);
 		for (u32 L = 0; L < levels; ++L) c->be.fill(c->lv[L].slotOf, 0xFF, (size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt * 4);
 		run_pipeline(c, p, levels);
@@ -452,6 +459,19 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 		}
 	}
 	return VX_OK;
+}
+
+int vx_set_stage_timing(vx_ctx* c, int enable)
+{
+	if (!c) return VX_ERR_INVALID;
+	c->be.stage_enable(enable != 0);
+	return VX_OK;
+}
+
+int vx_stage_times(vx_ctx* c, float ms[6])
+{
+	if (!c || !ms) return VX_ERR_INVALID;
+	return c->be.stage_ms(ms) ? VX_OK : fail(c, VX_ERR_INVALID, "vx_stage_times: stage timing was not enabled for the last run");
 }
 
 int vx_stats(vx_ctx* c, uint32_t stats[20])
