@@ -90,38 +90,15 @@ def main():
     d, m, b = synth.terrain(n, z0, z1, seed)
     flags_own = synth.block_empty_flags(d)
     t_gen = time.perf_counter() - t_gen
-    dist_t = torch.zeros((planes + 3, n, n), dtype=torch.int8, device=dev)     # plane 0 <-> global z0 - 1
-    mat_t = torch.zeros((planes + 1, n, n), dtype=torch.uint8, device=dev)     # plane 0 <-> global z0
-    blend_t = torch.zeros((planes + 1, n, n), dtype=torch.uint8, device=dev)
-    dist_t[1:planes + 1].copy_(torch.from_numpy(d))
-    mat_t[:planes].copy_(torch.from_numpy(m))
-    blend_t[:planes].copy_(torch.from_numpy(b))
-    flags_t = torch.zeros(((n // 16) ** 3,), dtype=torch.uint8, device=dev)
-    per = flags_own.size
-    flags_t[rank * per:(rank + 1) * per].copy_(torch.from_numpy(flags_own))
+    from voxels_amd.slab import SlabBuffers
+    slab = SlabBuffers(torch, n, rank, world, dev)
+    slab.fill_own(d, m, b, flags_own)
     del d, m, b
-    if world > 1:
-        chunks = [torch.empty(per, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist_pkg.all_gather(chunks, flags_t[rank * per:(rank + 1) * per].clone())
-        flags_t.copy_(torch.cat(chunks))
+    slab.gather_flags(dist_pkg)
 
     def halo_exchange():
         """1 distance plane from the slab below; 2 distance planes + 1 material + 1 blend plane from the slab above."""
-        if world == 1:
-            return
-        ops = []
-        if rank > 0:
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, dist_t[1:3], rank - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, mat_t[0:1], rank - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, blend_t[0:1], rank - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, dist_t[0:1], rank - 1))
-        if rank < world - 1:
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, dist_t[planes + 1:planes + 3], rank + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, mat_t[planes:planes + 1], rank + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, blend_t[planes:planes + 1], rank + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, dist_t[planes:planes + 1], rank + 1))
-        for w in dist_pkg.batch_isend_irecv(ops):
-            w.wait()
+        slab.halo_exchange(dist_pkg)
 
     halo_exchange()
     torch.cuda.synchronize()
@@ -130,7 +107,7 @@ def main():
     assert poly.backend == "hip:gfx950"
     poly.set_stream(torch.cuda.current_stream().cuda_stream)
     poly.set_materials(vxo.default_lut())
-    poly.attach(n, z0, z1, dist_t.data_ptr(), z0 - 1, mat_t.data_ptr(), blend_t.data_ptr(), z0, flags_t.data_ptr())
+    slab.attach(poly)
 
     def step():
         halo_exchange()

@@ -1,0 +1,140 @@
+"""CPU tests of the product's core logic: the closed-form per-cell formulation (voxels_amd/csrc/tv_core.h), the
+block phases (tv_block.h) and the host orchestration (vx_host.inl) — compiled with the CPU emulation backend
+(tests/emu) — against the reference fixtures and the oracle port.  The HIP kernels run the same phase code; their
+GPU-only parts (LDS staging, wave scans, atomics, bit-parallel classify) are covered by tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import fields
+import vxo
+from emu_lib import emu_library
+from golden_io import Golden
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_library()
+
+
+@pytest.fixture(scope="module")
+def port():
+    import subprocess, os
+    if not os.path.exists(vxo.PORT_SO):
+        subprocess.check_call(["make", "-C", os.path.join(vxo.ROOT, "oracle"), "port"])
+    return vxo.load_port()
+
+
+def make_poly(emu):
+    from voxels_amd.binding import Polygonizer
+    p = Polygonizer(library=emu)
+    p.set_materials(vxo.default_lut())
+    return p
+
+
+@pytest.mark.parametrize("name", ["sphere64", "terrain32_mat", "noise64_fullrange_mat"])
+def test_emu_matches_reference_fixture(emu, name):
+    gold = Golden(name)
+    p = make_poly(emu)
+    p.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    p.execute()
+    ok, msg = fields.surface_equal(p.all_levels(), gold.levels)
+    assert ok, msg
+    assert np.array_equal(p.stats(), gold.stats)
+
+
+def check(emu, port, d, m, b, label):
+    g = port.grid_from_dense(d, m, b)
+    s = port.execute(g)
+    p = make_poly(emu)
+    p.upload(d, m, b, g.block_flags())
+    p.execute()
+    ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+    assert ok, label + ": " + msg
+    assert np.array_equal(p.stats(), s.stats()), label
+
+
+def test_emu_zero_heavy_and_white_noise(emu, port):
+    rng = np.random.RandomState(0)
+    for seed in range(3):
+        n = 32
+        d = np.clip(np.round(fields.smooth_noise(n, 100 + seed, scale=8, amp=2.0) * 1.5), -4, 4).astype(np.int8)
+        m = rng.randint(0, 4, (n, n, n)).astype(np.uint8)
+        b = rng.randint(0, 256, (n, n, n)).astype(np.uint8)
+        check(emu, port, d, m, b, "zeros %d" % seed)
+    d = rng.randint(-128, 128, (32, 32, 32)).astype(np.int8)
+    check(emu, port, d, rng.randint(0, 3, (32, 32, 32)).astype(np.uint8), rng.randint(0, 256, (32, 32, 32)).astype(np.uint8), "white noise")
+
+
+@pytest.mark.parametrize("h", [15.5, 16.0, 31.5])
+def test_emu_planes_and_emptiness_skip(emu, port, h):
+    n = 64
+    z = np.arange(n).reshape(n, 1, 1) * np.ones((n, n, n))
+    d = np.ascontiguousarray(np.clip(np.sign(z - h) * np.ceil(np.abs(z - h)), -4, 4).astype(np.int8))
+    zero = np.zeros((n, n, n), np.uint8)
+    check(emu, port, d, zero, zero, "plane %g" % h)
+
+
+def test_emu_synth_terrain_vs_port(emu, port):
+    from voxels_amd import synth
+    d, m, b = synth.terrain(64)
+    g = port.grid_from_dense(d, m, b)
+    assert np.array_equal(synth.block_empty_flags(d), g.block_flags())
+    check(emu, port, d, m, b, "synth terrain 64")
+
+
+def test_emu_level_limit(emu):
+    gold = Golden("noise64_fullrange_mat")
+    p = make_poly(emu)
+    p.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    p.execute(2)
+    lv = p.all_levels()
+    assert len(lv) == 2
+    ok, msg = fields.surface_equal(lv, gold.levels[:2])
+    assert ok, msg
+
+
+def test_emu_pool_overflow_retry(emu):
+    """Output pools start from a size guess; a denser surface must trigger the transparent grow-and-rerun."""
+    rng = np.random.RandomState(3)
+    n = 32
+    d = rng.randint(-128, 128, (n, n, n)).astype(np.int8)
+    zero = np.zeros((n, n, n), np.uint8)
+    p = make_poly(emu)
+    port = vxo.load_port()
+    g = port.grid_from_dense(d, zero, zero)
+    p.upload(d, zero, zero, g.block_flags())
+    info = p.execute()
+    assert info.retries >= 1
+    ok, msg = fields.surface_equal(p.all_levels(), port.execute(g).all_levels())
+    assert ok, msg
+
+
+def test_emu_z_slabs_union_equals_whole(emu):
+    """Two contexts, each owning half the grid in z with the halo planes the path needs (1 below, 2 above for
+    distances; 1 above for material/blend): the union of their blocks is the single-context result."""
+    from voxels_amd import synth
+    from voxels_amd.slab import merge_rank_levels
+    n, levels = 128, 3           # coarsest block = 64 voxels -> two slabs of 64
+    d, m, b = synth.terrain(n, seed=5)
+    flags = synth.block_empty_flags(d)
+    whole = make_poly(emu)
+    whole.upload(d, m, b, flags)
+    whole.execute(levels)
+    ref_levels, ref_stats = whole.all_levels(), whole.stats()
+    parts, stats = [], np.zeros(20, np.uint64)
+    keep = []
+    for r in range(2):
+        z0, z1 = r * 64, (r + 1) * 64
+        lo, hi = max(z0 - 1, 0), min(z1 + 2, n)
+        dd = np.ascontiguousarray(d[lo:hi])
+        mm = np.ascontiguousarray(m[z0:min(z1 + 1, n)])
+        bb = np.ascontiguousarray(b[z0:min(z1 + 1, n)])
+        keep.append((dd, mm, bb))
+        p = make_poly(emu)
+        p.attach(n, z0, z1, dd.ctypes.data, lo, mm.ctypes.data, bb.ctypes.data, z0, flags.ctypes.data)
+        p.execute(levels)
+        parts.append(p.all_levels())
+        stats += p.stats()
+    ok, msg = fields.surface_equal(merge_rank_levels(parts), ref_levels)
+    assert ok, msg
+    assert np.array_equal(stats.astype(np.uint32), ref_stats)

@@ -1,0 +1,40 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU path: z-slab sharding + halo exchange (voxels_amd/slab.py) +
+per-rank polygonization through vx_grid_attach, merged and compared with the single-rank result."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import fields
+import vxo
+from emu_lib import emu_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_equal_one(tmp_path):
+    from voxels_amd import synth
+    from voxels_amd.binding import Level, Polygonizer
+    from voxels_amd.slab import merge_rank_levels
+    n, levels, world = 128, 3, 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"), str(tmp_path), str(n), str(levels)], env=e))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    parts, stats = [], np.zeros(20, np.uint64)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        parts.append([Level(z["L%d_infos" % l], z["L%d_verts" % l], z["L%d_idx" % l], z["L%d_tverts" % l], z["L%d_tidx" % l]) for l in range(levels)])
+        stats += z["stats"]
+    d, m, b = synth.terrain(n, seed=5)
+    whole = Polygonizer(library=emu_library())
+    whole.set_materials(vxo.default_lut())
+    whole.upload(d, m, b, synth.block_empty_flags(d))
+    whole.execute(levels)
+    ok, msg = fields.surface_equal(merge_rank_levels(parts), whole.all_levels())
+    assert ok, msg
+    assert np.array_equal(stats.astype(np.uint32), whole.stats())

@@ -72,6 +72,7 @@ struct Globals {
 	u32* stats;
 	u32 levels;             // number of levels being polygonized (0..levels-1)
 	u32 refLevels;          // the reference's levelsCount = log2(N/16)+1 (decides which levels get transitions)
+	u32 debugPhaseLimit;    // profiling aid: stop the per-block pipeline after this phase (0 = run everything)
 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }

@@ -280,9 +280,12 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
 			}
 			continue;
 		}
+		const u32 lim = p.G.debugPhaseLimit;
+		__syncthreads();
 		reg_phase_load_bits(st, L, b.slot, tid, WG);
 		stage_samples(p.G.grid, b.bx, b.by, b.bz, b.mult, st.samp, tid, WG);
 		__syncthreads();
+		if (lim == 1) continue;
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
 		__syncthreads();
 		{
@@ -290,22 +293,28 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
 			if (tid == 0) st.wordPrefix[128] = (u16)nt;
 		}
 		__syncthreads();
+		if (lim == 2) continue;
 		reg_phase_list(st, T, p.G, L, b, tid, WG);
 		__syncthreads();
+		if (lim == 3) continue;
 		reg_phase_count(st, T, b, tid, WG);
 		__syncthreads();
+		if (lim == 4) continue;
 		{
 			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[0], vt); }
 		}
 		__syncthreads();
+		if (lim == 5) continue;
 		reg_phase_emit_vertices(st, T, p.G, p.P, b, tid, WG);
 		__syncthreads();
+		if (lim == 6) continue;
 		{
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[1], it); }
 		}
 		__syncthreads();
+		if (lim == 7) continue;
 		reg_phase_emit_indices(st, T, p.P, b, tid, WG);
 		reg_phase_record(st, p.G, L, b, p.P, tid);
 		__syncthreads();

@@ -66,6 +66,7 @@ struct vx_ctx {
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
 	u32 hdr[32];
+	u32 debugPhaseLimit = 0;
 };
 
 namespace {
@@ -164,6 +165,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.stats = (u32*)c->dHeader + 12;
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
+	p.G.debugPhaseLimit = c->debugPhaseLimit;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
 	p.P.verts = (PolyVertex*)c->dVerts;
 	p.P.idx = (u32*)c->dIdx;
@@ -465,6 +467,13 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 {
 	if (!c) return VX_ERR_INVALID;
 	c->be.stage_enable(enable != 0);
+	return VX_OK;
+}
+
+int vx_debug_phase_limit(vx_ctx* c, uint32_t limit)
+{
+	if (!c) return VX_ERR_INVALID;
+	c->debugPhaseLimit = limit;
 	return VX_OK;
 }
 
