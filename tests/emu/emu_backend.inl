@@ -49,6 +49,9 @@ struct Backend {
 			L.slotCoord[slot] = id;
 			L.skip[slot] = skipped ? 1 : 0;
 			memcpy(L.ntBits + (size_t)slot * 128, bits, sizeof(bits));
+			u32 cnt = 0;
+			for (int w = 0; w < 128; ++w) cnt += (u32)TV_POPC(bits[w]);
+			L.ntCount[slot] = (u16)cnt;
 		}
 	}
 
@@ -88,32 +91,36 @@ struct Backend {
 		delete st;
 	}
 
-	template <typename P>
-	void run_regular(const P& p, u32 levels)
+	// one capacity class of the regular pass: blocks whose non-trivial cell count is in (lo, CAP]
+	template <int CAP, typename P>
+	void regular_pass(const P& p, u32 levels, u32 lo)
 	{
-		Tables T{ p.tables };
-		RegState* st = new RegState;
+		const Tables T = tables_from_image(p.tables);
+		typedef RegStateT<CAP> ST;
+		ST* st = new ST;
 		for (u32 level = 0; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];
 			for (u32 slot = 0; slot < *L.nActive; ++slot) {
+				const u32 ntc = L.ntCount[slot];
+				if (ntc <= lo || ntc > (u32)CAP) continue;
 				RegBlockCtx b;
 				b.level = level; b.slot = slot; b.mult = L.mult;
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
-				if (level == 0 && L.skip[slot]) {
-					BlockRecord& r = L.records[slot];
-					memset(&r, 0, sizeof(r));
-					r.coordId = L.slotCoord[slot];
-					continue;
-				}
-				reg_phase_load_bits(*st, L, slot, 0, 1);
-				stage_samples(p.G.grid, b.bx, b.by, b.bz, b.mult, st->samp, 0, 1);
+				if (level == 0 && L.skip[slot]) { reg_write_empty_record(L, slot); continue; }
+				reg_phase_begin(*st, L, slot, 0, 1);
+				reg_phase_stage(*st, p.G, L, b, 0, 1);
 				for (int w = 0; w < 128; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
 				st->wordPrefix[128] = (u16)exclusive_scan(st->wordPrefix, 128);
-				reg_phase_list(*st, T, p.G, L, b, 0, 1);
+				reg_phase_list(*st, L, b, 0, 1);
+				reg_phase_cells(*st, T, p.G, L, b, 0, 1);
 				reg_phase_count(*st, T, b, 0, 1);
 				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[128]);
 				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[0], st->vTotal);
-				reg_phase_emit_vertices(*st, T, p.G, p.P, b, 0, 1);
+				for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
+					reg_phase_describe(*st, chunk, 0, 1);
+					reg_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
+				}
+				reg_phase_keep(*st, T, p.G, b, 0, 1);
 				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[128]);
 				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
 				reg_phase_emit_indices(*st, T, p.P, b, 0, 1);
@@ -124,9 +131,16 @@ struct Backend {
 	}
 
 	template <typename P>
+	void run_regular(const P& p, u32 levels)
+	{
+		regular_pass<640>(p, levels, 0);      // same two capacity classes as the HIP kernels
+		regular_pass<4096>(p, levels, 640);
+	}
+
+	template <typename P>
 	void run_transition(const P& p, u32 levels)
 	{
-		Tables T{ p.tables };
+		const Tables T = tables_from_image(p.tables);
 		TrState* st = new TrState;
 		for (u32 level = 1; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];

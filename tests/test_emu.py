@@ -65,6 +65,15 @@ def test_emu_zero_heavy_and_white_noise(emu, port):
     check(emu, port, d, rng.randint(0, 3, (32, 32, 32)).astype(np.uint8), rng.randint(0, 256, (32, 32, 32)).astype(np.uint8), "white noise")
 
 
+def test_emu_degenerate_filter_at_coarse_levels(emu, port):
+    """Zero-heavy 128^3 field: degenerate triangles at cell sizes 1..8 (the suspect-cell shortcut must agree with the
+    reference's test everywhere)."""
+    n = 128
+    d = np.clip(np.round(fields.smooth_noise(n, 77, scale=16, amp=2.5) * 1.2), -4, 4).astype(np.int8)
+    zero = np.zeros((n, n, n), np.uint8)
+    check(emu, port, d, zero, zero, "zeros 128")
+
+
 @pytest.mark.parametrize("h", [15.5, 16.0, 31.5])
 def test_emu_planes_and_emptiness_skip(emu, port, h):
     n = 64

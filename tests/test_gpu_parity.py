@@ -106,6 +106,14 @@ def test_hip_zero_heavy_fields(poly, port):
         check_against(poly, port, d, m, b, "zeros seed=%d" % seed)
 
 
+def test_hip_degenerate_filter_at_coarse_levels(poly, port):
+    """Zero-heavy 256^3 field (cell sizes 1..16): thousands of degenerate triangles on every level."""
+    n = 256
+    d = np.clip(np.round(fields.smooth_noise(n, 78, scale=32, amp=2.5) * 1.2), -4, 4).astype(np.int8)
+    zero = np.zeros((n, n, n), np.uint8)
+    check_against(poly, port, d, zero, zero, "zeros 256")
+
+
 def test_hip_white_noise_worst_case(poly, port):
     """Every cell non-trivial: 4096 non-trivial cells per block (maximum per-block state)."""
     rng = np.random.RandomState(7)

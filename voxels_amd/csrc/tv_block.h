@@ -51,6 +51,7 @@ struct LevelDesc {
 	u32* ntBits;        // [cap][128] non-trivial cell bitmap of the block
 	u16* cache;         // [cap][4096] per-cell material cache (levels >= 1)
 	u8* skip;           // [cap] level 0: block skipped by the emptiness rule
+	u16* ntCount;       // [cap] number of non-trivial cells of the block (picks the LDS capacity class)
 	BlockRecord* records; // [cap]
 	u32 cap;
 	u32 hasTransitions; // 0 < level < levelsCount - 1
@@ -179,21 +180,85 @@ TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc*
 	}
 	u32* bitsOut = L.ntBits + (size_t)slot * 128;
 	for (int w = tid; w < 128; w += nth) bitsOut[w] = st.ntBits[w];
+	if (tid == 0) {
+		u32 cnt = 0;
+		for (int w = 0; w < 128; ++w) cnt += TV_POPC(st.ntBits[w]);
+		L.ntCount[slot] = (u16)cnt;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Regular-cell pass state
+// Regular-cell pass
+//
+// LDS sample layout: 19 x 19 rows of 24 bytes; sample (i,j,k), i,j,k in [-1,17] relative to the block origin (in
+// cells of the block's level) lives at (k+1)*SPLANE + (j+1)*SROW + (i+4), so every row starts 4-byte aligned at
+// local x = -4 and level-0 rows are filled with six aligned dword loads.  Level 0 stages the full [-1,17]^3
+// neighbourhood (central-difference normals then never leave LDS); levels >= 1 stage the 17^3 corner samples only
+// (their normals / LOD chain read level-0 voxels from HBM).
 // ---------------------------------------------------------------------------------------------------------
-struct RegState {
-	i8 samp[SAMPLES + 7];
+enum { SROW = 24, SPLANE = 19 * SROW, SAMP_BYTES = 19 * SPLANE, VDESC_CAP = 2048 };
+
+TV_HD int samp_index(int i, int j, int k) { return (k + 1) * SPLANE + (j + 1) * SROW + (i + 4); }
+
+TV_HD void reg_stage_level0(const GridView& g, u32 bx, u32 by, u32 bz, i8* samp, int tid, int nth)
+{
+	const int n = g.n, gx0 = (int)bx * 16 - 4;
+	for (int q = tid; q < 361 * 6; q += nth) {
+		const int r = q / 6, j = q - r * 6;
+		const int jj = r % 19, kk = r / 19;
+		const int y = clampi((int)by * 16 + jj - 1, 0, n - 1);
+		const int z = clampi((int)bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
+		const int x = clampi(gx0 + 4 * j, 0, n - 4);
+		const u32 v = *(const u32*)(g.dist + ((size_t)z * n + y) * n + x);
+		*(u32*)(samp + kk * SPLANE + jj * SROW + 4 * j) = v;
+	}
+}
+
+// x-clamp of the level-0 rows of border blocks (the dword loads above clamp whole dwords, not samples)
+TV_HD void reg_fix_borders(u32 bx, u32 cnt, i8* samp, int tid, int nth)
+{
+	if (bx == 0) for (int r = tid; r < 361; r += nth) { i8* row = samp + (r / 19) * SPLANE + (r % 19) * SROW; row[3] = row[4]; }
+	if (bx + 1 == cnt) for (int r = tid; r < 361; r += nth) { i8* row = samp + (r / 19) * SPLANE + (r % 19) * SROW; row[20] = row[19]; row[21] = row[19]; }
+}
+
+TV_HD void reg_stage_strided(const GridView& g, u32 bx, u32 by, u32 bz, u32 mult, i8* samp, int tid, int nth)
+{
+	for (int s = tid; s < SAMPLES; s += nth) {
+		const int i = s % 17, j = (s / 17) % 17, k = s / 289;
+		samp[samp_index(i, j, k)] = (i8)dist_at(g, (int)((bx * 16 + i) * mult), (int)((by * 16 + j) * mult), (int)((bz * 16 + k) * mult));
+	}
+}
+
+TV_HD void reg_cell_values(const i8* samp, int cx, int cy, int cz, i8 V[8])
+{
+	const i8* p = samp + samp_index(cx, cy, cz);
+	V[0] = p[0]; V[1] = p[1]; V[2] = p[SROW]; V[3] = p[SROW + 1];
+	V[4] = p[SPLANE]; V[5] = p[SPLANE + 1]; V[6] = p[SPLANE + SROW]; V[7] = p[SPLANE + SROW + 1];
+}
+
+// level-0 distance sampler over the staged neighbourhood (global voxel coordinates in, like GlobalDist)
+struct LocalDist {
+	const i8* samp;
+	int ox, oy, oz;
+	TV_HD int operator()(int x, int y, int z) const { return samp[samp_index(x - ox, y - oy, z - oz)]; }
+};
+
+template <int CAP>
+struct RegStateT {
+	i8 samp[SAMP_BYTES + 8];
 	u32 ntBits[128];
 	u16 wordPrefix[130];      // exclusive popcount prefix, [128] = number of non-trivial cells
-	u16 cellOf[BLOCK_CELLS];  // compact index -> cell id
-	u16 cellMat[BLOCK_CELLS]; // compact: id | blend << 8
-	u32 info[BLOCK_CELLS];    // compact: bits 0-15 slot ordinals (4 x 4), 16-19 slot valid, 20-23 new vertex count
-	u16 vbase[BLOCK_CELLS];   // compact: exclusive scan of new vertex counts
-	u16 ibase[BLOCK_CELLS];   // compact: exclusive scan of kept index counts
-	u8 keep[BLOCK_CELLS];     // compact: kept-triangle mask
+	u16 cellOf[CAP];          // compact index -> cell id
+	u16 cellMat[CAP];         // compact: id | blend << 8
+	u32 info[CAP];            // compact: bits 0-15 slot ordinals (4 x 4), 16-19 slot valid, 20-23 new vertex count, 24-28 kept triangles
+	u16 vbase[CAP];           // compact: exclusive scan of new vertex counts
+	u16 ibase[CAP];           // compact: exclusive scan of kept index counts
+	u16 newMask[CAP];         // compact: table vertices this cell creates
+	u16 atV0Mask[CAP];        // compact: created corner vertices placed at edge corner v0 (TransVoxelImpl.cpp:1637)
+	u16 invalidMask[CAP];     // compact: table vertices that resolve to INVALID_INDEX
+	unsigned long long reuseSrc[CAP]; // compact: 12 x 5 bits (direction << 2 | slot) of reused vertices
+	u16 vdesc[VDESC_CAP];     // one chunk of new-vertex descriptors: compact cell | table vertex << 12
+	u32 suspect[128];         // per cell id: touches a vertex that is not strictly inside its edge (may be degenerate)
 	u32 perCase[16];
 	u32 vOff, iOff, vTotal, iTotal, degenerate;
 };
@@ -202,25 +267,44 @@ struct RegBlockCtx {
 	u32 level, slot, bx, by, bz, mult;
 };
 
-TV_HD void reg_phase_load_bits(RegState& st, const LevelDesc& L, u32 slot, int tid, int nth)
+template <typename ST>
+TV_HD void reg_phase_begin(ST& st, const LevelDesc& L, u32 slot, int tid, int nth)
 {
 	const u32* src = L.ntBits + (size_t)slot * 128;
 	for (int w = tid; w < 128; w += nth) st.ntBits[w] = src[w];
 	for (int i = tid; i < 16; i += nth) st.perCase[i] = 0;
+	for (int w = tid; w < 128; w += nth) st.suspect[w] = 0;
 	if (tid == 0) st.degenerate = 0;
 }
 
-// after wordPrefix is known: compact list, cell material, slot-valid mask
-TV_HD void reg_phase_list(RegState& st, const Tables& T, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+template <typename ST>
+TV_HD void reg_phase_stage(ST& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
 {
+	if (b.level == 0) reg_stage_level0(G.grid, b.bx, b.by, b.bz, st.samp, tid, nth);
+	else reg_stage_strided(G.grid, b.bx, b.by, b.bz, b.mult, st.samp, tid, nth);
+}
+
+// after wordPrefix is known: compact list of the non-trivial cells, in cell order
+template <typename ST>
+TV_HD void reg_phase_list(ST& st, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+{
+	if (b.level == 0) reg_fix_borders(b.bx, L.cnt, st.samp, tid, nth);
 	for (int c = tid; c < BLOCK_CELLS; c += nth) {
-		if (!bit_get(st.ntBits, (u32)c)) continue;
-		const u32 k = bit_rank(st.ntBits, st.wordPrefix, (u32)c);
+		if (bit_get(st.ntBits, (u32)c)) st.cellOf[bit_rank(st.ntBits, st.wordPrefix, (u32)c)] = (u16)c;
+	}
+}
+
+// dense over the compact list: cell material, slot-valid mask, per-class statistics
+template <typename ST>
+TV_HD void reg_phase_cells(ST& st, const Tables& T, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[128];
+	for (int k = tid; k < nt; k += nth) {
+		const int c = st.cellOf[k];
 		const int cx = c & 15, cy = (c >> 4) & 15, cz = c >> 8;
 		i8 V[8];
-		cell_values(st.samp, cx, cy, cz, V);
+		reg_cell_values(st.samp, cx, cy, cz, V);
 		const u32 code = reg_case_code(V);
-		st.cellOf[k] = (u16)c;
 		st.info[k] = reg_slot_valid(T, V, code) << 16;
 		u32 m;
 		if (b.level == 0) m = mat_at(G.grid, (int)(b.bx * 16 + cx), (int)(b.by * 16 + cy), (int)(b.bz * 16 + cz));
@@ -230,8 +314,9 @@ TV_HD void reg_phase_list(RegState& st, const Tables& T, const Globals& G, const
 	}
 }
 
+template <typename ST>
 struct RegNeighbour {
-	const RegState* st;
+	const ST* st;
 	int cx, cy, cz;
 	TV_HD void operator()(int dx, int dy, int dz, u32 slot, bool& valid, u32& mat) const
 	{
@@ -245,13 +330,13 @@ struct RegNeighbour {
 };
 
 // reuseValidityMask of cell c from the bitmap: x-bit, y-bit, z-bit
-TV_HD u32 reg_mask3(const RegState& st, int cx, int cy, int cz)
+template <typename ST>
+TV_HD u32 reg_mask3(const ST& st, int cx, int cy, int cz)
 {
 	const u32 row = (u32)((cz << 4) | cy);              // 16 cells = half a word
 	const u32 word = st.ntBits[row >> 1];
 	const u32 rowBits = (word >> ((row & 1) * 16)) & 0xFFFFu;
 	u32 m = (rowBits & ((1u << cx) - 1u)) ? 1u : 0u;
-	// cells of this slice before row cy
 	const u32 sliceStart = (u32)cz * 256, before = (u32)cz * 256 + (u32)cy * 16;
 	const u32 nBeforeRow = bit_rank(st.ntBits, st.wordPrefix, before) - st.wordPrefix[sliceStart >> 5];
 	if (nBeforeRow) m |= 2u;
@@ -259,18 +344,21 @@ TV_HD u32 reg_mask3(const RegState& st, int cx, int cy, int cz)
 	return m;
 }
 
-TV_HD void reg_cell_setup(const RegState& st, const RegBlockCtx& b, u32 k, int& cx, int& cy, int& cz, i8 V[8], CellGeom& geo)
+template <typename ST>
+TV_HD void reg_cell_setup(const ST& st, const RegBlockCtx& b, u32 k, int& cx, int& cy, int& cz, i8 V[8], CellGeom& geo)
 {
 	const u32 c = st.cellOf[k];
 	cx = c & 15; cy = (c >> 4) & 15; cz = c >> 8;
-	cell_values(st.samp, cx, cy, cz, V);
+	reg_cell_values(st.samp, cx, cy, cz, V);
 	geo.mult = (int)b.mult; geo.level = (int)b.level;
 	geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
 	geo.base[0] = (int)((b.bx * 16 + cx) * b.mult); geo.base[1] = (int)((b.by * 16 + cy) * b.mult); geo.base[2] = (int)((b.bz * 16 + cz) * b.mult);
 }
 
-// new-vertex count and slot ordinals of every non-trivial cell
-TV_HD void reg_phase_count(RegState& st, const Tables& T, const RegBlockCtx& b, int tid, int nth)
+// resolution of every table vertex of every non-trivial cell, stored compactly: new-vertex count, slot ordinals,
+// which vertices are created / invalid / placed at v0, and the (direction, slot) each reused vertex comes from
+template <typename ST>
+TV_HD void reg_phase_count(ST& st, const Tables& T, const RegBlockCtx& b, int tid, int nth)
 {
 	const int nt = st.wordPrefix[128];
 	for (int k = tid; k < nt; k += nth) {
@@ -280,113 +368,208 @@ TV_HD void reg_phase_count(RegState& st, const Tables& T, const RegBlockCtx& b, 
 		const u32 nv = (u32)T.regCell(T.regClass(code))[0] >> 4;
 		const u32 mask3 = reg_mask3(st, cx, cy, cz);
 		const u32 myMat = st.cellMat[k] & 0xFFu;
-		RegNeighbour nb{ &st, cx, cy, cz };
-		u32 count = 0, ords = 0;
+		RegNeighbour<ST> nb{ &st, cx, cy, cz };
+		u32 count = 0, ords = 0, newMask = 0, atV0 = 0, invalid = 0;
+		unsigned long long src = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
-			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, myMat, nb);
+			const u32 w = T.regVert(code, vi);
+			const Resolution r = reg_resolve(V, w, mask3, myMat, nb);
 			if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
 				if (r.store != NO_SLOT) ords = (ords & ~(0xFu << (r.store * 4))) | (count << (r.store * 4));
 				++count;
+				newMask |= 1u << vi;
+				if (r.kind == RK_NEW_CORNER && r.a == ((w >> 4) & 15)) atV0 |= 1u << vi;
+			} else if (r.kind == RK_REUSE) {
+				src |= (unsigned long long)(((u32)r.a << 2) | r.b) << (vi * 5);
+			} else {
+				invalid |= 1u << vi;
 			}
 		}
 		st.info[k] = (st.info[k] & 0x000F0000u) | (count << 20) | ords;
 		st.vbase[k] = (u16)count;
+		st.newMask[k] = (u16)newMask; st.atV0Mask[k] = (u16)atV0; st.invalidMask[k] = (u16)invalid;
+		st.reuseSrc[k] = src;
 	}
 }
 
-// vertices out + kept-triangle mask; requires vbase scanned and st.vOff set
-TV_HD void reg_phase_emit_vertices(RegState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+// Per cell, after vbase is scanned: publish descriptors of this chunk's new vertices
+template <typename ST>
+TV_HD void reg_phase_describe(ST& st, u32 chunkBase, int tid, int nth)
 {
 	const int nt = st.wordPrefix[128];
+	for (int k = tid; k < nt; k += nth) {
+		u32 m = st.newMask[k];
+		u32 j = st.vbase[k];
+		if (j >= chunkBase + VDESC_CAP || j + 12 <= chunkBase) continue;
+		while (m) {
+			const u32 vi = (u32)__builtin_ctz(m);
+			m &= m - 1;
+			if (j >= chunkBase && j < chunkBase + VDESC_CAP) st.vdesc[j - chunkBase] = (u16)((u32)k | (vi << 12));
+			++j;
+		}
+	}
+}
+
+// every cell that may reference a vertex created by cell (cx,cy,cz) lies at +0/+1 offsets from it
+template <typename ST>
+TV_HD void reg_mark_suspect(ST& st, int cx, int cy, int cz)
+{
+	for (int o = 0; o < 8; ++o) {
+		const int x = cx + (o & 1), y = cy + ((o >> 1) & 1), z = cz + (o >> 2);
+		if (x > 15 || y > 15 || z > 15) continue;
+		const u32 c = (u32)((z << 8) | (y << 4) | x);
+		TV_ATOMIC_OR(&st.suspect[c >> 5], 1u << (c & 31));
+	}
+}
+
+// One lane = one new vertex of the chunk: uniform work, consecutive 48-byte stores.
+template <typename ST, typename D>
+TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
+{
 	const bool room = st.vOff + st.vTotal <= P.vertCap;
+	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
+	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
+		const u32 desc = st.vdesc[j];
+		const u32 k = desc & 0xFFFu, vi = desc >> 12;
+		int cx, cy, cz; i8 V[8]; CellGeom geo;
+		reg_cell_setup(st, b, k, cx, cy, cz, V, geo);
+		const u32 w = T.regVert(reg_case_code(V), vi);
+		const int v0 = (w >> 4) & 15, v1 = w & 15;
+		const int t = edge_t(V[v0], V[v1]);
+		const u32 cellMat = st.cellMat[k];
+		RawVertex rv;
+		bool interior = false;
+		if ((t & 0xFF) == 0) {
+			const int corner = ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((t == 0) ? v1 : v0);
+			reg_corner_vertex(d, G.grid, geo, corner, cellMat, rv);
+		} else {
+			interior = reg_edge_vertex(d, G.grid, geo, v0, v1, t, V[v0], V[v1], cellMat, rv);
+		}
+		if (!interior) reg_mark_suspect(st, cx, cy, cz);
+		if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + chunkBase + j);
+	}
+}
+
+template <typename ST>
+TV_HD void reg_phase_emit_vertices(ST& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
+{
+	if (b.level == 0) {
+		const LocalDist d{ st.samp, (int)(b.bx * 16), (int)(b.by * 16), (int)(b.bz * 16) };
+		reg_vertices_emit_with(st, d, T, G, P, b, chunkBase, tid, nth);
+	} else {
+		const GlobalDist d{ &G.grid };
+		reg_vertices_emit_with(st, d, T, G, P, b, chunkBase, tid, nth);
+	}
+}
+
+// Kept-triangle mask (PushBlocksToResult's degenerate filter).  A triangle whose three vertices lie strictly inside
+// three distinct cell edges cannot be degenerate, and for cell sizes <= 16 the reference's fp32 test is exact integer
+// arithmetic, so only "suspect" cells (marked during vertex emission) evaluate it; larger cells always do.
+template <typename ST, typename D>
+TV_HD void reg_keep_with(ST& st, const D& d, const Tables& T, const RegBlockCtx& b, int tid, int nth)
+{
+	const int nt = st.wordPrefix[128];
 	for (int k = tid; k < nt; k += nth) {
 		int cx, cy, cz; i8 V[8]; CellGeom geo;
 		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
 		const u32 code = reg_case_code(V);
 		const u8* cd = T.regCell(T.regClass(code));
-		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
-		const u32 mask3 = reg_mask3(st, cx, cy, cz);
-		const u32 cellMat = st.cellMat[k];
-		RegNeighbour nb{ &st, cx, cy, cz };
-		float pos[12][3];
-		bool invalid[12];
-		u32 ord = 0;
-		for (u32 vi = 0; vi < nv; ++vi) {
-			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, cellMat & 0xFFu, nb);
-			invalid[vi] = r.kind == RK_INVALID;
-			if (r.kind == RK_NEW_EDGE) {
-				RawVertex rv;
-				reg_edge_vertex(G.grid, geo, r.a, r.b, r.t, cellMat, rv);
-				pos[vi][0] = rv.p[0]; pos[vi][1] = rv.p[1]; pos[vi][2] = rv.p[2];
-				if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
-				++ord;
-			} else if (r.kind == RK_NEW_CORNER) {
-				RawVertex rv;
-				reg_corner_vertex(G.grid, geo, r.a, cellMat, rv);
-				pos[vi][0] = rv.p[0]; pos[vi][1] = rv.p[1]; pos[vi][2] = rv.p[2];
-				if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
-				++ord;
-			} else if (r.kind == RK_REUSE) {
-				// same physical vertex as the owner's: recompute its position from this cell's own data
-				const u32 w = T.regVert(code, vi);
-				const int v0 = (w >> 4) & 15, v1 = w & 15;
-				if ((r.t & 0xFF) == 0) reg_corner_position(geo, (r.t == 0) ? v1 : v0, pos[vi]);
-				else { int P0[3], P1[3], t; reg_edge_position(G.grid, geo, v0, v1, r.t, P0, P1, t, pos[vi]); }
-			} else {
-				pos[vi][0] = pos[vi][1] = pos[vi][2] = 0.f;
+		const u32 ntri = (u32)cd[0] & 15;
+		u32 keepMask = (1u << ntri) - 1u, kept = ntri;
+		if (b.mult > 16 || bit_get(st.suspect, (u32)st.cellOf[k])) {
+			const u32 invalidMask = st.invalidMask[k], atV0Mask = st.atV0Mask[k];
+			keepMask = 0; kept = 0;
+			for (u32 tr = 0; tr < ntri; ++tr) {
+				const u32 a = cd[1 + tr * 3], bb = cd[2 + tr * 3], c = cd[3 + tr * 3];
+				bool keepIt = true;
+				if (!(((invalidMask >> a) | (invalidMask >> bb) | (invalidMask >> c)) & 1u)) {
+					float pa[3], pb[3], pc[3];
+					reg_vertex_position(d, geo, V, T.regVert(code, a), ((atV0Mask >> a) & 1u) != 0, pa);
+					reg_vertex_position(d, geo, V, T.regVert(code, bb), ((atV0Mask >> bb) & 1u) != 0, pb);
+					reg_vertex_position(d, geo, V, T.regVert(code, c), ((atV0Mask >> c) & 1u) != 0, pc);
+					keepIt = !triangle_degenerate(pa, pb, pc);
+				}
+				if (keepIt) { keepMask |= 1u << tr; ++kept; }
 			}
+			if (kept != ntri) TV_ATOMIC_ADD(&st.degenerate, ntri - kept);
 		}
-		u32 keepMask = 0, kept = 0;
-		for (u32 tr = 0; tr < ntri; ++tr) {
-			const u32 a = cd[1 + tr * 3], bb = cd[2 + tr * 3], c = cd[3 + tr * 3];
-			bool keepIt = true;
-			if (!(invalid[a] || invalid[bb] || invalid[c])) keepIt = !triangle_degenerate(pos[a], pos[bb], pos[c]);
-			if (keepIt) { keepMask |= 1u << tr; ++kept; }
-		}
-		st.keep[k] = (u8)keepMask;
+		st.info[k] = (st.info[k] & 0x00FFFFFFu) | (keepMask << 24);
 		st.ibase[k] = (u16)(kept * 3);
-		if (kept != ntri) TV_ATOMIC_ADD(&st.degenerate, ntri - kept);
 	}
 }
 
-// indices out; requires ibase scanned and st.iOff set
-TV_HD void reg_phase_emit_indices(RegState& st, const Tables& T, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+template <typename ST>
+TV_HD void reg_phase_keep(ST& st, const Tables& T, const Globals& G, const RegBlockCtx& b, int tid, int nth)
+{
+	if (b.level == 0) {
+		const LocalDist d{ st.samp, (int)(b.bx * 16), (int)(b.by * 16), (int)(b.bz * 16) };
+		reg_keep_with(st, d, T, b, tid, nth);
+	} else {
+		const GlobalDist d{ &G.grid };
+		reg_keep_with(st, d, T, b, tid, nth);
+	}
+}
+
+// indices out; requires ibase scanned and st.iOff set.  Nothing is re-resolved: created vertices count up from the
+// cell's vbase, reused ones come from the stored (direction, slot) of the owner cell.
+template <typename ST>
+TV_HD void reg_phase_emit_indices(ST& st, const Tables& T, const Pools& P, const RegBlockCtx& b, int tid, int nth)
 {
 	const int nt = st.wordPrefix[128];
 	if (st.iOff + st.iTotal > P.idxCap) return;
 	for (int k = tid; k < nt; k += nth) {
-		int cx, cy, cz; i8 V[8]; CellGeom geo;
-		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
-		const u32 code = reg_case_code(V);
-		const u8* cd = T.regCell(T.regClass(code));
+		const u32 c = st.cellOf[k];
+		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+		i8 V[8];
+		reg_cell_values(st.samp, cx, cy, cz, V);
+		const u8* cd = T.regCell(T.regClass(reg_case_code(V)));
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
-		const u32 mask3 = reg_mask3(st, cx, cy, cz);
-		RegNeighbour nb{ &st, cx, cy, cz };
-		u32 vidx[12];
+		const u32 newMask = st.newMask[k], invalidMask = st.invalidMask[k];
+		const unsigned long long src = st.reuseSrc[k];
+		// local vertex indices (< 49152) packed 4 x u16 per 64-bit register, 0xFFFF = INVALID_INDEX
+		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0;
 		u32 ord = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
-			const Resolution r = reg_resolve(V, T.regVert(code, vi), mask3, st.cellMat[k] & 0xFFu, nb);
-			if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
-				vidx[vi] = (u32)st.vbase[k] + ord; ++ord;
-			} else if (r.kind == RK_REUSE) {
-				const u32 c2 = (u32)(((cz - ((r.a >> 2) & 1)) << 8) | ((cy - ((r.a >> 1) & 1)) << 4) | (cx - (r.a & 1)));
-				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-				vidx[vi] = (u32)st.vbase[k2] + ((st.info[k2] >> (r.b * 4)) & 0xFu);
+			u32 id;
+			if ((newMask >> vi) & 1u) {
+				id = (u32)st.vbase[k] + ord; ++ord;
+			} else if ((invalidMask >> vi) & 1u) {
+				id = 0xFFFFu;
 			} else {
-				vidx[vi] = INVALID_INDEX;
+				const u32 ds = (u32)(src >> (vi * 5)) & 31u, dir = ds >> 2, slot = ds & 3u;
+				const u32 c2 = (u32)(((cz - (int)((dir >> 2) & 1)) << 8) | ((cy - (int)((dir >> 1) & 1)) << 4) | (cx - (int)(dir & 1)));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);
 			}
+			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
+			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
 		}
 		u32* out = P.idx + st.iOff + st.ibase[k];
-		const u32 keepMask = st.keep[k];
+		const u32 keepMask = st.info[k] >> 24;
 		for (u32 tr = 0; tr < ntri; ++tr) {
 			if (!((keepMask >> tr) & 1u)) continue;
-			out[0] = vidx[cd[1 + tr * 3]]; out[1] = vidx[cd[2 + tr * 3]]; out[2] = vidx[cd[3 + tr * 3]];
+			for (u32 e = 0; e < 3; ++e) {
+				const u32 vi = cd[1 + tr * 3 + e];
+				const unsigned long long pk = (vi < 4) ? pk0 : ((vi < 8) ? pk1 : pk2);
+				const u32 id = (u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu;
+				out[e] = (id == 0xFFFFu) ? INVALID_INDEX : id;
+			}
 			out += 3;
 		}
 	}
 }
 
-TV_HD void reg_phase_record(const RegState& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
+TV_HD void reg_write_empty_record(const LevelDesc& L, u32 slot)
+{
+	BlockRecord& r = L.records[slot];
+	r.coordId = L.slotCoord[slot];
+	r.vOff = r.vCount = r.iOff = r.iCount = 0;
+	for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
+	r.degenerate = 0; r.ntCells = 0; r.pad = 0;
+}
+
+template <typename ST>
+TV_HD void reg_phase_record(const ST& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
 {
 	if (tid != 0) return;
 	BlockRecord& r = L.records[b.slot];

@@ -47,7 +47,7 @@ enum : u32 { EMPTY_MATERIAL = 255u };   // VoxelGrid.h:16 — material id 255 is
 enum : u16 { EMPTY_MATINFO = 0x00FFu }; // id = 255, blend = 0 (TransVoxelImpl.cpp:424)
 
 // 48-byte output vertex, bit-compatible with Voxels::PolygonVertex (include/Polygonizer.h:14-48)
-struct PolyVertex {
+struct alignas(16) PolyVertex {
 	float pos[3];
 	float sec[3];
 	u32 secW;     // adjacency bit mask, raw integer bits (never touched by float ops: values 1..63 are denormals)
@@ -68,15 +68,31 @@ enum : u32 {
 };
 
 struct Tables {
-	const u8* base; // TAB_BYTES image, 16-byte aligned
-	TV_HD u32 regClass(u32 code) const { return base[TAB_REG_CLASS + code]; }
-	TV_HD const u8* regCell(u32 cls) const { return base + TAB_REG_CELL + cls * 16; }
-	TV_HD u32 regVert(u32 code, u32 i) const { return ((const u16*)(base + TAB_REG_VERT))[code * 12 + i]; }
-	TV_HD u32 trClass(u32 code) const { return base[TAB_TR_CLASS + code]; }
-	TV_HD const u8* trCell(u32 cls) const { return base + TAB_TR_CELL + cls * 40; }
-	TV_HD u32 trCorner(u32 c) const { return base[TAB_TR_CORNER + c]; }
-	TV_HD u32 trVert(u32 code, u32 i) const { return ((const u16*)(base + TAB_TR_VERT))[code * 12 + i]; }
+	const u8* regClassP;   // 256
+	const u8* regCellP;    // 16 x 16
+	const u16* regVertP;   // 256 x 12
+	const u8* trClassP;    // 512
+	const u8* trCornerP;   // 16
+	const u8* trCellP;     // 56 x 40
+	const u16* trVertP;    // 512 x 12
+	TV_HD u32 regClass(u32 code) const { return regClassP[code]; }
+	TV_HD const u8* regCell(u32 cls) const { return regCellP + cls * 16; }
+	TV_HD u32 regVert(u32 code, u32 i) const { return regVertP[code * 12 + i]; }
+	TV_HD u32 trClass(u32 code) const { return trClassP[code]; }
+	TV_HD const u8* trCell(u32 cls) const { return trCellP + cls * 40; }
+	TV_HD u32 trCorner(u32 c) const { return trCornerP[c]; }
+	TV_HD u32 trVert(u32 code, u32 i) const { return trVertP[code * 12 + i]; }
 };
+
+// all tables from one TAB_BYTES image
+TV_HD Tables tables_from_image(const u8* base)
+{
+	Tables T;
+	T.regClassP = base + TAB_REG_CLASS; T.regCellP = base + TAB_REG_CELL; T.regVertP = (const u16*)(base + TAB_REG_VERT);
+	T.trClassP = base + TAB_TR_CLASS; T.trCornerP = base + TAB_TR_CORNER; T.trCellP = base + TAB_TR_CELL;
+	T.trVertP = (const u16*)(base + TAB_TR_VERT);
+	return T;
+}
 
 // Dense voxel field resident in HBM: x fastest, then y, then z.  A rank of a multi-GPU run holds the z-planes
 // [zOrigin, zOrigin + planes) of the global grid (its slab plus halo); coordinates are always global and are
@@ -113,28 +129,40 @@ TV_HD void normalize_fix_zero(float v[3])
 	v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len;
 }
 
+// distance sampler reading the dense field in HBM (global coordinates, clamped like every reference fetch)
+struct GlobalDist {
+	const GridView* g;
+	TV_HD int operator()(int x, int y, int z) const { return dist_at(*g, x, y, z); }
+};
+
 // level-0 central differences; components come out ordered (x, z, y) — the output is Y-up
-TV_HD void normal_at(const GridView& g, int x, int y, int z, float out[3])
+template <typename D>
+TV_HD void normal_at(const D& d, int x, int y, int z, float out[3])
 {
-	out[0] = (float)(dist_at(g, x + 1, y, z) - dist_at(g, x - 1, y, z)) * 0.5f;
-	out[1] = (float)(dist_at(g, x, y, z + 1) - dist_at(g, x, y, z - 1)) * 0.5f;
-	out[2] = (float)(dist_at(g, x, y + 1, z) - dist_at(g, x, y - 1, z)) * 0.5f;
+	out[0] = (float)(d(x + 1, y, z) - d(x - 1, y, z)) * 0.5f;
+	out[1] = (float)(d(x, y, z + 1) - d(x, y, z - 1)) * 0.5f;
+	out[2] = (float)(d(x, y + 1, z) - d(x, y - 1, z)) * 0.5f;
 	normalize_fix_zero(out);
 }
 
-// `level` bisection steps toward the level-0 edge that holds the crossing
-TV_HD void lod_chain(const GridView& g, int level, int P0[3], int P1[3])
+// `level` bisection steps toward the level-0 edge that holds the crossing.  val0/val1 are the samples at P0/P1
+// (the reference re-fetches them every step, TransVoxelImpl.cpp:1495-1497; they are carried here, so the chain
+// costs one fetch per level).
+template <typename D>
+TV_HD void lod_chain(const D& d, int level, int P0[3], int P1[3], int& val0, int& val1)
 {
 	for (int lev = level; lev > 0; --lev) {
 		const int mx = P0[0] + (P1[0] - P0[0]) / 2, my = P0[1] + (P1[1] - P0[1]) / 2, mz = P0[2] + (P1[2] - P0[2]) / 2;
-		const int midV = dist_at(g, mx, my, mz);
-		const int p0V = dist_at(g, P0[0], P0[1], P0[2]);
-		if (p0V * midV <= 0) { P1[0] = mx; P1[1] = my; P1[2] = mz; }
-		else { P0[0] = mx; P0[1] = my; P0[2] = mz; }
+		const int midV = d(mx, my, mz);
+		if (val0 * midV <= 0) { P1[0] = mx; P1[1] = my; P1[2] = mz; val1 = midV; }
+		else { P0[0] = mx; P0[1] = my; P0[2] = mz; val0 = midV; }
 	}
 }
 
-TV_HD int edge_t(int v0, int v1) { return (v1 * 256) / (v1 - v0); } // C truncating division, v0 != v1
+// (v1 << 8) / (v1 - v0) with C truncation.  Evaluated as a correctly rounded fp32 division: for |v| <= 128 the
+// quotient is either an integer or at least 1/255 away from one while fp32 resolves 1/1024 there, so truncating
+// the rounded quotient is exact (checked exhaustively over all 65280 int8 pairs in tests/test_core_math.py).
+TV_HD int edge_t(int v0, int v1) { return (int)((float)(v1 * 256) / (float)(v1 - v0)); }
 
 TV_HD u32 lerp_blend(int t, int u, u32 b0, u32 b1)
 {
@@ -317,31 +345,35 @@ TV_HD void finish_secondary(RawVertex& o, int mult)
 }
 
 // x256 position of an edge vertex (after the LOD chain); also returns the final t and endpoints
-TV_HD void reg_edge_position(const GridView& g, const CellGeom& c, int v0, int v1, int t0,
+template <typename D>
+TV_HD bool reg_edge_position(const D& d, const CellGeom& c, int v0, int v1, int t0, int val0, int val1,
                              int P0[3], int P1[3], int& t, float pos[3])
 {
 	corner_pos(c, v0, P0);
 	corner_pos(c, v1, P1);
 	t = t0;
+	int p0 = val0, p1 = val1;
 	if (c.level > 0) {
-		lod_chain(g, c.level, P0, P1);
-		const int p0 = dist_at(g, P0[0], P0[1], P0[2]), p1 = dist_at(g, P1[0], P1[1], P1[2]);
-		t = (p0 != p1) ? (p1 * 256) / (p1 - p0) : 0;
+		lod_chain(d, c.level, P0, P1, p0, p1);
+		t = (p0 != p1) ? edge_t(p0, p1) : 0;
 	}
+	const bool interior = p0 * p1 < 0; // samples of strictly opposite sign: 0 < t < 256, vertex strictly inside its edge
 	const float ft = (float)t, fu = (float)(256 - t);
 	pos[0] = ft * (float)P0[0] + fu * (float)P1[0];
 	pos[1] = ft * (float)P0[1] + fu * (float)P1[1];
 	pos[2] = ft * (float)P0[2] + fu * (float)P1[2];
+	return interior;
 }
 
-TV_HD void reg_edge_vertex(const GridView& g, const CellGeom& c, int v0, int v1, int t0, u32 cellMat, RawVertex& o)
+template <typename D>
+TV_HD bool reg_edge_vertex(const D& d, const GridView& g, const CellGeom& c, int v0, int v1, int t0, int val0, int val1, u32 cellMat, RawVertex& o)
 {
 	int P0[3], P1[3], t;
-	reg_edge_position(g, c, v0, v1, t0, P0, P1, t, o.p);
+	const bool interior = reg_edge_position(d, c, v0, v1, t0, val0, val1, P0, P1, t, o.p);
 	const int u = 256 - t;
 	float N0[3], N1[3];
-	normal_at(g, P0[0], P0[1], P0[2], N0);
-	normal_at(g, P1[0], P1[1], P1[2], N1);
+	normal_at(d, P0[0], P0[1], P0[2], N0);
+	normal_at(d, P1[0], P1[1], P1[2], N1);
 	const u32 M0 = mat_at(g, P0[0], P0[1], P0[2]), M1 = mat_at(g, P1[0], P1[1], P1[2]);
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, v0, v1);
 	if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (cellMat & 0xFF)) o.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
@@ -350,7 +382,11 @@ TV_HD void reg_edge_vertex(const GridView& g, const CellGeom& c, int v0, int v1,
 	o.n[0] = N0[0] * wt + N1[0] * wu; o.n[1] = N0[1] * wt + N1[1] * wu; o.n[2] = N0[2] * wt + N1[2] * wu;
 	normalize_fix_zero(o.n);
 	finish_secondary(o, c.mult);
+	return interior;
 }
+
+template <typename D>
+TV_HD void reg_vertex_position(const D& d, const CellGeom& c, const i8 V[8], u32 w, bool atV0, float pos[3]);
 
 TV_HD void reg_corner_position(const CellGeom& c, int corner, float pos[3])
 {
@@ -359,12 +395,25 @@ TV_HD void reg_corner_position(const CellGeom& c, int corner, float pos[3])
 	pos[0] = (float)P[0] * 256.f; pos[1] = (float)P[1] * 256.f; pos[2] = (float)P[2] * 256.f;
 }
 
-TV_HD void reg_corner_vertex(const GridView& g, const CellGeom& c, int corner, u32 cellMat, RawVertex& o)
+// x256 position of the vertex described by table word w, as the cell that references it sees it: `atV0` marks the
+// one case where the reference places a fresh vertex at corner v0 whatever the endpoint (TransVoxelImpl.cpp:1637)
+template <typename D>
+TV_HD void reg_vertex_position(const D& d, const CellGeom& c, const i8 V[8], u32 w, bool atV0, float pos[3])
+{
+	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	const int t = edge_t(V[v0], V[v1]);
+	if (atV0) reg_corner_position(c, v0, pos);
+	else if ((t & 0xFF) == 0) reg_corner_position(c, (t == 0) ? v1 : v0, pos);
+	else { int P0[3], P1[3], tt; reg_edge_position(d, c, v0, v1, t, V[v0], V[v1], P0, P1, tt, pos); }
+}
+
+template <typename D>
+TV_HD void reg_corner_vertex(const D& d, const GridView& g, const CellGeom& c, int corner, u32 cellMat, RawVertex& o)
 {
 	int P[3];
 	corner_pos(c, corner, P);
 	o.p[0] = (float)P[0] * 256.f; o.p[1] = (float)P[1] * 256.f; o.p[2] = (float)P[2] * 256.f;
-	normal_at(g, P[0], P[1], P[2], o.n);
+	normal_at(d, P[0], P[1], P[2], o.n);
 	const u32 mine = mat_at(g, P[0], P[1], P[2]);
 	o.mat = ((cellMat & 0xFF) != (mine & 0xFF)) ? cellMat : mine;
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, corner, corner);
@@ -520,6 +569,7 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
                          const TrResolution& r, u32 lowMat, RawVertex& o)
 {
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	const GlobalDist d{ &g };
 	int I0[3], I1[3];
 	tr_sample_pos(fg, c, v0, I0);
 	tr_sample_pos(fg, c, v1, I1);
@@ -529,23 +579,23 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
 	if (r.endpoint) {
 		if (t == 0) {
 			u = 256;
-			normal_at(g, I1[0], I1[1], I1[2], N1);
+			normal_at(d, I1[0], I1[1], I1[2], N1);
 			if (v1 >= 9) { const int cid = low_corner_id(fg, v1 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		} else {
 			u = 0; t = 256;
-			normal_at(g, I0[0], I0[1], I0[2], N0);
+			normal_at(d, I0[0], I0[1], I0[2], N0);
 			if (v0 >= 9) { const int cid = low_corner_id(fg, v0 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		}
 	} else {
 		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
 		if (lodOfEdge > 0) {
-			lod_chain(g, lodOfEdge, I0, I1);
-			const int p0 = dist_at(g, I0[0], I0[1], I0[2]), p1 = dist_at(g, I1[0], I1[1], I1[2]);
-			t = (p0 != p1) ? (p1 * 256) / (p1 - p0) : 0;
+			int p0 = v[v0], p1 = v[v1];
+			lod_chain(d, lodOfEdge, I0, I1, p0, p1);
+			t = (p0 != p1) ? edge_t(p0, p1) : 0;
 		}
 		u = 256 - t;
-		normal_at(g, I0[0], I0[1], I0[2], N0);
-		normal_at(g, I1[0], I1[1], I1[2], N1);
+		normal_at(d, I0[0], I0[1], I0[2], N0);
+		normal_at(d, I1[0], I1[1], I1[2], N1);
 		if (v0 >= 9 && v1 >= 9) adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, low_corner_id(fg, v0 - 9), low_corner_id(fg, v1 - 9));
 	}
 	const u32 M0 = mat_at(g, I0[0], I0[1], I0[2]), M1 = mat_at(g, I1[0], I1[1], I1[2]);

@@ -38,6 +38,7 @@ struct ExecParamsDev {
 };
 
 constexpr int WG = 256;
+constexpr int REG_CAP_SMALL = 640; // LDS capacity class of the regular pass that covers ordinary surfaces
 
 // ------------------------------------------------------------------------------------------------------
 // workgroup helpers
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	__shared__ u8 halo[292];                                     // sign of the voxel right of the tile, per row
 	__shared__ __attribute__((aligned(16))) u16 blockBits[8 * 256];
 	__shared__ u32 blockAny[8];
+	__shared__ u32 blockCnt[8];
 	__shared__ int blockSlot[8];
 
 	const LevelDesc& L = p.levels[0];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	const int validCells = (n - x0) < 128 ? (n - x0) : 128; // multiple of 16
 	const int tid = threadIdx.x;
 
-	if (tid < 8) { blockAny[tid] = 0; blockSlot[tid] = -1; }
+	if (tid < 8) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; }
 
 	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line) ----------
 	for (int q = tid; q < 289 * 8; q += WG) {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			u32 bits = (nt[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
 			if (j * 16 >= validCells) bits = 0;
 			blockBits[j * 256 + tid] = (u16)bits;
-			if (bits) blockAny[j] = 1; // benign race: every writer stores 1
+			if (bits) { blockAny[j] = 1; atomicAdd(&blockCnt[j], (u32)__popc(bits)); }
 		}
 	}
 	__syncthreads();
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			L.slotOf[id] = (int)slot;
 			L.slotCoord[slot] = id;
 			L.skip[slot] = skipped ? 1 : 0;
+			L.ntCount[slot] = (u16)blockCnt[tid];
 			blockSlot[tid] = (int)slot;
 		}
 	}
@@ -244,46 +247,73 @@ __device__ __forceinline__ void decode_item(const WorkList& wl, u32 levels, u32 
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-constexpr size_t TAB_LDS = (TAB_BYTES + 15) & ~size_t(15);
+// LDS images of the table subsets each kernel needs
+constexpr u32 REG_TAB_LDS = 512 + 6144;                 // regClass + regCell | regVert
+constexpr u32 TR_TAB_LDS = 2768 + 12288;                // trClass + trCorner + trCell | trVert
 
-__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
+__device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes)
 {
+	const uint4* s = (const uint4*)src;
+	uint4* d = (uint4*)dst;
+	for (u32 i = threadIdx.x; i < bytes / 16; i += WG) d[i] = s[i];
+}
+
+__device__ __forceinline__ Tables stage_regular_tables(u8* lds, const u8* image)
+{
+	copy16(lds, image + TAB_REG_CLASS, 512);
+	copy16(lds + 512, image + TAB_REG_VERT, 6144);
+	Tables T;
+	T.regClassP = lds; T.regCellP = lds + 256; T.regVertP = (const u16*)(lds + 512);
+	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr;
+	return T;
+}
+
+__device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* image)
+{
+	copy16(lds, image + TAB_TR_CLASS, 2768);
+	copy16(lds + 2768, image + TAB_TR_VERT, 12288);
+	Tables T;
+	T.regClassP = nullptr; T.regCellP = nullptr; T.regVertP = nullptr;
+	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trVertP = (const u16*)(lds + 2768);
+	return T;
+}
+
+// One capacity class of the regular pass: blocks with lo < non-trivial cells <= CAP
+template <int CAP>
+__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32 lo)
+{
+	typedef RegStateT<CAP> ST;
 	u8* tab = smem;
-	RegState& st = *(RegState*)(smem + TAB_LDS);
+	ST& st = *(ST*)(smem + REG_TAB_LDS);
 	__shared__ WorkList wl;
 	__shared__ u32 scanScratch[8];
 
-	stage_tables(tab, p.tables);
+	const Tables T = stage_regular_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
 		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; run += *p.levels[l].nActive; }
 		for (u32 l = levels; l <= MAX_LEVELS; ++l) wl.start[l] = run;
 	}
 	__syncthreads();
-	const Tables T{ tab };
 	const u32 total = wl.start[MAX_LEVELS];
 	const int tid = threadIdx.x;
+	const u32 lim = p.G.debugPhaseLimit;
 
 	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
 		RegBlockCtx b;
 		decode_item(wl, levels, item, b.level, b.slot);
 		const LevelDesc& L = p.levels[b.level];
+		const u32 ntc = L.ntCount[b.slot];
+		if (ntc <= lo || ntc > (u32)CAP) continue;
 		b.mult = L.mult;
 		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
 		if (b.level == 0 && L.skip[b.slot]) {
-			if (tid == 0) {
-				BlockRecord& r = L.records[b.slot];
-				r.coordId = L.slotCoord[b.slot];
-				r.vOff = r.vCount = r.iOff = r.iCount = 0;
-				for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
-				r.degenerate = 0; r.ntCells = 0; r.pad = 0;
-			}
+			if (tid == 0) reg_write_empty_record(L, b.slot);
 			continue;
 		}
-		const u32 lim = p.G.debugPhaseLimit;
 		__syncthreads();
-		reg_phase_load_bits(st, L, b.slot, tid, WG);
-		stage_samples(p.G.grid, b.bx, b.by, b.bz, b.mult, st.samp, tid, WG);
+		reg_phase_begin(st, L, b.slot, tid, WG);
+		reg_phase_stage(st, p.G, L, b, tid, WG);
 		__syncthreads();
 		if (lim == 1) continue;
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
@@ -294,7 +324,9 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
 		}
 		__syncthreads();
 		if (lim == 2) continue;
-		reg_phase_list(st, T, p.G, L, b, tid, WG);
+		reg_phase_list(st, L, b, tid, WG);
+		__syncthreads();
+		reg_phase_cells(st, T, p.G, L, b, tid, WG);
 		__syncthreads();
 		if (lim == 3) continue;
 		reg_phase_count(st, T, b, tid, WG);
@@ -306,29 +338,36 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels)
 		}
 		__syncthreads();
 		if (lim == 5) continue;
-		reg_phase_emit_vertices(st, T, p.G, p.P, b, tid, WG);
+		for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
+			if (chunk) __syncthreads();
+			reg_phase_describe(st, chunk, tid, WG);
+			__syncthreads();
+			reg_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+		}
 		__syncthreads();
 		if (lim == 6) continue;
+		reg_phase_keep(st, T, p.G, b, tid, WG);
+		__syncthreads();
+		if (lim == 7) continue;
 		{
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[1], it); }
 		}
 		__syncthreads();
-		if (lim == 7) continue;
+		if (lim == 8) continue;
 		reg_phase_emit_indices(st, T, p.P, b, tid, WG);
 		reg_phase_record(st, p.G, L, b, p.P, tid);
-		__syncthreads();
 	}
 }
 
 __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 {
 	u8* tab = smem;
-	TrState& st = *(TrState*)(smem + TAB_LDS);
+	TrState& st = *(TrState*)(smem + TR_TAB_LDS);
 	__shared__ WorkList wl;
 	__shared__ u32 scanScratch[8];
 
-	stage_tables(tab, p.tables);
+	const Tables T = stage_transition_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
@@ -338,7 +377,6 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		wl.start[MAX_LEVELS] = run;
 	}
 	__syncthreads();
-	const Tables T{ tab };
 	const u32 total = wl.start[MAX_LEVELS];
 	const int tid = threadIdx.x;
 
@@ -414,8 +452,10 @@ struct Backend {
 		stream = ownStream;
 		hipEventCreate(&ev0);
 		hipEventCreate(&ev1);
-		const int regLds = (int)(TAB_LDS + sizeof(RegState)), trLds = (int)(TAB_LDS + sizeof(TrState));
-		if (!check(hipFuncSetAttribute((const void*)k_regular, hipFuncAttributeMaxDynamicSharedMemorySize, regLds), "hipFuncSetAttribute(k_regular)")
+		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
+		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
+		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")) {
 			err = lastError;
 			return false;
@@ -520,8 +560,9 @@ struct Backend {
 	{
 		u32 cap = 0;
 		for (u32 l = 0; l < levels; ++l) cap += p.levels[l].cap;
-		const u32 grid = std::min<u32>(cap, (u32)cus * 2);
-		hipLaunchKernelGGL(k_regular, dim3(grid), dim3(WG), TAB_LDS + sizeof(RegState), stream, dev(p), levels);
+		const u32 gridS = std::min<u32>(cap, (u32)cus * 5), gridL = std::min<u32>(cap, (u32)cus * 2);
+		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), stream, dev(p), levels, 0u);
+		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), stream, dev(p), levels, (u32)REG_CAP_SMALL);
 		check(hipGetLastError(), "k_regular launch");
 	}
 	template <typename P>
@@ -531,7 +572,7 @@ struct Backend {
 		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
 		if (!cap) return;
 		const u32 grid = std::min<u32>(cap, (u32)cus * 2);
-		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TAB_LDS + sizeof(TrState), stream, dev(p), levels);
+		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		check(hipGetLastError(), "k_transition launch");
 	}
 };

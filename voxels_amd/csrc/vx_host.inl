@@ -128,9 +128,10 @@ bool ensure_level_tables(vx_ctx* c)
 		d.ntBits = (u32*)alloc(cap * 512);
 		d.cache = L ? (u16*)alloc(cap * BLOCK_CELLS * 2) : nullptr;
 		d.skip = L ? nullptr : (u8*)alloc(cap);
+		d.ntCount = (u16*)alloc(cap * 2);
 		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
 		d.nActive = (u32*)c->dHeader + L;
-		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || (L && !d.cache) || (!L && !d.skip)) return false;
+		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1;
 	return true;
