@@ -10,7 +10,12 @@ struct Backend {
 	void shutdown() {}
 	void set_stream(void*) {}
 	std::string error() const { return lastError; }
-	void* alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+	void* alloc(size_t bytes)
+	{
+		void* p = malloc(bytes ? bytes : 1);
+		if (p) memset(p, 0xA5, bytes); // poison: device memory is not zeroed either
+		return p;
+	}
 	void free(void* p) { ::free(p); }
 	bool fill(void* p, int v, size_t bytes) { memset(p, v, bytes); return true; }
 	bool h2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
@@ -86,6 +91,7 @@ struct Backend {
 			stage_samples(p.G.grid, bx, by, bz, L.mult, st->samp, 0, 1);
 			memset(st->ntBits, 0, sizeof(st->ntBits));
 			mat_phase_classify(*st, 0, 1);
+			mat_phase_children(*st, p.levels, level, bx, by, bz, 0, 1);
 			mat_phase_vote(*st, p.G, p.levels, level, slot, bx, by, bz, 0, 1);
 		}
 		delete st;
@@ -102,11 +108,11 @@ struct Backend {
 			const LevelDesc& L = p.levels[level];
 			for (u32 slot = 0; slot < *L.nActive; ++slot) {
 				const u32 ntc = L.ntCount[slot];
-				if (ntc <= lo || ntc > (u32)CAP) continue;
+				if ((lo && ntc <= lo) || ntc > (u32)CAP) continue; // the first class (lo == 0) also owns empty blocks
 				RegBlockCtx b;
 				b.level = level; b.slot = slot; b.mult = L.mult;
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
-				if (level == 0 && L.skip[slot]) { reg_write_empty_record(L, slot); continue; }
+				if (ntc == 0 || (level == 0 && L.skip[slot])) { reg_write_empty_record(L, slot); continue; }
 				reg_phase_begin(*st, L, slot, 0, 1);
 				reg_phase_stage(*st, p.G, L, b, 0, 1);
 				for (int w = 0; w < 128; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);

@@ -91,6 +91,16 @@ def test_emu_synth_terrain_vs_port(emu, port):
     check(emu, port, d, m, b, "synth terrain 64")
 
 
+def test_emu_coarse_block_without_cells(emu, port):
+    """A bubble smaller than a level-1 cell makes its level-1 (and level-2) block surface-bearing (it contains
+    level-0 cells) although no coarse cell is non-trivial: such blocks must yield empty records, not stale data."""
+    n = 64
+    d = np.full((n, n, n), 4, np.int8)
+    d[21, 21, 21] = -3            # odd coordinates: invisible to every coarser sampling
+    zero = np.zeros((n, n, n), np.uint8)
+    check(emu, port, d, zero, zero, "bubble")
+
+
 def test_emu_level_limit(emu):
     gold = Golden("noise64_fullrange_mat")
     p = make_poly(emu)

@@ -114,6 +114,17 @@ def test_hip_degenerate_filter_at_coarse_levels(poly, port):
     check_against(poly, port, d, zero, zero, "zeros 256")
 
 
+def test_hip_coarse_block_without_cells(poly, port):
+    """Surface-bearing coarse blocks without any non-trivial coarse cell (regression: their record was left stale)."""
+    n = 64
+    d = np.full((n, n, n), 4, np.int8)
+    d[21, 21, 21] = -3
+    d[40:43, 9, 50] = -2
+    zero = np.zeros((n, n, n), np.uint8)
+    for _ in range(2):
+        check_against(poly, port, d, zero, zero, "bubble")
+
+
 def test_hip_white_noise_worst_case(poly, port):
     """Every cell non-trivial: 4096 non-trivial cells per block (maximum per-block state)."""
     rng = np.random.RandomState(7)
@@ -198,3 +209,18 @@ def test_hip_256_properties(poly, port):
         if len(l.verts):
             ln = np.linalg.norm(l.verts["nrm"], axis=1)
             assert np.all((np.abs(ln - 1) < 1e-4) | (ln == 0))
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_hip_bench_terrain_full_parity(poly, port, n):
+    """The bench workload itself (synthetic terrain, LOD levels 0..3) against the oracle port, every byte, twice
+    (pool offsets differ between runs, block contents must not)."""
+    from voxels_amd import synth
+    d, m, b = synth.terrain(n)
+    g = port.grid_from_dense(d, m, b)
+    ref = port.execute(g).all_levels()[:4]
+    poly.upload(d, m, b, g.block_flags())
+    for _ in range(2):
+        poly.execute(4)
+        ok, msg = fields.surface_equal(poly.all_levels(), ref, nrm_tol=NRM_TOL)
+        assert ok, msg

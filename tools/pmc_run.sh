@@ -1,0 +1,11 @@
+#!/bin/bash
+# Collect PMC counters for the bench kernels with rocprofv3 (counters in their own passes, kernel-trace only).
+# Usage (on the GPU box): bash tools/pmc_run.sh <outdir> "<counters pass 1>" "<counters pass 2>" ...
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=$1; shift
+i=0
+for c in "$@"; do
+  i=$((i+1))
+  rocprofv3 --pmc $c --kernel-trace -d "$out/pass$i" -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/pass$i.log" 2>&1
+  python tools/rocpd_summary.py "$out/pass$i/pmc_results.db" "$out/pass$i.txt" --pmc > /dev/null 2>&1 || echo "summary failed for pass $i"
+done

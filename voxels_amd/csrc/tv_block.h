@@ -127,7 +127,34 @@ TV_HD bool block_skipped_by_emptiness(const u8* emptyFlags, u32 cnt, u32 bx, u32
 struct MatState {
 	i8 samp[SAMPLES + 7];
 	u32 ntBits[128];
+	int childSlot[8];          // active slot of the 2x2x2 child blocks (level - 1), -1 = none / outside / skipped
+	u32 childBits[8][128];     // level 1 only: non-trivial bitmaps of the child blocks (the level-0 consistency cache)
 };
+
+// stage what the vote needs to know about the 8 child blocks
+TV_HD void mat_phase_children(MatState& st, const LevelDesc* levels, u32 level, u32 bx, u32 by, u32 bz, int tid, int nth)
+{
+	const LevelDesc& C = levels[level - 1];
+	for (int i = tid; i < 8; i += nth) {
+		const u32 cx = bx * 2 + (i & 1), cy = by * 2 + ((i >> 1) & 1), cz = bz * 2 + (i >> 2);
+		int slot = -1;
+		if (cx < C.cnt && cy < C.cnt && cz < C.cnt) slot = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
+		if (slot >= 0 && level == 1 && C.skip[slot]) slot = -1;
+		st.childSlot[i] = slot;
+	}
+	if (level == 1) {
+		for (int q = tid; q < 8 * 128; q += nth) {
+			const int i = q >> 7;
+			const u32 cx = bx * 2 + (i & 1), cy = by * 2 + ((i >> 1) & 1), cz = bz * 2 + (i >> 2);
+			u32 v = 0;
+			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) {
+				const int slot = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
+				if (slot >= 0 && !C.skip[slot]) v = C.ntBits[(size_t)slot * 128 + (q & 127)];
+			}
+			st.childBits[i][q & 127] = v;
+		}
+	}
+}
 
 TV_HD void mat_phase_classify(MatState& st, int tid, int nth)
 {
@@ -168,13 +195,25 @@ TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc*
                           u32 bx, u32 by, u32 bz, int tid, int nth)
 {
 	const LevelDesc& L = levels[level];
+	const LevelDesc& C = levels[level - 1];
 	u16* out = L.cache + (size_t)slot * BLOCK_CELLS;
 	for (int c = tid; c < BLOCK_CELLS; c += nth) {
 		const int lx = c & 15, ly = (c >> 4) & 15, lz = c >> 8;
 		u32 entry = EMPTY_MATINFO;
 		if (bit_get(st.ntBits, (u32)c) || cell_on_transition_face(L, bx, by, bz, lx, ly, lz)) {
-			const u32 gx = (bx * 16 + lx) * 2, gy = (by * 16 + ly) * 2, gz = (bz * 16 + lz) * 2;
-			entry = vote_material([&](u32 i) { return child_entry(G, levels, level - 1, gx + (i & 1), gy + ((i >> 1) & 1), gz + (i >> 2)); });
+			// child cell (dx,dy,dz) of this cell lives in child block ((2l+d) >> 4) at local (2l+d) & 15
+			entry = vote_material([&](u32 i) -> u32 {
+				const u32 ccx = (u32)lx * 2 + (i & 1), ccy = (u32)ly * 2 + ((i >> 1) & 1), ccz = (u32)lz * 2 + (i >> 2);
+				const u32 cb = (ccx >> 4) | ((ccy >> 4) << 1) | ((ccz >> 4) << 2);
+				const int cslot = st.childSlot[cb];
+				if (cslot < 0) return EMPTY_MATINFO;
+				const u32 local = ((ccz & 15) << 8) | ((ccy & 15) << 4) | (ccx & 15);
+				if (level == 1) {
+					if (!bit_get(st.childBits[cb], local)) return EMPTY_MATINFO;
+					return mat_at(G.grid, (int)((bx * 16 + lx) * 2 + (i & 1)), (int)((by * 16 + ly) * 2 + ((i >> 1) & 1)), (int)((bz * 16 + lz) * 2 + (i >> 2)));
+				}
+				return C.cache[(size_t)cslot * BLOCK_CELLS + local];
+			});
 		}
 		out[c] = (u16)entry;
 	}

@@ -87,6 +87,58 @@ __device__ __forceinline__ void stage_tables(u8* dst, const u8* src)
 	for (u32 i = threadIdx.x; i < TAB_BYTES / 16; i += WG) d[i] = s[i];
 }
 
+// Gather COUNT elements with 256 threads so that ALL loads of a thread are in flight before the first use: the
+// plain "for (q = tid; q < COUNT; q += 256) lds[q] = load(q)" form is compiled into one dependent round trip per
+// iteration (load, s_waitcnt, ds_write), which made every staging loop latency-bound.
+template <int COUNT, typename T, int BATCH, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void batched_gather(LoadFn load, StoreFn store)
+{
+	constexpr int ITER = (COUNT + WG - 1) / WG;
+#pragma unroll 1
+	for (int i0 = 0; i0 < ITER; i0 += BATCH) {
+		T v[BATCH];
+#pragma unroll
+		for (int i = 0; i < BATCH; ++i) {
+			const int q = (int)threadIdx.x + (i0 + i) * WG;
+			if (q < COUNT) v[i] = load(q);
+		}
+#pragma unroll
+		for (int i = 0; i < BATCH; ++i) {
+			const int q = (int)threadIdx.x + (i0 + i) * WG;
+			if (q < COUNT) store(q, v[i]);
+		}
+	}
+}
+
+// GPU forms of the staging phases of tv_block.h (same results, batched loads)
+__device__ __forceinline__ void gpu_stage_samples17(const GridView& g, u32 bx, u32 by, u32 bz, u32 mult, i8* samp)
+{
+	batched_gather<SAMPLES, i8, 5>(
+		[&](int s) { const int i = s % 17, j = (s / 17) % 17, k = s / 289;
+		             return (i8)dist_at(g, (int)((bx * 16 + i) * mult), (int)((by * 16 + j) * mult), (int)((bz * 16 + k) * mult)); },
+		[&](int s, i8 v) { samp[s] = v; });
+}
+
+__device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockCtx& b, i8* samp)
+{
+	if (b.level == 0) {
+		const int n = g.n, gx0 = (int)b.bx * 16 - 4;
+		batched_gather<361 * 6, u32, 3>(
+			[&](int q) { const int r = q / 6, j = q - r * 6, jj = r % 19, kk = r / 19;
+			             const int y = clampi((int)b.by * 16 + jj - 1, 0, n - 1);
+			             const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
+			             const int x = clampi(gx0 + 4 * j, 0, n - 4);
+			             return *(const u32*)(g.dist + ((size_t)z * n + y) * n + x); },
+			[&](int q, u32 v) { const int r = q / 6, j = q - r * 6, jj = r % 19, kk = r / 19;
+			                    *(u32*)(samp + kk * SPLANE + jj * SROW + 4 * j) = v; });
+	} else {
+		batched_gather<SAMPLES, i8, 5>(
+			[&](int s) { const int i = s % 17, j = (s / 17) % 17, k = s / 289;
+			             return (i8)dist_at(g, (int)((b.bx * 16 + i) * b.mult), (int)((b.by * 16 + j) * b.mult), (int)((b.bz * 16 + k) * b.mult)); },
+			[&](int s, i8 v) { const int i = s % 17, j = (s / 17) % 17, k = s / 289; samp[samp_index(i, j, k)] = v; });
+	}
+}
+
 // ------------------------------------------------------------------------------------------------------
 // k_classify
 // ------------------------------------------------------------------------------------------------------
@@ -113,19 +165,23 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 
 	if (tid < 8) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; }
 
-	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line) ----------
-	for (int q = tid; q < 289 * 8; q += WG) {
-		const int r = q >> 3, seg = q & 7;
-		const int ry = r % 17, rz = r / 17;
-		u32 m = 0;
-		if (seg * 16 < validCells) {
-			const int y = clampi((int)by * 16 + ry, 0, n - 1);
-			const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
-			const uint4 d = *(const uint4*)(g.dist + ((size_t)z * n + y) * n + x0 + seg * 16);
-			m = sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12);
-		}
-		sgn[q] = (u16)m;
-	}
+	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line); all ten loads
+	//      of a thread are issued before the first sign mask is formed ----------------------------------------
+	batched_gather<289 * 8, uint4, 5>(
+		[&](int q) {
+			const int r = q >> 3, seg = q & 7;
+			const int ry = r % 17, rz = r / 17;
+			uint4 d = make_uint4(0, 0, 0, 0);
+			if (seg * 16 < validCells) {
+				const int y = clampi((int)by * 16 + ry, 0, n - 1);
+				const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
+				d = *(const uint4*)(g.dist + ((size_t)z * n + y) * n + x0 + seg * 16);
+			}
+			return d;
+		},
+		[&](int q, uint4 d) {
+			sgn[q] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
+		});
 	for (int r = tid; r < 289; r += WG) {
 		const int ry = r % 17, rz = r / 17;
 		const int y = clampi((int)by * 16 + ry, 0, n - 1);
@@ -217,17 +273,31 @@ __global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
 {
 	__shared__ MatState st;
 	const LevelDesc& L = p.levels[level];
+	const LevelDesc& C = p.levels[level - 1];
 	const u32 nAct = *L.nActive;
+	const int tid = threadIdx.x;
 	for (u32 slot = blockIdx.x; slot < nAct; slot += gridDim.x) {
 		u32 bx, by, bz;
 		block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
-		stage_samples(p.G.grid, bx, by, bz, L.mult, st.samp, threadIdx.x, WG);
-		for (int w = threadIdx.x; w < 128; w += WG) st.ntBits[w] = 0;
 		__syncthreads();
-		mat_phase_classify(st, threadIdx.x, WG);
+		gpu_stage_samples17(p.G.grid, bx, by, bz, L.mult, st.samp);
+		for (int w = tid; w < 128; w += WG) st.ntBits[w] = 0;
+		if (tid < 8) {
+			const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
+			int cs = -1;
+			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) cs = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
+			if (cs >= 0 && level == 1 && C.skip[cs]) cs = -1;
+			st.childSlot[tid] = cs;
+		}
 		__syncthreads();
-		mat_phase_vote(st, p.G, p.levels, level, slot, bx, by, bz, threadIdx.x, WG);
+		if (level == 1) {
+			batched_gather<8 * 128, u32, 4>(
+				[&](int q) { const int cs = st.childSlot[q >> 7]; return cs >= 0 ? C.ntBits[(size_t)cs * 128 + (q & 127)] : 0u; },
+				[&](int q, u32 v) { st.childBits[q >> 7][q & 127] = v; });
+		}
+		mat_phase_classify(st, tid, WG);
 		__syncthreads();
+		mat_phase_vote(st, p.G, p.levels, level, slot, bx, by, bz, tid, WG);
 	}
 }
 
@@ -304,16 +374,16 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 		decode_item(wl, levels, item, b.level, b.slot);
 		const LevelDesc& L = p.levels[b.level];
 		const u32 ntc = L.ntCount[b.slot];
-		if (ntc <= lo || ntc > (u32)CAP) continue;
+		if ((lo && ntc <= lo) || ntc > (u32)CAP) continue;   // the first class (lo == 0) also owns empty blocks
 		b.mult = L.mult;
 		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
-		if (b.level == 0 && L.skip[b.slot]) {
+		if (ntc == 0 || (b.level == 0 && L.skip[b.slot])) {
 			if (tid == 0) reg_write_empty_record(L, b.slot);
 			continue;
 		}
 		__syncthreads();
 		reg_phase_begin(st, L, b.slot, tid, WG);
-		reg_phase_stage(st, p.G, L, b, tid, WG);
+		gpu_reg_stage(p.G.grid, b, st.samp);
 		__syncthreads();
 		if (lim == 1) continue;
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
@@ -389,7 +459,31 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		b.mult = L.mult;
 		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
 
-		tr_phase_load(st, p.G, L, b, tid, WG);
+		{
+			u32 on = 0;
+			const u32 bc[3] = { b.bx, b.by, b.bz };
+			for (int f = 0; f < 6; ++f) {
+				const FaceGeom fg = face_geom(f);
+				if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
+			}
+			__syncthreads();
+			if (tid == 0) st.faceOn = on;
+			for (int w = tid; w < 48; w += WG) st.ntBits[w] = 0;
+			const int half = (int)b.mult >> 1;
+			const GridView& g = p.G.grid;
+			batched_gather<6 * PLANE, i8, 5>(
+				[&](int s) -> i8 {
+					const int f = s / PLANE, r = s - f * PLANE;
+					if (!((on >> f) & 1u)) return 0;
+					const FaceGeom fg = face_geom(f);
+					int q[3];
+					q[fg.ua] = (int)(bc[fg.ua] * 16 * b.mult) + (r % 33) * half;
+					q[fg.va] = (int)(bc[fg.va] * 16 * b.mult) + (r / 33) * half;
+					q[fg.axis] = (int)((bc[fg.axis] * 16 + (fg.positive ? 16 : 0)) * b.mult);
+					return (i8)dist_at(g, q[0], q[1], q[2]);
+				},
+				[&](int s, i8 v) { const int f = s / PLANE, r = s - f * PLANE; st.plane[f][r] = v; });
+		}
 		__syncthreads();
 		tr_phase_classify(st, tid, WG);
 		__syncthreads();
@@ -450,8 +544,8 @@ struct Backend {
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
 		stream = ownStream;
-		hipEventCreate(&ev0);
-		hipEventCreate(&ev1);
+		(void)hipEventCreate(&ev0);
+		(void)hipEventCreate(&ev1);
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
 		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
@@ -464,10 +558,10 @@ struct Backend {
 	}
 	void shutdown()
 	{
-		if (ev0) hipEventDestroy(ev0);
-		if (ev1) hipEventDestroy(ev1);
-		for (int i = 0; i < 7; ++i) if (stageEv[i]) hipEventDestroy(stageEv[i]);
-		if (ownStream) hipStreamDestroy(ownStream);
+		if (ev0) (void)hipEventDestroy(ev0);
+		if (ev1) (void)hipEventDestroy(ev1);
+		for (int i = 0; i < 7; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
+		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
 	std::string error() const { return lastError; }
@@ -477,7 +571,7 @@ struct Backend {
 		if (!check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
 		return p;
 	}
-	void free(void* p) { if (p) hipFree(p); }
+	void free(void* p) { if (p) (void)hipFree(p); }
 	bool fill(void* p, int v, size_t bytes) { return check(hipMemsetAsync(p, v, bytes, stream), "hipMemsetAsync"); }
 	bool h2d(void* d, const void* s, size_t bytes)
 	{
@@ -489,33 +583,33 @@ struct Backend {
 		return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")
 		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
-	void sync() { hipStreamSynchronize(stream); }
+	void sync() { (void)hipStreamSynchronize(stream); }
 	void stage_enable(bool on)
 	{
 		stageOn = on;
 		stageValid = false;
-		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i]) hipEventCreate(&stageEv[i]);
+		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i]) (void)hipEventCreate(&stageEv[i]);
 	}
 	void stage_mark(int i)
 	{
 		if (!stageOn) return;
-		hipEventRecord(stageEv[i], stream);
+		(void)hipEventRecord(stageEv[i], stream);
 		if (i == 6) stageValid = true;
 	}
 	bool stage_ms(float* ms)
 	{
 		if (!stageOn || !stageValid) return false;
 		if (hipEventSynchronize(stageEv[6]) != hipSuccess) return false;
-		for (int i = 0; i < 6; ++i) { ms[i] = 0.f; hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
+		for (int i = 0; i < 6; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
 		return true;
 	}
-	void begin_timing() { hipEventRecord(ev0, stream); }
+	void begin_timing() { (void)hipEventRecord(ev0, stream); }
 	float end_timing_ms()
 	{
-		hipEventRecord(ev1, stream);
+		(void)hipEventRecord(ev1, stream);
 		if (hipEventSynchronize(ev1) != hipSuccess) return -1.f;
 		float ms = 0.f;
-		hipEventElapsedTime(&ms, ev0, ev1);
+		(void)hipEventElapsedTime(&ms, ev0, ev1);
 		return ms;
 	}
 
