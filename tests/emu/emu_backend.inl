@@ -27,6 +27,23 @@ struct Backend {
 	void stage_mark(int) {}
 	bool stage_ms(float*) { return false; }
 
+	// classification of one level-0 block (portable form of k_classify)
+	template <typename P>
+	static void classify_block(const P& p, u32 bx, u32 by, u32 bz, bool accumulate, std::vector<i8>& samp)
+	{
+		stage_samples(p.G.grid, bx, by, bz, 1, samp.data(), 0, 1);
+		u32 bits[128];
+		memset(bits, 0, sizeof(bits));
+		u32 cnt = 0;
+		for (int c = 0; c < BLOCK_CELLS; ++c) {
+			i8 V[8];
+			cell_values(samp.data(), c & 15, (c >> 4) & 15, c >> 8, V);
+			const u32 code = reg_case_code(V);
+			if (code != 0 && code != 255) { bits[c >> 5] |= 1u << (c & 31); ++cnt; }
+		}
+		publish_level0_block(p.G, p.levels[0], bx, by, bz, bits, cnt, accumulate);
+	}
+
 	template <typename P>
 	void run_classify(const P& p)
 	{
@@ -34,31 +51,45 @@ struct Backend {
 		std::vector<i8> samp(SAMPLES + 7);
 		for (u32 bz = L.zb0; bz < L.zb1; ++bz)
 		for (u32 by = 0; by < L.cnt; ++by)
-		for (u32 bx = 0; bx < L.cnt; ++bx) {
-			const bool skipped = block_skipped_by_emptiness(p.G.emptyFlags, L.cnt, bx, by, bz);
-			if (!skipped) ++p.G.stats[2];
-			stage_samples(p.G.grid, bx, by, bz, 1, samp.data(), 0, 1);
-			u32 bits[128];
-			memset(bits, 0, sizeof(bits));
-			bool any = false;
-			for (int c = 0; c < BLOCK_CELLS; ++c) {
-				i8 V[8];
-				cell_values(samp.data(), c & 15, (c >> 4) & 15, c >> 8, V);
-				const u32 code = reg_case_code(V);
-				if (code != 0 && code != 255) { bits[c >> 5] |= 1u << (c & 31); any = true; }
-			}
-			if (!any) continue;
-			const u32 slot = (*L.nActive)++;
-			const u32 id = block_coord_id(bx, by, bz, L.cnt);
-			L.slotOf[id] = (int)slot;
-			L.slotCoord[slot] = id;
-			L.skip[slot] = skipped ? 1 : 0;
-			memcpy(L.ntBits + (size_t)slot * 128, bits, sizeof(bits));
-			u32 cnt = 0;
-			for (int w = 0; w < 128; ++w) cnt += (u32)TV_POPC(bits[w]);
-			L.ntCount[slot] = (u16)cnt;
+		for (u32 bx = 0; bx < L.cnt; ++bx) classify_block(p, bx, by, bz, false, samp);
+	}
+
+	template <typename P>
+	void run_classify_blocks(const P& p, const u32* coords, u32 count)
+	{
+		const LevelDesc& L = p.levels[0];
+		std::vector<i8> samp(SAMPLES + 7);
+		for (u32 k = 0; k < count; ++k) {
+			u32 bx, by, bz;
+			block_coords(coords[k], L.cnt, bx, by, bz);
+			classify_block(p, bx, by, bz, true, samp);
 		}
 	}
+
+	template <typename P>
+	void run_build_worklist(const P& p, const u32* coords, const u32* start, const u32* cnt, u32 levels, u32* work)
+	{
+		for (u32 l = 0; l < levels; ++l) {
+			const LevelDesc& L = p.levels[l];
+			for (u32 k = 0; k < cnt[l]; ++k) {
+				const int slot = L.slotOf[coords[start[l] + k]];
+				if (slot >= 0) work[start[l] + p.G.workCount[l]++] = (u32)slot;
+			}
+		}
+	}
+
+	template <typename P>
+	void run_gather_records(const P& p, u32 levels, const u32* start, BlockRecord* out)
+	{
+		for (u32 l = 0; l < levels; ++l)
+			for (u32 i = 0; i < p.G.workCount[l]; ++i) out[start[l] + i] = p.levels[l].records[p.G.workItems[l][i]];
+	}
+
+	// slots to process on a level: all of them (full run) or the work list (incremental run)
+	template <typename P>
+	static u32 item_count(const P& p, u32 level) { return p.G.dirty ? p.G.workCount[level] : *p.levels[level].nActive; }
+	template <typename P>
+	static u32 item_slot(const P& p, u32 level, u32 i) { return p.G.dirty ? p.G.workItems[level][i] : i; }
 
 	template <typename P>
 	void run_hierarchy(const P& p, u32 levels)
@@ -85,7 +116,8 @@ struct Backend {
 	{
 		const LevelDesc& L = p.levels[level];
 		MatState* st = new MatState;
-		for (u32 slot = 0; slot < *L.nActive; ++slot) {
+		for (u32 it = 0; it < item_count(p, level); ++it) {
+			const u32 slot = item_slot(p, level, it);
 			u32 bx, by, bz;
 			block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
 			stage_samples(p.G.grid, bx, by, bz, L.mult, st->samp, 0, 1);
@@ -106,7 +138,8 @@ struct Backend {
 		ST* st = new ST;
 		for (u32 level = 0; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];
-			for (u32 slot = 0; slot < *L.nActive; ++slot) {
+			for (u32 it = 0; it < item_count(p, level); ++it) {
+				const u32 slot = item_slot(p, level, it);
 				const u32 ntc = L.ntCount[slot];
 				if ((lo && ntc <= lo) || ntc > (u32)CAP) continue; // the first class (lo == 0) also owns empty blocks
 				RegBlockCtx b;
@@ -151,7 +184,8 @@ struct Backend {
 		for (u32 level = 1; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];
 			if (!L.hasTransitions) continue;
-			for (u32 slot = 0; slot < *L.nActive; ++slot) {
+			for (u32 it = 0; it < item_count(p, level); ++it) {
+				const u32 slot = item_slot(p, level, it);
 				RegBlockCtx b;
 				b.level = level; b.slot = slot; b.mult = L.mult;
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);

@@ -91,3 +91,21 @@ def surface_equal(a_levels, b_levels, nrm_tol=0.0):
                 if err > nrm_tol:
                     return False, "L%d %s.nrm max err %g" % (li, kind, err)
     return True, "ok"
+
+
+def edited_blocks(pre, post):
+    """ids + data of the 16^3 blocks that differ between two dense grids (what Grid edits hand to the device)."""
+    n = pre[0].shape[0]
+    nb = n // 16
+    diff = np.zeros((n, n, n), bool)
+    for a, b in zip(pre, post):
+        diff |= a != b
+    blk = diff.reshape(nb, 16, nb, 16, nb, 16).any(axis=(1, 3, 5))
+    ids = np.flatnonzero(blk.ravel()).astype(np.uint32)
+    out = []
+    for arr in post:
+        v = arr.reshape(nb, 16, nb, 16, nb, 16).transpose(0, 2, 4, 1, 3, 5).reshape(nb ** 3, 4096)
+        out.append(np.ascontiguousarray(v[ids]))
+    return ids, out
+
+

@@ -157,3 +157,47 @@ def test_emu_z_slabs_union_equals_whole(emu):
     ok, msg = fields.surface_equal(merge_rank_levels(parts), ref_levels)
     assert ok, msg
     assert np.array_equal(stats.astype(np.uint32), ref_stats)
+
+
+def test_emu_carve_modify_matches_reference_fixture(emu):
+    """Config 5 in small: full run, sphere carve (Grid::InjectSurface result taken from the fixture), incremental
+    re-polygonization of the dirty box — against the reference's own Modification run."""
+    gold = Golden("terrain64_carve_modify")
+    p = make_poly(emu)
+    port = vxo.load_port()
+    pre = (gold["pre_dist"], gold["pre_mat"], gold["pre_blend"])
+    p.upload(*pre, port.grid_from_dense(*pre).block_flags())
+    p.execute()
+    ids, (d, m, b) = fields.edited_blocks(pre, (gold.dist, gold.mat, gold.blend))
+    p.update_blocks(ids, d.view(np.int8), m, b, gold.flags)
+    mod = p.execute_dirty(gold["box_min"], gold["box_max"])
+    assert np.array_equal(mod, gold["modified_ids"])
+    ok, msg = fields.surface_equal(p.all_levels(), gold.levels)
+    assert ok, msg
+    assert np.array_equal(p.stats(), gold.stats)
+
+
+def test_emu_repeated_edits_vs_port(emu, port):
+    """Several edits in a row (carve, add, carve at a grid corner): caches persist across incremental runs."""
+    n = 64
+    f = fields.terrain_field(n, 9)
+    m, b = fields.materials_for(n, 9)
+    g = port.grid_from_float(f, m, b)
+    s = port.execute(g)
+    p = make_poly(emu)
+    pre = g.read_dense()
+    p.upload(*pre, g.block_flags())
+    p.execute()
+    for t, pos, ext, r in ((2, (30.0, 33.5, 31.25), (20, 20, 20), 7.0), (0, (40, 20, 25), (16, 16, 16), 6.0),
+                           (2, (3.0, 60.0, 30.0), (12, 12, 12), 5.0), (2, (31.0, 33.0, 31.0), (10, 10, 10), 4.0)):
+        mn, mx = g.inject_ball(pos, ext, r, t)
+        ref_ids = port.execute_modify(g, s, mn, mx)
+        post = g.read_dense()
+        ids, (dd, mm, bb) = fields.edited_blocks(pre, post)
+        p.update_blocks(ids, dd.view(np.int8), mm, bb, g.block_flags())
+        pre = post
+        got = p.execute_dirty(mn, mx)
+        assert np.array_equal(got, ref_ids)
+        ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+        assert ok, msg
+        assert np.array_equal(p.stats(), s.stats())

@@ -224,3 +224,45 @@ def test_hip_bench_terrain_full_parity(poly, port, n):
         poly.execute(4)
         ok, msg = fields.surface_equal(poly.all_levels(), ref, nrm_tol=NRM_TOL)
         assert ok, msg
+
+
+def test_hip_carve_modify_matches_reference_fixture(poly, port):
+    """Config 5 in small (reference fixture): full run, sphere carve, incremental re-polygonization of the dirty box."""
+    gold = Golden("terrain64_carve_modify")
+    pre = (gold["pre_dist"], gold["pre_mat"], gold["pre_blend"])
+    poly.upload(*pre, port.grid_from_dense(*pre).block_flags())
+    poly.execute()
+    ids, (d, m, b) = fields.edited_blocks(pre, (gold.dist, gold.mat, gold.blend))
+    poly.update_blocks(ids, d.view(np.int8), m, b, gold.flags)
+    mod = poly.execute_dirty(gold["box_min"], gold["box_max"])
+    assert np.array_equal(mod, gold["modified_ids"])
+    ok, msg = fields.surface_equal(poly.all_levels(), gold.levels, nrm_tol=NRM_TOL)
+    assert ok, msg
+    assert np.array_equal(poly.stats(), gold.stats)
+
+
+@pytest.mark.parametrize("n", [64, 256])
+def test_hip_repeated_edits_vs_port(poly, port, n):
+    """Chained edits with incremental runs: device-resident caches persist like the reference's PolygonMap caches."""
+    from voxels_amd import synth
+    d0, m0, b0 = synth.terrain(n, seed=21)
+    g = port.grid_from_dense(d0, m0, b0)
+    s = port.execute(g)
+    pre = g.read_dense()
+    poly.upload(*pre, g.block_flags())
+    poly.execute()
+    c = n / 2.0
+    edits = ((2, (c - 2.0, c + 1.5, c - 0.75), (20, 20, 20), 7.0), (0, (c + 8, c - 12, c - 7), (16, 16, 16), 6.0),
+             (2, (3.0, n - 4.0, c - 2), (12, 12, 12), 5.0), (2, (c - 1.0, c + 1.0, c - 1.0), (10, 10, 10), 4.0))
+    for t, pos, ext, r in edits:
+        mn, mx = g.inject_ball(pos, ext, r, t)
+        ref_ids = port.execute_modify(g, s, mn, mx)
+        post = g.read_dense()
+        ids, (dd, mm, bb) = fields.edited_blocks(pre, post)
+        poly.update_blocks(ids, dd.view(np.int8), mm, bb, g.block_flags())
+        pre = post
+        got = poly.execute_dirty(mn, mx)
+        assert np.array_equal(got, ref_ids)
+        ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+        assert ok, msg
+        assert np.array_equal(poly.stats(), s.stats())

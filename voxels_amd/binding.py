@@ -147,6 +147,20 @@ class Polygonizer:
         self.info = info
         return info
 
+    def execute_dirty(self, min_corner, max_corner):
+        """Polygonizer::Execute with a Modification: re-polygonize the dirty box (output, Y-up, coordinates).
+        Returns the ids of the rebuilt blocks (Modification::GetModifiedBlocks)."""
+        mn = np.ascontiguousarray(min_corner, np.float32)
+        mx = np.ascontiguousarray(max_corner, np.float32)
+        info = ExecInfo()
+        cap = 1 << 20
+        ids = np.zeros(cap, np.uint32)
+        cnt = C.c_uint32()
+        self._check(self._lib.vx_polygonize_dirty(self._h, _ptr(mn), _ptr(mx), C.byref(info), _ptr(ids), cap, C.byref(cnt)),
+                    "vx_polygonize_dirty")
+        self.info = info
+        return ids[:cnt.value].copy()
+
     def level(self, lvl, with_data=True):
         nb = C.c_uint32()
         tot = np.zeros(4, np.uint64)

@@ -48,7 +48,9 @@ struct LevelDesc {
 	int* slotOf;        // [cnt^3] block coordinate id -> active slot, -1 = none
 	u32* slotCoord;     // [cap] slot -> coordinate id
 	u32* nActive;       // number of slots in use
-	u32* ntBits;        // [cap][128] non-trivial cell bitmap of the block
+	u32* ntBits;        // [cap][128] non-trivial cell bitmap of the block (current geometry)
+	u32* consBits;      // level 0: [cap][128] the reference's Level0ConsistencyCache: bits of every cell that was ever
+	                    //          polygonized as non-trivial (only set, never cleared, TransVoxelImpl.cpp:757)
 	u16* cache;         // [cap][4096] per-cell material cache (levels >= 1)
 	u8* skip;           // [cap] level 0: block skipped by the emptiness rule
 	u16* ntCount;       // [cap] number of non-trivial cells of the block (picks the LDS capacity class)
@@ -74,6 +76,11 @@ struct Globals {
 	u32 levels;             // number of levels being polygonized (0..levels-1)
 	u32 refLevels;          // the reference's levelsCount = log2(N/16)+1 (decides which levels get transitions)
 	u32 debugPhaseLimit;    // profiling aid: stop the per-block pipeline after this phase (0 = run everything)
+	// incremental (Modification) runs: only the listed blocks are re-polygonized, caches keep their old contents
+	u32 dirty;                        // 0 = full run
+	const u32* workItems[MAX_LEVELS]; // dirty: active slots to process per level
+	u32* workCount;                   // dirty: [MAX_LEVELS] number of items per level
+	u32 prevActive[MAX_LEVELS];       // dirty: slots >= prevActive[level] were created by this run
 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
@@ -121,6 +128,33 @@ TV_HD bool block_skipped_by_emptiness(const u8* emptyFlags, u32 cnt, u32 bx, u32
 	return true;
 }
 
+// Publish the classification of one level-0 block: slot (existing, or new when the block has non-trivial cells),
+// current bitmap, emptiness-skip flag, accumulated consistency bits.  `bits` = 128 words, one caller per block.
+TV_HD void publish_level0_block(const Globals& G, const LevelDesc& L, u32 bx, u32 by, u32 bz, const u32* bits, u32 ntCells, bool accumulate)
+{
+	const bool skipped = block_skipped_by_emptiness(G.emptyFlags, L.cnt, bx, by, bz);
+	if (!skipped) TV_ATOMIC_ADD(&G.stats[2], 1u);
+	const u32 id = block_coord_id(bx, by, bz, L.cnt);
+	int slot = L.slotOf[id];
+	bool fresh = false;
+	if (slot < 0) {
+		if (!ntCells) return;
+		slot = (int)TV_ATOMIC_ADD(L.nActive, 1u);
+		L.slotOf[id] = slot;
+		L.slotCoord[slot] = id;
+		fresh = true;
+	}
+	L.skip[slot] = skipped ? 1 : 0;
+	L.ntCount[slot] = (u16)ntCells;
+	u32* nt = L.ntBits + (size_t)slot * 128;
+	u32* cons = L.consBits + (size_t)slot * 128;
+	for (int w = 0; w < 128; ++w) {
+		nt[w] = bits[w];
+		const u32 add = skipped ? 0u : bits[w];
+		cons[w] = (accumulate && !fresh) ? (cons[w] | add) : add;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Material pass state (levels >= 1)
 // ---------------------------------------------------------------------------------------------------------
@@ -139,7 +173,6 @@ TV_HD void mat_phase_children(MatState& st, const LevelDesc* levels, u32 level, 
 		const u32 cx = bx * 2 + (i & 1), cy = by * 2 + ((i >> 1) & 1), cz = bz * 2 + (i >> 2);
 		int slot = -1;
 		if (cx < C.cnt && cy < C.cnt && cz < C.cnt) slot = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
-		if (slot >= 0 && level == 1 && C.skip[slot]) slot = -1;
 		st.childSlot[i] = slot;
 	}
 	if (level == 1) {
@@ -149,7 +182,7 @@ TV_HD void mat_phase_children(MatState& st, const LevelDesc* levels, u32 level, 
 			u32 v = 0;
 			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) {
 				const int slot = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
-				if (slot >= 0 && !C.skip[slot]) v = C.ntBits[(size_t)slot * 128 + (q & 127)];
+				if (slot >= 0) v = C.consBits[(size_t)slot * 128 + (q & 127)];
 			}
 			st.childBits[i][q & 127] = v;
 		}
@@ -164,23 +197,6 @@ TV_HD void mat_phase_classify(MatState& st, int tid, int nth)
 		const u32 code = reg_case_code(V);
 		if (code != 0 && code != 255) TV_ATOMIC_OR(&st.ntBits[c >> 5], 1u << (c & 31));
 	}
-}
-
-// entry of the level-(L-1) cache / level-0 consistency for one child cell, id 255 = none
-TV_HD u32 child_entry(const Globals& G, const LevelDesc* levels, u32 childLevel, u32 ccx, u32 ccy, u32 ccz)
-{
-	const LevelDesc& C = levels[childLevel];
-	const u32 bx = ccx >> 4, by = ccy >> 4, bz = ccz >> 4;
-	if (bx >= C.cnt || by >= C.cnt || bz >= C.cnt) return EMPTY_MATINFO;
-	const int slot = C.slotOf[block_coord_id(bx, by, bz, C.cnt)];
-	if (slot < 0) return EMPTY_MATINFO;
-	const u32 local = ((ccz & 15) << 8) | ((ccy & 15) << 4) | (ccx & 15);
-	if (childLevel == 0) {
-		if (C.skip[slot]) return EMPTY_MATINFO;
-		if (!bit_get(C.ntBits + (size_t)slot * 128, local)) return EMPTY_MATINFO;
-		return mat_at(G.grid, (int)ccx, (int)ccy, (int)ccz);
-	}
-	return C.cache[(size_t)slot * BLOCK_CELLS + local];
 }
 
 // does the transition pass of this block visit cell (lx,ly,lz)?  (boundary cell on a face with a neighbour block)
@@ -215,7 +231,10 @@ TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc*
 				return C.cache[(size_t)cslot * BLOCK_CELLS + local];
 			});
 		}
-		out[c] = (u16)entry;
+		// full run / slot created by this run: every entry is defined (EMPTY when no vote applies); incremental run
+		// on an existing slot: the reference only overwrites an entry when the vote finds a child (:829-837)
+		if (!G.dirty || slot >= G.prevActive[level]) out[c] = (u16)entry;
+		else if (entry != EMPTY_MATINFO) out[c] = (u16)entry;
 	}
 	u32* bitsOut = L.ntBits + (size_t)slot * 128;
 	for (int w = tid; w < 128; w += nth) bitsOut[w] = st.ntBits[w];

@@ -1,0 +1,420 @@
+// vx_api_cpp.cpp — libVoxels.so: the reference's public C++ API (include/Voxels.h) implemented on the host and
+// backed by the HIP kernels of libvoxels_hip.so through the C ABI (include/voxels_hip.h).
+//
+// Replaces (by interface, not by code):
+//   Grid::* forwarding            reference src/VoxelGrid.cpp:755-919      -> Voxels::VoxelGrid (vx_grid_host.cpp)
+//   Polygonizer::Execute          reference src/TransVoxelImpl.cpp:74-79   -> vx_grid_upload/update + vx_polygonize[_dirty]
+//   PolygonMap / PolygonBlock     reference src/TransVoxelImpl.h:33-142    -> SurfaceImpl / BlockImpl below (host copies of
+//                                                                             the meshes the kernels wrote to the device pools)
+//   Initialize/DeinitializeVoxels reference src/Voxels.cpp:35-76
+// There is no CPU polygonizer here: without a HIP device Execute logs an error and returns nullptr.
+#include "../../include/Voxels.h"
+#include "../../include/voxels_hip.h"
+#include "vx_grid_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace Voxels
+{
+
+static_assert(sizeof(PolygonVertex) == 48, "PolygonVertex must stay 48 bytes (include/Polygonizer.h of the reference)");
+static_assert(sizeof(PolygonVertex) == sizeof(vx_vertex), "C ABI vertex layout");
+
+namespace
+{
+LogMessage g_Logger = nullptr;
+bool g_Initialized = false;
+
+void Log(LogSeverity s, const char* msg)
+{
+	if (g_Logger) g_Logger(s, msg);
+}
+} // namespace
+
+const unsigned PolygonSurface::INVALID_ID = 0xFFFFFFFF;
+
+// ------------------------------------------------------------------------------------------------ Grid
+Grid::Grid(VoxelGrid* impl) : m_InternalGrid(impl) {}
+Grid::~Grid() { delete m_InternalGrid; }
+
+static bool CubeOfBlocks(unsigned w, unsigned d, unsigned h)
+{
+	// like the reference, only cubes work (VoxelGrid.cpp:103, TransVoxelImpl.cpp:490); unlike it we say so
+	if (w == d && d == h && w >= 16 && (w % 16) == 0) return true;
+	Log(LS_Error, "Grid: only cubic grids with an edge that is a multiple of 16 are supported");
+	return false;
+}
+
+Grid* Grid::Create(unsigned w, unsigned d, unsigned h, float startX, float startY, float startZ, float step, VoxelSurface* surface)
+{
+	if (!CubeOfBlocks(w, d, h) || !surface) return nullptr;
+	return new Grid(VoxelGrid::FromSurface(w, startX, startY, startZ, step, surface));
+}
+
+Grid* Grid::Create(unsigned w, unsigned d, unsigned h)
+{
+	if (!CubeOfBlocks(w, d, h)) return nullptr;
+	return new Grid(new VoxelGrid(w));
+}
+
+Grid* Grid::Create(unsigned w, const char* heightmap)
+{
+	if (!CubeOfBlocks(w, w, w) || !heightmap) return nullptr;
+	return new Grid(VoxelGrid::FromHeightmap(w, heightmap));
+}
+
+Grid* Grid::Load(const char* blob, unsigned)
+{
+	VoxelGrid* g = blob ? VoxelGrid::Load(blob) : nullptr;
+	if (!g) { Log(LS_Error, "Voxel grid file version not supported!"); return nullptr; }
+	return new Grid(g);
+}
+
+void Grid::Destroy() { delete this; }
+
+namespace
+{
+struct PackedGridImpl : public Grid::PackedGrid
+{
+	std::vector<char> Data;
+	void Destroy() override { delete this; }
+	unsigned GetSize() const override { return (unsigned)Data.size(); }
+	const char* GetData() const override { return Data.data(); }
+};
+} // namespace
+
+Grid::PackedGrid* Grid::PackForSave() const
+{
+	PackedGridImpl* p = new PackedGridImpl;
+	m_InternalGrid->Pack(p->Data);
+	return p;
+}
+
+unsigned Grid::GetWidth() const { return m_InternalGrid->Size(); }
+unsigned Grid::GetDepth() const { return m_InternalGrid->Size(); }
+unsigned Grid::GetHeight() const { return m_InternalGrid->Size(); }
+unsigned Grid::GetBlockExtent() const { return VoxelGrid::BLOCK; }
+unsigned Grid::GetGridBlocksMemorySize() { return (unsigned)m_InternalGrid->MemoryForBlocks(); }
+VoxelGrid* Grid::GetInternalRepresentation() const { return m_InternalGrid; }
+
+float3pair Grid::InjectSurface(const float3& position, const float3& extents, VoxelSurface* surface, InjectionType type)
+{
+	const float pos[3] = { position.x, position.y, position.z }, ext[3] = { extents.x, extents.y, extents.z };
+	float mn[3], mx[3];
+	m_InternalGrid->InjectSurface(pos, ext, surface, (int)type, mn, mx);
+	float3pair r;
+	r.first = float3(mn[0], mn[1], mn[2]);
+	r.second = float3(mx[0], mx[1], mx[2]);
+	return r;
+}
+
+float3pair Grid::InjectMaterial(const float3& position, const float3& extents, MaterialId material, bool addSubtractBlend)
+{
+	const float pos[3] = { position.x, position.y, position.z }, ext[3] = { extents.x, extents.y, extents.z };
+	float mn[3], mx[3];
+	m_InternalGrid->InjectMaterial(pos, ext, material, addSubtractBlend, mn, mx);
+	float3pair r;
+	r.first = float3(mn[0], mn[1], mn[2]);
+	r.second = float3(mx[0], mx[1], mx[2]);
+	return r;
+}
+
+bool Grid::GetBlockDistanceData(const float3& c, char* output) const
+{
+	m_InternalGrid->GetBlock((unsigned)c.x, (unsigned)c.y, (unsigned)c.z, (int8_t*)output, nullptr, nullptr);
+	return true;
+}
+
+void Grid::ModifyBlockDistanceData(const float3& c, const char* distances)
+{
+	m_InternalGrid->SetBlockDistances((unsigned)c.x, (unsigned)c.y, (unsigned)c.z, (const int8_t*)distances);
+}
+
+bool Grid::GetBlockMaterialData(const float3& c, MaterialId* materials, BlendFactor* blends) const
+{
+	m_InternalGrid->GetBlock((unsigned)c.x, (unsigned)c.y, (unsigned)c.z, nullptr, materials, blends);
+	return true;
+}
+
+void Grid::ModifyBlockMaterialData(const float3& c, const MaterialId* materials, const BlendFactor* blends)
+{
+	m_InternalGrid->SetBlockMaterials((unsigned)c.x, (unsigned)c.y, (unsigned)c.z, materials, blends);
+}
+
+// ------------------------------------------------------------------------------------------------ surface
+namespace
+{
+
+struct BlockImpl : public BlockPolygons
+{
+	unsigned Id = 0;
+	float3 MinCorner, MaxCorner;
+	std::vector<PolygonVertex> Vertices;
+	std::vector<unsigned> Indices;
+	std::vector<PolygonVertex> TVertices[6];
+	std::vector<unsigned> TIndices[6];
+
+	unsigned GetId() const override { return Id; }
+	const PolygonVertex* GetVertices(unsigned* count) const override
+	{
+		if (count) *count = (unsigned)Vertices.size();
+		return Vertices.empty() ? nullptr : Vertices.data();
+	}
+	const unsigned* GetIndices(unsigned* count) const override
+	{
+		if (count) *count = (unsigned)Indices.size();
+		return Indices.empty() ? nullptr : Indices.data();
+	}
+	const PolygonVertex* GetTransitionVertices(TransitionFaceId face, unsigned* count) const override
+	{
+		if (count) *count = (unsigned)TVertices[face].size();
+		return TVertices[face].empty() ? nullptr : TVertices[face].data();
+	}
+	const unsigned* GetTransitionIndices(TransitionFaceId face, unsigned* count) const override
+	{
+		if (count) *count = (unsigned)TIndices[face].size();
+		return TIndices[face].empty() ? nullptr : TIndices[face].data();
+	}
+	float3 GetMinimalCorner() const override { return MinCorner; }
+	float3 GetMaximalCorner() const override { return MaxCorner; }
+};
+
+struct SurfaceImpl : public PolygonSurface
+{
+	float3 Extents;
+	std::vector<std::vector<std::unique_ptr<BlockImpl> > > Levels;
+	PolygonizationStatistics Stats;
+	unsigned GridSize = 0;
+	vx_ctx* Owner = nullptr; // context whose device caches belong to this surface (needed by Modification)
+
+	float3 GetExtents() const override { return Extents; }
+	unsigned GetLevelsCount() const override { return (unsigned)Levels.size(); }
+	unsigned GetBlocksForLevelCount(unsigned level) const override { return (unsigned)Levels[level].size(); }
+	const BlockPolygons* GetBlockForLevel(unsigned level, unsigned id) const override
+	{
+		if (id >= Levels[level].size()) return nullptr;
+		return Levels[level][id].get();
+	}
+	const PolygonizationStatistics* GetStatistics() const override { return &Stats; }
+	unsigned GetCacheSizeBytes() const override
+	{
+		// what the reference's caches would hold (TransVoxelImpl.cpp:196-220): one bit per level-0 cell plus two
+		// bytes per cell of every coarser level
+		size_t total = 0;
+		unsigned blocks = GridSize / 16;
+		total += (size_t(blocks) * blocks * blocks * 4096) >> 3;
+		for (unsigned l = 1; l < Levels.size(); ++l) {
+			const unsigned b = (GridSize / 16) >> l;
+			total += size_t(b) * b * b * 4096 * 2;
+		}
+		return (unsigned)total;
+	}
+	unsigned GetPolygonDataSizeBytes() const override
+	{
+		size_t r = 0;
+		for (const auto& lvl : Levels)
+			for (const auto& b : lvl) r += b->Vertices.size() * sizeof(PolygonVertex) + b->Indices.size() * sizeof(unsigned) + 12 * sizeof(std::vector<unsigned>);
+		return (unsigned)r;
+	}
+	void Destroy() override { delete this; }
+};
+
+struct ModificationImpl : public Modification
+{
+	std::vector<unsigned> ModifiedBlocks;
+	const unsigned* GetModifiedBlocks(unsigned* count) const override
+	{
+		if (count) *count = (unsigned)ModifiedBlocks.size();
+		return ModifiedBlocks.empty() ? nullptr : ModifiedBlocks.data();
+	}
+	void Destroy() override { delete this; }
+};
+
+// copies one level out of the context into host-owned blocks
+bool FetchLevel(vx_ctx* ctx, unsigned level, std::vector<std::unique_ptr<BlockImpl> >& out)
+{
+	uint32_t nb = 0;
+	uint64_t tot[4];
+	if (vx_level_counts(ctx, level, &nb, tot) != VX_OK) return false;
+	std::vector<vx_block_info> infos(nb);
+	std::vector<vx_vertex> v(tot[0]), tv(tot[2]);
+	std::vector<uint32_t> i(tot[1]), ti(tot[3]);
+	if (vx_download_level(ctx, level, infos.data(), v.data(), i.data(), tv.data(), ti.data()) != VX_OK) return false;
+	out.clear();
+	out.reserve(nb);
+	size_t ov = 0, oi = 0, otv = 0, oti = 0;
+	for (uint32_t k = 0; k < nb; ++k) {
+		const vx_block_info& in = infos[k];
+		std::unique_ptr<BlockImpl> b(new BlockImpl);
+		b->Id = in.id;
+		b->MinCorner = float3(in.min_corner[0], in.min_corner[1], in.min_corner[2]);
+		b->MaxCorner = float3(in.max_corner[0], in.max_corner[1], in.max_corner[2]);
+		const PolygonVertex* pv = (const PolygonVertex*)v.data();
+		const PolygonVertex* ptv = (const PolygonVertex*)tv.data();
+		b->Vertices.assign(pv + ov, pv + ov + in.n_verts); ov += in.n_verts;
+		b->Indices.assign(i.begin() + oi, i.begin() + oi + in.n_idx); oi += in.n_idx;
+		for (int f = 0; f < 6; ++f) {
+			b->TVertices[f].assign(ptv + otv, ptv + otv + in.n_tverts[f]); otv += in.n_tverts[f];
+			b->TIndices[f].assign(ti.begin() + oti, ti.begin() + oti + in.n_tidx[f]); oti += in.n_tidx[f];
+		}
+		out.push_back(std::move(b));
+	}
+	return true;
+}
+
+} // namespace
+
+Modification* Modification::Create()
+{
+	ModificationImpl* m = new ModificationImpl;
+	m->Map = nullptr;
+	return m;
+}
+
+Modification::~Modification() {}
+
+// ------------------------------------------------------------------------------------------------ polygonizer
+class TransVoxelImpl
+{
+public:
+	vx_ctx* Ctx = nullptr;
+	const VoxelGrid* ResidentGrid = nullptr;
+	uint64_t ResidentGeneration = 0;
+
+	~TransVoxelImpl() { if (Ctx) vx_ctx_destroy(Ctx); }
+
+	bool EnsureContext()
+	{
+		if (Ctx) return true;
+		if (vx_ctx_create(0, &Ctx) != VX_OK) {
+			Ctx = nullptr;
+			Log(LS_CriticalError, "Voxels: no usable HIP device (libvoxels_hip has no CPU fallback)");
+			return false;
+		}
+		return true;
+	}
+
+	// mirror the host grid into HBM: whole grid the first time, edited blocks afterwards
+	bool SyncGrid(VoxelGrid& g)
+	{
+		std::vector<uint8_t> flags;
+		g.EmptyFlags(flags);
+		if (ResidentGrid != &g) {
+			if (vx_grid_upload(Ctx, g.Size(), g.Distances(), g.Materials(), g.Blends(), flags.data()) != VX_OK) return false;
+			ResidentGrid = &g;
+		} else if (ResidentGeneration != g.Generation()) {
+			std::vector<uint32_t> ids = g.DirtyBlocks();
+			std::sort(ids.begin(), ids.end());
+			ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+			std::vector<int8_t> d(ids.size() * 4096);
+			std::vector<uint8_t> m(ids.size() * 4096), b(ids.size() * 4096);
+			const uint32_t nb = g.BlocksPerAxis();
+			for (size_t i = 0; i < ids.size(); ++i)
+				g.GetBlock(ids[i] % nb, (ids[i] / nb) % nb, ids[i] / (nb * nb), d.data() + i * 4096, m.data() + i * 4096, b.data() + i * 4096);
+			if (vx_grid_update_blocks(Ctx, (uint32_t)ids.size(), ids.data(), d.data(), m.data(), b.data(), flags.data()) != VX_OK) return false;
+		}
+		g.ClearDirty();
+		ResidentGeneration = g.Generation();
+		return true;
+	}
+
+	bool SyncMaterials(const MaterialMap* materials)
+	{
+		uint8_t lut[256 * 6], valid[256];
+		memset(lut, 0, sizeof(lut));
+		for (int id = 0; id < 256; ++id) {
+			MaterialMap::Material* m = materials ? materials->GetMaterial((unsigned char)id) : nullptr;
+			valid[id] = m ? 1 : 0;
+			if (m) { memcpy(lut + id * 6, m->DiffuseIds0, 3); memcpy(lut + id * 6 + 3, m->DiffuseIds1, 3); }
+		}
+		return vx_material_lut(Ctx, lut, valid) == VX_OK;
+	}
+
+	static void FillStats(vx_ctx* ctx, PolygonizationStatistics& st)
+	{
+		uint32_t s[20];
+		if (vx_stats(ctx, s) != VX_OK) memset(s, 0, sizeof(s));
+		st.BlocksCalculated = s[0]; st.TrivialCells = s[1]; st.NonTrivialCells = s[2]; st.DegenerateTrianglesRemoved = s[3];
+		for (int i = 0; i < 16; ++i) st.PerCaseCellsCount[i] = s[4 + i];
+	}
+
+	PolygonSurface* Execute(const Grid& grid, const MaterialMap* materials, Modification* modification)
+	{
+		VoxelGrid* g = grid.GetInternalRepresentation();
+		if (!g || !EnsureContext()) return nullptr;
+		if (!SyncGrid(*g) || !SyncMaterials(materials)) {
+			Log(LS_Error, vx_last_error(Ctx));
+			return nullptr;
+		}
+		vx_exec_info info;
+		if (!modification) {
+			if (vx_polygonize(Ctx, 0, &info) != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+			SurfaceImpl* s = new SurfaceImpl;
+			s->GridSize = g->Size();
+			s->Owner = Ctx;
+			s->Extents = float3((float)g->Size(), (float)g->Size(), (float)g->Size());
+			s->Levels.resize(info.levels);
+			for (unsigned l = 0; l < info.levels; ++l)
+				if (!FetchLevel(Ctx, l, s->Levels[l])) { Log(LS_Error, vx_last_error(Ctx)); delete s; return nullptr; }
+			FillStats(Ctx, s->Stats);
+			return s;
+		}
+		// incremental run over the modification's dirty box: the same Map object is updated in place
+		SurfaceImpl* s = static_cast<SurfaceImpl*>(modification->Map);
+		ModificationImpl* mod = static_cast<ModificationImpl*>(modification);
+		if (!s || s->Owner != Ctx) {
+			Log(LS_Error, "Modification: the surface was not produced by this Polygonizer's last full Execute");
+			return nullptr;
+		}
+		const float mn[3] = { modification->MinCornerModified.x, modification->MinCornerModified.y, modification->MinCornerModified.z };
+		const float mx[3] = { modification->MaxCornerModified.x, modification->MaxCornerModified.y, modification->MaxCornerModified.z };
+		std::vector<uint32_t> ids(1u << 16);
+		uint32_t count = 0;
+		int rc = vx_polygonize_dirty(Ctx, mn, mx, &info, ids.data(), (uint32_t)ids.size(), &count);
+		if (rc == VX_OK && count > ids.size()) {
+			Log(LS_Error, "Modification: too many modified blocks");
+			return nullptr;
+		}
+		if (rc != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+		mod->ModifiedBlocks.insert(mod->ModifiedBlocks.end(), ids.begin(), ids.begin() + count);
+		for (unsigned l = 0; l < info.levels && l < s->Levels.size(); ++l)
+			if (!FetchLevel(Ctx, l, s->Levels[l])) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+		FillStats(Ctx, s->Stats);
+		return s;
+	}
+};
+
+Polygonizer::Polygonizer() : m_Impl(new TransVoxelImpl) {}
+Polygonizer::~Polygonizer() { delete m_Impl; }
+
+PolygonSurface* Polygonizer::Execute(const Grid& grid, const MaterialMap* materials, Modification* modification)
+{
+	return m_Impl->Execute(grid, materials, modification);
+}
+
+} // namespace Voxels
+
+// ------------------------------------------------------------------------------------------------ library init
+extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage logger, Voxels::VoxelsAllocators*)
+{
+	if ((VOXELS_VERSION & 0xFFFF) != (version & 0xFFFF)) return Voxels::IE_VersionMismatch; // low 16 bits, like Voxels.cpp:35-40
+	Voxels::g_Logger = logger;
+	Voxels::g_Initialized = true;
+	char buffer[128];
+	snprintf(buffer, sizeof(buffer), "Voxels library initialized - ver. %#010x (MI355X / %s)", VOXELS_VERSION, vx_backend());
+	Voxels::Log(Voxels::LS_Info, buffer);
+	return Voxels::IE_Ok;
+}
+
+extern "C" void DeinitializeVoxels()
+{
+	Voxels::Log(Voxels::LS_Info, "Voxels library deinitialized");
+	Voxels::g_Logger = nullptr;
+	Voxels::g_Initialized = false;
+}
+
+extern "C" unsigned GetBuildVersion() { return VOXELS_VERSION; }

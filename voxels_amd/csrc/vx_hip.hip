@@ -151,6 +151,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	__shared__ __attribute__((aligned(16))) u16 blockBits[8 * 256];
 	__shared__ u32 blockAny[8];
 	__shared__ u32 blockCnt[8];
+	__shared__ u32 blockSkipped[8];
 	__shared__ int blockSlot[8];
 
 	const LevelDesc& L = p.levels[0];
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			L.slotCoord[slot] = id;
 			L.skip[slot] = skipped ? 1 : 0;
 			L.ntCount[slot] = (u16)blockCnt[tid];
+			blockSkipped[tid] = skipped ? 1u : 0u;
 			blockSlot[tid] = (int)slot;
 		}
 	}
@@ -239,7 +241,11 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		const int slot = blockSlot[j];
-		if (slot >= 0) ((u16*)(L.ntBits + (size_t)slot * 128))[tid] = blockBits[j * 256 + tid];
+		if (slot >= 0) {
+			const u16 bits = blockBits[j * 256 + tid];
+			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = bits;
+			((u16*)(L.consBits + (size_t)slot * 128))[tid] = blockSkipped[j] ? (u16)0 : bits;
+		}
 	}
 }
 
@@ -274,9 +280,10 @@ __global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
 	__shared__ MatState st;
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
-	const u32 nAct = *L.nActive;
+	const u32 nItems = p.G.dirty ? p.G.workCount[level] : *L.nActive;
 	const int tid = threadIdx.x;
-	for (u32 slot = blockIdx.x; slot < nAct; slot += gridDim.x) {
+	for (u32 it = blockIdx.x; it < nItems; it += gridDim.x) {
+		const u32 slot = p.G.dirty ? p.G.workItems[level][it] : it;
 		u32 bx, by, bz;
 		block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
 		__syncthreads();
@@ -286,13 +293,12 @@ __global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
 			const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
 			int cs = -1;
 			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) cs = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
-			if (cs >= 0 && level == 1 && C.skip[cs]) cs = -1;
 			st.childSlot[tid] = cs;
 		}
 		__syncthreads();
 		if (level == 1) {
 			batched_gather<8 * 128, u32, 4>(
-				[&](int q) { const int cs = st.childSlot[q >> 7]; return cs >= 0 ? C.ntBits[(size_t)cs * 128 + (q & 127)] : 0u; },
+				[&](int q) { const int cs = st.childSlot[q >> 7]; return cs >= 0 ? C.consBits[(size_t)cs * 128 + (q & 127)] : 0u; },
 				[&](int q, u32 v) { st.childBits[q >> 7][q & 127] = v; });
 		}
 		mat_phase_classify(st, tid, WG);
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 	const Tables T = stage_regular_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
-		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; run += *p.levels[l].nActive; }
+		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive; }
 		for (u32 l = levels; l <= MAX_LEVELS; ++l) wl.start[l] = run;
 	}
 	__syncthreads();
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
 		RegBlockCtx b;
 		decode_item(wl, levels, item, b.level, b.slot);
+		if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
 		const LevelDesc& L = p.levels[b.level];
 		const u32 ntc = L.ntCount[b.slot];
 		if ((lo && ntc <= lo) || ntc > (u32)CAP) continue;   // the first class (lo == 0) also owns empty blocks
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		u32 run = 0;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
 			wl.start[l] = run;
-			if (l < levels && p.levels[l].hasTransitions) run += *p.levels[l].nActive;
+			if (l < levels && p.levels[l].hasTransitions) run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive;
 		}
 		wl.start[MAX_LEVELS] = run;
 	}
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		b.level = 0;
 		for (u32 l = 1; l < MAX_LEVELS; ++l) if (item >= wl.start[l] && wl.start[l + 1] > wl.start[l]) b.level = l;
 		b.slot = item - wl.start[b.level];
+		if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
 		const LevelDesc& L = p.levels[b.level];
 		b.mult = L.mult;
 		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
@@ -513,6 +521,53 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		tr_phase_record(st, L, b, p.P, tid);
 		__syncthreads();
 	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// incremental (Modification) runs: classify only the dirty level-0 blocks, list the slots to rebuild
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_classify_blocks(ExecParamsDev p, const u32* coords, u32 count)
+{
+	__shared__ MatState st; // samp + ntBits are all that is used here
+	__shared__ u32 ntCells;
+	const LevelDesc& L = p.levels[0];
+	const int tid = threadIdx.x;
+	for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+		u32 bx, by, bz;
+		block_coords(coords[k], L.cnt, bx, by, bz);
+		__syncthreads();
+		gpu_stage_samples17(p.G.grid, bx, by, bz, 1, st.samp);
+		for (int w = tid; w < 128; w += WG) st.ntBits[w] = 0;
+		if (tid == 0) ntCells = 0;
+		__syncthreads();
+		mat_phase_classify(st, tid, WG);
+		__syncthreads();
+		if (tid < 128) atomicAdd(&ntCells, (u32)__popc(st.ntBits[tid]));
+		__syncthreads();
+		if (tid == 0) publish_level0_block(p.G, L, bx, by, bz, st.ntBits, ntCells, true);
+	}
+}
+
+struct DirtyRanges { u32 start[MAX_LEVELS + 1]; };
+
+__global__ __launch_bounds__(WG) void k_build_worklist(ExecParamsDev p, const u32* coords, DirtyRanges r, u32 levels, u32* work)
+{
+	const u32 k = blockIdx.x * WG + threadIdx.x;
+	if (k >= r.start[levels]) return;
+	u32 l = 0;
+	for (u32 i = 1; i < levels; ++i) if (k >= r.start[i]) l = i;
+	const int slot = p.levels[l].slotOf[coords[k]];
+	if (slot >= 0) work[r.start[l] + atomicAdd(&p.G.workCount[l], 1u)] = (u32)slot;
+}
+
+__global__ __launch_bounds__(WG) void k_gather_records(ExecParamsDev p, DirtyRanges r, u32 levels, BlockRecord* out)
+{
+	const u32 k = blockIdx.x * WG + threadIdx.x;
+	if (k >= r.start[levels]) return;
+	u32 l = 0;
+	for (u32 i = 1; i < levels; ++i) if (k >= r.start[i]) l = i;
+	const u32 i = k - r.start[l];
+	if (i < p.G.workCount[l]) out[k] = p.levels[l].records[p.G.workItems[l][i]];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -631,6 +686,31 @@ struct Backend {
 		if (!grid) return;
 		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p));
 		check(hipGetLastError(), "k_classify launch");
+	}
+	template <typename P>
+	void run_classify_blocks(const P& p, const u32* coords, u32 count)
+	{
+		if (!count) return;
+		hipLaunchKernelGGL(k_classify_blocks, dim3(std::min<u32>(count, (u32)cus * 4)), dim3(WG), 0, stream, dev(p), coords, count);
+		check(hipGetLastError(), "k_classify_blocks launch");
+	}
+	template <typename P>
+	void run_build_worklist(const P& p, const u32* coords, const u32* start, const u32*, u32 levels, u32* work)
+	{
+		DirtyRanges r;
+		for (u32 l = 0; l <= MAX_LEVELS; ++l) r.start[l] = start[l < levels ? l : levels];
+		if (!r.start[levels]) return;
+		hipLaunchKernelGGL(k_build_worklist, dim3((r.start[levels] + WG - 1) / WG), dim3(WG), 0, stream, dev(p), coords, r, levels, work);
+		check(hipGetLastError(), "k_build_worklist launch");
+	}
+	template <typename P>
+	void run_gather_records(const P& p, u32 levels, const u32* start, BlockRecord* out)
+	{
+		DirtyRanges r;
+		for (u32 l = 0; l <= MAX_LEVELS; ++l) r.start[l] = start[l < levels ? l : levels];
+		if (!r.start[levels]) return;
+		hipLaunchKernelGGL(k_gather_records, dim3((r.start[levels] + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, levels, out);
+		check(hipGetLastError(), "k_gather_records launch");
 	}
 	template <typename P>
 	void run_hierarchy(const P& p, u32 levels)

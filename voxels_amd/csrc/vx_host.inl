@@ -11,6 +11,7 @@
 #include "tv_block.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -33,7 +34,14 @@ struct EmittedBlock {
 	BlockRecord rec;
 	u32 id;
 	float minc[3], maxc[3];
+	// meshes live in the downloaded pools (offsets in rec) until an incremental run needs the pools again; then
+	// every block takes ownership of a host copy
+	bool owned = false;
+	std::vector<PolyVertex> v, tv[6];
+	std::vector<u32> i, ti[6];
 };
+
+enum { HDR_WORDS = 48, HDR_CURSORS = 8, HDR_STATS = 12, HDR_WORK = 32 };
 
 } // namespace
 
@@ -46,7 +54,9 @@ struct vx_ctx {
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
-	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header: nActive[8] | cursors[4] | stats[20]
+	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header: nActive[8] | cursors[4] | stats[20] | workCount[8]
+	void *dDirty = nullptr, *dWork = nullptr, *dGather = nullptr;  // incremental runs: dirty block coords, work items, gathered records
+	u32 dirtyCap = 0;
 	// level tables
 	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0;
 	u32 refLevels = 0;
@@ -65,7 +75,7 @@ struct vx_ctx {
 	bool poolsOnHost = false;
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
-	u32 hdr[32];
+	u32 hdr[HDR_WORDS];
 	u32 debugPhaseLimit = 0;
 };
 
@@ -126,6 +136,7 @@ bool ensure_level_tables(vx_ctx* c)
 		d.slotOf = (int*)alloc(total * 4);
 		d.slotCoord = (u32*)alloc(cap * 4);
 		d.ntBits = (u32*)alloc(cap * 512);
+		d.consBits = L ? nullptr : (u32*)alloc(cap * 512);
 		d.cache = L ? (u16*)alloc(cap * BLOCK_CELLS * 2) : nullptr;
 		d.skip = L ? nullptr : (u8*)alloc(cap);
 		d.ntCount = (u16*)alloc(cap * 2);
@@ -163,14 +174,15 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.grid.zOriginMat = c->matZ0;
 	p.G.emptyFlags = (const u8*)c->dFlags;
 	p.G.lut = (const u8*)c->dLut;
-	p.G.stats = (u32*)c->dHeader + 12;
+	p.G.stats = (u32*)c->dHeader + HDR_STATS;
+	p.G.workCount = (u32*)c->dHeader + HDR_WORK;
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	p.G.debugPhaseLimit = c->debugPhaseLimit;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
 	p.P.verts = (PolyVertex*)c->dVerts;
 	p.P.idx = (u32*)c->dIdx;
-	p.P.cursors = (u32*)c->dHeader + 8;
+	p.P.cursors = (u32*)c->dHeader + HDR_CURSORS;
 	p.P.vertCap = c->vertCap;
 	p.P.idxCap = c->idxCap;
 	p.tables = (const u8*)c->dTables;
@@ -224,6 +236,20 @@ bool fetch_pools(vx_ctx* c)
 	return true;
 }
 
+// copy a block's meshes out of the host pool image into the block itself
+void own_block(const vx_ctx* c, EmittedBlock& e)
+{
+	if (e.owned) return;
+	const BlockRecord& r = e.rec;
+	e.v.assign(c->hVerts.begin() + r.vOff, c->hVerts.begin() + r.vOff + r.vCount);
+	e.i.assign(c->hIdx.begin() + r.iOff, c->hIdx.begin() + r.iOff + r.iCount);
+	for (int f = 0; f < 6; ++f) {
+		e.tv[f].assign(c->hVerts.begin() + r.tvOff[f], c->hVerts.begin() + r.tvOff[f] + r.tvCount[f]);
+		e.ti[f].assign(c->hIdx.begin() + r.tiOff[f], c->hIdx.begin() + r.tiOff[f] + r.tiCount[f]);
+	}
+	e.owned = true;
+}
+
 } // namespace
 
 extern "C" {
@@ -242,7 +268,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	build_table_image(img);
 	c->dTables = c->be.alloc(TAB_BYTES);
 	c->dLut = c->be.alloc(256 * 8);
-	c->dHeader = c->be.alloc(32 * 4);
+	c->dHeader = c->be.alloc(HDR_WORDS * 4);
 	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_BYTES)) {
 		vx_ctx_destroy(c);
 		return VX_ERR_DEVICE;
@@ -263,6 +289,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	free_level_tables(c);
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
+	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.shutdown();
 	delete c;
 }
@@ -361,18 +388,18 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		fill_params(c, p, levels);
 		c->be.begin_timing();
 		c->be.stage_mark(0);
-		c->be.fill(c->dHeader, 0, 32 * 4);
+		c->be.fill(c->dHeader, 0, HDR_WORDS * 4);
 		for (u32 L = 0; L < levels; ++L) c->be.fill(c->lv[L].slotOf, 0xFF, (size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt * 4);
 		run_pipeline(c, p, levels);
 		ms = c->be.end_timing_ms();
-		if (!c->be.d2h(c->hdr, c->dHeader, 32 * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
-		const u32 usedV = c->hdr[8], usedI = c->hdr[9], overflow = c->hdr[10];
+		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
+		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + 1], overflow = c->hdr[HDR_CURSORS + 2];
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
 	}
 	c->levelsRun = levels;
-	c->poolVerts = c->hdr[8]; c->poolIdx = c->hdr[9];
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + 1];
 	c->poolsOnHost = false;
 	c->haveSurface = true;
 	// block lists: every surface-bearing block with at least one regular vertex, in coordinate order; ids number
@@ -397,14 +424,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		const u32 owned = d.cnt * d.cnt * (d.zb1 - d.zb0);
 		idBase += d.cnt * d.cnt * d.cnt;
 		blocksCalculated += owned;
-		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[12 + 2] : owned);
+		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
 	c->nextId = idBase;
 	c->stats[0] = blocksCalculated;
-	c->stats[2] = c->hdr[12 + 0];
+	c->stats[2] = c->hdr[HDR_STATS + 0];
 	c->stats[1] = trivial - c->stats[2];
-	c->stats[3] = c->hdr[12 + 1];
-	for (int i = 0; i < 16; ++i) c->stats[4 + i] = c->hdr[12 + 4 + i];
+	c->stats[3] = c->hdr[HDR_STATS + 1];
+	for (int i = 0; i < 16; ++i) c->stats[4 + i] = c->hdr[HDR_STATS + 4 + i];
 	if (info) {
 		memset(info, 0, sizeof(*info));
 		info->levels = levels;
@@ -418,9 +445,140 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	return VX_OK;
 }
 
-int vx_polygonize_dirty(vx_ctx* c, const float*, const float*, vx_exec_info*, uint32_t*, uint32_t, uint32_t*)
+// Incremental re-polygonization (TransVoxelRun::Execute with a Modification, TransVoxelImpl.cpp:429-465): per level the
+// blocks of the dirty box plus one ring are dropped and rebuilt; the material caches keep their old contents.
+int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
+                        uint32_t* modified_ids, uint32_t cap, uint32_t* count)
 {
-	return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not implemented in this build");
+	if (!c || !min_corner || !max_corner) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: null argument");
+	if (!c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: run vx_polygonize first");
+	if (c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on z-slabs");
+	const u32 levels = c->levelsRun;
+	// the pools are about to be reused: every existing block takes a host copy of its meshes
+	bool anyInPool = false;
+	for (u32 L = 0; L < levels; ++L) for (const EmittedBlock& e : c->blocks[L]) if (!e.owned) anyInPool = true;
+	if (anyInPool) {
+		if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
+		for (u32 L = 0; L < levels; ++L) for (EmittedBlock& e : c->blocks[L]) own_block(c, e);
+	}
+	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
+	std::vector<u32> coords, ids;
+	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
+	const float ext = (float)c->n;
+	for (u32 L = 0; L < levels; ++L) {
+		const LevelDesc& d = c->lv[L];
+		const float bm = (float)(d.mult * 16);
+		float lo[3], hi[3];
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = std::floor(min_corner[k] / bm - 1.0f) * bm;
+			hi[k] = std::floor(max_corner[k] / bm + 2.0f) * bm;
+			lo[k] = std::min(std::max(lo[k], 0.f), ext);
+			hi[k] = std::min(std::max(hi[k], 0.f), ext);
+		}
+		std::vector<EmittedBlock>& old = c->blocks[L];
+		old.erase(std::remove_if(old.begin(), old.end(), [&](const EmittedBlock& e) {
+			return e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2];
+		}), old.end());
+		start[L] = (u32)coords.size();
+		for (u32 z = (u32)(lo[1] / bm); z < (u32)(hi[1] / bm); ++z)      // internal z = output y
+		for (u32 y = (u32)(lo[2] / bm); y < (u32)(hi[2] / bm); ++y)
+		for (u32 x = (u32)(lo[0] / bm); x < (u32)(hi[0] / bm); ++x) {
+			coords.push_back(block_coord_id(x, y, z, d.cnt));
+			ids.push_back(c->nextId++);
+		}
+		cnt[L] = (u32)coords.size() - start[L];
+	}
+	start[levels] = (u32)coords.size();
+	const u32 total = (u32)coords.size();
+	if (count) *count = total;
+	for (u32 k = 0; k < total && k < cap && modified_ids; ++k) modified_ids[k] = ids[k];
+	if (total > c->dirtyCap) {
+		c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
+		c->dirtyCap = total + total / 2 + 64;
+		c->dDirty = c->be.alloc((size_t)c->dirtyCap * 4);
+		c->dWork = c->be.alloc((size_t)c->dirtyCap * 4);
+		c->dGather = c->be.alloc((size_t)c->dirtyCap * sizeof(BlockRecord));
+		if (!c->dDirty || !c->dWork || !c->dGather) { c->dirtyCap = 0; return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: allocation failed"); }
+	}
+	if (total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
+	u32 prevActive[MAX_LEVELS];
+	for (u32 L = 0; L < MAX_LEVELS; ++L) prevActive[L] = c->hdr[L];
+	u32 retries = 0;
+	float ms = 0.f;
+	for (;;) {
+		ExecParams p;
+		fill_params(c, p, levels);
+		p.G.dirty = 1;
+		for (u32 L = 0; L < levels; ++L) { p.G.workItems[L] = (const u32*)c->dWork + start[L]; p.G.prevActive[L] = prevActive[L]; }
+		c->be.begin_timing();
+		c->be.stage_mark(0);
+		c->be.fill((u32*)c->dHeader + HDR_CURSORS, 0, (HDR_WORDS - HDR_CURSORS) * 4); // cursors, stats, work counts — NOT the slot counts
+		c->be.stage_mark(1);
+		c->be.run_classify_blocks(p, (const u32*)c->dDirty + start[0], cnt[0]);
+		c->be.stage_mark(2);
+		c->be.run_hierarchy(p, levels);
+		c->be.run_build_worklist(p, (const u32*)c->dDirty, start, cnt, levels, (u32*)c->dWork);
+		c->be.stage_mark(3);
+		for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
+		c->be.stage_mark(4);
+		c->be.run_regular(p, levels);
+		c->be.stage_mark(5);
+		c->be.run_transition(p, levels);
+		c->be.run_gather_records(p, levels, start, (BlockRecord*)c->dGather);
+		c->be.stage_mark(6);
+		ms = c->be.end_timing_ms();
+		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
+		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + 1], overflow = c->hdr[HDR_CURSORS + 2];
+		if (!overflow) break;
+		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
+		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+	}
+	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + 1];
+	c->poolsOnHost = false;
+	if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
+	std::vector<BlockRecord> recs(total);
+	if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
+	u32 trivialBlocks = c->hdr[HDR_STATS + 2];
+	for (u32 L = 0; L < levels; ++L) {
+		const LevelDesc& d = c->lv[L];
+		const u32 nWork = c->hdr[HDR_WORK + L];
+		// gathered records are in work-list (arbitrary) order: index them by block coordinate
+		std::vector<std::pair<u32, u32> > byCoord;
+		byCoord.reserve(nWork);
+		for (u32 k = 0; k < nWork; ++k) byCoord.push_back(std::make_pair(recs[start[L] + k].coordId, start[L] + k));
+		std::sort(byCoord.begin(), byCoord.end());
+		for (u32 k = 0; k < cnt[L]; ++k) {
+			const u32 coord = coords[start[L] + k];
+			auto it = std::lower_bound(byCoord.begin(), byCoord.end(), std::make_pair(coord, 0u));
+			if (it == byCoord.end() || it->first != coord) continue; // no surface in this block
+			const BlockRecord& r = recs[it->second];
+			if (!r.vCount) continue;
+			EmittedBlock e;
+			e.rec = r;
+			e.id = ids[start[L] + k];
+			block_corners(d, coord, e.minc, e.maxc);
+			own_block(c, e);
+			c->blocks[L].push_back(std::move(e));
+		}
+		if (L) trivialBlocks += cnt[L];
+	}
+	c->stats[0] = total;
+	c->stats[2] = c->hdr[HDR_STATS + 0];
+	c->stats[1] = BLOCK_CELLS * trivialBlocks - c->stats[2];
+	c->stats[3] = c->hdr[HDR_STATS + 1];
+	for (int i = 0; i < 16; ++i) c->stats[4 + i] = c->hdr[HDR_STATS + 4 + i];
+	if (info) {
+		memset(info, 0, sizeof(*info));
+		info->levels = levels;
+		info->retries = retries;
+		info->device_ms = ms;
+		info->total_verts = c->poolVerts;
+		info->total_indices = c->poolIdx;
+		for (u32 L = 0; L < levels && L < 8; ++L) info->active_blocks[L] = c->hdr[HDR_WORK + L];
+		info->algorithmic_bytes = (uint64_t)4096 * 3 * cnt[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
+	}
+	return VX_OK;
 }
 
 int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t totals[4])
@@ -439,7 +597,9 @@ int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t tota
 int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx, vx_vertex* tverts, uint32_t* tidx)
 {
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
-	if ((verts || idx || tverts || tidx) && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
+	bool needPools = false;
+	for (const EmittedBlock& e : c->blocks[level]) if (!e.owned) needPools = true;
+	if ((verts || idx || tverts || tidx) && needPools && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
 	size_t ov = 0, oi = 0, otv = 0, oti = 0, k = 0;
 	for (const EmittedBlock& e : c->blocks[level]) {
 		const BlockRecord& r = e.rec;
@@ -450,14 +610,14 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 			memcpy(b.min_corner, e.minc, 12); memcpy(b.max_corner, e.maxc, 12);
 		}
 		++k;
-		if (verts) memcpy(verts + ov, c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
+		if (verts && r.vCount) memcpy(verts + ov, e.owned ? e.v.data() : c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
 		ov += r.vCount;
-		if (idx) memcpy(idx + oi, c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
+		if (idx && r.iCount) memcpy(idx + oi, e.owned ? e.i.data() : c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
 		oi += r.iCount;
 		for (int f = 0; f < 6; ++f) {
-			if (tverts && r.tvCount[f]) memcpy(tverts + otv, c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
+			if (tverts && r.tvCount[f]) memcpy(tverts + otv, e.owned ? e.tv[f].data() : c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
 			otv += r.tvCount[f];
-			if (tidx && r.tiCount[f]) memcpy(tidx + oti, c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
+			if (tidx && r.tiCount[f]) memcpy(tidx + oti, e.owned ? e.ti[f].data() : c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
 			oti += r.tiCount[f];
 		}
 	}
