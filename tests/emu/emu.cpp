@@ -28,3 +28,6 @@ u32 exclusive_scan(T* a, u32 n)
 
 #include "emu_backend.inl"
 #include "../../voxels_amd/csrc/vx_host.inl"
+
+// test hook for tests/test_core_math.py
+extern "C" int emu_edge_t(int v0, int v1) { return tv::edge_t(v0, v1); }

@@ -1,0 +1,39 @@
+"""Drop-in test of the C++ API: tests/cpp/dropin_test.cpp, written only against the reference's public API, built
+against (a) the reference's headers + the unmodified reference library and (b) this repo's include/ + libVoxels.so.
+Both binaries must write byte-identical dumps (all levels, blocks, vertices, indices, statistics, the modification's
+block ids, block accessors, the packed grid).  (a) is built where /root/reference exists and travels in oracle/_ref."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OURS = os.path.join(ROOT, "tests", "cpp", "dropin_ours")
+REF = os.path.join(ROOT, "oracle", "_ref", "dropin_ref")
+
+
+def test_public_headers_compile_standalone(tmp_path):
+    """Every reference header name resolves and the API surface compiles (no GPU needed)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "Declarations.h"\n#include "Structs.h"\n#include "Version.h"\n#include "Library.h"\n'
+                   '#include "VoxelSurface.h"\n#include "MaterialMap.h"\n#include "Grid.h"\n#include "Polygonizer.h"\n'
+                   '#include <Voxels.h>\nstatic_assert(sizeof(Voxels::PolygonVertex) == 48, "");\nint main() { return VOXELS_VERSION == 0x00050001 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 128])
+def test_same_application_same_bytes(tmp_path, n):
+    from voxels_amd import build
+    build.build_cpp_api()
+    build.build_dropin_tests()
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/dropin_ref not built (needs /root/reference at build time)")
+    a, b = str(tmp_path / "ours.bin"), str(tmp_path / "ref.bin")
+    subprocess.check_call([OURS, str(n), a])
+    subprocess.check_call([REF, str(n), b])
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert len(da) == len(db), (len(da), len(db))
+    if da != db:
+        first = next(i for i in range(len(da)) if da[i] != db[i])
+        raise AssertionError("dumps differ at byte %d of %d" % (first, len(da)))

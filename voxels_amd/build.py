@@ -43,6 +43,36 @@ def build_synth(force=False):
     return out
 
 
+def build_cpp_api(force=False):
+    """libVoxels.so: the reference's public C++ API (include/Voxels.h) on top of libvoxels_hip.so."""
+    out = os.path.join(CSRC, "libVoxels.so")
+    srcs = [os.path.join(CSRC, f) for f in ("vx_api_cpp.cpp", "vx_grid_host.cpp", "vx_grid_host.h")]
+    srcs += [os.path.join(ROOT, "include", f) for f in ("Voxels.h", "voxels_hip.h")]
+    if not force and not _newer(out, srcs + [os.path.join(CSRC, "libvoxels_hip.so")]):
+        return out
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-o", out,
+                           os.path.join(CSRC, "vx_api_cpp.cpp"), os.path.join(CSRC, "vx_grid_host.cpp"),
+                           "-L" + CSRC, "-lvoxels_hip", "-Wl,-rpath,$ORIGIN"], cwd=CSRC)
+    return out
+
+
+def build_dropin_tests(force=False):
+    """tests/cpp/dropin_test.cpp compiled against OUR headers + libVoxels.so, and (where /root/reference exists)
+    the very same source against the REFERENCE headers + the unmodified reference library (oracle/_ref)."""
+    src = os.path.join(ROOT, "tests", "cpp", "dropin_test.cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "dropin_ours")
+    if force or _newer(out, [src, os.path.join(CSRC, "libVoxels.so")]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-o", out, src, "-I" + os.path.join(ROOT, "include"),
+                               "-L" + CSRC, "-lVoxels", "-Wl,-rpath," + CSRC])
+    ref_out = os.path.join(ROOT, "oracle", "_ref", "dropin_ref")
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libvoxels_ref.so")
+    if os.path.isdir("/root/reference/include") and os.path.exists(ref_lib) and (force or _newer(ref_out, [src, ref_lib])):
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++14", "-O2", "-w", "-fms-extensions", "-fdeclspec",
+                               "-DVOXELS_API=", "-DVOXELS_CDECL=", "-o", ref_out, src, "-I/root/reference/include",
+                               "-L" + os.path.dirname(ref_lib), "-lvoxels_ref", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"])
+    return out, ref_out
+
+
 def build_emu(force=False):
     """CPU emulation of the device phases — tests only (tests/emu)."""
     d = os.path.join(ROOT, "tests", "emu")

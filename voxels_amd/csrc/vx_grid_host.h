@@ -5,6 +5,7 @@
 // codec is kept as per-block metadata, computed by the same rules: BF_Empty / *Uncompressed flags and encoded sizes
 // (VoxelGrid.cpp:52-77, :610-672) for IsBlockEmpty, GetGridBlocksMemorySize and the v1 file format (:215-315).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <vector>
 
