@@ -21,6 +21,10 @@ struct Backend {
 	bool h2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void sync() {}
+	bool sync_ok() { return true; }
+	bool d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	void* alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
+	void free_pinned(void* p) { ::free(p); }
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
 	void stage_enable(bool) {}
@@ -124,6 +128,8 @@ struct Backend {
 			memset(st->ntBits, 0, sizeof(st->ntBits));
 			mat_phase_classify(*st, 0, 1);
 			mat_phase_children(*st, p.levels, level, bx, by, bz, 0, 1);
+			st->voteCount = 0;
+			mat_phase_select(*st, p.G, p.levels, level, slot, bx, by, bz, 0, 1);
 			mat_phase_vote(*st, p.G, p.levels, level, slot, bx, by, bz, 0, 1);
 		}
 		delete st;

@@ -163,6 +163,8 @@ struct MatState {
 	u32 ntBits[128];
 	int childSlot[8];          // active slot of the 2x2x2 child blocks (level - 1), -1 = none / outside / skipped
 	u32 childBits[8][128];     // level 1 only: non-trivial bitmaps of the child blocks (the level-0 consistency cache)
+	u16 voteList[BLOCK_CELLS]; // cells that have at least one child entry to look at (compact, any order)
+	u32 voteCount;
 };
 
 // stage what the vote needs to know about the 8 child blocks
@@ -207,34 +209,34 @@ TV_HD bool cell_on_transition_face(const LevelDesc& L, u32 bx, u32 by, u32 bz, i
 	    || (lz == 15 && bz + 1 < L.cnt) || (ly == 15 && by + 1 < L.cnt) || (lx == 15 && bx + 1 < L.cnt);
 }
 
-TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc* levels, u32 level, u32 slot,
-                          u32 bx, u32 by, u32 bz, int tid, int nth)
+// child cell i (x fastest) of cell (lx,ly,lz): child block index (0..7) and cell id inside it
+TV_HD void child_location(int lx, int ly, int lz, u32 i, u32& cb, u32& local)
+{
+	const u32 ccx = (u32)lx * 2 + (i & 1), ccy = (u32)ly * 2 + ((i >> 1) & 1), ccz = (u32)lz * 2 + (i >> 2);
+	cb = (ccx >> 4) | ((ccy >> 4) << 1) | ((ccz >> 4) << 2);
+	local = ((ccz & 15) << 8) | ((ccy & 15) << 4) | (ccx & 15);
+}
+
+// Pass 1 (LDS only): which cells need a vote and have anything to vote on; everything else is final already
+TV_HD void mat_phase_select(MatState& st, const Globals& G, const LevelDesc* levels, u32 level, u32 slot,
+                            u32 bx, u32 by, u32 bz, int tid, int nth)
 {
 	const LevelDesc& L = levels[level];
-	const LevelDesc& C = levels[level - 1];
 	u16* out = L.cache + (size_t)slot * BLOCK_CELLS;
+	const bool defineAll = !G.dirty || slot >= G.prevActive[level];
 	for (int c = tid; c < BLOCK_CELLS; c += nth) {
 		const int lx = c & 15, ly = (c >> 4) & 15, lz = c >> 8;
-		u32 entry = EMPTY_MATINFO;
+		bool candidate = false;
 		if (bit_get(st.ntBits, (u32)c) || cell_on_transition_face(L, bx, by, bz, lx, ly, lz)) {
-			// child cell (dx,dy,dz) of this cell lives in child block ((2l+d) >> 4) at local (2l+d) & 15
-			entry = vote_material([&](u32 i) -> u32 {
-				const u32 ccx = (u32)lx * 2 + (i & 1), ccy = (u32)ly * 2 + ((i >> 1) & 1), ccz = (u32)lz * 2 + (i >> 2);
-				const u32 cb = (ccx >> 4) | ((ccy >> 4) << 1) | ((ccz >> 4) << 2);
-				const int cslot = st.childSlot[cb];
-				if (cslot < 0) return EMPTY_MATINFO;
-				const u32 local = ((ccz & 15) << 8) | ((ccy & 15) << 4) | (ccx & 15);
-				if (level == 1) {
-					if (!bit_get(st.childBits[cb], local)) return EMPTY_MATINFO;
-					return mat_at(G.grid, (int)((bx * 16 + lx) * 2 + (i & 1)), (int)((by * 16 + ly) * 2 + ((i >> 1) & 1)), (int)((bz * 16 + lz) * 2 + (i >> 2)));
-				}
-				return C.cache[(size_t)cslot * BLOCK_CELLS + local];
-			});
+			for (u32 i = 0; i < 8 && !candidate; ++i) {
+				u32 cb, local;
+				child_location(lx, ly, lz, i, cb, local);
+				if (st.childSlot[cb] < 0) continue;
+				candidate = (level == 1) ? bit_get(st.childBits[cb], local) != 0 : true;
+			}
 		}
-		// full run / slot created by this run: every entry is defined (EMPTY when no vote applies); incremental run
-		// on an existing slot: the reference only overwrites an entry when the vote finds a child (:829-837)
-		if (!G.dirty || slot >= G.prevActive[level]) out[c] = (u16)entry;
-		else if (entry != EMPTY_MATINFO) out[c] = (u16)entry;
+		if (candidate) st.voteList[TV_ATOMIC_ADD(&st.voteCount, 1u)] = (u16)c;
+		else if (defineAll) out[c] = (u16)EMPTY_MATINFO; // incremental runs keep the old entry (TransVoxelImpl.cpp:829)
 	}
 	u32* bitsOut = L.ntBits + (size_t)slot * 128;
 	for (int w = tid; w < 128; w += nth) bitsOut[w] = st.ntBits[w];
@@ -242,6 +244,33 @@ TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc*
 		u32 cnt = 0;
 		for (int w = 0; w < 128; ++w) cnt += TV_POPC(st.ntBits[w]);
 		L.ntCount[slot] = (u16)cnt;
+	}
+}
+
+// Pass 2: dense over the selected cells, the eight child fetches of a cell in flight together
+TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc* levels, u32 level, u32 slot,
+                          u32 bx, u32 by, u32 bz, int tid, int nth)
+{
+	const LevelDesc& L = levels[level];
+	const LevelDesc& C = levels[level - 1];
+	u16* out = L.cache + (size_t)slot * BLOCK_CELLS;
+	const bool defineAll = !G.dirty || slot >= G.prevActive[level];
+	const int n = (int)st.voteCount;
+	for (int k = tid; k < n; k += nth) {
+		const int c = st.voteList[k];
+		const int lx = c & 15, ly = (c >> 4) & 15, lz = c >> 8;
+		const u32 entry = vote_material([&](u32 i) -> u32 {
+			u32 cb, local;
+			child_location(lx, ly, lz, i, cb, local);
+			const int cslot = st.childSlot[cb];
+			if (cslot < 0) return EMPTY_MATINFO;
+			if (level == 1) {
+				if (!bit_get(st.childBits[cb], local)) return EMPTY_MATINFO;
+				return mat_at(G.grid, (int)((bx * 16 + lx) * 2 + (i & 1)), (int)((by * 16 + ly) * 2 + ((i >> 1) & 1)), (int)((bz * 16 + lz) * 2 + (i >> 2)));
+			}
+			return C.cache[(size_t)cslot * BLOCK_CELLS + local];
+		});
+		if (defineAll || entry != EMPTY_MATINFO) out[c] = (u16)entry;
 	}
 }
 

@@ -423,13 +423,12 @@ TV_HD void reg_corner_vertex(const D& d, const GridView& g, const CellGeom& c, i
 // ---------------------------------------------------------------------------------------------------------
 // Material vote of a level >= 1 cell over its 8 children (child(i) -> id | blend << 8, id 255 = no entry)
 // ---------------------------------------------------------------------------------------------------------
-template <typename ChildFn>
-TV_HD u32 vote_material(const ChildFn& child)
+TV_HD u32 vote_entries(const u32 e[8])
 {
 	u32 ids[8], cnt[8], bl[8];
 	u32 count = 0;
 	for (u32 i = 0; i < 8; ++i) { // children in x-fastest order
-		const u32 c = child(i);
+		const u32 c = e[i];
 		const u32 id = c & 0xFF;
 		if (id == EMPTY_MATERIAL) continue;
 		bool found = false;
@@ -442,6 +441,16 @@ TV_HD u32 vote_material(const ChildFn& child)
 	u32 best = 0;
 	for (u32 k = 1; k < count; ++k) if (cnt[k] > cnt[best]) best = k; // first maximum wins
 	return ids[best] | (((bl[best] / cnt[best]) & 0xFF) << 8);
+}
+
+// all eight child entries are fetched before the vote so that the loads are in flight together
+template <typename ChildFn>
+TV_HD u32 vote_material(const ChildFn& child)
+{
+	u32 e[8];
+#pragma unroll
+	for (u32 i = 0; i < 8; ++i) e[i] = child(i);
+	return vote_entries(e);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -158,13 +158,38 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	const GridView& g = p.G.grid;
 	const int n = g.n;
 	const u32 tilesX = (L.cnt + 7) / 8;
-	const u32 tile = blockIdx.x;
+	// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Give every
+	// XCD a contiguous range of block rows and walk each row's tiles (whole 1 KB+ voxel rows) back to back, so an
+	// XCD's L2 sees all address bits (all of its channels) and consecutive rows share their halo lines in that L2.
+	u32 tile = blockIdx.x;
+	{
+		const u32 rows = L.cnt * (L.zb1 - L.zb0);
+		if ((rows & 7u) == 0) {
+			const u32 xcd = tile & 7u, m = tile >> 3;
+			tile = (xcd * (rows >> 3) + m / tilesX) * tilesX + m % tilesX;
+		}
+	}
 	const u32 tx = tile % tilesX, by = (tile / tilesX) % L.cnt, bz = L.zb0 + tile / (tilesX * L.cnt);
 	const int x0 = (int)tx * 128;
 	const int validCells = (n - x0) < 128 ? (n - x0) : 128; // multiple of 16
 	const int tid = threadIdx.x;
 
-	if (tid < 8) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; }
+	__shared__ u32 blockNonEmpty[8];
+	if (tid < 8) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockNonEmpty[tid] = 0; }
+
+	// emptiness rule (TransVoxelImpl.cpp:1511-1527): one lane per (block, neighbour); the 216 flag loads are issued
+	// before the density loads and only consumed after them, so their latency is hidden
+	u32 neighbourNotEmpty = 0;
+	if (tid < 216) {
+		const int j = tid / 27, k = tid - j * 27;
+		const u32 bx = tx * 8 + (u32)j;
+		if (bx < L.cnt) {
+			const u32 cx = (u32)clampi((int)bx + (k % 3) - 1, 0, (int)L.cnt - 1);
+			const u32 cy = (u32)clampi((int)by + ((k / 3) % 3) - 1, 0, (int)L.cnt - 1);
+			const u32 cz = (u32)clampi((int)bz + (k / 9) - 1, 0, (int)L.cnt - 1);
+			neighbourNotEmpty = p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)] ? 0u : 1u;
+		}
+	}
 
 	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line); all ten loads
 	//      of a thread are issued before the first sign mask is formed ----------------------------------------
@@ -183,13 +208,16 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 		[&](int q, uint4 d) {
 			sgn[q] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
 		});
-	for (int r = tid; r < 289; r += WG) {
-		const int ry = r % 17, rz = r / 17;
-		const int y = clampi((int)by * 16 + ry, 0, n - 1);
-		const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
-		const int x = clampi(x0 + validCells, 0, n - 1);
-		halo[r] = (u8)((u32)(g.dist[((size_t)z * n + y) * n + x] >> 7) & 1u);
-	}
+	batched_gather<289, i8, 2>(
+		[&](int r) {
+			const int ry = r % 17, rz = r / 17;
+			const int y = clampi((int)by * 16 + ry, 0, n - 1);
+			const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
+			const int x = clampi(x0 + validCells, 0, n - 1);
+			return g.dist[((size_t)z * n + y) * n + x];
+		},
+		[&](int r, i8 v) { halo[r] = (u8)((u32)(v >> 7) & 1u); });
+	if (neighbourNotEmpty) atomicAdd(&blockNonEmpty[tid / 27], 1u);
 	__syncthreads();
 
 	// ---- classify 128 cells of one (y,z) row per thread, bit-parallel ---------------------------------
@@ -224,7 +252,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	// ---- one lane per block: emptiness rule, slot allocation ------------------------------------------
 	if (tid < 8 && tid * 16 < validCells) {
 		const u32 bx = tx * 8 + tid;
-		const bool skipped = block_skipped_by_emptiness(p.G.emptyFlags, L.cnt, bx, by, bz);
+		const bool skipped = blockNonEmpty[tid] == 0;
 		if (!skipped) atomicAdd(&p.G.stats[2], 1u);
 		if (blockAny[tid]) {
 			const u32 slot = atomicAdd(L.nActive, 1u);
@@ -289,6 +317,7 @@ __global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
 		__syncthreads();
 		gpu_stage_samples17(p.G.grid, bx, by, bz, L.mult, st.samp);
 		for (int w = tid; w < 128; w += WG) st.ntBits[w] = 0;
+		if (tid == 0) st.voteCount = 0;
 		if (tid < 8) {
 			const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
 			int cs = -1;
@@ -302,6 +331,8 @@ __global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
 				[&](int q, u32 v) { st.childBits[q >> 7][q & 127] = v; });
 		}
 		mat_phase_classify(st, tid, WG);
+		__syncthreads();
+		mat_phase_select(st, p.G, p.levels, level, slot, bx, by, bz, tid, WG);
 		__syncthreads();
 		mat_phase_vote(st, p.G, p.levels, level, slot, bx, by, bz, tid, WG);
 	}
@@ -639,6 +670,15 @@ struct Backend {
 		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	void sync() { (void)hipStreamSynchronize(stream); }
+	bool sync_ok() { return check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+	bool d2h_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)"); }
+	void* alloc_pinned(size_t bytes)
+	{
+		void* p = nullptr;
+		if (!check(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+		return p;
+	}
+	void free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 	void stage_enable(bool on)
 	{
 		stageOn = on;

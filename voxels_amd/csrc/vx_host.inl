@@ -11,9 +11,12 @@
 #include "tv_block.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -36,9 +39,11 @@ struct EmittedBlock {
 	float minc[3], maxc[3];
 	// meshes live in the downloaded pools (offsets in rec) until an incremental run needs the pools again; then
 	// every block takes ownership of a host copy
-	bool owned = false;
-	std::vector<PolyVertex> v, tv[6];
-	std::vector<u32> i, ti[6];
+	struct Meshes {
+		std::vector<PolyVertex> v, tv[6];
+		std::vector<u32> i, ti[6];
+	};
+	std::shared_ptr<Meshes> own;
 };
 
 enum { HDR_WORDS = 48, HDR_CURSORS = 8, HDR_STATS = 12, HDR_WORK = 32 };
@@ -73,9 +78,12 @@ struct vx_ctx {
 	std::vector<PolyVertex> hVerts;
 	std::vector<u32> hIdx;
 	bool poolsOnHost = false;
+	bool listsReady = false;
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
 	u32 hdr[HDR_WORDS];
+	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
+	size_t hRecCap = 0;
 	u32 debugPhaseLimit = 0;
 };
 
@@ -239,15 +247,65 @@ bool fetch_pools(vx_ctx* c)
 // copy a block's meshes out of the host pool image into the block itself
 void own_block(const vx_ctx* c, EmittedBlock& e)
 {
-	if (e.owned) return;
+	if (e.own) return;
 	const BlockRecord& r = e.rec;
-	e.v.assign(c->hVerts.begin() + r.vOff, c->hVerts.begin() + r.vOff + r.vCount);
-	e.i.assign(c->hIdx.begin() + r.iOff, c->hIdx.begin() + r.iOff + r.iCount);
+	e.own = std::make_shared<EmittedBlock::Meshes>();
+	e.own->v.assign(c->hVerts.begin() + r.vOff, c->hVerts.begin() + r.vOff + r.vCount);
+	e.own->i.assign(c->hIdx.begin() + r.iOff, c->hIdx.begin() + r.iOff + r.iCount);
 	for (int f = 0; f < 6; ++f) {
-		e.tv[f].assign(c->hVerts.begin() + r.tvOff[f], c->hVerts.begin() + r.tvOff[f] + r.tvCount[f]);
-		e.ti[f].assign(c->hIdx.begin() + r.tiOff[f], c->hIdx.begin() + r.tiOff[f] + r.tiCount[f]);
+		e.own->tv[f].assign(c->hVerts.begin() + r.tvOff[f], c->hVerts.begin() + r.tvOff[f] + r.tvCount[f]);
+		e.own->ti[f].assign(c->hIdx.begin() + r.tiOff[f], c->hIdx.begin() + r.tiOff[f] + r.tiCount[f]);
 	}
-	e.owned = true;
+}
+
+// Block lists of a full run: every surface-bearing block with at least one regular vertex, in coordinate order; ids
+// number ALL blocks of all levels in level-major order (TransVoxelImpl.cpp:395-401).  Part of the result download
+// (not of the device run): done on first access.
+int ensure_lists(vx_ctx* c)
+{
+	if (c->listsReady) return VX_OK;
+	const u32 levels = c->levelsRun;
+	size_t recTotal = 0;
+	for (u32 L = 0; L < levels; ++L) recTotal += c->hdr[L];
+	if (recTotal > c->hRecCap) {
+		c->be.free_pinned(c->hRecs);
+		c->hRecCap = recTotal + recTotal / 4 + 256;
+		c->hRecs = (BlockRecord*)c->be.alloc_pinned(c->hRecCap * sizeof(BlockRecord));
+		if (!c->hRecs) { c->hRecCap = 0; return fail(c, VX_ERR_DEVICE, "block lists: pinned allocation failed"); }
+	}
+	{
+		size_t off = 0;
+		bool ok = true;
+		for (u32 L = 0; L < levels; ++L) {
+			if (c->hdr[L]) ok = ok && c->be.d2h_async(c->hRecs + off, c->lv[L].records, (size_t)c->hdr[L] * sizeof(BlockRecord));
+			off += c->hdr[L];
+		}
+		if (!ok || !c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "block lists: record download failed: " + c->be.error());
+	}
+	size_t recOff = 0;
+	u32 idBase = 0;
+	std::vector<std::pair<u32, u32> > order;
+	for (u32 L = 0; L < levels; ++L) {
+		const LevelDesc& d = c->lv[L];
+		const u32 nAct = c->hdr[L];
+		const BlockRecord* recs = c->hRecs + recOff;
+		recOff += nAct;
+		order.clear();
+		for (u32 k = 0; k < nAct; ++k) if (recs[k].vCount) order.push_back(std::make_pair(recs[k].coordId, k));
+		std::sort(order.begin(), order.end());
+		std::vector<EmittedBlock>& out = c->blocks[L];
+		out.clear();
+		out.resize(order.size());
+		for (size_t k = 0; k < order.size(); ++k) {
+			EmittedBlock& e = out[k];
+			e.rec = recs[order[k].second];
+			e.id = idBase + e.rec.coordId;
+			block_corners(d, e.rec.coordId, e.minc, e.maxc);
+		}
+		idBase += d.cnt * d.cnt * d.cnt;
+	}
+	c->listsReady = true;
+	return VX_OK;
 }
 
 } // namespace
@@ -290,6 +348,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
+	c->be.free_pinned(c->hRecs);
 	c->be.shutdown();
 	delete c;
 }
@@ -383,6 +442,11 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	}
 	u32 retries = 0;
 	float ms = 0.f;
+	const bool hostTiming = getenv("VX_HOST_TIMING") != nullptr;
+	auto tNow = []() { return std::chrono::steady_clock::now(); };
+	auto tUs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
+	const auto t0 = tNow();
+	auto t1 = t0, t2 = t0, t3 = t0;
 	for (;;) {
 		ExecParams p;
 		fill_params(c, p, levels);
@@ -391,8 +455,11 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		c->be.fill(c->dHeader, 0, HDR_WORDS * 4);
 		for (u32 L = 0; L < levels; ++L) c->be.fill(c->lv[L].slotOf, 0xFF, (size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt * 4);
 		run_pipeline(c, p, levels);
+		t1 = tNow();
 		ms = c->be.end_timing_ms();
+		t2 = tNow();
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
+		t3 = tNow();
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + 1], overflow = c->hdr[HDR_CURSORS + 2];
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
@@ -402,29 +469,20 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + 1];
 	c->poolsOnHost = false;
 	c->haveSurface = true;
-	// block lists: every surface-bearing block with at least one regular vertex, in coordinate order; ids number
-	// ALL blocks of all levels in level-major order (TransVoxelImpl.cpp:395-401)
+	c->listsReady = false; // block lists (record read-back + ordering) are materialised on first access
 	u32 idBase = 0;
 	u32 blocksCalculated = 0, trivial = 0;
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
-		const u32 nAct = c->hdr[L];
-		std::vector<BlockRecord> recs(nAct);
-		if (nAct && !c->be.d2h(recs.data(), d.records, (size_t)nAct * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: record download failed");
-		std::sort(recs.begin(), recs.end(), [](const BlockRecord& a, const BlockRecord& b) { return a.coordId < b.coordId; });
-		c->blocks[L].clear();
-		for (const BlockRecord& r : recs) {
-			if (!r.vCount) continue;
-			EmittedBlock e;
-			e.rec = r;
-			e.id = idBase + r.coordId;
-			block_corners(d, r.coordId, e.minc, e.maxc);
-			c->blocks[L].push_back(e);
-		}
 		const u32 owned = d.cnt * d.cnt * (d.zb1 - d.zb0);
 		idBase += d.cnt * d.cnt * d.cnt;
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
+	}
+	if (hostTiming) {
+		const auto t5 = tNow();
+		fprintf(stderr, "[vx host] enqueue %.0f us, wait+events %.0f us, header %.0f us, after-header %.0f us, device %.0f us\n",
+		        tUs(t0, t1), tUs(t1, t2), tUs(t2, t3), tUs(t3, t5), ms * 1e3);
 	}
 	c->nextId = idBase;
 	c->stats[0] = blocksCalculated;
@@ -454,9 +512,10 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (!c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: run vx_polygonize first");
 	if (c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on z-slabs");
 	const u32 levels = c->levelsRun;
+	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	// the pools are about to be reused: every existing block takes a host copy of its meshes
 	bool anyInPool = false;
-	for (u32 L = 0; L < levels; ++L) for (const EmittedBlock& e : c->blocks[L]) if (!e.owned) anyInPool = true;
+	for (u32 L = 0; L < levels; ++L) for (const EmittedBlock& e : c->blocks[L]) if (!e.own) anyInPool = true;
 	if (anyInPool) {
 		if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
 		for (u32 L = 0; L < levels; ++L) for (EmittedBlock& e : c->blocks[L]) own_block(c, e);
@@ -584,6 +643,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t totals[4])
 {
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_level_counts: no such level");
+	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	uint64_t t[4] = { 0, 0, 0, 0 };
 	for (const EmittedBlock& e : c->blocks[level]) {
 		t[0] += e.rec.vCount; t[1] += e.rec.iCount;
@@ -597,8 +657,9 @@ int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t tota
 int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx, vx_vertex* tverts, uint32_t* tidx)
 {
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
+	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	bool needPools = false;
-	for (const EmittedBlock& e : c->blocks[level]) if (!e.owned) needPools = true;
+	for (const EmittedBlock& e : c->blocks[level]) if (!e.own) needPools = true;
 	if ((verts || idx || tverts || tidx) && needPools && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
 	size_t ov = 0, oi = 0, otv = 0, oti = 0, k = 0;
 	for (const EmittedBlock& e : c->blocks[level]) {
@@ -610,14 +671,14 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 			memcpy(b.min_corner, e.minc, 12); memcpy(b.max_corner, e.maxc, 12);
 		}
 		++k;
-		if (verts && r.vCount) memcpy(verts + ov, e.owned ? e.v.data() : c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
+		if (verts && r.vCount) memcpy(verts + ov, e.own ? e.own->v.data() : c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
 		ov += r.vCount;
-		if (idx && r.iCount) memcpy(idx + oi, e.owned ? e.i.data() : c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
+		if (idx && r.iCount) memcpy(idx + oi, e.own ? e.own->i.data() : c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
 		oi += r.iCount;
 		for (int f = 0; f < 6; ++f) {
-			if (tverts && r.tvCount[f]) memcpy(tverts + otv, e.owned ? e.tv[f].data() : c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
+			if (tverts && r.tvCount[f]) memcpy(tverts + otv, e.own ? e.own->tv[f].data() : c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
 			otv += r.tvCount[f];
-			if (tidx && r.tiCount[f]) memcpy(tidx + oti, e.owned ? e.ti[f].data() : c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
+			if (tidx && r.tiCount[f]) memcpy(tidx + oti, e.own ? e.own->ti[f].data() : c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
 			oti += r.tiCount[f];
 		}
 	}
