@@ -168,7 +168,10 @@ struct Backend {
 				reg_phase_keep(*st, T, p.G, b, 0, 1);
 				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[128]);
 				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
-				reg_phase_emit_indices(*st, T, p.P, b, 0, 1);
+				for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
+					reg_phase_stage_indices(*st, T, chunk, 0, 1);
+					reg_phase_flush_indices(*st, p.P, chunk, 0, 1);
+				}
 				reg_phase_record(*st, p.G, L, b, p.P, 0);
 			}
 		}

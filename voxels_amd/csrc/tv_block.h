@@ -371,13 +371,20 @@ TV_HD void reg_phase_stage(ST& st, const Globals& G, const LevelDesc& L, const R
 	else reg_stage_strided(G.grid, b.bx, b.by, b.bz, b.mult, st.samp, tid, nth);
 }
 
-// after wordPrefix is known: compact list of the non-trivial cells, in cell order
+// after wordPrefix is known: compact list of the non-trivial cells, in cell order (one 16-cell row per step)
 template <typename ST>
 TV_HD void reg_phase_list(ST& st, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
 {
 	if (b.level == 0) reg_fix_borders(b.bx, L.cnt, st.samp, tid, nth);
-	for (int c = tid; c < BLOCK_CELLS; c += nth) {
-		if (bit_get(st.ntBits, (u32)c)) st.cellOf[bit_rank(st.ntBits, st.wordPrefix, (u32)c)] = (u16)c;
+	for (int row = tid; row < 256; row += nth) {
+		u32 bits = (st.ntBits[row >> 1] >> ((row & 1) * 16)) & 0xFFFFu;
+		if (!bits) continue;
+		u32 k = bit_rank(st.ntBits, st.wordPrefix, (u32)row * 16);
+		while (bits) {
+			const u32 x = (u32)__builtin_ctz(bits);
+			bits &= bits - 1;
+			st.cellOf[k++] = (u16)(row * 16 + x);
+		}
 	}
 }
 
@@ -597,14 +604,17 @@ TV_HD void reg_phase_keep(ST& st, const Tables& T, const Globals& G, const RegBl
 	}
 }
 
-// indices out; requires ibase scanned and st.iOff set.  Nothing is re-resolved: created vertices count up from the
-// cell's vbase, reused ones come from the stored (direction, slot) of the owner cell.
+// indices of one chunk of the block's index list into the LDS staging buffer (st.vdesc, free after vertex emission);
+// requires ibase scanned.  Nothing is re-resolved: created vertices count up from the cell's vbase, reused ones come
+// from the stored (direction, slot) of the owner cell.  Local indices (< 49152) fit 16 bits, 0xFFFF = INVALID_INDEX.
 template <typename ST>
-TV_HD void reg_phase_emit_indices(ST& st, const Tables& T, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int tid, int nth)
 {
 	const int nt = st.wordPrefix[128];
-	if (st.iOff + st.iTotal > P.idxCap) return;
 	for (int k = tid; k < nt; k += nth) {
+		const u32 keepMask = st.info[k] >> 24;
+		const u32 first = st.ibase[k], count = 3u * (u32)TV_POPC(keepMask);
+		if (first >= chunkBase + VDESC_CAP || first + count <= chunkBase) continue;
 		const u32 c = st.cellOf[k];
 		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
 		i8 V[8];
@@ -613,8 +623,7 @@ TV_HD void reg_phase_emit_indices(ST& st, const Tables& T, const Pools& P, const
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
 		const u32 newMask = st.newMask[k], invalidMask = st.invalidMask[k];
 		const unsigned long long src = st.reuseSrc[k];
-		// local vertex indices (< 49152) packed 4 x u16 per 64-bit register, 0xFFFF = INVALID_INDEX
-		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0;
+		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0; // 4 x u16 per register
 		u32 ord = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
 			u32 id;
@@ -631,18 +640,29 @@ TV_HD void reg_phase_emit_indices(ST& st, const Tables& T, const Pools& P, const
 			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
 			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
 		}
-		u32* out = P.idx + st.iOff + st.ibase[k];
-		const u32 keepMask = st.info[k] >> 24;
+		u32 pos = first;
 		for (u32 tr = 0; tr < ntri; ++tr) {
 			if (!((keepMask >> tr) & 1u)) continue;
-			for (u32 e = 0; e < 3; ++e) {
+			for (u32 e = 0; e < 3; ++e, ++pos) {
+				if (pos < chunkBase || pos >= chunkBase + VDESC_CAP) continue;
 				const u32 vi = cd[1 + tr * 3 + e];
 				const unsigned long long pk = (vi < 4) ? pk0 : ((vi < 8) ? pk1 : pk2);
-				const u32 id = (u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu;
-				out[e] = (id == 0xFFFFu) ? INVALID_INDEX : id;
+				st.vdesc[pos - chunkBase] = (u16)((u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu);
 			}
-			out += 3;
 		}
+	}
+}
+
+// staged chunk -> index pool: consecutive lanes write consecutive dwords
+template <typename ST>
+TV_HD void reg_phase_flush_indices(const ST& st, const Pools& P, u32 chunkBase, int tid, int nth)
+{
+	if (st.iOff + st.iTotal > P.idxCap) return;
+	const u32 end = (st.iTotal - chunkBase < (u32)VDESC_CAP) ? st.iTotal - chunkBase : (u32)VDESC_CAP;
+	u32* out = P.idx + st.iOff + chunkBase;
+	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
+		const u32 id = st.vdesc[j];
+		out[j] = (id == 0xFFFFu) ? INVALID_INDEX : id;
 	}
 }
 

@@ -122,15 +122,24 @@ __device__ __forceinline__ void gpu_stage_samples17(const GridView& g, u32 bx, u
 __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockCtx& b, i8* samp)
 {
 	if (b.level == 0) {
+		// one lane per 24-byte row (361 rows): the row address is formed once, the six aligned dwords follow from it
 		const int n = g.n, gx0 = (int)b.bx * 16 - 4;
-		batched_gather<361 * 6, u32, 3>(
-			[&](int q) { const int r = q / 6, j = q - r * 6, jj = r % 19, kk = r / 19;
-			             const int y = clampi((int)b.by * 16 + jj - 1, 0, n - 1);
-			             const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
-			             const int x = clampi(gx0 + 4 * j, 0, n - 4);
-			             return *(const u32*)(g.dist + ((size_t)z * n + y) * n + x); },
-			[&](int q, u32 v) { const int r = q / 6, j = q - r * 6, jj = r % 19, kk = r / 19;
-			                    *(u32*)(samp + kk * SPLANE + jj * SROW + 4 * j) = v; });
+		const int xFirst = gx0 < 0 ? 0 : gx0, xLast = (gx0 + 20 > n - 4) ? n - 4 : gx0 + 20; // dword clamps of j = 0 / j = 5
+#pragma unroll 1
+		for (int r = (int)threadIdx.x; r < 361; r += WG) {
+			const int jj = r % 19, kk = r / 19;
+			const int y = clampi((int)b.by * 16 + jj - 1, 0, n - 1);
+			const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
+			const i8* row = g.dist + ((size_t)z * n + y) * n;
+			u32 v[6];
+			v[0] = *(const u32*)(row + xFirst);
+#pragma unroll
+			for (int j = 1; j < 5; ++j) v[j] = *(const u32*)(row + gx0 + 4 * j);
+			v[5] = *(const u32*)(row + xLast);
+			u32* dst = (u32*)(samp + kk * SPLANE + jj * SROW);
+#pragma unroll
+			for (int j = 0; j < 6; ++j) dst[j] = v[j];
+		}
 	} else {
 		batched_gather<SAMPLES, i8, 5>(
 			[&](int s) { const int i = s % 17, j = (s / 17) % 17, k = s / 289;
@@ -463,7 +472,12 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 		}
 		__syncthreads();
 		if (lim == 8) continue;
-		reg_phase_emit_indices(st, T, p.P, b, tid, WG);
+		for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
+			if (chunk) __syncthreads();
+			reg_phase_stage_indices(st, T, chunk, tid, WG);
+			__syncthreads();
+			reg_phase_flush_indices(st, p.P, chunk, tid, WG);
+		}
 		reg_phase_record(st, p.G, L, b, p.P, tid);
 	}
 }
@@ -774,7 +788,9 @@ struct Backend {
 	{
 		u32 cap = 0;
 		for (u32 l = 0; l < levels; ++l) cap += p.levels[l].cap;
-		const u32 gridS = std::min<u32>(cap, (u32)cus * 5), gridL = std::min<u32>(cap, (u32)cus * 2);
+		const char* wgEnv = getenv("VX_REG_WGS_PER_CU"); // tuning aid
+		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : 4u;
+		const u32 gridS = std::min<u32>(cap, (u32)cus * perCu), gridL = std::min<u32>(cap, (u32)cus * 1);
 		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), stream, dev(p), levels, 0u);
 		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), stream, dev(p), levels, (u32)REG_CAP_SMALL);
 		check(hipGetLastError(), "k_regular launch");
