@@ -172,7 +172,7 @@ struct Backend {
 					reg_phase_stage_indices(*st, T, chunk, 0, 1);
 					reg_phase_flush_indices(*st, p.P, chunk, 0, 1);
 				}
-				reg_phase_record(*st, p.G, L, b, p.P, 0);
+				reg_phase_record(*st, p.G.stats, L, b, p.P, 0);
 			}
 		}
 		delete st;

@@ -675,8 +675,10 @@ TV_HD void reg_write_empty_record(const LevelDesc& L, u32 slot)
 	r.degenerate = 0; r.ntCells = 0; r.pad = 0;
 }
 
+// `acc` = 20 counters (layout of Globals::stats) private to the caller: the HIP kernels keep them in LDS for the whole
+// launch and flush them once per workgroup — per-block global atomics on one cache line serialise chip-wide.
 template <typename ST>
-TV_HD void reg_phase_record(const ST& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
+TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
 {
 	if (tid != 0) return;
 	BlockRecord& r = L.records[b.slot];
@@ -688,9 +690,9 @@ TV_HD void reg_phase_record(const ST& st, const Globals& G, const LevelDesc& L, 
 	r.ntCells = st.wordPrefix[128];
 	r.pad = 0;
 	if (!ok) TV_ATOMIC_OR(&P.cursors[2], 1u);
-	TV_ATOMIC_ADD(&G.stats[0], (u32)st.wordPrefix[128]);
-	if (st.vTotal) TV_ATOMIC_ADD(&G.stats[1], st.degenerate);
-	for (int i = 0; i < 16; ++i) if (st.perCase[i]) TV_ATOMIC_ADD(&G.stats[4 + i], st.perCase[i]);
+	acc[0] += (u32)st.wordPrefix[128];
+	if (st.vTotal) acc[1] += st.degenerate;
+	for (int i = 0; i < 16; ++i) acc[4 + i] += st.perCase[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------

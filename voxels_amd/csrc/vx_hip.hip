@@ -403,7 +403,9 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 	ST& st = *(ST*)(smem + REG_TAB_LDS);
 	__shared__ WorkList wl;
 	__shared__ u32 scanScratch[8];
+	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
 
+	if (threadIdx.x < 20) wgStats[threadIdx.x] = 0;
 	const Tables T = stage_regular_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
@@ -478,8 +480,10 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 			__syncthreads();
 			reg_phase_flush_indices(st, p.P, chunk, tid, WG);
 		}
-		reg_phase_record(st, p.G, L, b, p.P, tid);
+		reg_phase_record(st, wgStats, L, b, p.P, tid);
 	}
+	__syncthreads();
+	if (threadIdx.x < 20 && wgStats[threadIdx.x]) atomicAdd(&p.G.stats[threadIdx.x], wgStats[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
