@@ -160,14 +160,14 @@ struct Backend {
 				reg_phase_cells(*st, T, p.G, L, b, 0, 1);
 				reg_phase_count(*st, T, b, 0, 1);
 				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[128]);
-				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[0], st->vTotal);
+				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_V], st->vTotal);
 				for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
 					reg_phase_describe(*st, chunk, 0, 1);
 					reg_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
 				}
 				reg_phase_keep(*st, T, p.G, b, 0, 1);
 				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[128]);
-				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
+				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
 				for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
 					reg_phase_stage_indices(*st, T, chunk, 0, 1);
 					reg_phase_flush_indices(*st, p.P, chunk, 0, 1);
@@ -207,8 +207,8 @@ struct Backend {
 				tr_phase_count(*st, T, 0, 1);
 				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);
 				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[48]);
-				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[0], st->vTotal);
-				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[1], st->iTotal);
+				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_V], st->vTotal);
+				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
 				tr_phase_emit(*st, T, p.G, p.P, b, 0, 1);
 				tr_phase_record(*st, L, b, p.P, 0);
 			}

@@ -29,6 +29,7 @@ template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v;
 namespace tv {
 
 enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
+enum { CUR_V = 0, CUR_I = 32, CUR_OVF = 64 }; // hot device counters live in separate cache lines (atomics serialise per line)
 
 // One emitted block (regular mesh + 6 transition meshes) inside the shared vertex/index pools
 struct BlockRecord {
@@ -62,7 +63,7 @@ struct LevelDesc {
 struct Pools {
 	PolyVertex* verts;
 	u32* idx;
-	u32* cursors;       // [0] vertices used, [1] indices used, [2] overflow flag
+	u32* cursors;       // [CUR_V] vertices used, [CUR_I] indices used, [CUR_OVF] overflow flag — one 128-byte line each
 	u32 vertCap, idxCap;
 };
 
@@ -689,7 +690,7 @@ TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const Re
 	r.degenerate = st.degenerate;
 	r.ntCells = st.wordPrefix[128];
 	r.pad = 0;
-	if (!ok) TV_ATOMIC_OR(&P.cursors[2], 1u);
+	if (!ok) TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u);
 	acc[0] += (u32)st.wordPrefix[128];
 	if (st.vTotal) acc[1] += st.degenerate;
 	for (int i = 0; i < 16; ++i) acc[4 + i] += st.perCase[i];
@@ -890,7 +891,7 @@ TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlock
 	if (tid != 0) return;
 	BlockRecord& r = L.records[b.slot];
 	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
-	if (!ok) { TV_ATOMIC_OR(&P.cursors[2], 1u); return; }
+	if (!ok) { TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u); return; }
 	const u32 nt = st.wordPrefix[48];
 	for (int f = 0; f < 6; ++f) {
 		const u32 k0 = st.wordPrefix[f * 8], k1 = st.wordPrefix[f * 8 + 8];

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 		if (lim == 4) continue;
 		{
 			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[128], scanScratch);
-			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[0], vt); }
+			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt); }
 		}
 		__syncthreads();
 		if (lim == 5) continue;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 		if (lim == 7) continue;
 		{
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
-			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[1], it); }
+			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[CUR_I], it); }
 		}
 		__syncthreads();
 		if (lim == 8) continue;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
 			if (tid == 0) {
 				st.vTotal = vt; st.iTotal = it;
-				st.vOff = atomicAdd(&p.P.cursors[0], vt);
-				st.iOff = atomicAdd(&p.P.cursors[1], it);
+				st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt);
+				st.iOff = atomicAdd(&p.P.cursors[CUR_I], it);
 			}
 		}
 		__syncthreads();

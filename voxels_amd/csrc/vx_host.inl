@@ -46,7 +46,7 @@ struct EmittedBlock {
 	std::shared_ptr<Meshes> own;
 };
 
-enum { HDR_WORDS = 48, HDR_CURSORS = 8, HDR_STATS = 12, HDR_WORK = 32 };
+enum { HDR_WORDS = 192, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -59,7 +59,7 @@ struct vx_ctx {
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
-	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header: nActive[8] | cursors[4] | stats[20] | workCount[8]
+	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header (HDR_WORDS u32): slot counts | vertex cursor | index cursor | overflow | stats[20] | workCount[8], one line each
 	void *dDirty = nullptr, *dWork = nullptr, *dGather = nullptr;  // incremental runs: dirty block coords, work items, gathered records
 	u32 dirtyCap = 0;
 	// level tables
@@ -460,13 +460,13 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		t2 = tNow();
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
 		t3 = tNow();
-		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + 1], overflow = c->hdr[HDR_CURSORS + 2];
+		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
 	}
 	c->levelsRun = levels;
-	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + 1];
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->poolsOnHost = false;
 	c->haveSurface = true;
 	c->listsReady = false; // block lists (record read-back + ordering) are materialised on first access
@@ -587,13 +587,13 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		c->be.stage_mark(6);
 		ms = c->be.end_timing_ms();
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
-		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + 1], overflow = c->hdr[HDR_CURSORS + 2];
+		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
-	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + 1];
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->poolsOnHost = false;
 	if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
 	std::vector<BlockRecord> recs(total);
