@@ -209,7 +209,11 @@ struct Backend {
 				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[48]);
 				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_V], st->vTotal);
 				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
-				tr_phase_emit(*st, T, p.G, p.P, b, 0, 1);
+				for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
+					tr_phase_describe(*st, chunk, 0, 1);
+					tr_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
+				}
+				tr_phase_emit_indices(*st, T, p.P, 0, 1);
 				tr_phase_record(*st, L, b, p.P, 0);
 			}
 		}

@@ -711,6 +711,8 @@ struct TrState {
 	u8 ords[TR_CELLS][10];    // compact: ordinal of the vertex stored in each slot
 	u16 vbase[TR_CELLS];      // compact: exclusive scan of new vertex counts (flat over faces)
 	u16 ibase[TR_CELLS];      // compact: exclusive scan of index counts (flat over faces)
+	u16 newMask[TR_CELLS];    // compact: table vertices this cell creates
+	u16 vdesc[VDESC_CAP];     // one chunk of new-vertex descriptors: compact cell | table vertex << 11
 	u32 faceOn;               // bit f = face has a neighbour block
 	u32 vOff, iOff, vTotal, iTotal;
 };
@@ -819,28 +821,82 @@ TV_HD void tr_phase_count(TrState& st, const Tables& T, int tid, int nth)
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
 		const u32 mask2 = tr_mask2(st, f, row, col);
 		TrNeighbour nb{ &st, f, row, col };
-		u32 count = 0;
+		u32 count = 0, newMask = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
 			const TrResolution r = tr_resolve(T, v, T.trVert(code, vi), mask2, st.cellMat[k] & 0xFFu, nb);
 			if (r.kind == RK_NEW_EDGE) {
 				if (r.store != NO_SLOT) st.ords[k][r.store] = (u8)count;
 				++count;
+				newMask |= 1u << vi;
 			}
 		}
 		st.vbase[k] = (u16)count;
 		st.ibase[k] = (u16)(ntri * 3);
+		st.newMask[k] = (u16)newMask;
 	}
 }
 
-// vertices and indices of all transition cells; requires vbase/ibase scanned, vOff/iOff set
-TV_HD void tr_phase_emit(TrState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, int tid, int nth)
+TV_HD void tr_cell_geom(const FaceGeom& fg, const RegBlockCtx& b, int row, int col, TrCellGeom& geo)
+{
+	tr_low_local(fg, row, col, geo.local);
+	geo.mult = (int)b.mult; geo.level = (int)b.level;
+	geo.lowBase[0] = (int)((b.bx * 16 + geo.local[0]) * b.mult);
+	geo.lowBase[1] = (int)((b.by * 16 + geo.local[1]) * b.mult);
+	geo.lowBase[2] = (int)((b.bz * 16 + geo.local[2]) * b.mult);
+}
+
+// descriptors of this chunk's new vertices (after vbase is scanned)
+TV_HD void tr_phase_describe(TrState& st, u32 chunkBase, int tid, int nth)
+{
+	const int nt = st.wordPrefix[48];
+	for (int k = tid; k < nt; k += nth) {
+		u32 m = st.newMask[k];
+		u32 j = st.vbase[k];
+		if (j >= chunkBase + VDESC_CAP || j + 12 <= chunkBase) continue;
+		while (m) {
+			const u32 vi = (u32)__builtin_ctz(m);
+			m &= m - 1;
+			if (j >= chunkBase && j < chunkBase + VDESC_CAP) st.vdesc[j - chunkBase] = (u16)((u32)k | (vi << 11));
+			++j;
+		}
+	}
+}
+
+// one lane = one new transition vertex of the chunk
+TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
+{
+	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
+	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
+	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
+		const u32 desc = st.vdesc[j];
+		const u32 k = desc & 0x7FFu, vi = desc >> 11;
+		const u32 c = st.cellOf[k];
+		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
+		const FaceGeom fg = face_geom(f);
+		i8 v9[9], v[13];
+		tr_cell_values(st, f, row, col, v9);
+		tr_expand_values(v9, v);
+		const u32 w = T.trVert(tr_case_code(v9), vi);
+		TrResolution r;
+		int corner; u32 dir, slot; bool endpoint;
+		tr_vertex_dir_slot(T, v, w, r.t, dir, slot, endpoint, corner);
+		r.endpoint = endpoint ? 1 : 0; r.dir = (u8)dir; r.slot = (u8)slot; r.kind = RK_NEW_EDGE; r.store = NO_SLOT;
+		TrCellGeom geo;
+		tr_cell_geom(fg, b, row, col, geo);
+		RawVertex rv;
+		tr_new_vertex(G.grid, fg, geo, v, w, r, st.cellMat[k], rv);
+		pack_vertex(rv, G.lut, P.verts + st.vOff + chunkBase + j);
+	}
+}
+
+// indices of all transition cells; requires vbase/ibase scanned, vOff/iOff set
+TV_HD void tr_phase_emit_indices(TrState& st, const Tables& T, const Pools& P, int tid, int nth)
 {
 	const int nt = st.wordPrefix[48];
 	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
 	for (int k = tid; k < nt; k += nth) {
 		const u32 c = st.cellOf[k];
 		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
-		const FaceGeom fg = face_geom(f);
 		i8 v9[9], v[13];
 		tr_cell_values(st, f, row, col, v9);
 		tr_expand_values(v9, v);
@@ -848,39 +904,34 @@ TV_HD void tr_phase_emit(TrState& st, const Tables& T, const Globals& G, const P
 		const u32 cls = T.trClass(code);
 		const u8* cd = T.trCell(cls & 0x7F);
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
-		const u32 mask2 = tr_mask2(st, f, row, col);
-		const u32 lowMat = st.cellMat[k];
-		TrNeighbour nb{ &st, f, row, col };
-		TrCellGeom geo;
-		tr_low_local(fg, row, col, geo.local);
-		geo.mult = (int)b.mult; geo.level = (int)b.level;
-		geo.lowBase[0] = (int)((b.bx * 16 + geo.local[0]) * b.mult);
-		geo.lowBase[1] = (int)((b.by * 16 + geo.local[1]) * b.mult);
-		geo.lowBase[2] = (int)((b.bz * 16 + geo.local[2]) * b.mult);
-		const u32 faceFirst = st.wordPrefix[f * 8];           // compact index of the face's first cell
-		const u32 faceVBase = st.vbase[faceFirst];            // valid: this face has at least cell k
-		u32 vidx[12];
+		const u32 newMask = st.newMask[k];
+		const u32 faceVBase = st.vbase[st.wordPrefix[f * 8]]; // compact index of the face's first cell exists: cell k is in it
+		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0;          // per-face local indices (< 3072), 4 x u16 per register
 		u32 ord = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
-			const u32 w = T.trVert(code, vi);
-			const TrResolution r = tr_resolve(T, v, w, mask2, lowMat & 0xFFu, nb);
-			if (r.kind == RK_REUSE) {
-				const u32 c2 = (u32)((f << 8) | ((row - ((r.dir >> 1) & 1)) << 4) | (col - (r.dir & 1)));
-				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-				vidx[vi] = (u32)st.vbase[k2] - faceVBase + st.ords[k2][r.slot];
+			u32 id;
+			if ((newMask >> vi) & 1u) {
+				id = (u32)st.vbase[k] - faceVBase + ord; ++ord;
 			} else {
-				RawVertex rv;
-				tr_new_vertex(G.grid, fg, geo, v, w, r, lowMat, rv);
-				pack_vertex(rv, G.lut, P.verts + st.vOff + st.vbase[k] + ord);
-				vidx[vi] = (u32)st.vbase[k] - faceVBase + ord;
-				++ord;
+				int t, corner; u32 dir, slot; bool endpoint;
+				tr_vertex_dir_slot(T, v, T.trVert(code, vi), t, dir, slot, endpoint, corner);
+				const u32 c2 = (u32)((f << 8) | ((row - (int)((dir >> 1) & 1)) << 4) | (col - (int)(dir & 1)));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				id = (u32)st.vbase[k2] - faceVBase + st.ords[k2][slot];
 			}
+			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
+			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
 		}
 		u32* out = P.idx + st.iOff + st.ibase[k];
 		const bool flip = ((cls >> 7) ^ (u32)(f & 1)) != 0; // reverseWinding = {0,1,0,1,0,1}
 		for (u32 tr = 0; tr < ntri; ++tr) {
-			const u32 a = vidx[cd[1 + tr * 3]], bb = vidx[cd[2 + tr * 3]], cc = vidx[cd[3 + tr * 3]];
-			out[0] = a; out[1] = flip ? cc : bb; out[2] = flip ? bb : cc;
+			u32 id3[3];
+			for (u32 e = 0; e < 3; ++e) {
+				const u32 vi = cd[1 + tr * 3 + e];
+				const unsigned long long pk = (vi < 4) ? pk0 : ((vi < 8) ? pk1 : pk2);
+				id3[e] = (u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu;
+			}
+			out[0] = id3[0]; out[1] = flip ? id3[2] : id3[1]; out[2] = flip ? id3[1] : id3[2];
 			out += 3;
 		}
 	}

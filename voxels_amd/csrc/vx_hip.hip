@@ -566,7 +566,13 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			}
 		}
 		__syncthreads();
-		tr_phase_emit(st, T, p.G, p.P, b, tid, WG);
+		for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
+			if (chunk) __syncthreads();
+			tr_phase_describe(st, chunk, tid, WG);
+			__syncthreads();
+			tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+		}
+		tr_phase_emit_indices(st, T, p.P, tid, WG);
 		tr_phase_record(st, L, b, p.P, tid);
 		__syncthreads();
 	}
