@@ -113,7 +113,7 @@ __device__ __forceinline__ void batched_gather(LoadFn load, StoreFn store)
 // GPU forms of the staging phases of tv_block.h (same results, batched loads)
 __device__ __forceinline__ void gpu_stage_samples17(const GridView& g, u32 bx, u32 by, u32 bz, u32 mult, i8* samp)
 {
-	batched_gather<SAMPLES, i8, 5>(
+	batched_gather<SAMPLES, i8, 10>(
 		[&](int s) { const int i = s % 17, j = (s / 17) % 17, k = s / 289;
 		             return (i8)dist_at(g, (int)((bx * 16 + i) * mult), (int)((by * 16 + j) * mult), (int)((bz * 16 + k) * mult)); },
 		[&](int s, i8 v) { samp[s] = v; });
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			for (int w = tid; w < 48; w += WG) st.ntBits[w] = 0;
 			const int half = (int)b.mult >> 1;
 			const GridView& g = p.G.grid;
-			batched_gather<6 * PLANE, i8, 5>(
+			batched_gather<6 * PLANE, i8, 13>(
 				[&](int s) -> i8 {
 					const int f = s / PLANE, r = s - f * PLANE;
 					if (!((on >> f) & 1u)) return 0;
