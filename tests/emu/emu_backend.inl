@@ -27,6 +27,8 @@ struct Backend {
 	void free_pinned(void* p) { ::free(p); }
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
+	bool stage_timing_on() const { return true; } // the emulation always runs the serial order
+	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
 	bool stage_ms(float*) { return false; }
@@ -202,7 +204,7 @@ struct Backend {
 				tr_phase_classify(*st, 0, 1);
 				for (int w = 0; w < 48; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
 				st->wordPrefix[48] = (u16)exclusive_scan(st->wordPrefix, 48);
-				if (!st->wordPrefix[48]) continue;
+				if (!st->wordPrefix[48]) { tr_write_empty_record(L, slot); continue; }
 				tr_phase_list(*st, T, L, b, 0, 1);
 				tr_phase_count(*st, T, 0, 1);
 				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);

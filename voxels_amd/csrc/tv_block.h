@@ -344,7 +344,6 @@ struct RegStateT {
 	u16 newMask[CAP];         // compact: table vertices this cell creates
 	u16 atV0Mask[CAP];        // compact: created corner vertices placed at edge corner v0 (TransVoxelImpl.cpp:1637)
 	u16 invalidMask[CAP];     // compact: table vertices that resolve to INVALID_INDEX
-	unsigned long long reuseSrc[CAP]; // compact: 12 x 5 bits (direction << 2 | slot) of reused vertices
 	u16 vdesc[VDESC_CAP];     // one chunk of new-vertex descriptors: compact cell | table vertex << 12
 	u32 suspect[128];         // per cell id: touches a vertex that is not strictly inside its edge (may be degenerate)
 	u32 perCase[16];
@@ -465,7 +464,6 @@ TV_HD void reg_phase_count(ST& st, const Tables& T, const RegBlockCtx& b, int ti
 		const u32 myMat = st.cellMat[k] & 0xFFu;
 		RegNeighbour<ST> nb{ &st, cx, cy, cz };
 		u32 count = 0, ords = 0, newMask = 0, atV0 = 0, invalid = 0;
-		unsigned long long src = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
 			const u32 w = T.regVert(code, vi);
 			const Resolution r = reg_resolve(V, w, mask3, myMat, nb);
@@ -474,16 +472,13 @@ TV_HD void reg_phase_count(ST& st, const Tables& T, const RegBlockCtx& b, int ti
 				++count;
 				newMask |= 1u << vi;
 				if (r.kind == RK_NEW_CORNER && r.a == ((w >> 4) & 15)) atV0 |= 1u << vi;
-			} else if (r.kind == RK_REUSE) {
-				src |= (unsigned long long)(((u32)r.a << 2) | r.b) << (vi * 5);
-			} else {
+			} else if (r.kind != RK_REUSE) {
 				invalid |= 1u << vi;
 			}
 		}
 		st.info[k] = (st.info[k] & 0x000F0000u) | (count << 20) | ords;
 		st.vbase[k] = (u16)count;
 		st.newMask[k] = (u16)newMask; st.atV0Mask[k] = (u16)atV0; st.invalidMask[k] = (u16)invalid;
-		st.reuseSrc[k] = src;
 	}
 }
 
@@ -620,10 +615,10 @@ TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int t
 		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
 		i8 V[8];
 		reg_cell_values(st.samp, cx, cy, cz, V);
-		const u8* cd = T.regCell(T.regClass(reg_case_code(V)));
+		const u32 code = reg_case_code(V);
+		const u8* cd = T.regCell(T.regClass(code));
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
 		const u32 newMask = st.newMask[k], invalidMask = st.invalidMask[k];
-		const unsigned long long src = st.reuseSrc[k];
 		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0; // 4 x u16 per register
 		u32 ord = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
@@ -633,7 +628,8 @@ TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int t
 			} else if ((invalidMask >> vi) & 1u) {
 				id = 0xFFFFu;
 			} else {
-				const u32 ds = (u32)(src >> (vi * 5)) & 31u, dir = ds >> 2, slot = ds & 3u;
+				u32 dir, slot;
+				reg_reuse_source(V, T.regVert(code, vi), dir, slot);
 				const u32 c2 = (u32)(((cz - (int)((dir >> 2) & 1)) << 8) | ((cy - (int)((dir >> 1) & 1)) << 4) | (cx - (int)(dir & 1)));
 				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
 				id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);
@@ -672,7 +668,8 @@ TV_HD void reg_write_empty_record(const LevelDesc& L, u32 slot)
 	BlockRecord& r = L.records[slot];
 	r.coordId = L.slotCoord[slot];
 	r.vOff = r.vCount = r.iOff = r.iCount = 0;
-	for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
+	// the transition fields belong to the transition pass wherever it runs (it may run concurrently on another stream)
+	if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
 	r.degenerate = 0; r.ntCells = 0; r.pad = 0;
 }
 
@@ -686,7 +683,7 @@ TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const Re
 	r.coordId = L.slotCoord[b.slot];
 	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
 	r.vOff = st.vOff; r.vCount = ok ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = ok ? st.iTotal : 0;
-	for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
+	if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
 	r.degenerate = st.degenerate;
 	r.ntCells = st.wordPrefix[128];
 	r.pad = 0;
@@ -937,12 +934,19 @@ TV_HD void tr_phase_emit_indices(TrState& st, const Tables& T, const Pools& P, i
 	}
 }
 
+// a block of a transition level without any transition geometry
+TV_HD void tr_write_empty_record(const LevelDesc& L, u32 slot)
+{
+	BlockRecord& r = L.records[slot];
+	for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
+}
+
 TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
 {
 	if (tid != 0) return;
 	BlockRecord& r = L.records[b.slot];
 	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
-	if (!ok) { TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u); return; }
+	if (!ok) { TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u); tr_write_empty_record(L, b.slot); return; }
 	const u32 nt = st.wordPrefix[48];
 	for (int f = 0; f < 6; ++f) {
 		const u32 k0 = st.wordPrefix[f * 8], k1 = st.wordPrefix[f * 8 + 8];

@@ -26,6 +26,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -220,7 +221,12 @@ TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out)
 	if (f) f = (f >> 3) | ((f & 7u) << 3);
 	o.secW = f;
 	o.nrm[0] = r.n[0]; o.nrm[1] = r.n[1]; o.nrm[2] = r.n[2];
-	const u8* e = lut + (r.mat & 0xFFu) * 8;
+	// one aligned 8-byte fetch of the LUT row {Ids0[3], Ids1[3], valid, pad}
+	unsigned long long row;
+	memcpy(&row, lut + (r.mat & 0xFFu) * 8, 8);
+	u8 e[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) e[i] = (u8)(row >> (8 * i));
 	const bool ok = e[6] != 0;
 	o.tex[0] = 0;
 	o.tex[1] = ok ? (u8)(r.mat >> 8) : 0;
@@ -317,6 +323,15 @@ TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const
 		r.store = ((w >> 12) == 8u) ? (u8)slot : (u8)NO_SLOT;
 	}
 	return r;
+}
+
+// (direction, slot) a reused vertex `w` comes from, as reg_resolve derives them
+TV_HD void reg_reuse_source(const i8 V[8], u32 w, u32& dir, u32& slot)
+{
+	const int v0 = (w >> 4) & 15, v1 = w & 15;
+	const int t = edge_t(V[v0], V[v1]);
+	dir = w >> 12; slot = (w >> 8) & 15;
+	if ((t & 0xFF) == 0) { dir = (u32)((t == 0) ? v1 : v0) ^ 7u; slot = 0; }
 }
 
 struct CellGeom {

@@ -396,7 +396,7 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 
 // One capacity class of the regular pass: blocks with lo < non-trivial cells <= CAP
 template <int CAP>
-__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32 lo)
+__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
 	u8* tab = smem;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levels, u32
 	const Tables T = stage_regular_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
-		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive; }
+		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; if (l >= levelBegin) run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive; }
 		for (u32 l = levels; l <= MAX_LEVELS; ++l) wl.start[l] = run;
 	}
 	__syncthreads();
@@ -551,7 +551,11 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			if (tid == 0) st.wordPrefix[48] = (u16)nt;
 		}
 		__syncthreads();
-		if (st.wordPrefix[48] == 0) { __syncthreads(); continue; }
+		if (st.wordPrefix[48] == 0) {
+			if (tid == 0) tr_write_empty_record(L, b.slot);
+			__syncthreads();
+			continue;
+		}
 		tr_phase_list(st, T, L, b, tid, WG);
 		__syncthreads();
 		tr_phase_count(st, T, tid, WG);
@@ -630,6 +634,8 @@ __global__ __launch_bounds__(WG) void k_gather_records(ExecParamsDev p, DirtyRan
 // ------------------------------------------------------------------------------------------------------
 struct Backend {
 	hipStream_t ownStream = nullptr, stream = nullptr;
+	hipStream_t sideA = nullptr, sideB = nullptr;      // level-0 regular pass / transition pass run beside the material chain
+	hipEvent_t evClassified = nullptr, evMaterial = nullptr, evSideA = nullptr, evSideB = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipEvent_t stageEv[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	bool stageOn = false, stageValid = false;
@@ -654,6 +660,12 @@ struct Backend {
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
 		stream = ownStream;
+		(void)hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking);
+		(void)hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking);
+		(void)hipEventCreateWithFlags(&evClassified, hipEventDisableTiming);
+		(void)hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming);
+		(void)hipEventCreateWithFlags(&evSideA, hipEventDisableTiming);
+		(void)hipEventCreateWithFlags(&evSideB, hipEventDisableTiming);
 		(void)hipEventCreate(&ev0);
 		(void)hipEventCreate(&ev1);
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
@@ -671,6 +683,9 @@ struct Backend {
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		for (int i = 0; i < 7; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
+		if (sideA) (void)hipStreamDestroy(sideA);
+		if (sideB) (void)hipStreamDestroy(sideB);
+		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB }) if (e) (void)hipEventDestroy(e);
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
@@ -794,17 +809,49 @@ struct Backend {
 		check(hipGetLastError(), "k_material launch");
 	}
 	template <typename P>
-	void run_regular(const P& p, u32 levels)
+	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on)
 	{
 		u32 cap = 0;
-		for (u32 l = 0; l < levels; ++l) cap += p.levels[l].cap;
+		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
+		if (!cap) return;
 		const char* wgEnv = getenv("VX_REG_WGS_PER_CU"); // tuning aid
 		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : 4u;
 		const u32 gridS = std::min<u32>(cap, (u32)cus * perCu), gridL = std::min<u32>(cap, (u32)cus * 1);
-		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), stream, dev(p), levels, 0u);
-		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), stream, dev(p), levels, (u32)REG_CAP_SMALL);
+		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
+		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
 		check(hipGetLastError(), "k_regular launch");
 	}
+	template <typename P>
+	void run_regular(const P& p, u32 levels) { launch_regular(p, 0, levels, stream); }
+
+	// Overlapped tail of a full run (after classify + hierarchy on the main stream):
+	//   side stream A : regular cells of level 0 (independent of the material caches)
+	//   main stream   : material chain L1..Lmax, then regular cells of levels >= 1
+	//   side stream B : transition cells (after the material chain)
+	// The small, latency-bound material launches no longer leave the chip idle.
+	template <typename P>
+	void run_overlapped_tail(const P& p, u32 levels)
+	{
+		(void)hipEventRecord(evClassified, stream);
+		(void)hipStreamWaitEvent(sideA, evClassified, 0);
+		launch_regular(p, 0, 1, sideA);
+		(void)hipEventRecord(evSideA, sideA);
+		for (u32 L = 1; L < levels; ++L) run_material(p, L);
+		(void)hipEventRecord(evMaterial, stream);
+		(void)hipStreamWaitEvent(sideB, evMaterial, 0);
+		{
+			hipStream_t keep = stream;
+			stream = sideB;
+			run_transition(p, levels);
+			stream = keep;
+		}
+		(void)hipEventRecord(evSideB, sideB);
+		if (levels > 1) launch_regular(p, 1, levels, stream);
+		(void)hipStreamWaitEvent(stream, evSideA, 0);
+		(void)hipStreamWaitEvent(stream, evSideB, 0);
+	}
+	bool stage_timing_on() const { return stageOn; }
+
 	template <typename P>
 	void run_transition(const P& p, u32 levels)
 	{

@@ -215,6 +215,11 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	c->be.run_classify(p);
 	c->be.stage_mark(2);
 	c->be.run_hierarchy(p, levels);
+	if (!c->be.stage_timing_on()) {
+		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless)
+		c->be.run_overlapped_tail(p, levels);
+		return;
+	}
 	c->be.stage_mark(3);
 	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
 	c->be.stage_mark(4);
