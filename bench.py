@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("VOXELS_BENCH_N", "1024")))
     ap.add_argument("--levels", type=int, default=int(os.environ.get("VOXELS_BENCH_LEVELS", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serialize", action="store_true", help="run the timed steps with the library's streams serialised (one kernel at a time), for per-kernel profiling")
     return ap.parse_args()
 
 
@@ -109,6 +110,9 @@ def main():
     poly.set_materials(vxo.default_lut())
     slab.attach(poly)
 
+    if args.serialize:
+        poly.set_stage_timing(True)
+
     def step():
         halo_exchange()
         return poly.execute(levels)
@@ -122,9 +126,12 @@ def main():
         info = step()
     barrier()
     t0 = time.perf_counter()
+    run_dev_ms = 0.0
     for _ in range(args.steps):
         info = step()
+        run_dev_ms += info.device_ms
     barrier()
+    run_dev_ms /= max(args.steps, 1)
     elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -132,7 +139,9 @@ def main():
         elapsed = float(te.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- per-kernel device timing of the dominant kernel (HIP events on the stream the kernels run on) ----
+    # ---- per-kernel device timing (HIP events on the stream the kernels run on).  With stage timing enabled the
+    #      library serialises its streams so that every kernel's duration is its own; the timed steps above ran the
+    #      normal, overlapped pipeline (level-0 regular pass and transition pass beside the material chain). ----
     poly.set_stage_timing(True)
     stage = np.zeros(6, np.float64)
     reps = 5
@@ -169,9 +178,10 @@ def main():
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": stage_ms[dominant]}
-    whole = {"algorithmic_bytes": int(info.algorithmic_bytes), "device_ms": round(dev_ms, 4),
-             "achieved_GBps": round(info.algorithmic_bytes / (dev_ms * 1e-3) / 1e9, 2),
-             "frac_of_8TBps": round(info.algorithmic_bytes / (dev_ms * 1e-3) / 8e12, 5)}
+    whole = {"algorithmic_bytes": int(info.algorithmic_bytes), "device_ms": round(run_dev_ms, 4),
+             "device_ms_serialized": round(dev_ms, 4),
+             "achieved_GBps": round(info.algorithmic_bytes / (run_dev_ms * 1e-3) / 1e9, 2),
+             "frac_of_8TBps": round(info.algorithmic_bytes / (run_dev_ms * 1e-3) / 8e12, 5)}
 
     if rank == 0:
         out = {
@@ -190,7 +200,7 @@ def main():
                        "grid": n, "levels": levels, "parallelism": "zslab%d" % world,
                        "active_blocks": [int(x) for x in info.active_blocks[:levels]],
                        "verts": int(totals[0]), "indices": int(totals[1]), "tverts": int(totals[2]), "tindices": int(totals[3]),
-                       "stage_ms": stage_ms, "whole_execute": whole, "host_gen_s": round(t_gen, 2),
+                       "stage_ms_serialized": stage_ms, "whole_execute": whole, "host_gen_s": round(t_gen, 2),
                        "halo_exchange_in_step": world > 1},
             "roofline": roofline,
         }

@@ -809,13 +809,13 @@ struct Backend {
 		check(hipGetLastError(), "k_material launch");
 	}
 	template <typename P>
-	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on)
+	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 4)
 	{
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
 		if (!cap) return;
 		const char* wgEnv = getenv("VX_REG_WGS_PER_CU"); // tuning aid
-		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : 4u;
+		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : defaultPerCu;
 		const u32 gridS = std::min<u32>(cap, (u32)cus * perCu), gridL = std::min<u32>(cap, (u32)cus * 1);
 		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
 		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
@@ -834,7 +834,7 @@ struct Backend {
 	{
 		(void)hipEventRecord(evClassified, stream);
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		launch_regular(p, 0, 1, sideA);
+		launch_regular(p, 0, 1, sideA, 3); // 3 workgroups per CU leave LDS for the concurrent material / transition workgroups
 		(void)hipEventRecord(evSideA, sideA);
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
 		(void)hipEventRecord(evMaterial, stream);
@@ -846,7 +846,7 @@ struct Backend {
 			stream = keep;
 		}
 		(void)hipEventRecord(evSideB, sideB);
-		if (levels > 1) launch_regular(p, 1, levels, stream);
+		if (levels > 1) launch_regular(p, 1, levels, stream, 3);
 		(void)hipStreamWaitEvent(stream, evSideA, 0);
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}
