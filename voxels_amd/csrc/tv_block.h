@@ -29,7 +29,8 @@ template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v;
 namespace tv {
 
 enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
-enum { CUR_V = 0, CUR_I = 32, CUR_OVF = 64 }; // hot device counters live in separate cache lines (atomics serialise per line)
+enum { CUR_V = 0, CUR_I = 32, CUR_OVF = 64 };
+enum { LARGE_THRESHOLD = 640 }; // blocks with more non-trivial cells use the 4096-cell LDS class of the regular pass // hot device counters live in separate cache lines (atomics serialise per line)
 
 // One emitted block (regular mesh + 6 transition meshes) inside the shared vertex/index pools
 struct BlockRecord {
@@ -82,6 +83,7 @@ struct Globals {
 	const u32* workItems[MAX_LEVELS]; // dirty: active slots to process per level
 	u32* workCount;                   // dirty: [MAX_LEVELS] number of items per level
 	u32 prevActive[MAX_LEVELS];       // dirty: slots >= prevActive[level] were created by this run
+	u32* largeBlocks;                 // number of classified blocks whose non-trivial cell count exceeds LARGE_THRESHOLD
 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
@@ -147,6 +149,7 @@ TV_HD void publish_level0_block(const Globals& G, const LevelDesc& L, u32 bx, u3
 	}
 	L.skip[slot] = skipped ? 1 : 0;
 	L.ntCount[slot] = (u16)ntCells;
+	if (ntCells > LARGE_THRESHOLD) TV_ATOMIC_ADD(G.largeBlocks, 1u);
 	u32* nt = L.ntBits + (size_t)slot * 128;
 	u32* cons = L.consBits + (size_t)slot * 128;
 	for (int w = 0; w < 128; ++w) {
@@ -245,6 +248,7 @@ TV_HD void mat_phase_select(MatState& st, const Globals& G, const LevelDesc* lev
 		u32 cnt = 0;
 		for (int w = 0; w < 128; ++w) cnt += TV_POPC(st.ntBits[w]);
 		L.ntCount[slot] = (u16)cnt;
+		if (cnt > LARGE_THRESHOLD) TV_ATOMIC_ADD(G.largeBlocks, 1u);
 	}
 }
 

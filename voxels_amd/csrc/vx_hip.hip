@@ -38,7 +38,7 @@ struct ExecParamsDev {
 };
 
 constexpr int WG = 256;
-constexpr int REG_CAP_SMALL = 640; // LDS capacity class of the regular pass that covers ordinary surfaces
+constexpr int REG_CAP_SMALL = LARGE_THRESHOLD; // LDS capacity class of the regular pass that covers ordinary surfaces
 
 // ------------------------------------------------------------------------------------------------------
 // workgroup helpers
@@ -153,23 +153,27 @@ __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockC
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >> 7) * 0x01020408u) >> 24; }
 
+constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
+constexpr int TW = TB / 2;        // 32-bit words of sign bits per tile row
+
 __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 {
-	__shared__ __attribute__((aligned(16))) u16 sgn[289 * 8];   // sign masks: row r = rz*17+ry, 8 x 16 voxels
+	__shared__ __attribute__((aligned(16))) u16 sgn[289 * TB];  // sign masks: row r = rz*17+ry, TB x 16 voxels
 	__shared__ u8 halo[292];                                     // sign of the voxel right of the tile, per row
-	__shared__ __attribute__((aligned(16))) u16 blockBits[8 * 256];
-	__shared__ u32 blockAny[8];
-	__shared__ u32 blockCnt[8];
-	__shared__ u32 blockSkipped[8];
-	__shared__ int blockSlot[8];
+	__shared__ __attribute__((aligned(16))) u16 blockBits[TB * 256];
+	__shared__ u32 blockAny[TB];
+	__shared__ u32 blockCnt[TB];
+	__shared__ u32 blockSkipped[TB];
+	__shared__ u32 blockNonEmpty[TB];
+	__shared__ int blockSlot[TB];
 
 	const LevelDesc& L = p.levels[0];
 	const GridView& g = p.G.grid;
 	const int n = g.n;
-	const u32 tilesX = (L.cnt + 7) / 8;
+	const u32 tilesX = (L.cnt + TB - 1) / TB;
 	// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Give every
-	// XCD a contiguous range of block rows and walk each row's tiles (whole 1 KB+ voxel rows) back to back, so an
-	// XCD's L2 sees all address bits (all of its channels) and consecutive rows share their halo lines in that L2.
+	// XCD a contiguous range of block rows and walk each row's tiles (whole voxel rows) back to back, so an XCD's L2
+	// sees all address bits (all of its channels) and consecutive rows share their halo lines in that L2.
 	u32 tile = blockIdx.x;
 	{
 		const u32 rows = L.cnt * (L.zb1 - L.zb0);
@@ -179,32 +183,31 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 		}
 	}
 	const u32 tx = tile % tilesX, by = (tile / tilesX) % L.cnt, bz = L.zb0 + tile / (tilesX * L.cnt);
-	const int x0 = (int)tx * 128;
-	const int validCells = (n - x0) < 128 ? (n - x0) : 128; // multiple of 16
+	const int x0 = (int)tx * 16 * TB;
+	const int validCells = (n - x0) < 16 * TB ? (n - x0) : 16 * TB; // multiple of 16
 	const int tid = threadIdx.x;
 
-	__shared__ u32 blockNonEmpty[8];
-	if (tid < 8) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockNonEmpty[tid] = 0; }
+	if (tid < TB) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockNonEmpty[tid] = 0; }
+	__syncthreads();
 
-	// emptiness rule (TransVoxelImpl.cpp:1511-1527): one lane per (block, neighbour); the 216 flag loads are issued
-	// before the density loads and only consumed after them, so their latency is hidden
-	u32 neighbourNotEmpty = 0;
-	if (tid < 216) {
-		const int j = tid / 27, k = tid - j * 27;
-		const u32 bx = tx * 8 + (u32)j;
+	// emptiness rule (TransVoxelImpl.cpp:1511-1527): one lane per (block, neighbour); the flag loads are issued before
+	// the density loads, so their latency is hidden
+	for (int q = tid; q < TB * 27; q += WG) {
+		const int j = q / 27, k = q - j * 27;
+		const u32 bx = tx * TB + (u32)j;
 		if (bx < L.cnt) {
 			const u32 cx = (u32)clampi((int)bx + (k % 3) - 1, 0, (int)L.cnt - 1);
 			const u32 cy = (u32)clampi((int)by + ((k / 3) % 3) - 1, 0, (int)L.cnt - 1);
 			const u32 cz = (u32)clampi((int)bz + (k / 9) - 1, 0, (int)L.cnt - 1);
-			neighbourNotEmpty = p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)] ? 0u : 1u;
+			if (!p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)]) atomicAdd(&blockNonEmpty[j], 1u);
 		}
 	}
 
-	// ---- load: 289 rows x 8 segments of 16 bytes, fully coalesced (8 lanes = one 128-byte line); all ten loads
-	//      of a thread are issued before the first sign mask is formed ----------------------------------------
-	batched_gather<289 * 8, uint4, 5>(
+	// ---- load: 289 rows x TB segments of 16 bytes, fully coalesced; several loads of a thread are in flight
+	//      before the first sign mask is formed -------------------------------------------------------------
+	batched_gather<289 * TB, uint4, 6>(
 		[&](int q) {
-			const int r = q >> 3, seg = q & 7;
+			const int r = q / TB, seg = q - r * TB;
 			const int ry = r % 17, rz = r / 17;
 			uint4 d = make_uint4(0, 0, 0, 0);
 			if (seg * 16 < validCells) {
@@ -226,41 +229,50 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			return g.dist[((size_t)z * n + y) * n + x];
 		},
 		[&](int r, i8 v) { halo[r] = (u8)((u32)(v >> 7) & 1u); });
-	if (neighbourNotEmpty) atomicAdd(&blockNonEmpty[tid / 27], 1u);
 	__syncthreads();
 
-	// ---- classify 128 cells of one (y,z) row per thread, bit-parallel ---------------------------------
+	// ---- classify the 16*TB cells of one (y,z) row per thread, bit-parallel -----------------------------
 	{
 		const int y = tid & 15, z = tid >> 4;
 		const int r00 = z * 17 + y, r01 = r00 + 1, r10 = r00 + 17, r11 = r00 + 18;
-		const uint4 a0 = *(const uint4*)(sgn + r00 * 8), a1 = *(const uint4*)(sgn + r01 * 8);
-		const uint4 a2 = *(const uint4*)(sgn + r10 * 8), a3 = *(const uint4*)(sgn + r11 * 8);
-		u32 A[5] = { a0.x & a1.x & a2.x & a3.x, a0.y & a1.y & a2.y & a3.y, a0.z & a1.z & a2.z & a3.z, a0.w & a1.w & a2.w & a3.w, 0 };
-		u32 O[5] = { a0.x | a1.x | a2.x | a3.x, a0.y | a1.y | a2.y | a3.y, a0.z | a1.z | a2.z | a3.z, a0.w | a1.w | a2.w | a3.w, 0 };
+		const u32* s00 = (const u32*)(sgn + r00 * TB);
+		const u32* s01 = (const u32*)(sgn + r01 * TB);
+		const u32* s10 = (const u32*)(sgn + r10 * TB);
+		const u32* s11 = (const u32*)(sgn + r11 * TB);
+		u32 A[TW + 1], O[TW + 1];
+#pragma unroll
+		for (int i = 0; i < TW; ++i) {
+			const u32 a = s00[i], b = s01[i], c = s10[i], d = s11[i];
+			A[i] = a & b & c & d;
+			O[i] = a | b | c | d;
+		}
+		A[TW] = 0; O[TW] = 0;
 		const u32 hAnd = halo[r00] & halo[r01] & halo[r10] & halo[r11];
 		const u32 hOr = halo[r00] | halo[r01] | halo[r10] | halo[r11];
-		// the sample right of the last valid cell sits at bit `validCells` of the 160-bit row
-		A[validCells >> 5] |= hAnd << (validCells & 31);
-		O[validCells >> 5] |= hOr << (validCells & 31);
-		u32 nt[4];
+		// the sample right of the last valid cell sits at bit `validCells` of the row
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const u32 sA = (A[i] >> 1) | (A[i + 1] << 31), sO = (O[i] >> 1) | (O[i + 1] << 31);
-			nt[i] = (O[i] | sO) & ~(A[i] & sA);
+		for (int i = 0; i <= TW; ++i) {
+			if (i == (validCells >> 5)) { A[i] |= hAnd << (validCells & 31); O[i] |= hOr << (validCells & 31); }
 		}
 #pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			u32 bits = (nt[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-			if (j * 16 >= validCells) bits = 0;
-			blockBits[j * 256 + tid] = (u16)bits;
-			if (bits) { blockAny[j] = 1; atomicAdd(&blockCnt[j], (u32)__popc(bits)); }
+		for (int i = 0; i < TW; ++i) {
+			const u32 sA = (A[i] >> 1) | (A[i + 1] << 31), sO = (O[i] >> 1) | (O[i + 1] << 31);
+			const u32 nt = (O[i] | sO) & ~(A[i] & sA);
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int j = 2 * i + h;
+				u32 bits = (nt >> (h * 16)) & 0xFFFFu;
+				if (j * 16 >= validCells) bits = 0;
+				blockBits[j * 256 + tid] = (u16)bits;
+				if (bits) { blockAny[j] = 1; atomicAdd(&blockCnt[j], (u32)__popc(bits)); }
+			}
 		}
 	}
 	__syncthreads();
 
 	// ---- one lane per block: emptiness rule, slot allocation ------------------------------------------
-	if (tid < 8 && tid * 16 < validCells) {
-		const u32 bx = tx * 8 + tid;
+	if (tid < TB && tid * 16 < validCells) {
+		const u32 bx = tx * TB + tid;
 		const bool skipped = blockNonEmpty[tid] == 0;
 		if (!skipped) atomicAdd(&p.G.stats[2], 1u);
 		if (blockAny[tid]) {
@@ -270,13 +282,14 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			L.slotCoord[slot] = id;
 			L.skip[slot] = skipped ? 1 : 0;
 			L.ntCount[slot] = (u16)blockCnt[tid];
+			if (blockCnt[tid] > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
 			blockSkipped[tid] = skipped ? 1u : 0u;
 			blockSlot[tid] = (int)slot;
 		}
 	}
 	__syncthreads();
 #pragma unroll
-	for (int j = 0; j < 8; ++j) {
+	for (int j = 0; j < TB; ++j) {
 		const int slot = blockSlot[j];
 		if (slot >= 0) {
 			const u16 bits = blockBits[j * 256 + tid];
@@ -354,6 +367,11 @@ struct WorkList {
 	u32 start[MAX_LEVELS + 1];
 };
 
+// Slots are handed out in tile order, so neighbouring item numbers are x-neighbour blocks sharing cache lines.
+// Workgroup b runs on XCD b % 8 (observed; speed only): transpose every group of 64 items so that 8 consecutive
+// items go to workgroups of the same XCD and meet in that XCD's L2 (grids are multiples of 8 workgroups).
+__device__ __forceinline__ u32 xcd_item(u32 i) { return (i & ~63u) | ((i & 7u) << 3) | ((i >> 3) & 7u); }
+
 __device__ __forceinline__ void decode_item(const WorkList& wl, u32 levels, u32 item, u32& level, u32& slot)
 {
 	level = 0;
@@ -399,6 +417,7 @@ template <int CAP>
 __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
+	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
 	u8* tab = smem;
 	ST& st = *(ST*)(smem + REG_TAB_LDS);
 	__shared__ WorkList wl;
@@ -417,7 +436,9 @@ __global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levelBegin,
 	const int tid = threadIdx.x;
 	const u32 lim = p.G.debugPhaseLimit;
 
-	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
+		const u32 item = xcd_item(it);
+		if (item >= total) continue;
 		RegBlockCtx b;
 		decode_item(wl, levels, item, b.level, b.slot);
 		if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
@@ -506,7 +527,9 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 	const u32 total = wl.start[MAX_LEVELS];
 	const int tid = threadIdx.x;
 
-	for (u32 item = blockIdx.x; item < total; item += gridDim.x) {
+	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
+		const u32 item = xcd_item(it);
+		if (item >= total) continue;
 		RegBlockCtx b;
 		b.level = 0;
 		for (u32 l = 1; l < MAX_LEVELS; ++l) if (item >= wl.start[l] && wl.start[l + 1] > wl.start[l]) b.level = l;
@@ -760,7 +783,7 @@ struct Backend {
 	void run_classify(const P& p)
 	{
 		const LevelDesc& L = p.levels[0];
-		const u32 tilesX = (L.cnt + 7) / 8;
+		const u32 tilesX = (L.cnt + TB - 1) / TB;
 		const u32 grid = tilesX * L.cnt * (L.zb1 - L.zb0);
 		if (!grid) return;
 		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p));

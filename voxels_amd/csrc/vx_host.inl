@@ -46,7 +46,7 @@ struct EmittedBlock {
 	std::shared_ptr<Meshes> own;
 };
 
-enum { HDR_WORDS = 192, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 192, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -184,6 +184,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.lut = (const u8*)c->dLut;
 	p.G.stats = (u32*)c->dHeader + HDR_STATS;
 	p.G.workCount = (u32*)c->dHeader + HDR_WORK;
+	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	p.G.debugPhaseLimit = c->debugPhaseLimit;
