@@ -266,3 +266,43 @@ def test_hip_repeated_edits_vs_port(poly, port, n):
         ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
         assert ok, msg
         assert np.array_equal(poly.stats(), s.stats())
+
+
+def test_hip_config2_256_lod0_only(poly, port):
+    """BASELINE config 2: 256^3 noise terrain, LOD 0 regular cells only."""
+    from voxels_amd import synth
+    d, m, b = synth.terrain(256)
+    g = port.grid_from_dense(d, m, b)
+    ref = port.execute(g).all_levels()[:1]
+    poly.upload(d, m, b, g.block_flags())
+    info = poly.execute(1)
+    assert info.levels == 1
+    ok, msg = fields.surface_equal(poly.all_levels(), ref, nrm_tol=NRM_TOL)
+    assert ok, msg
+
+
+def test_hip_config5_512_carve_incremental(poly, port):
+    """BASELINE config 5: 512^3 terrain, sphere carve (IT_Subtract, r = 20) at the surface, incremental re-polygonization
+    of the dirty blocks; parity with the oracle doing the same two calls."""
+    from voxels_amd import synth
+    n = 512
+    d, m, b = synth.terrain(n)
+    g = port.grid_from_dense(d, m, b)
+    s = port.execute(g)
+    pre = g.read_dense()
+    poly.upload(*pre, g.block_flags())
+    poly.execute()
+    # surface height under (256, 256): first non-negative distance going up
+    col = pre[0][:, 256, 256]
+    h = float(np.argmax(col >= 0))
+    mn, mx = g.inject_ball((256.0, 256.0, h), (48, 48, 48), 20.0, 2)
+    ref_ids = port.execute_modify(g, s, mn, mx)
+    post = g.read_dense()
+    ids, (dd, mm, bb) = fields.edited_blocks(pre, post)
+    poly.update_blocks(ids, dd.view(np.int8), mm, bb, g.block_flags())
+    got = poly.execute_dirty(mn, mx)
+    print("edit: %d grid blocks uploaded, %d polygon blocks rebuilt, device %.3f ms" % (len(ids), len(got), poly.info.device_ms))
+    assert np.array_equal(got, ref_ids)
+    ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+    assert ok, msg
+    assert np.array_equal(poly.stats(), s.stats())
