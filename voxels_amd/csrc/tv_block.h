@@ -84,7 +84,16 @@ struct Globals {
 	u32* workCount;                   // dirty: [MAX_LEVELS] number of items per level
 	u32 prevActive[MAX_LEVELS];       // dirty: slots >= prevActive[level] were created by this run
 	u32* largeBlocks;                 // number of classified blocks whose non-trivial cell count exceeds LARGE_THRESHOLD
+	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
+	u8* blockSummary;                 // bit0 = BF_Empty, bit1 = sign of the block's samples (an empty block has one sign)
+	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
 };
+
+// BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the
+// first one.  A block whose 27-neighbourhood is BF_Empty is skipped by the reference (TransVoxelImpl.cpp:520); if all
+// 27 also share one sign, no cell of the block — including the cells that reach into the +x/+y/+z neighbours — can
+// be non-trivial, so the classify pass does not have to read it ("quiet").
+enum { BC_SKIPPED = 1, BC_QUIET = 2, BC_NEGATIVE = 4 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
 
@@ -288,7 +297,7 @@ TV_HD void mat_phase_vote(const MatState& st, const Globals& G, const LevelDesc*
 // neighbourhood (central-difference normals then never leave LDS); levels >= 1 stage the 17^3 corner samples only
 // (their normals / LOD chain read level-0 voxels from HBM).
 // ---------------------------------------------------------------------------------------------------------
-enum { SROW = 24, SPLANE = 19 * SROW, SAMP_BYTES = 19 * SPLANE, VDESC_CAP = 2048 };
+enum { SROW = 24, SPLANE = 19 * SROW, SAMP_BYTES = 19 * SPLANE, VDESC_CAP = 1024 };
 
 TV_HD int samp_index(int i, int j, int k) { return (k + 1) * SPLANE + (j + 1) * SROW + (i + 4); }
 

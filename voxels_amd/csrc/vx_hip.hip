@@ -153,10 +153,58 @@ __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockC
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >> 7) * 0x01020408u) >> 24; }
 
+// ---- what the emptiness flags already say about a block (two tiny launches ahead of k_classify) ------------
+// summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign)
+__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi)
+{
+	const LevelDesc& L = p.levels[0];
+	const u32 per = L.cnt * L.cnt;
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (i >= per * (zbHi - zbLo)) return;
+	const u32 id = zbLo * per + i;
+	u32 s = 0;
+	if (p.G.emptyFlags[id]) {
+		u32 bx, by, bz;
+		block_coords(id, L.cnt, bx, by, bz);
+		const GridView& g = p.G.grid;
+		int z = (int)bz * 16;
+		if (z < g.zOrigin) z = g.zOrigin; // the slab below: only its top plane is resident (still inside the block)
+		const i8 v = g.dist[((size_t)(z - g.zOrigin) * g.n + by * 16) * g.n + bx * 16];
+		s = 1u | (((u32)(v >> 7) & 1u) << 1);
+	}
+	p.G.blockSummary[id] = (u8)s;
+}
+
+__global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
+{
+	const LevelDesc& L = p.levels[0];
+	const u32 per = L.cnt * L.cnt;
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (i >= per * (L.zb1 - L.zb0)) return;
+	const u32 id = L.zb0 * per + i;
+	u32 bx, by, bz;
+	block_coords(id, L.cnt, bx, by, bz);
+	u32 all = 3u, any = 0u; // AND / OR over the 27 summaries (neighbour coordinates clamped like the reference's)
+#pragma unroll
+	for (int k = 0; k < 27; ++k) {
+		const u32 cx = (u32)clampi((int)bx + (k % 3) - 1, 0, (int)L.cnt - 1);
+		const u32 cy = (u32)clampi((int)by + ((k / 3) % 3) - 1, 0, (int)L.cnt - 1);
+		const u32 cz = (u32)clampi((int)bz + (k / 9) - 1, 0, (int)L.cnt - 1);
+		const u32 s = p.G.blockSummary[block_coord_id(cx, cy, cz, L.cnt)];
+		all &= s; any |= s;
+	}
+	u32 c = 0;
+	if (all & 1u) {
+		c = BC_SKIPPED;
+		if (((all ^ any) & 2u) == 0) c |= BC_QUIET | ((all & 2u) ? BC_NEGATIVE : 0u);
+	}
+	p.G.blockClass[id] = (u8)c;
+}
+
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
 constexpr int TW = TB / 2;        // 32-bit words of sign bits per tile row
 
-__global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
+__global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 {
 	__shared__ __attribute__((aligned(16))) u16 sgn[289 * TB];  // sign masks: row r = rz*17+ry, TB x 16 voxels
 	__shared__ u8 halo[292];                                     // sign of the voxel right of the tile, per row
@@ -164,22 +212,26 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	__shared__ u32 blockAny[TB];
 	__shared__ u32 blockCnt[TB];
 	__shared__ u32 blockSkipped[TB];
-	__shared__ u32 blockNonEmpty[TB];
+	__shared__ u32 blockCls[TB];
 	__shared__ int blockSlot[TB];
 
 	const LevelDesc& L = p.levels[0];
 	const GridView& g = p.G.grid;
 	const int n = g.n;
 	const u32 tilesX = (L.cnt + TB - 1) / TB;
-	// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Give every
-	// XCD a contiguous range of block rows and walk each row's tiles (whole voxel rows) back to back, so an XCD's L2
-	// sees all address bits (all of its channels) and consecutive rows share their halo lines in that L2.
+	// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  An XCD walks
+	// whole block rows (all tiles of a row back to back), R consecutive rows at a time, so its L2 sees all address bits
+	// (all of its channels) and consecutive rows share their halo lines in that L2.
 	u32 tile = blockIdx.x;
 	{
 		const u32 rows = L.cnt * (L.zb1 - L.zb0);
-		if ((rows & 7u) == 0) {
+		if (rowGroup) {
+			// groups of R block rows go round-robin over the XCDs: the surface usually sits in a narrow z band, and
+			// tiles of quiet blocks cost nothing, so contiguous per-XCD ranges would leave most XCDs idle
+			const u32 R = rowGroup;
 			const u32 xcd = tile & 7u, m = tile >> 3;
-			tile = (xcd * (rows >> 3) + m / tilesX) * tilesX + m % tilesX;
+			const u32 lr = m / tilesX;
+			tile = (((lr / R) * 8u + xcd) * R + lr % R) * tilesX + m % tilesX;
 		}
 	}
 	const u32 tx = tile % tilesX, by = (tile / tilesX) % L.cnt, bz = L.zb0 + tile / (tilesX * L.cnt);
@@ -187,21 +239,14 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	const int validCells = (n - x0) < 16 * TB ? (n - x0) : 16 * TB; // multiple of 16
 	const int tid = threadIdx.x;
 
-	if (tid < TB) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockNonEmpty[tid] = 0; }
-	__syncthreads();
-
-	// emptiness rule (TransVoxelImpl.cpp:1511-1527): one lane per (block, neighbour); the flag loads are issued before
-	// the density loads, so their latency is hidden
-	for (int q = tid; q < TB * 27; q += WG) {
-		const int j = q / 27, k = q - j * 27;
-		const u32 bx = tx * TB + (u32)j;
-		if (bx < L.cnt) {
-			const u32 cx = (u32)clampi((int)bx + (k % 3) - 1, 0, (int)L.cnt - 1);
-			const u32 cy = (u32)clampi((int)by + ((k / 3) % 3) - 1, 0, (int)L.cnt - 1);
-			const u32 cz = (u32)clampi((int)bz + (k / 9) - 1, 0, (int)L.cnt - 1);
-			if (!p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)]) atomicAdd(&blockNonEmpty[j], 1u);
-		}
+	// what the flags say: quiet blocks are not read at all, a tile of quiet blocks is done
+	u32 myClass = BC_SKIPPED | BC_QUIET;
+	if (tid < TB) {
+		const u32 bx = tx * TB + (u32)tid;
+		if (bx < L.cnt) myClass = p.G.blockClass[block_coord_id(bx, by, bz, L.cnt)];
+		blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockCls[tid] = myClass;
 	}
+	if (__syncthreads_and((myClass & BC_QUIET) != 0)) return;
 
 	// ---- load: 289 rows x TB segments of 16 bytes, fully coalesced; several loads of a thread are in flight
 	//      before the first sign mask is formed -------------------------------------------------------------
@@ -210,7 +255,10 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 			const int r = q / TB, seg = q - r * TB;
 			const int ry = r % 17, rz = r / 17;
 			uint4 d = make_uint4(0, 0, 0, 0);
-			if (seg * 16 < validCells) {
+			const u32 cls = blockCls[seg];
+			if (cls & BC_QUIET) {
+				if (cls & BC_NEGATIVE) d = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+			} else if (seg * 16 < validCells) {
 				const int y = clampi((int)by * 16 + ry, 0, n - 1);
 				const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
 				d = *(const uint4*)(g.dist + ((size_t)z * n + y) * n + x0 + seg * 16);
@@ -273,7 +321,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p)
 	// ---- one lane per block: emptiness rule, slot allocation ------------------------------------------
 	if (tid < TB && tid * 16 < validCells) {
 		const u32 bx = tx * TB + tid;
-		const bool skipped = blockNonEmpty[tid] == 0;
+		const bool skipped = (blockCls[tid] & BC_SKIPPED) != 0;
 		if (!skipped) atomicAdd(&p.G.stats[2], 1u);
 		if (blockAny[tid]) {
 			const u32 slot = atomicAdd(L.nActive, 1u);
@@ -414,7 +462,7 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 
 // One capacity class of the regular pass: blocks with lo < non-trivial cells <= CAP
 template <int CAP>
-__global__ __launch_bounds__(WG) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
 	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
@@ -786,7 +834,19 @@ struct Backend {
 		const u32 tilesX = (L.cnt + TB - 1) / TB;
 		const u32 grid = tilesX * L.cnt * (L.zb1 - L.zb0);
 		if (!grid) return;
-		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p));
+		const u32 per = L.cnt * L.cnt;
+		const u32 zbLo = L.zb0 ? L.zb0 - 1 : 0, zbHi = std::min<u32>(L.zb1 + 1, L.cnt);
+		hipLaunchKernelGGL(k_block_summary, dim3((per * (zbHi - zbLo) + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi);
+		hipLaunchKernelGGL(k_block_class, dim3((per * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
+		const u32 rows = L.cnt * (L.zb1 - L.zb0);
+		u32 rowGroup = 0; // 0 = no remap
+		if ((rows & 7u) == 0) {
+			const char* rgEnv = getenv("VX_CLASSIFY_ROWGROUP"); // tuning aid
+			rowGroup = rgEnv ? (u32)atoi(rgEnv) : 4u;
+			while (rowGroup > 1 && rows % (8 * rowGroup)) rowGroup >>= 1;
+			if (!rowGroup) rowGroup = 1;
+		}
+		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p), rowGroup);
 		check(hipGetLastError(), "k_classify launch");
 	}
 	template <typename P>

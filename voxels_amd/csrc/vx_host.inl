@@ -57,6 +57,7 @@ struct vx_ctx {
 	u32 n = 0, zBegin = 0, zEnd = 0;
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
+	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
 	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header (HDR_WORDS u32): slot counts | vertex cursor | index cursor | overflow | stats[20] | workCount[8], one line each
@@ -151,6 +152,11 @@ bool ensure_level_tables(vx_ctx* c)
 		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
 		d.nActive = (u32*)c->dHeader + L;
 		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
+		if (!L) {
+			c->dBlockSummary = alloc(total);
+			c->dBlockClass = alloc(total);
+			if (!c->dBlockSummary || !c->dBlockClass) return false;
+		}
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1;
 	return true;
@@ -185,6 +191,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.stats = (u32*)c->dHeader + HDR_STATS;
 	p.G.workCount = (u32*)c->dHeader + HDR_WORK;
 	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
+	p.G.blockSummary = (u8*)c->dBlockSummary;
+	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	p.G.debugPhaseLimit = c->debugPhaseLimit;
