@@ -21,6 +21,10 @@ NRM_TOL = 1e-5
 
 @pytest.fixture(scope="module")
 def poly():
+    # torch's bundled HIP runtime must initialise before libvoxels_hip.so pulls in the system one (same order as
+    # bench.py), or torch cannot see the GPU later in this process (the slab tests use torch device tensors)
+    import torch
+    torch.cuda.init()
     from voxels_amd import Polygonizer
     p = Polygonizer(device=0)
     assert p.backend == "hip:gfx950", "the native HIP library must be the one running"
@@ -306,3 +310,41 @@ def test_hip_config5_512_carve_incremental(poly, port):
     ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
     assert ok, msg
     assert np.array_equal(poly.stats(), s.stats())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_hip_slab_attach_matches_full_run(poly, port, world):
+    """The multi-GPU data path on one GPU: every rank's slab (own planes + halo planes, attached device tensors) is
+    polygonized on its own and the concatenation must equal the reference's surface of the whole grid — including the
+    quiet-block shortcut, which samples the halo planes for the neighbouring slabs' signs."""
+    import torch
+    from voxels_amd import synth
+    from voxels_amd.slab import SlabBuffers, merge_rank_levels
+    n, levels, seed = 256, 3, 11
+    d, m, b = synth.terrain(n, 0, n, seed)
+    g = port.grid_from_dense(d, m, b)
+    ref = port.execute(g)
+    flags = np.ascontiguousarray(g.block_flags(), np.uint8)
+    assert np.array_equal(flags, synth.block_empty_flags(d))
+    dev = torch.device("cuda", 0)
+    per_rank, stats = [], np.zeros(20, np.int64)
+    for r in range(world):
+        slab = SlabBuffers(torch, n, r, world, dev)
+        z0, z1 = slab.z0, slab.z1
+        slab.flags.copy_(torch.from_numpy(flags))
+        lo, hi = max(z0 - 1, 0), min(z1 + 2, n)
+        slab.dist[lo - (z0 - 1):hi - (z0 - 1)].copy_(torch.from_numpy(d[lo:hi]))
+        hi_m = min(z1 + 1, n)
+        slab.mat[:hi_m - z0].copy_(torch.from_numpy(m[z0:hi_m]))
+        slab.blend[:hi_m - z0].copy_(torch.from_numpy(b[z0:hi_m]))
+        torch.cuda.synchronize()
+        slab.attach(poly)
+        poly.execute(levels)
+        per_rank.append(poly.all_levels())
+        stats += poly.stats().astype(np.int64)
+    merged = merge_rank_levels(per_rank)
+    want = ref.all_levels()[:levels]
+    # only the first `levels` levels are compared; the reference ran all of them
+    ok, msg = fields.surface_equal(merged, want, nrm_tol=NRM_TOL)
+    assert ok, msg
