@@ -31,3 +31,4 @@ u32 exclusive_scan(T* a, u32 n)
 
 // test hook for tests/test_core_math.py
 extern "C" int emu_edge_t(int v0, int v1) { return tv::edge_t(v0, v1); }
+extern "C" int emu_edge_end(int v0, int v1) { return tv::edge_end(v0, v1); }

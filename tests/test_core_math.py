@@ -32,3 +32,20 @@ def test_float_division_is_exact_vectorised():
     qi = (np.abs(a) // np.abs(b)) * np.sign(a) * np.sign(b)
     qf = np.trunc(a.astype(np.float32) / b.astype(np.float32)).astype(np.int32)
     assert np.array_equal(qi, qf)
+
+
+def test_edge_end_classifies_like_edge_t_on_crossed_edges():
+    """edge_end (no division) must agree with edge_t about "vertex on corner v1 / on corner v0 / inside" for every
+    pair of samples an edge vertex can have: one negative, one non-negative (the case code puts vertices only there)."""
+    lib = emu_library().lib
+    for f in (lib.emu_edge_t, lib.emu_edge_end):
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_int]
+    bad = 0
+    for v0 in range(-128, 128):
+        for v1 in range(-128, 128):
+            if (v0 < 0) == (v1 < 0):
+                continue
+            t, e = lib.emu_edge_t(v0, v1), lib.emu_edge_end(v0, v1)
+            bad += (t == 0) != (e == 0) or (t == 256) != (e == 256) or ((t & 0xFF) == 0) != ((e & 0xFF) == 0)
+    assert bad == 0

@@ -125,7 +125,8 @@ TV_HD u32 mat_at(const GridView& g, int x, int y, int z)
 
 TV_HD void normalize_fix_zero(float v[3])
 {
-	const float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+	const float len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+	const float len = sqrtf(len2);
 	if (len <= 1.1920929e-07f) { v[0] = v[1] = v[2] = 0.f; return; }
 	v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len;
 }
@@ -164,6 +165,11 @@ TV_HD void lod_chain(const D& d, int level, int P0[3], int P1[3], int& val0, int
 // quotient is either an integer or at least 1/255 away from one while fp32 resolves 1/1024 there, so truncating
 // the rounded quotient is exact (checked exhaustively over all 65280 int8 pairs in tests/test_core_math.py).
 TV_HD int edge_t(int v0, int v1) { return (int)((float)(v1 * 256) / (float)(v1 - v0)); }
+
+// Where edge_t lands without dividing, for the decisions that only ask "is the vertex on a corner, and which":
+// 0 <=> edge_t == 0 (v1 == 0: |v1 * 256| >= |v1 - v0| otherwise), 256 <=> edge_t == 256 (v0 == 0, the samples
+// of a crossed edge never share a strict sign), 1 = strictly inside the edge.  Same exhaustive test as edge_t.
+TV_HD int edge_end(int v0, int v1) { return v1 == 0 ? 0 : (v0 == 0 ? 256 : 1); }
 
 TV_HD u32 lerp_blend(int t, int u, u32 b0, u32 b1)
 {
@@ -268,7 +274,7 @@ TV_HD u32 reg_slot_valid(const Tables& T, const i8 V[8], u32 code)
 	for (u32 vi = 0; vi < nv; ++vi) {
 		const u32 w = T.regVert(code, vi);
 		const int v0 = (w >> 4) & 15, v1 = w & 15;
-		const int t = edge_t(V[v0], V[v1]);
+		const int t = edge_end(V[v0], V[v1]);
 		if ((t & 0xFF) == 0) { if (t == 0 && v1 == 7) m |= 1u; }
 		else if ((w >> 12) == 8u) m |= 1u << ((w >> 8) & 15);
 	}
@@ -283,7 +289,7 @@ struct Resolution {
 	u8 a;      // NEW_EDGE: v0 | NEW_CORNER: corner | REUSE: direction
 	u8 b;      // NEW_EDGE: v1 |                     | REUSE: slot
 	u8 store;  // slot this new vertex is stored in, or NO_SLOT
-	int t;     // NEW_EDGE: interpolation parameter from the cell's own corner values
+	int t;     // edge_end() of the cell's own corner values
 };
 
 // How vertex `w` (table word) of the non-trivial cell (cx,cy,cz) gets its index.
@@ -296,7 +302,7 @@ TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const
 	Resolution r;
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
 	u32 dir = w >> 12, slot = (w >> 8) & 15;
-	const int t = edge_t(V[v0], V[v1]);
+	const int t = edge_end(V[v0], V[v1]);
 	const bool endpoint = (t & 0xFF) == 0;
 	bool check = true;
 	if (endpoint) {
@@ -329,7 +335,7 @@ TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const
 TV_HD void reg_reuse_source(const i8 V[8], u32 w, u32& dir, u32& slot)
 {
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
-	const int t = edge_t(V[v0], V[v1]);
+	const int t = edge_end(V[v0], V[v1]);
 	dir = w >> 12; slot = (w >> 8) & 15;
 	if ((t & 0xFF) == 0) { dir = (u32)((t == 0) ? v1 : v0) ^ 7u; slot = 0; }
 }
@@ -523,7 +529,7 @@ TV_HD void tr_vertex_dir_slot(const Tables& T, const i8 v[13], u32 w, int& t, u3
 {
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
 	dir = w >> 12; slot = (w >> 8) & 15;
-	t = edge_t(v[v0], v[v1]);
+	t = edge_end(v[v0], v[v1]); // 0 / 256 / 1 = inside
 	corner = (t == 0) ? v1 : v0;
 	endpoint = (t & 0xFF) == 0;
 	if (endpoint) { const u32 cd = T.trCorner(corner); dir = cd >> 4; slot = cd & 15; }
@@ -547,7 +553,7 @@ struct TrResolution {
 	u8 dir, slot;
 	u8 store;  // slot or NO_SLOT
 	u8 endpoint;
-	int t;
+	int t;     // edge_end() of the cell's own sample values
 };
 
 //   mask2 : bit0 = a non-trivial transition cell exists earlier in this row, bit1 = row > 0
@@ -612,11 +618,9 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
 		}
 	} else {
 		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
-		if (lodOfEdge > 0) {
-			int p0 = v[v0], p1 = v[v1];
-			lod_chain(d, lodOfEdge, I0, I1, p0, p1);
-			t = (p0 != p1) ? edge_t(p0, p1) : 0;
-		}
+		int p0 = v[v0], p1 = v[v1];
+		if (lodOfEdge > 0) lod_chain(d, lodOfEdge, I0, I1, p0, p1);
+		t = (p0 != p1) ? edge_t(p0, p1) : 0;
 		u = 256 - t;
 		normal_at(d, I0[0], I0[1], I0[2], N0);
 		normal_at(d, I1[0], I1[1], I1[2], N1);
