@@ -22,14 +22,14 @@ def main():
     p.set_stage_timing(True)
     names = ["1 load bits+samples", "2 prefix", "3 list+cells", "4 count", "5 scan+alloc v", "6 describe+emit verts", "7 keep masks", "8 scan+alloc i", "0 full"]
     prev = 0.0
-    for lim in [1, 2, 3, 4, 5, 6, 7, 8, 0]:
+    for lim in [int(x, 0) for x in os.environ.get('VX_LIMS', '1,2,3,4,5,6,7,8,0').split(',')]:
         p.debug_phase_limit(lim)
         acc = np.zeros(6)
         for _ in range(6):
             p.execute(levels)
             acc += p.stage_times()
         acc /= 6
-        print("limit %-22s k_regular %.4f ms (+%.4f)   [classify %.4f material %.4f transition %.4f]" % (names[lim - 1 if lim else 8], acc[4], acc[4] - prev, acc[1], acc[3], acc[5]))
+        print("limit %-22s k_regular %.4f ms (+%.4f)   [classify %.4f material %.4f transition %.4f]" % (names[(lim & 0xFF) - 1 if (lim & 0xFF) else 8] + " flags %x" % (lim >> 8), acc[4], acc[4] - prev, acc[1], acc[3], acc[5]))
         prev = acc[4]
 
 

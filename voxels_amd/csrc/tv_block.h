@@ -525,31 +525,88 @@ TV_HD void reg_mark_suspect(ST& st, int cx, int cy, int cz)
 	}
 }
 
-// One lane = one new vertex of the chunk: uniform work, consecutive 48-byte stores.
-template <typename ST, typename D>
+// what a new vertex needs from HBM, requested before anything is computed
+struct VertexFetch {
+	u32 key;                  // compact cell | table vertex << 12 | table word << 16
+	u32 m0, m1;               // mat_at() of the two end points (level 0: the cell corners themselves)
+	unsigned long long lut;   // LUT row of the cell's material id (every vertex of a cell carries that id)
+};
+
+struct FetchedMaterials {
+	u32 m0, m1;
+	TV_HD u32 operator()(int which, const int*) const { return which ? m1 : m0; }
+};
+
+enum { EMIT_BATCH = 4 };     // vertices per lane whose fetches are in flight together
+
+// One lane = one new vertex of the chunk: uniform work, consecutive 48-byte stores.  The global reads of a vertex
+// (end-point materials, LUT row) do not depend on its arithmetic, so a lane requests them for all of its vertices
+// first: one memory round trip per chunk instead of two per vertex.  Levels >= 1 read their materials at the
+// LOD-shifted end points, which only the chain knows; they still get the LUT row ahead.
+template <typename ST, typename D, bool LEVEL0>
 TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
 {
 	const bool room = st.vOff + st.vTotal <= P.vertCap;
 	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
-	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
-		const u32 desc = st.vdesc[j];
-		const u32 k = desc & 0xFFFu, vi = desc >> 12;
-		int cx, cy, cz; i8 V[8]; CellGeom geo;
-		reg_cell_setup(st, b, k, cx, cy, cz, V, geo);
-		const u32 w = T.regVert(reg_case_code(V), vi);
-		const int v0 = (w >> 4) & 15, v1 = w & 15;
-		const int t = edge_t(V[v0], V[v1]);
-		const u32 cellMat = st.cellMat[k];
-		RawVertex rv;
-		bool interior = false;
-		if ((t & 0xFF) == 0) {
-			const int corner = ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((t == 0) ? v1 : v0);
-			reg_corner_vertex(d, G.grid, geo, corner, cellMat, rv);
-		} else {
-			interior = reg_edge_vertex(d, G.grid, geo, v0, v1, t, V[v0], V[v1], cellMat, rv);
+	for (u32 j0 = (u32)tid; j0 < end; j0 += (u32)nth * EMIT_BATCH) {
+		VertexFetch f[EMIT_BATCH];
+#pragma unroll
+		for (int r = 0; r < EMIT_BATCH; ++r) {
+			const u32 j = j0 + (u32)r * (u32)nth;
+			if (j >= end) continue;
+			const u32 desc = st.vdesc[j];
+			const u32 k = desc & 0xFFFu, vi = desc >> 12;
+			int cx, cy, cz; i8 V[8]; CellGeom geo;
+			reg_cell_setup(st, b, k, cx, cy, cz, V, geo);
+			const u32 w = T.regVert(reg_case_code(V), vi);
+			f[r].key = desc | (w << 16);
+			f[r].lut = lut_row(G.lut, st.cellMat[k]);
+			if (LEVEL0 && !(G.debugPhaseLimit & 0x400u)) {
+				const int v0 = (w >> 4) & 15, v1 = w & 15;
+				const int e = edge_end(V[v0], V[v1]);
+				int A[3], B[3];
+				if (e != 1) {
+					corner_pos(geo, ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0), A);
+					B[0] = A[0]; B[1] = A[1]; B[2] = A[2];
+				} else {
+					corner_pos(geo, v0, A);
+					corner_pos(geo, v1, B);
+				}
+				f[r].m0 = mat_at(G.grid, A[0], A[1], A[2]);
+				f[r].m1 = mat_at(G.grid, B[0], B[1], B[2]);
+			}
 		}
-		if (!interior) reg_mark_suspect(st, cx, cy, cz);
-		if (room) pack_vertex(rv, G.lut, P.verts + st.vOff + chunkBase + j);
+#pragma unroll
+		for (int r = 0; r < EMIT_BATCH; ++r) {
+			const u32 j = j0 + (u32)r * (u32)nth;
+			if (j >= end) continue;
+			const u32 k = f[r].key & 0xFFFu, vi = (f[r].key >> 12) & 15u, w = f[r].key >> 16;
+			const u32 c = st.cellOf[k];
+			const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+			CellGeom geo;
+			geo.mult = (int)b.mult; geo.level = (int)b.level;
+			geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
+			geo.base[0] = (int)((b.bx * 16 + cx) * b.mult); geo.base[1] = (int)((b.by * 16 + cy) * b.mult); geo.base[2] = (int)((b.bz * 16 + cz) * b.mult);
+			const int v0 = (w >> 4) & 15, v1 = w & 15;
+			const int val0 = st.samp[samp_index(cx + (v0 & 1), cy + ((v0 >> 1) & 1), cz + (v0 >> 2))];
+			const int val1 = st.samp[samp_index(cx + (v1 & 1), cy + ((v1 >> 1) & 1), cz + (v1 >> 2))];
+			const u32 cellMat = st.cellMat[k];
+			const int e = edge_end(val0, val1);
+			RawVertex rv;
+			bool interior = false;
+			if (G.debugPhaseLimit & 0x200u) { rv.p[0] = (float)cx; rv.p[1] = (float)val0; rv.p[2] = (float)val1; rv.s[0] = rv.s[1] = rv.s[2] = 0.f; rv.n[0] = rv.n[1] = rv.n[2] = 0.f; rv.flags = 0; rv.mat = cellMat + f[r].m0 + f[r].m1; interior = true; }
+			else if (e != 1) {
+				const int corner = ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0);
+				if (LEVEL0) reg_corner_vertex(d, FetchedMaterials{ f[r].m0, f[r].m1 }, geo, corner, cellMat, rv);
+				else reg_corner_vertex(d, GridMaterials{ &G.grid }, geo, corner, cellMat, rv);
+			} else {
+				const int t = edge_t(val0, val1);
+				if (LEVEL0) interior = reg_edge_vertex(d, FetchedMaterials{ f[r].m0, f[r].m1 }, geo, v0, v1, t, val0, val1, cellMat, rv);
+				else interior = reg_edge_vertex(d, GridMaterials{ &G.grid }, geo, v0, v1, t, val0, val1, cellMat, rv);
+			}
+			if (!interior && !(G.debugPhaseLimit & 0x800u)) reg_mark_suspect(st, cx, cy, cz);
+			if (room && !(G.debugPhaseLimit & 0x100u)) pack_vertex_row(rv, f[r].lut, P.verts + st.vOff + chunkBase + j);
+		}
 	}
 }
 
@@ -558,10 +615,10 @@ TV_HD void reg_phase_emit_vertices(ST& st, const Tables& T, const Globals& G, co
 {
 	if (b.level == 0) {
 		const LocalDist d{ st.samp, (int)(b.bx * 16), (int)(b.by * 16), (int)(b.bz * 16) };
-		reg_vertices_emit_with(st, d, T, G, P, b, chunkBase, tid, nth);
+		reg_vertices_emit_with<ST, LocalDist, true>(st, d, T, G, P, b, chunkBase, tid, nth);
 	} else {
 		const GlobalDist d{ &G.grid };
-		reg_vertices_emit_with(st, d, T, G, P, b, chunkBase, tid, nth);
+		reg_vertices_emit_with<ST, GlobalDist, false>(st, d, T, G, P, b, chunkBase, tid, nth);
 	}
 }
 

@@ -217,7 +217,15 @@ struct RawVertex {
 
 // PushBlocksToResult packing: x(1/256), y<->z swap, flag swizzle, texture ids from the material LUT
 // lut = 256 x 8 bytes: {Ids0[0..2], Ids1[0..2], valid, pad}
-TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out)
+TV_HD unsigned long long lut_row(const u8* lut, u32 materialId)
+{
+	// one aligned 8-byte fetch of the LUT row {Ids0[3], Ids1[3], valid, pad}
+	unsigned long long row;
+	memcpy(&row, lut + (materialId & 0xFFu) * 8, 8);
+	return row;
+}
+
+TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVertex* out)
 {
 	const float k = 1.f / 256.f;
 	PolyVertex o;
@@ -227,9 +235,6 @@ TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out)
 	if (f) f = (f >> 3) | ((f & 7u) << 3);
 	o.secW = f;
 	o.nrm[0] = r.n[0]; o.nrm[1] = r.n[1]; o.nrm[2] = r.n[2];
-	// one aligned 8-byte fetch of the LUT row {Ids0[3], Ids1[3], valid, pad}
-	unsigned long long row;
-	memcpy(&row, lut + (r.mat & 0xFFu) * 8, 8);
 	u8 e[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) e[i] = (u8)(row >> (8 * i));
@@ -244,6 +249,8 @@ TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out)
 	o.tex[7] = ok ? e[0] : 0; // Tpy = Ids0[0]
 	*out = o;
 }
+
+TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out) { pack_vertex_row(r, lut_row(lut, r.mat), out); }
 
 // degenerate-triangle test of PushBlocksToResult on x256 positions, plain fp32 (no fused multiply-add)
 TV_HD bool triangle_degenerate(const float* v0, const float* v1, const float* v2)
@@ -386,8 +393,15 @@ TV_HD bool reg_edge_position(const D& d, const CellGeom& c, int v0, int v1, int 
 	return interior;
 }
 
-template <typename D>
-TV_HD bool reg_edge_vertex(const D& d, const GridView& g, const CellGeom& c, int v0, int v1, int t0, int val0, int val1, u32 cellMat, RawVertex& o)
+// material source reading the grid in HBM at the (possibly LOD-shifted) end points
+struct GridMaterials {
+	const GridView* g;
+	TV_HD u32 operator()(int, const int P[3]) const { return mat_at(*g, P[0], P[1], P[2]); }
+};
+
+// `mats(which, P)` = id | blend << 8 at end point `which` (0/1) located at P: the grid, or values fetched ahead
+template <typename D, typename MF>
+TV_HD bool reg_edge_vertex(const D& d, const MF& mats, const CellGeom& c, int v0, int v1, int t0, int val0, int val1, u32 cellMat, RawVertex& o)
 {
 	int P0[3], P1[3], t;
 	const bool interior = reg_edge_position(d, c, v0, v1, t0, val0, val1, P0, P1, t, o.p);
@@ -395,7 +409,7 @@ TV_HD bool reg_edge_vertex(const D& d, const GridView& g, const CellGeom& c, int
 	float N0[3], N1[3];
 	normal_at(d, P0[0], P0[1], P0[2], N0);
 	normal_at(d, P1[0], P1[1], P1[2], N1);
-	const u32 M0 = mat_at(g, P0[0], P0[1], P0[2]), M1 = mat_at(g, P1[0], P1[1], P1[2]);
+	const u32 M0 = mats(0, P0), M1 = mats(1, P1);
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, v0, v1);
 	if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (cellMat & 0xFF)) o.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
 	else o.mat = cellMat;
@@ -428,14 +442,14 @@ TV_HD void reg_vertex_position(const D& d, const CellGeom& c, const i8 V[8], u32
 	else { int P0[3], P1[3], tt; reg_edge_position(d, c, v0, v1, t, V[v0], V[v1], P0, P1, tt, pos); }
 }
 
-template <typename D>
-TV_HD void reg_corner_vertex(const D& d, const GridView& g, const CellGeom& c, int corner, u32 cellMat, RawVertex& o)
+template <typename D, typename MF>
+TV_HD void reg_corner_vertex(const D& d, const MF& mats, const CellGeom& c, int corner, u32 cellMat, RawVertex& o)
 {
 	int P[3];
 	corner_pos(c, corner, P);
 	o.p[0] = (float)P[0] * 256.f; o.p[1] = (float)P[1] * 256.f; o.p[2] = (float)P[2] * 256.f;
 	normal_at(d, P[0], P[1], P[2], o.n);
-	const u32 mine = mat_at(g, P[0], P[1], P[2]);
+	const u32 mine = mats(0, P);
 	o.mat = ((cellMat & 0xFF) != (mine & 0xFF)) ? cellMat : mine;
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, corner, corner);
 	finish_secondary(o, c.mult);

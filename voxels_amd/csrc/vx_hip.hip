@@ -371,40 +371,214 @@ __global__ __launch_bounds__(WG) void k_hierarchy(ExecParamsDev p, u32 levels)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_material
+// k_material: LevelMaterialCache of one level >= 1 (same results as the mat_phase_* functions of tv_block.h,
+// which the CPU emulation runs).  The block's cells are classified and selected bit-parallel, one (y,z) cell row
+// per lane; only the sign of a sample is kept.  Global reads happen in four waves per block: block coordinates;
+// samples + child slots; child bitmaps; child entries of the voted cells.  The 8 KB cache block is assembled in
+// LDS and written with 16-byte stores.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_material(ExecParamsDev p, u32 level)
+struct MatLds {
+	u32 rowMask[292];          // sign bits of the 17 samples of sample row r = k * 17 + j
+	u16 ntRow[256];            // non-trivial cells of cell row (y,z) = the block's ntBits
+	u32 childBits[8][128];     // level 1: consistency bitmaps of the 2x2x2 child blocks
+	int childSlot[8];
+	u32 voteCount, ntTotal;
+	u16 voteList[BLOCK_CELLS];
+	__attribute__((aligned(16))) u16 out[BLOCK_CELLS];
+};
+
+// majority vote over eight id | blend << 8 entries (255 = no entry): vote_entries() of tv_core.h without
+// dynamically indexed arrays — an entry's count is compared in order of first appearance, first maximum wins
+__device__ __forceinline__ u32 vote8(const u32 e[8])
 {
-	__shared__ MatState st;
+	u32 bestCnt = 0, bestId = 0, bestBl = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const u32 id = e[i] & 0xFFu;
+		u32 cnt = 0, bl = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const bool same = (e[j] & 0xFFu) == id;
+			cnt += same ? 1u : 0u;
+			bl += same ? (e[j] >> 8) : 0u;
+		}
+		if (id != EMPTY_MATERIAL && cnt > bestCnt) { bestCnt = cnt; bestId = id; bestBl = bl; }
+	}
+	if (!bestCnt) return EMPTY_MATINFO;
+	// bl <= 8 * 255, cnt <= 8: the quotient is an integer or at least 1/8 away from one, fp32 division is exact enough
+	const u32 avg = (u32)((float)bestBl / (float)bestCnt);
+	return bestId | ((avg & 0xFFu) << 8);
+}
+
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8))) void k_material(ExecParamsDev p, u32 level)
+{
+	__shared__ MatLds st;
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
+	const GridView& g = p.G.grid;
 	const u32 nItems = p.G.dirty ? p.G.workCount[level] : *L.nActive;
 	const int tid = threadIdx.x;
+	const int n = g.n;
+	const int mult = (int)L.mult;
+	constexpr int PER = (SAMPLES + WG - 1) / WG; // 20 samples per lane
+	constexpr int MAT_BATCH = 10;                 // of which this many are in flight together
 	for (u32 it = blockIdx.x; it < nItems; it += gridDim.x) {
 		const u32 slot = p.G.dirty ? p.G.workItems[level][it] : it;
 		u32 bx, by, bz;
 		block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
-		__syncthreads();
-		gpu_stage_samples17(p.G.grid, bx, by, bz, L.mult, st.samp);
-		for (int w = tid; w < 128; w += WG) st.ntBits[w] = 0;
-		if (tid == 0) st.voteCount = 0;
+		const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
+		u16* cacheOut = L.cache + (size_t)slot * BLOCK_CELLS;
+		__syncthreads(); // the previous block of this workgroup is done with the LDS state
+
+		// ---- requests: child slots, old cache contents (incremental runs), samples ----------------------
+		int cs = -1;
 		if (tid < 8) {
 			const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
-			int cs = -1;
 			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) cs = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
-			st.childSlot[tid] = cs;
 		}
+		uint4 old0, old1;
+		if (!defineAll) { old0 = ((const uint4*)cacheOut)[tid]; old1 = ((const uint4*)cacheOut)[tid + WG]; }
+		const int x0 = (int)(bx * 16) * mult, y0 = (int)(by * 16) * mult, z0 = (int)(bz * 16) * mult;
+		const i8* base = g.dist + ((size_t)(z0 - g.zOrigin) * n + y0) * n + x0; // uniform; lanes add 32-bit offsets
+		for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
+		if (tid < 8) st.childSlot[tid] = cs;
+		if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
+		if (defineAll) {
+			const u32 e2 = (u32)EMPTY_MATINFO | ((u32)EMPTY_MATINFO << 16);
+			old0 = make_uint4(e2, e2, e2, e2); old1 = old0;
+		}
+		((uint4*)st.out)[tid] = old0; ((uint4*)st.out)[tid + WG] = old1;
 		__syncthreads();
+#pragma unroll 1
+		for (int q0 = 0; q0 < PER; q0 += MAT_BATCH) {
+			i8 v[MAT_BATCH];
+#pragma unroll
+			for (int q = 0; q < MAT_BATCH; ++q) {
+				const int sIdx = tid + (q0 + q) * WG;
+				if (sIdx < SAMPLES) {
+					const int i = sIdx % 17, j = (sIdx / 17) % 17, k = sIdx / 289;
+					const int dx = min(x0 + i * mult, n - 1) - x0, dy = min(y0 + j * mult, n - 1) - y0, dz = min(z0 + k * mult, n - 1) - z0;
+					v[q] = base[(u32)((dz * n + dy) * n + dx)];
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < MAT_BATCH; ++q) {
+				const int sIdx = tid + (q0 + q) * WG;
+				if (sIdx < SAMPLES) atomicOr(&st.rowMask[sIdx / 17], (((u32)(v[q] >> 7)) & 1u) << (sIdx % 17));
+			}
+		}
+		// ---- child bitmaps (level 1) requested while the rows are classified -----------------------------
+		u32 cb4[4] = { 0, 0, 0, 0 };
 		if (level == 1) {
-			batched_gather<8 * 128, u32, 4>(
-				[&](int q) { const int cs = st.childSlot[q >> 7]; return cs >= 0 ? C.consBits[(size_t)cs * 128 + (q & 127)] : 0u; },
-				[&](int q, u32 v) { st.childBits[q >> 7][q & 127] = v; });
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int w = tid + q * WG;
+				const int c = st.childSlot[w >> 7];
+				if (c >= 0) cb4[q] = C.consBits[(size_t)c * 128 + (w & 127)];
+			}
 		}
-		mat_phase_classify(st, tid, WG);
 		__syncthreads();
-		mat_phase_select(st, p.G, p.levels, level, slot, bx, by, bz, tid, WG);
+		const int y = tid & 15, z = tid >> 4;
+		u32 nt;
+		{
+			const u32 a = st.rowMask[z * 17 + y], b2 = st.rowMask[z * 17 + y + 1], c = st.rowMask[(z + 1) * 17 + y], d = st.rowMask[(z + 1) * 17 + y + 1];
+			const u32 A = a & b2 & c & d, O = a | b2 | c | d;
+			nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+			st.ntRow[tid] = (u16)nt;
+			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
+			if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
+		}
+		if (level == 1) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
+		}
 		__syncthreads();
-		mat_phase_vote(st, p.G, p.levels, level, slot, bx, by, bz, tid, WG);
+		// ---- selection: cells that need an entry (non-trivial, or visited by the transition pass) and have
+		//      any child entry to vote on.  All eight children of a cell live in one child block. -----------
+		{
+			u32 want = nt;
+			if (L.hasTransitions) {
+				const bool wholeRow = (z == 0 && bz > 0) || (y == 0 && by > 0) || (z == 15 && bz + 1 < L.cnt) || (y == 15 && by + 1 < L.cnt);
+				if (wholeRow) want = 0xFFFFu;
+				else { if (bx > 0) want |= 1u; if (bx + 1 < L.cnt) want |= 0x8000u; }
+			}
+			const u32 cbLo = (u32)(((y >> 3) << 1) | ((z >> 3) << 2));
+			u32 have = 0;
+#pragma unroll
+			for (u32 h = 0; h < 2; ++h) {
+				const u32 cb = cbLo | h;
+				if (st.childSlot[cb] < 0) continue;
+				u32 r = 0xFFFFu;
+				if (level == 1) {
+					r = 0;
+#pragma unroll
+					for (int dd = 0; dd < 4; ++dd) {
+						const u32 row = (u32)((((2 * z + (dd >> 1)) & 15) << 4) | ((2 * y + (dd & 1)) & 15));
+						r |= (st.childBits[cb][row >> 1] >> ((row & 1u) * 16u)) & 0xFFFFu;
+					}
+					r |= r >> 1;                       // child pair (2x', 2x'+1) -> even bit
+					r &= 0x5555u; r = (r | (r >> 1)) & 0x3333u; r = (r | (r >> 2)) & 0x0F0Fu; r = (r | (r >> 4)) & 0x00FFu;
+				} else {
+					r = 0xFFu;
+				}
+				have |= (r & 0xFFu) << (8u * h);
+			}
+			u32 cand = want & have;
+			if (cand) {
+				u32 pos = atomicAdd(&st.voteCount, (u32)__popc(cand));
+				const u32 rowBase = (u32)tid << 4;
+				while (cand) {
+					const u32 x = (u32)__builtin_ctz(cand);
+					cand &= cand - 1;
+					st.voteList[pos++] = (u16)(rowBase | x);
+				}
+			}
+			if (tid == 0) {
+				const u32 cnt = st.ntTotal;
+				L.ntCount[slot] = (u16)cnt;
+				if (cnt > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
+			}
+		}
+		__syncthreads();
+		// ---- vote: the eight child entries of a cell are requested together --------------------------------
+		{
+			const int nVote = (int)st.voteCount;
+			const u8* matBase = g.mat + ((size_t)((int)(bz * 32) - g.zOriginMat) * n + by * 32) * n + bx * 32;
+			const u8* blendBase = g.blend + ((size_t)((int)(bz * 32) - g.zOriginMat) * n + by * 32) * n + bx * 32;
+			for (int k = tid; k < nVote; k += WG) {
+				const u32 c = st.voteList[k];
+				const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+				const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
+				u32 e[8];
+				if (level == 1) {
+					u32 m[8], bl[8];
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
+						const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
+						m[i] = EMPTY_MATERIAL; bl[i] = 0;
+						if ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) {
+							const u32 off = (u32)((czz * n + cyy) * n + cxx);
+							m[i] = matBase[off]; bl[i] = blendBase[off];
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < 8; ++i) e[i] = m[i] | (bl[i] << 8);
+				} else {
+					const u16* child = C.cache + (size_t)st.childSlot[cb] * BLOCK_CELLS;
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
+						e[i] = child[((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15)];
+					}
+				}
+				const u32 entry = vote8(e);
+				if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
+			}
+		}
+		__syncthreads();
+		((uint4*)cacheOut)[tid] = ((const uint4*)st.out)[tid];
+		((uint4*)cacheOut)[tid + WG] = ((const uint4*)st.out)[tid + WG];
 	}
 }
 
@@ -482,7 +656,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	__syncthreads();
 	const u32 total = wl.start[MAX_LEVELS];
 	const int tid = threadIdx.x;
-	const u32 lim = p.G.debugPhaseLimit;
+	const u32 lim = p.G.debugPhaseLimit & 0xFFu;
 
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
