@@ -20,7 +20,7 @@ def main():
         return
     which = int(sys.argv[3]) if len(sys.argv) > 3 else -2
     i0 = starts[which]
-    i1 = starts[which + 1] if which + 1 < 0 and which + 1 != 0 else len(rows)
+    i1 = starts[which + 1] if which + 1 < len(starts) and which + 1 != 0 else len(rows)
     t0 = rows[i0][1]
     for r in rows[i0:i1]:
         name = r[0].replace("_ZN12_GLOBAL__N_1", "")[:40]

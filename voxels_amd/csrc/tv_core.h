@@ -63,35 +63,42 @@ enum : u32 {
 	TAB_TR_CLASS = 512,      // 512 B
 	TAB_TR_CORNER = 1024,    // 16 B
 	TAB_TR_CELL = 1040,      // 56 x 40 B = 2240 -> 3280
-	TAB_REG_VERT = 3280,     // 256 x 12 u16 = 6144 -> 9424
-	TAB_TR_VERT = 9424,      // 512 x 12 u16 = 12288 -> 21712
-	TAB_BYTES = 21712
+	// The vertex data of a case is a function of the edge alone (12 distinct words in the regular table, 16 in the
+	// transition table), so the per-case rows hold 4-bit indices into two 16-entry word tables: 4.5 KB instead of 18 KB.
+	TAB_REG_EDGE = 3280,     // 16 x u16: (reuseDir<<12)|(reuseSlot<<8)|(corner0<<4)|corner1 of each regular edge
+	TAB_TR_EDGE = 3312,      // 16 x u16: the same for the transition cell edges
+	TAB_REG_VERT = 3344,     // 256 x 12 nibbles = 1536 -> 4880
+	TAB_TR_VERT = 4880,      // 512 x 12 nibbles = 3072 -> 7952
+	TAB_BYTES = 7952
 };
 
 struct Tables {
 	const u8* regClassP;   // 256
 	const u8* regCellP;    // 16 x 16
-	const u16* regVertP;   // 256 x 12
+	const u8* regVertP;    // 256 x 6: twelve edge indices per case
+	const u16* regEdgeP;   // 16
 	const u8* trClassP;    // 512
 	const u8* trCornerP;   // 16
 	const u8* trCellP;     // 56 x 40
-	const u16* trVertP;    // 512 x 12
+	const u8* trVertP;     // 512 x 6
+	const u16* trEdgeP;    // 16
 	TV_HD u32 regClass(u32 code) const { return regClassP[code]; }
 	TV_HD const u8* regCell(u32 cls) const { return regCellP + cls * 16; }
-	TV_HD u32 regVert(u32 code, u32 i) const { return regVertP[code * 12 + i]; }
+	TV_HD u32 regVert(u32 code, u32 i) const { return regEdgeP[(regVertP[code * 6 + (i >> 1)] >> ((i & 1u) * 4u)) & 15u]; }
 	TV_HD u32 trClass(u32 code) const { return trClassP[code]; }
 	TV_HD const u8* trCell(u32 cls) const { return trCellP + cls * 40; }
 	TV_HD u32 trCorner(u32 c) const { return trCornerP[c]; }
-	TV_HD u32 trVert(u32 code, u32 i) const { return trVertP[code * 12 + i]; }
+	TV_HD u32 trVert(u32 code, u32 i) const { return trEdgeP[(trVertP[code * 6 + (i >> 1)] >> ((i & 1u) * 4u)) & 15u]; }
 };
 
 // all tables from one TAB_BYTES image
 TV_HD Tables tables_from_image(const u8* base)
 {
 	Tables T;
-	T.regClassP = base + TAB_REG_CLASS; T.regCellP = base + TAB_REG_CELL; T.regVertP = (const u16*)(base + TAB_REG_VERT);
+	T.regClassP = base + TAB_REG_CLASS; T.regCellP = base + TAB_REG_CELL; T.regVertP = base + TAB_REG_VERT;
+	T.regEdgeP = (const u16*)(base + TAB_REG_EDGE);
 	T.trClassP = base + TAB_TR_CLASS; T.trCornerP = base + TAB_TR_CORNER; T.trCellP = base + TAB_TR_CELL;
-	T.trVertP = (const u16*)(base + TAB_TR_VERT);
+	T.trVertP = base + TAB_TR_VERT; T.trEdgeP = (const u16*)(base + TAB_TR_EDGE);
 	return T;
 }
 

@@ -604,8 +604,8 @@ __device__ __forceinline__ void decode_item(const WorkList& wl, u32 levels, u32 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 // LDS images of the table subsets each kernel needs
-constexpr u32 REG_TAB_LDS = 512 + 6144;                 // regClass + regCell | regVert
-constexpr u32 TR_TAB_LDS = 2768 + 12288;                // trClass + trCorner + trCell | trVert
+constexpr u32 REG_TAB_LDS = 512 + 1600;                 // regClass + regCell | edge words + regVert rows
+constexpr u32 TR_TAB_LDS = 2832 + 3072;                 // trClass + trCorner + trCell + edge words | trVert rows
 
 __device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes)
 {
@@ -617,20 +617,20 @@ __device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes)
 __device__ __forceinline__ Tables stage_regular_tables(u8* lds, const u8* image)
 {
 	copy16(lds, image + TAB_REG_CLASS, 512);
-	copy16(lds + 512, image + TAB_REG_VERT, 6144);
+	copy16(lds + 512, image + TAB_REG_EDGE, 1600); // both edge word tables + the regular rows (contiguous in the image)
 	Tables T;
-	T.regClassP = lds; T.regCellP = lds + 256; T.regVertP = (const u16*)(lds + 512);
-	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr;
+	T.regClassP = lds; T.regCellP = lds + 256; T.regEdgeP = (const u16*)(lds + 512); T.regVertP = lds + 512 + 64;
+	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr; T.trEdgeP = nullptr;
 	return T;
 }
 
 __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* image)
 {
-	copy16(lds, image + TAB_TR_CLASS, 2768);
-	copy16(lds + 2768, image + TAB_TR_VERT, 12288);
+	copy16(lds, image + TAB_TR_CLASS, 2832);       // class, corner, cell tables + both edge word tables
+	copy16(lds + 2832, image + TAB_TR_VERT, 3072);
 	Tables T;
-	T.regClassP = nullptr; T.regCellP = nullptr; T.regVertP = nullptr;
-	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trVertP = (const u16*)(lds + 2768);
+	T.regClassP = nullptr; T.regCellP = nullptr; T.regVertP = nullptr; T.regEdgeP = nullptr;
+	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trEdgeP = (const u16*)(lds + 2768 + 32); T.trVertP = lds + 2832;
 	return T;
 }
 
@@ -905,8 +905,15 @@ struct Backend {
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
 		stream = ownStream;
-		(void)hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking);
-		(void)hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking);
+		{
+			// the transition pass is the short-handed one (LDS-heavy workgroups): let it win the dispatch race
+			int prLow = 0, prHigh = 0;
+			(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+			const char* prEnv = getenv("VX_STREAM_PRIORITIES"); // tuning aid: 0 = all default
+			const bool usePr = !prEnv || atoi(prEnv) != 0;
+			(void)hipStreamCreateWithPriority(&sideA, hipStreamNonBlocking, usePr ? prLow : 0);
+			(void)hipStreamCreateWithPriority(&sideB, hipStreamNonBlocking, usePr ? prHigh : 0);
+		}
 		(void)hipEventCreateWithFlags(&evClassified, hipEventDisableTiming);
 		(void)hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming);
 		(void)hipEventCreateWithFlags(&evSideA, hipEventDisableTiming);
@@ -1066,7 +1073,7 @@ struct Backend {
 		check(hipGetLastError(), "k_material launch");
 	}
 	template <typename P>
-	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 4)
+	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 5)
 	{
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
@@ -1091,7 +1098,7 @@ struct Backend {
 	{
 		(void)hipEventRecord(evClassified, stream);
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		launch_regular(p, 0, 1, sideA, 3); // 3 workgroups per CU leave LDS for the concurrent material / transition workgroups
+		launch_regular(p, 0, 1, sideA);
 		(void)hipEventRecord(evSideA, sideA);
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
 		(void)hipEventRecord(evMaterial, stream);
@@ -1103,7 +1110,7 @@ struct Backend {
 			stream = keep;
 		}
 		(void)hipEventRecord(evSideB, sideB);
-		if (levels > 1) launch_regular(p, 1, levels, stream, 3);
+		if (levels > 1) launch_regular(p, 1, levels, stream);
 		(void)hipStreamWaitEvent(stream, evSideA, 0);
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}

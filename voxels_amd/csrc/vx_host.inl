@@ -213,8 +213,26 @@ void build_table_image(std::vector<u8>& img)
 	memcpy(&img[TAB_TR_CLASS], TVT_TR_CLASS, 512);
 	memcpy(&img[TAB_TR_CORNER], TVT_TR_CORNER, 16);
 	memcpy(&img[TAB_TR_CELL], TVT_TR_CELL, 56 * 40);
-	memcpy(&img[TAB_REG_VERT], TVT_REG_VERT, 256 * 12 * 2);
-	memcpy(&img[TAB_TR_VERT], TVT_TR_VERT, 512 * 12 * 2);
+	// vertex words -> 16-entry word table + 4-bit indices (padding entries, never read, index 0)
+	auto pack = [&](const unsigned short* words, u32 cases, u32 edgeOff, u32 vertOff) {
+		u16 distinct[16];
+		u32 nDistinct = 0;
+		for (u32 i = 0; i < cases * 12; ++i) {
+			const u16 w = words[i];
+			u32 idx = 0;
+			if (w) {
+				for (idx = 0; idx < nDistinct && distinct[idx] != w; ++idx) {}
+				if (idx == nDistinct) {
+					if (nDistinct == 16) abort(); // the Transvoxel tables have 12 / 16 distinct edge words
+					distinct[nDistinct++] = w;
+				}
+			}
+			img[vertOff + i / 2] |= (u8)(idx << ((i & 1u) * 4u));
+		}
+		memcpy(&img[edgeOff], distinct, nDistinct * 2);
+	};
+	pack(TVT_REG_VERT, 256, TAB_REG_EDGE, TAB_REG_VERT);
+	pack(TVT_TR_VERT, 512, TAB_TR_EDGE, TAB_TR_VERT);
 }
 
 // one pass of the device pipeline over the blocks listed in the level tables
