@@ -202,21 +202,27 @@ struct Backend {
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
 				tr_phase_load(*st, p.G, L, b, 0, 1);
 				tr_phase_classify(*st, 0, 1);
-				for (int w = 0; w < 48; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
-				st->wordPrefix[48] = (u16)exclusive_scan(st->wordPrefix, 48);
-				if (!st->wordPrefix[48]) { tr_write_empty_record(L, slot); continue; }
-				tr_phase_list(*st, T, L, b, 0, 1);
-				tr_phase_count(*st, T, 0, 1);
-				st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);
-				st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[48]);
-				st->vOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_V], st->vTotal);
-				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
-				for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
-					tr_phase_describe(*st, chunk, 0, 1);
-					tr_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
+				for (int f0 = 0; f0 < 6;) {
+					const int f1 = tr_batch_end(*st, f0);
+					tr_phase_batch_bits(*st, f0, f1, 0, 1);
+					st->wordPrefix[48] = (u16)exclusive_scan(st->wordPrefix, 48);
+					st->vTotal = st->iTotal = st->vOff = st->iOff = 0;
+					if (st->wordPrefix[48]) {
+						tr_phase_list(*st, T, L, b, 0, 1);
+						tr_phase_count(*st, T, 0, 1);
+						st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);
+						st->iTotal = exclusive_scan(st->ibase, st->wordPrefix[48]);
+						st->vOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_V], st->vTotal);
+						st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
+						for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
+							tr_phase_describe(*st, chunk, 0, 1);
+							tr_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
+						}
+						tr_phase_emit_indices(*st, T, p.P, 0, 1);
+					}
+					tr_phase_record(*st, L, b, p.P, f0, f1, 0);
+					f0 = f1;
 				}
-				tr_phase_emit_indices(*st, T, p.P, 0, 1);
-				tr_phase_record(*st, L, b, p.P, 0);
 			}
 		}
 		delete st;

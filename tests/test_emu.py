@@ -201,3 +201,12 @@ def test_emu_repeated_edits_vs_port(emu, port):
         ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
         assert ok, msg
         assert np.array_equal(p.stats(), s.stats())
+
+
+def test_emu_transition_face_batches(emu, port):
+    """White noise at 64^3: every level-1 block has three neighbour faces whose 3 x 256 transition cells are all
+    non-trivial — more than the 512-cell transition state holds, so the faces go through in several batches."""
+    rng = np.random.RandomState(7)
+    n = 64
+    d = rng.randint(-128, 128, (n, n, n)).astype(np.int8)
+    check(emu, port, d, rng.randint(0, 3, (n, n, n)).astype(np.uint8), rng.randint(0, 256, (n, n, n)).astype(np.uint8), "white noise 64")

@@ -766,23 +766,51 @@ TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const Re
 // ---------------------------------------------------------------------------------------------------------
 // Transition pass state: all 6 faces of a block at once; cell id = f * 256 + row * 16 + col
 // ---------------------------------------------------------------------------------------------------------
-enum { TR_CELLS = 6 * 256 };
+enum { TR_CELLS = 6 * 256, TR_CAP = 512 };
 
+// The six faces of a block are independent (reuse never crosses a face, every face has its own output ranges), so
+// the per-cell state is sized for TR_CAP non-trivial cells and a block is handled in batches of consecutive faces
+// whose non-trivial cells fit: nearly always one batch; any two faces (2 x 256 cells) always fit.
 struct TrState {
 	i8 plane[6][PLANE + 7];   // 33 x 33 full-resolution samples of each boundary plane, index v * 33 + u
-	u32 ntBits[48];
-	u16 wordPrefix[50];       // [48] = number of non-trivial transition cells
-	u16 cellOf[TR_CELLS];     // compact -> cell id
-	u16 cellMat[TR_CELLS];    // compact: low-res cell material
-	u16 valid[TR_CELLS];      // compact: slot valid mask (10 bits)
-	u8 ords[TR_CELLS][10];    // compact: ordinal of the vertex stored in each slot
-	u16 vbase[TR_CELLS];      // compact: exclusive scan of new vertex counts (flat over faces)
-	u16 ibase[TR_CELLS];      // compact: exclusive scan of index counts (flat over faces)
-	u16 newMask[TR_CELLS];    // compact: table vertices this cell creates
+	u32 ntAll[48];            // non-trivial transition cells of all faces
+	u32 ntBits[48];           // ... of the faces of the current batch
+	u16 wordPrefix[50];       // [48] = number of non-trivial transition cells of the batch
+	u16 cellOf[TR_CAP];       // compact -> cell id
+	u16 cellMat[TR_CAP];      // compact: low-res cell material
+	u16 valid[TR_CAP];        // compact: slot valid mask (10 bits)
+	unsigned long long ords[TR_CAP]; // compact: ordinal (4 bits) of the vertex stored in each of the 10 slots
+	u16 vbase[TR_CAP];        // compact: exclusive scan of new vertex counts (flat over the batch's faces)
+	u16 ibase[TR_CAP];        // compact: exclusive scan of index counts (flat over the batch's faces)
+	u16 newMask[TR_CAP];      // compact: table vertices this cell creates
 	u16 vdesc[VDESC_CAP];     // one chunk of new-vertex descriptors: compact cell | table vertex << 11
 	u32 faceOn;               // bit f = face has a neighbour block
 	u32 vOff, iOff, vTotal, iTotal;
 };
+
+// end of the batch of faces starting at f0: as many consecutive faces as fit TR_CAP cells (at least one)
+TV_HD int tr_batch_end(const TrState& st, int f0)
+{
+	u32 sum = 0;
+	int f = f0;
+	for (; f < 6; ++f) {
+		u32 cnt = 0;
+		for (int w = 0; w < 8; ++w) cnt += (u32)TV_POPC(st.ntAll[f * 8 + w]);
+		if (f > f0 && sum + cnt > (u32)TR_CAP) break;
+		sum += cnt;
+	}
+	return f;
+}
+
+// working bitmap of the batch [f0, f1) and its per-word counts (to be scanned into wordPrefix)
+TV_HD void tr_phase_batch_bits(TrState& st, int f0, int f1, int tid, int nth)
+{
+	for (int w = tid; w < 48; w += nth) {
+		const u32 bits = ((w >> 3) >= f0 && (w >> 3) < f1) ? st.ntAll[w] : 0u;
+		st.ntBits[w] = bits;
+		st.wordPrefix[w] = (u16)TV_POPC(bits);
+	}
+}
 
 TV_HD void tr_phase_load(TrState& st, const Globals& G, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
 {
@@ -793,7 +821,7 @@ TV_HD void tr_phase_load(TrState& st, const Globals& G, const LevelDesc& L, cons
 		if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
 	}
 	if (tid == 0) st.faceOn = on;
-	for (int w = tid; w < 48; w += nth) st.ntBits[w] = 0;
+	for (int w = tid; w < 48; w += nth) st.ntAll[w] = 0;
 	const int half = (int)b.mult >> 1;
 	for (int s = tid; s < 6 * PLANE; s += nth) {
 		const int f = s / PLANE, r = s % PLANE;
@@ -824,7 +852,7 @@ TV_HD void tr_phase_classify(TrState& st, int tid, int nth)
 		i8 v9[9];
 		tr_cell_values(st, f, (c >> 4) & 15, c & 15, v9);
 		const u32 code = tr_case_code(v9);
-		if (code != 0 && code != 511) TV_ATOMIC_OR(&st.ntBits[c >> 5], 1u << (c & 31));
+		if (code != 0 && code != 511) TV_ATOMIC_OR(&st.ntAll[c >> 5], 1u << (c & 31));
 	}
 }
 
@@ -889,14 +917,16 @@ TV_HD void tr_phase_count(TrState& st, const Tables& T, int tid, int nth)
 		const u32 mask2 = tr_mask2(st, f, row, col);
 		TrNeighbour nb{ &st, f, row, col };
 		u32 count = 0, newMask = 0;
+		unsigned long long ords = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
 			const TrResolution r = tr_resolve(T, v, T.trVert(code, vi), mask2, st.cellMat[k] & 0xFFu, nb);
 			if (r.kind == RK_NEW_EDGE) {
-				if (r.store != NO_SLOT) st.ords[k][r.store] = (u8)count;
+				if (r.store != NO_SLOT) ords = (ords & ~(0xFull << (r.store * 4))) | ((unsigned long long)count << (r.store * 4));
 				++count;
 				newMask |= 1u << vi;
 			}
 		}
+		st.ords[k] = ords;
 		st.vbase[k] = (u16)count;
 		st.ibase[k] = (u16)(ntri * 3);
 		st.newMask[k] = (u16)newMask;
@@ -984,7 +1014,7 @@ TV_HD void tr_phase_emit_indices(TrState& st, const Tables& T, const Pools& P, i
 				tr_vertex_dir_slot(T, v, T.trVert(code, vi), t, dir, slot, endpoint, corner);
 				const u32 c2 = (u32)((f << 8) | ((row - (int)((dir >> 1) & 1)) << 4) | (col - (int)(dir & 1)));
 				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-				id = (u32)st.vbase[k2] - faceVBase + st.ords[k2][slot];
+				id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
 			}
 			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
 			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
@@ -1011,14 +1041,16 @@ TV_HD void tr_write_empty_record(const LevelDesc& L, u32 slot)
 	for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
 }
 
-TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int tid)
+// output ranges of the faces [f0, f1) of the current batch (zero ranges when the pools overflowed or nothing came out)
+TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlockCtx& b, const Pools& P, int f0, int f1, int tid)
 {
 	if (tid != 0) return;
 	BlockRecord& r = L.records[b.slot];
-	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
-	if (!ok) { TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u); tr_write_empty_record(L, b.slot); return; }
 	const u32 nt = st.wordPrefix[48];
-	for (int f = 0; f < 6; ++f) {
+	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
+	if (!ok) TV_ATOMIC_OR(&P.cursors[CUR_OVF], 1u);
+	for (int f = f0; f < f1; ++f) {
+		if (!ok || !nt) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; continue; }
 		const u32 k0 = st.wordPrefix[f * 8], k1 = st.wordPrefix[f * 8 + 8];
 		const u32 v0 = (k0 < nt) ? st.vbase[k0] : st.vTotal, v1 = (k1 < nt) ? st.vbase[k1] : st.vTotal;
 		const u32 i0 = (k0 < nt) ? st.ibase[k0] : st.iTotal, i1 = (k1 < nt) ? st.ibase[k1] : st.iTotal;

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			}
 			__syncthreads();
 			if (tid == 0) st.faceOn = on;
-			for (int w = tid; w < 48; w += WG) st.ntBits[w] = 0;
+			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
 			const int half = (int)b.mult >> 1;
 			const GridView& g = p.G.grid;
 			batched_gather<6 * PLANE, i8, 13>(
@@ -789,40 +789,43 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 		__syncthreads();
 		tr_phase_classify(st, tid, WG);
 		__syncthreads();
-		for (int w = tid; w < 48; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
-		__syncthreads();
-		{
-			const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
-			if (tid == 0) st.wordPrefix[48] = (u16)nt;
-		}
-		__syncthreads();
-		if (st.wordPrefix[48] == 0) {
-			if (tid == 0) tr_write_empty_record(L, b.slot);
+		for (int f0 = 0; f0 < 6;) {
+			const int f1 = tr_batch_end(st, f0); // uniform
 			__syncthreads();
-			continue;
-		}
-		tr_phase_list(st, T, L, b, tid, WG);
-		__syncthreads();
-		tr_phase_count(st, T, tid, WG);
-		__syncthreads();
-		{
-			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
-			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
-			if (tid == 0) {
-				st.vTotal = vt; st.iTotal = it;
-				st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt);
-				st.iOff = atomicAdd(&p.P.cursors[CUR_I], it);
+			tr_phase_batch_bits(st, f0, f1, tid, WG);
+			if (tid == 0) { st.vTotal = st.iTotal = st.vOff = st.iOff = 0; }
+			__syncthreads();
+			{
+				const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
+				if (tid == 0) st.wordPrefix[48] = (u16)nt;
 			}
-		}
-		__syncthreads();
-		for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
-			if (chunk) __syncthreads();
-			tr_phase_describe(st, chunk, tid, WG);
 			__syncthreads();
-			tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+			if (st.wordPrefix[48] != 0) {
+				tr_phase_list(st, T, L, b, tid, WG);
+				__syncthreads();
+				tr_phase_count(st, T, tid, WG);
+				__syncthreads();
+				{
+					const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
+					const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
+					if (tid == 0) {
+						st.vTotal = vt; st.iTotal = it2;
+						st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt);
+						st.iOff = atomicAdd(&p.P.cursors[CUR_I], it2);
+					}
+				}
+				__syncthreads();
+				for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
+					if (chunk) __syncthreads();
+					tr_phase_describe(st, chunk, tid, WG);
+					__syncthreads();
+					tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+				}
+				tr_phase_emit_indices(st, T, p.P, tid, WG);
+			}
+			tr_phase_record(st, L, b, p.P, f0, f1, tid);
+			f0 = f1;
 		}
-		tr_phase_emit_indices(st, T, p.P, tid, WG);
-		tr_phase_record(st, L, b, p.P, tid);
 		__syncthreads();
 	}
 }
@@ -1122,7 +1125,7 @@ struct Backend {
 		u32 cap = 0;
 		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
 		if (!cap) return;
-		const u32 grid = std::min<u32>(cap, (u32)cus * 2);
+		const u32 grid = std::min<u32>(cap, (u32)cus * 5);
 		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		check(hipGetLastError(), "k_transition launch");
 	}
