@@ -561,7 +561,7 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 			const u32 w = T.regVert(reg_case_code(V), vi);
 			f[r].key = desc | (w << 16);
 			f[r].lut = lut_row(G.lut, st.cellMat[k]);
-			if (LEVEL0 && !(G.debugPhaseLimit & 0x400u)) {
+			if (LEVEL0) {
 				const int v0 = (w >> 4) & 15, v1 = w & 15;
 				const int e = edge_end(V[v0], V[v1]);
 				int A[3], B[3];
@@ -594,8 +594,7 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 			const int e = edge_end(val0, val1);
 			RawVertex rv;
 			bool interior = false;
-			if (G.debugPhaseLimit & 0x200u) { rv.p[0] = (float)cx; rv.p[1] = (float)val0; rv.p[2] = (float)val1; rv.s[0] = rv.s[1] = rv.s[2] = 0.f; rv.n[0] = rv.n[1] = rv.n[2] = 0.f; rv.flags = 0; rv.mat = cellMat + f[r].m0 + f[r].m1; interior = true; }
-			else if (e != 1) {
+			if (e != 1) {
 				const int corner = ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0);
 				if (LEVEL0) reg_corner_vertex(d, FetchedMaterials{ f[r].m0, f[r].m1 }, geo, corner, cellMat, rv);
 				else reg_corner_vertex(d, GridMaterials{ &G.grid }, geo, corner, cellMat, rv);
@@ -604,8 +603,8 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 				if (LEVEL0) interior = reg_edge_vertex(d, FetchedMaterials{ f[r].m0, f[r].m1 }, geo, v0, v1, t, val0, val1, cellMat, rv);
 				else interior = reg_edge_vertex(d, GridMaterials{ &G.grid }, geo, v0, v1, t, val0, val1, cellMat, rv);
 			}
-			if (!interior && !(G.debugPhaseLimit & 0x800u)) reg_mark_suspect(st, cx, cy, cz);
-			if (room && !(G.debugPhaseLimit & 0x100u)) pack_vertex_row(rv, f[r].lut, P.verts + st.vOff + chunkBase + j);
+			if (!interior) reg_mark_suspect(st, cx, cy, cz);
+			if (room) pack_vertex_row(rv, f[r].lut, P.verts + st.vOff + chunkBase + j);
 		}
 	}
 }

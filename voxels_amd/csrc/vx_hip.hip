@@ -1101,7 +1101,10 @@ struct Backend {
 	{
 		(void)hipEventRecord(evClassified, stream);
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		launch_regular(p, 0, 1, sideA);
+		{
+			const char* l0Env = getenv("VX_REG_WGS_L0"); // tuning aid
+			launch_regular(p, 0, 1, sideA, l0Env ? (u32)atoi(l0Env) : 5u);
+		}
 		(void)hipEventRecord(evSideA, sideA);
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
 		(void)hipEventRecord(evMaterial, stream);
