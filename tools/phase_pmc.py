@@ -43,6 +43,7 @@ def main():
     d, m, b = synth.terrain(n)
     p = Polygonizer()
     p.upload(d, m, b, synth.block_empty_flags(d))
+    p.set_stage_timing(True)  # serialised: one k_regular<640> dispatch per run
     p.execute(4)
     for lim in LIMS:
         p.debug_phase_limit(lim)

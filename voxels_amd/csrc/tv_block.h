@@ -351,6 +351,7 @@ struct RegStateT {
 	u16 wordPrefix[130];      // exclusive popcount prefix, [128] = number of non-trivial cells
 	u16 cellOf[CAP];          // compact index -> cell id
 	u16 cellMat[CAP];         // compact: id | blend << 8
+	u16 cellBits[CAP];        // compact: case code | (corner sample == 0) mask << 8 — all that the index logic needs of the samples
 	u32 info[CAP];            // compact: bits 0-15 slot ordinals (4 x 4), 16-19 slot valid, 20-23 new vertex count, 24-28 kept triangles
 	u16 vbase[CAP];           // compact: exclusive scan of new vertex counts
 	u16 ibase[CAP];           // compact: exclusive scan of kept index counts
@@ -412,6 +413,7 @@ TV_HD void reg_phase_cells(ST& st, const Tables& T, const Globals& G, const Leve
 		i8 V[8];
 		reg_cell_values(st.samp, cx, cy, cz, V);
 		const u32 code = reg_case_code(V);
+		st.cellBits[k] = (u16)(code | (reg_zero_mask(V) << 8));
 		st.info[k] = reg_slot_valid(T, V, code) << 16;
 		u32 m;
 		if (b.level == 0) m = mat_at(G.grid, (int)(b.bx * 16 + cx), (int)(b.by * 16 + cy), (int)(b.bz * 16 + cz));
@@ -469,9 +471,9 @@ TV_HD void reg_phase_count(ST& st, const Tables& T, const RegBlockCtx& b, int ti
 {
 	const int nt = st.wordPrefix[128];
 	for (int k = tid; k < nt; k += nth) {
-		int cx, cy, cz; i8 V[8]; CellGeom geo;
-		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
-		const u32 code = reg_case_code(V);
+		const u32 c = st.cellOf[k];
+		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+		const u32 bits = st.cellBits[k], code = bits & 0xFFu, zeroMask = bits >> 8;
 		const u32 nv = (u32)T.regCell(T.regClass(code))[0] >> 4;
 		const u32 mask3 = reg_mask3(st, cx, cy, cz);
 		const u32 myMat = st.cellMat[k] & 0xFFu;
@@ -479,7 +481,7 @@ TV_HD void reg_phase_count(ST& st, const Tables& T, const RegBlockCtx& b, int ti
 		u32 count = 0, ords = 0, newMask = 0, atV0 = 0, invalid = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
 			const u32 w = T.regVert(code, vi);
-			const Resolution r = reg_resolve(V, w, mask3, myMat, nb);
+			const Resolution r = reg_resolve(zeroMask, w, mask3, myMat, nb);
 			if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
 				if (r.store != NO_SLOT) ords = (ords & ~(0xFu << (r.store * 4))) | (count << (r.store * 4));
 				++count;
@@ -539,6 +541,29 @@ struct FetchedMaterials {
 
 enum { EMIT_BATCH = 4 };     // vertices per lane whose fetches are in flight together
 
+// mat_at() for the corners of a level-0 block's cells: one base address per block, 32-bit offsets per corner.
+// The only clamp that can bite is the far corner layer of the last block of an axis.
+struct BlockMaterials {
+	const u8* mat;
+	const u8* blend;
+	int n, maxX, maxY, maxZ;
+	TV_HD u32 at(int lx, int ly, int lz) const
+	{
+		lx = lx > maxX ? maxX : lx; ly = ly > maxY ? maxY : ly; lz = lz > maxZ ? maxZ : lz;
+		const u32 off = (u32)((lz * n + ly) * n + lx);
+		return (u32)mat[off] | ((u32)blend[off] << 8);
+	}
+};
+
+TV_HD BlockMaterials block_materials(const GridView& g, const RegBlockCtx& b)
+{
+	BlockMaterials m;
+	const size_t origin = ((size_t)((int)(b.bz * 16) - g.zOriginMat) * g.n + b.by * 16) * g.n + b.bx * 16;
+	m.mat = g.mat + origin; m.blend = g.blend + origin; m.n = g.n;
+	m.maxX = g.n - 1 - (int)(b.bx * 16); m.maxY = g.n - 1 - (int)(b.by * 16); m.maxZ = g.n - 1 - (int)(b.bz * 16);
+	return m;
+}
+
 // One lane = one new vertex of the chunk: uniform work, consecutive 48-byte stores.  The global reads of a vertex
 // (end-point materials, LUT row) do not depend on its arithmetic, so a lane requests them for all of its vertices
 // first: one memory round trip per chunk instead of two per vertex.  Levels >= 1 read their materials at the
@@ -548,6 +573,7 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 {
 	const bool room = st.vOff + st.vTotal <= P.vertCap;
 	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
+	const BlockMaterials bm = block_materials(G.grid, b);
 	for (u32 j0 = (u32)tid; j0 < end; j0 += (u32)nth * EMIT_BATCH) {
 		VertexFetch f[EMIT_BATCH];
 #pragma unroll
@@ -556,24 +582,19 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 			if (j >= end) continue;
 			const u32 desc = st.vdesc[j];
 			const u32 k = desc & 0xFFFu, vi = desc >> 12;
-			int cx, cy, cz; i8 V[8]; CellGeom geo;
-			reg_cell_setup(st, b, k, cx, cy, cz, V, geo);
-			const u32 w = T.regVert(reg_case_code(V), vi);
+			const u32 bits = st.cellBits[k];
+			const u32 w = T.regVert(bits & 0xFFu, vi);
 			f[r].key = desc | (w << 16);
 			f[r].lut = lut_row(G.lut, st.cellMat[k]);
 			if (LEVEL0) {
+				const u32 c = st.cellOf[k];
+				const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
 				const int v0 = (w >> 4) & 15, v1 = w & 15;
-				const int e = edge_end(V[v0], V[v1]);
-				int A[3], B[3];
-				if (e != 1) {
-					corner_pos(geo, ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0), A);
-					B[0] = A[0]; B[1] = A[1]; B[2] = A[2];
-				} else {
-					corner_pos(geo, v0, A);
-					corner_pos(geo, v1, B);
-				}
-				f[r].m0 = mat_at(G.grid, A[0], A[1], A[2]);
-				f[r].m1 = mat_at(G.grid, B[0], B[1], B[2]);
+				const int e = edge_end_bits(bits >> 8, v0, v1);
+				int a = v0, bb = v1; // the corners whose materials the vertex reads
+				if (e != 1) { a = ((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0); bb = a; }
+				f[r].m0 = bm.at(cx + (a & 1), cy + ((a >> 1) & 1), cz + (a >> 2));
+				f[r].m1 = bm.at(cx + (bb & 1), cy + ((bb >> 1) & 1), cz + (bb >> 2));
 			}
 		}
 #pragma unroll
@@ -629,13 +650,13 @@ TV_HD void reg_keep_with(ST& st, const D& d, const Tables& T, const RegBlockCtx&
 {
 	const int nt = st.wordPrefix[128];
 	for (int k = tid; k < nt; k += nth) {
-		int cx, cy, cz; i8 V[8]; CellGeom geo;
-		reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
-		const u32 code = reg_case_code(V);
+		const u32 code = st.cellBits[k] & 0xFFu;
 		const u8* cd = T.regCell(T.regClass(code));
 		const u32 ntri = (u32)cd[0] & 15;
 		u32 keepMask = (1u << ntri) - 1u, kept = ntri;
 		if (b.mult > 16 || bit_get(st.suspect, (u32)st.cellOf[k])) {
+			int cx, cy, cz; i8 V[8]; CellGeom geo;
+			reg_cell_setup(st, b, (u32)k, cx, cy, cz, V, geo);
 			const u32 invalidMask = st.invalidMask[k], atV0Mask = st.atV0Mask[k];
 			keepMask = 0; kept = 0;
 			for (u32 tr = 0; tr < ntri; ++tr) {
@@ -682,9 +703,7 @@ TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int t
 		if (first >= chunkBase + VDESC_CAP || first + count <= chunkBase) continue;
 		const u32 c = st.cellOf[k];
 		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
-		i8 V[8];
-		reg_cell_values(st.samp, cx, cy, cz, V);
-		const u32 code = reg_case_code(V);
+		const u32 bits = st.cellBits[k], code = bits & 0xFFu, zeroMask = bits >> 8;
 		const u8* cd = T.regCell(T.regClass(code));
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
 		const u32 newMask = st.newMask[k], invalidMask = st.invalidMask[k];
@@ -698,7 +717,7 @@ TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int t
 				id = 0xFFFFu;
 			} else {
 				u32 dir, slot;
-				reg_reuse_source(V, T.regVert(code, vi), dir, slot);
+				reg_reuse_source(zeroMask, T.regVert(code, vi), dir, slot);
 				const u32 c2 = (u32)(((cz - (int)((dir >> 2) & 1)) << 8) | ((cy - (int)((dir >> 1) & 1)) << 4) | (cx - (int)(dir & 1)));
 				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
 				id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);

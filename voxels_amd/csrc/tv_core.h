@@ -135,7 +135,23 @@ TV_HD void normalize_fix_zero(float v[3])
 	const float len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
 	const float len = sqrtf(len2);
 	if (len <= 1.1920929e-07f) { v[0] = v[1] = v[2] = 0.f; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+	// Three IEEE divisions by the same denominator: the compiler's fp32 division (reciprocal, two Newton steps on the
+	// quotient, final fused correction) with the reciprocal refined once instead of three times.  The operands are far
+	// from the ranges where v_div_scale / v_div_fixup would intervene (len in [1e-7, 256], |v| <= 128 and never a
+	// denormal), so every quotient is the correctly rounded one, bit for bit what v / len gives on the host.
+	const float y0 = __builtin_amdgcn_rcpf(len);
+	const float y = __builtin_fmaf(__builtin_fmaf(-len, y0, 1.0f), y0, y0);
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		const float n = v[i];
+		const float q0 = n * y;
+		const float q1 = __builtin_fmaf(__builtin_fmaf(-len, q0, n), y, q0);
+		v[i] = __builtin_fmaf(__builtin_fmaf(-len, q1, n), y, q1);
+	}
+#else
 	v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len;
+#endif
 }
 
 // distance sampler reading the dense field in HBM (global coordinates, clamped like every reference fetch)
@@ -177,6 +193,17 @@ TV_HD int edge_t(int v0, int v1) { return (int)((float)(v1 * 256) / (float)(v1 -
 // 0 <=> edge_t == 0 (v1 == 0: |v1 * 256| >= |v1 - v0| otherwise), 256 <=> edge_t == 256 (v0 == 0, the samples
 // of a crossed edge never share a strict sign), 1 = strictly inside the edge.  Same exhaustive test as edge_t.
 TV_HD int edge_end(int v0, int v1) { return v1 == 0 ? 0 : (v0 == 0 ? 256 : 1); }
+
+// the same from a cell's "corner sample == 0" mask
+TV_HD int edge_end_bits(u32 zeroMask, int c0, int c1) { return ((zeroMask >> c1) & 1u) ? 0 : (((zeroMask >> c0) & 1u) ? 256 : 1); }
+
+TV_HD u32 reg_zero_mask(const i8 V[8])
+{
+	u32 m = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) m |= (V[i] == 0 ? 1u : 0u) << i;
+	return m;
+}
 
 TV_HD u32 lerp_blend(int t, int u, u32 b0, u32 b1)
 {
@@ -310,13 +337,14 @@ struct Resolution {
 //   mask3  : bit0 = a non-trivial cell exists earlier in this row, bit1 = in an earlier row of this slice,
 //            bit2 = in an earlier slice (the reference's reuseValidityMask)
 //   nb(dx,dy,dz, slot, &valid, &mat): reuse slot of the neighbour cell at (cx-dx, cy-dy, cz-dz)
+//   zeroMask: bit i = corner sample i is exactly 0 (all the resolution needs to know about the values)
 template <typename NB>
-TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const NB& nb)
+TV_HD Resolution reg_resolve(u32 zeroMask, u32 w, u32 mask3, u32 myMatId, const NB& nb)
 {
 	Resolution r;
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
 	u32 dir = w >> 12, slot = (w >> 8) & 15;
-	const int t = edge_end(V[v0], V[v1]);
+	const int t = edge_end_bits(zeroMask, v0, v1);
 	const bool endpoint = (t & 0xFF) == 0;
 	bool check = true;
 	if (endpoint) {
@@ -346,10 +374,10 @@ TV_HD Resolution reg_resolve(const i8 V[8], u32 w, u32 mask3, u32 myMatId, const
 }
 
 // (direction, slot) a reused vertex `w` comes from, as reg_resolve derives them
-TV_HD void reg_reuse_source(const i8 V[8], u32 w, u32& dir, u32& slot)
+TV_HD void reg_reuse_source(u32 zeroMask, u32 w, u32& dir, u32& slot)
 {
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
-	const int t = edge_end(V[v0], V[v1]);
+	const int t = edge_end_bits(zeroMask, v0, v1);
 	dir = w >> 12; slot = (w >> 8) & 15;
 	if ((t & 0xFF) == 0) { dir = (u32)((t == 0) ? v1 : v0) ^ 7u; slot = 0; }
 }
