@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""profiles/pmc_latest.json from the per-pass summaries of tools/pmc_run.sh (FETCH_SIZE, WRITE_SIZE, TCC hit/miss passes).
+Usage: tools/pmc_json.py <dir with pass1.txt pass2.txt [pass3.txt]> <n> <levels> <gpus> <label of the committed copies>"""
+import json
+import re
+import sys
+
+CLASSES = {"k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular": "k_regular",
+           "k_block_summary": "k_classify", "k_block_class": "k_classify"}
+
+
+def parse(path):
+    """-> ({kernel class: {counter: sum}}, executes) ; executes = number of k_classify dispatches"""
+    sums, executes = {}, 0
+    for line in open(path):
+        parts = line.split()
+        if len(parts) == 5 and re.match(r"^[0-9.]+$", parts[-1]) and re.match(r"^\d+$", parts[2]):
+            name, counter, samples, total = parts[0], parts[1], int(parts[2]), float(parts[3])
+            for key, cls in CLASSES.items():
+                if key in name:
+                    sums.setdefault(cls, {}).setdefault(counter, 0.0)
+                    sums[cls][counter] += total
+                    if key == "k_classify":
+                        executes = samples
+    return sums, executes
+
+
+def main():
+    d, n, levels, gpus, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    fetch, ex1 = parse(d + "/pass1.txt")
+    write, ex2 = parse(d + "/pass2.txt")
+    out = {"n": n, "levels": levels, "gpus": gpus,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) of "
+                     "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; summaries committed as profiles/%s_pmc_*.txt" % label,
+           "units": "FETCH_SIZE/WRITE_SIZE are KiB, summed over the dispatches of a kernel and divided by the number of polygonizations",
+           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced (16 B/lane) "
+                         "reads. k_classify's density stream is 16 B/lane, so its FETCH_SIZE is doubled; the other kernels read with 1-8 byte "
+                         "gathers (uncalibrated, taken as reported). WRITE_SIZE is uncalibrated."}
+    fk = {k: v.get("FETCH_SIZE", 0.0) / max(ex1, 1) for k, v in fetch.items()}
+    wk = {k: v.get("WRITE_SIZE", 0.0) / max(ex2, 1) for k, v in write.items()}
+    out["fetch_kib_per_execute"] = {k: round(v, 1) for k, v in fk.items()}
+    out["write_kib_per_execute"] = {k: round(v, 1) for k, v in wk.items()}
+    out["hbm_bytes_per_launch"] = {k: int((fk.get(k, 0.0) * (2.0 if k == "k_classify" else 1.0) + wk.get(k, 0.0)) * 1024) for k in fk}
+    try:
+        tcc, _ = parse(d + "/pass3.txt")
+        out["l2_hit_rate"] = {k: round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 3) for k, v in tcc.items()}
+    except OSError:
+        pass
+    json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
+    print(json.dumps(out["hbm_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@
 # Usage (on the GPU box): bash tools/pmc_run.sh <outdir> "<counters pass 1>" "<counters pass 2>" ...
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=$1; shift
+mkdir -p "$out"
 i=0
 for c in "$@"; do
   i=$((i+1))
