@@ -27,6 +27,14 @@ struct Backend {
 	void free_pinned(void* p) { ::free(p); }
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
+	void end_timing_record() {}
+	float elapsed_ms() { return 0.f; }
+	template <typename P>
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
+	{
+		memset(header, 0, (size_t)headerWords * 4);
+		for (u32 l = 0; l < levels; ++l) memset(p.levels[l].slotOf, 0xFF, (size_t)p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt * 4);
+	}
 	bool stage_timing_on() const { return true; } // the emulation always runs the serial order
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}

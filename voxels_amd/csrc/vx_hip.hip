@@ -153,6 +153,30 @@ __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockC
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >> 7) * 0x01020408u) >> 24; }
 
+// ---- start of a full run: header = 0, block -> slot maps = -1 (one launch instead of a memset per array) -------------
+struct ResetRanges {
+	u32* header;
+	u32 headerWords;
+	u32 start[MAX_LEVELS + 1]; // word ranges of the flat index space: [0, headerWords) header, then slotOf of level 0, 1, ...
+};
+
+__global__ __launch_bounds__(WG) void k_reset(ExecParamsDev p, ResetRanges r)
+{
+	const u32 total = r.start[MAX_LEVELS];
+	// four consecutive words per lane; ranges are multiples of 4 words except possibly tiny coarse levels
+	const u32 first = (blockIdx.x * WG + threadIdx.x) * 4;
+#pragma unroll
+	for (u32 k = 0; k < 4; ++k) {
+		const u32 i = first + k;
+		if (i >= total) return;
+		if (i < r.headerWords) { r.header[i] = 0; continue; }
+		u32 l = 0;
+#pragma unroll
+		for (u32 q = 1; q < MAX_LEVELS; ++q) if (i >= r.start[q]) l = q;
+		p.levels[l].slotOf[i - r.start[l]] = -1;
+	}
+}
+
 // ---- what the emptiness flags already say about a block (two tiny launches ahead of k_classify) ------------
 // summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign)
 __global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi)
@@ -1000,6 +1024,29 @@ struct Backend {
 		float ms = 0.f;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
 		return ms;
+	}
+	void end_timing_record() { (void)hipEventRecord(ev1, stream); }
+	float elapsed_ms() // after the stream was synchronised
+	{
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.f;
+		return ms;
+	}
+
+	// header words = 0 and every level's block -> slot map = -1, in one launch
+	template <typename P>
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
+	{
+		ResetRanges r;
+		u32 run = headerWords;
+		r.header = header; r.headerWords = headerWords;
+		for (u32 l = 0; l < MAX_LEVELS; ++l) {
+			r.start[l] = run;
+			if (l < levels) run += p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt;
+		}
+		r.start[MAX_LEVELS] = run;
+		hipLaunchKernelGGL(k_reset, dim3((run / 4 + WG) / WG), dim3(WG), 0, stream, dev(p), r);
+		check(hipGetLastError(), "k_reset launch");
 	}
 
 	template <typename P>

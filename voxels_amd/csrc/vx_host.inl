@@ -83,6 +83,7 @@ struct vx_ctx {
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
 	u32 hdr[HDR_WORDS];
+	u32* hdrPinned = nullptr; // pinned landing buffer of the header read-back
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
 	size_t hRecCap = 0;
 	u32 debugPhaseLimit = 0;
@@ -381,6 +382,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
+	c->be.free_pinned(c->hdrPinned);
 	c->be.shutdown();
 	delete c;
 }
@@ -484,13 +486,19 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		fill_params(c, p, levels);
 		c->be.begin_timing();
 		c->be.stage_mark(0);
-		c->be.fill(c->dHeader, 0, HDR_WORDS * 4);
-		for (u32 L = 0; L < levels; ++L) c->be.fill(c->lv[L].slotOf, 0xFF, (size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt * 4);
+		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS); // header = 0, slot maps = -1
 		run_pipeline(c, p, levels);
+		c->be.end_timing_record();
+		// the header travels right behind the kernels: one host wait per run
+		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned(HDR_WORDS * 4);
+		if (!c->hdrPinned) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed");
+		bool okRun = c->be.d2h_async(c->hdrPinned, c->dHeader, HDR_WORDS * 4);
 		t1 = tNow();
-		ms = c->be.end_timing_ms();
+		okRun = okRun && c->be.sync_ok();
 		t2 = tNow();
-		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
+		if (!okRun) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
+		ms = c->be.elapsed_ms();
+		memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
 		t3 = tNow();
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (!overflow) break;
