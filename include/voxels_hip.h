@@ -72,6 +72,15 @@ int vx_set_stream(vx_ctx* ctx, void* hip_stream);
  * (src/VoxelGrid.h:139-144); mat/blend may be NULL (all zero). */
 int vx_grid_upload(vx_ctx* ctx, uint32_t n, const int8_t* dist, const uint8_t* mat, const uint8_t* blend,
                    const uint8_t* empty_flags);
+/* The same, from the Grid file format v1 (what Grid::PackForSave writes and Grid::Load reads, src/VoxelGrid.cpp:215-315):
+ * header {1, w, d, h}, 3 stream sizes per block, then per block in id order {flags, distance stream, material stream,
+ * blend stream}; a stream is RLE pairs (u8 run length, value) or 4096 raw bytes when its BF_*Uncompressed flag is set
+ * (CompressBlock / DecompressBlock, :610-694).  The blob goes to the device as it is and is expanded there; BF_Empty
+ * comes from the per-block flags.  Replaces Grid::Load + vx_grid_upload (no host decode, no 3 bytes/voxel transfer). */
+int vx_grid_upload_packed(vx_ctx* ctx, const void* blob, uint64_t size);
+/* One 16^3 block of the resident grid back to the host, x fastest (Grid::GetBlockDistanceData / GetBlockMaterialData,
+ * src/VoxelGrid.cpp:586-608); any output may be NULL.  empty_flag receives BF_Empty. */
+int vx_grid_read_block(vx_ctx* ctx, uint32_t block_id, int8_t* dist, uint8_t* mat, uint8_t* blend, uint8_t* empty_flag);
 /* Use caller-owned DEVICE memory (multi-GPU slabs, PyTorch tensors).  This rank polygonizes the z-range
  * [z_begin, z_end) of the global n^3 grid.  d_dist holds the z-planes [dist_z0, ...) and must cover
  * [z_begin-1, z_end+1] clamped to the grid; d_mat/d_blend hold planes [mat_z0, ...) covering [z_begin, z_end]

@@ -27,6 +27,34 @@ struct Backend {
 	void free_pinned(void* p) { ::free(p); }
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
+	// Grid file format v1 expanded block by block (the HIP backend does this in k_decode_grid)
+	void run_decode_grid(const u8* blob, const uint64_t* where, u32 n, i8* dist, u8* mat, u8* blend, u8* flags)
+	{
+		const u32 nb = n / 16;
+		for (u32 id = 0; id < nb * nb * nb; ++id) {
+			const u8* rec = blob + where[id * 2];
+			const uint64_t sizes = where[id * 2 + 1];
+			u32 fl; memcpy(&fl, rec, 4);
+			flags[id] = (u8)(fl & 1u);
+			const u8* src = rec + 4;
+			u8* outs[3] = { (u8*)dist, mat, blend };
+			const u32 rawBit[3] = { 2u, 4u, 8u };
+			const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+			for (int s = 0; s < 3; ++s) {
+				const u32 sz = (u32)((sizes >> (16 * s)) & 0xFFFFu);
+				u8 tmp[4096];
+				memset(tmp, 0, sizeof(tmp));
+				if (fl & rawBit[s]) memcpy(tmp, src, sz < 4096 ? sz : 4096);
+				else {
+					u32 pos = 0;
+					for (u32 i = 0; i + 1 < sz; i += 2) for (u32 k = 0; k < src[i] && pos < 4096; ++k) tmp[pos++] = src[i + 1];
+				}
+				for (u32 z = 0; z < 16; ++z) for (u32 y = 0; y < 16; ++y)
+					memcpy(outs[s] + ((size_t)(bz * 16 + z) * n + by * 16 + y) * n + bx * 16, tmp + z * 256 + y * 16, 16);
+				src += sz;
+			}
+		}
+	}
 	void end_timing_record() {}
 	float elapsed_ms() { return 0.f; }
 	template <typename P>

@@ -210,3 +210,55 @@ def test_emu_transition_face_batches(emu, port):
     n = 64
     d = rng.randint(-128, 128, (n, n, n)).astype(np.int8)
     check(emu, port, d, rng.randint(0, 3, (n, n, n)).astype(np.uint8), rng.randint(0, 256, (n, n, n)).astype(np.uint8), "white noise 64")
+
+
+def _packed_case(n, seed, noisy):
+    rng = np.random.RandomState(seed)
+    if noisy:
+        d = rng.randint(-128, 128, (n, n, n)).astype(np.int8)          # incompressible: raw distance streams
+        d[: n // 2] = np.clip(d[: n // 2], 3, 9)                          # ... next to compressible ones
+    else:
+        f = fields.terrain_field(n, seed)
+        d = fields.quantize_full_range(f, scale=2.0)
+    m, b = fields.materials_for(n, seed)
+    return np.ascontiguousarray(d), m, b
+
+
+def check_packed(poly_factory, port, d, m, b, label):
+    """Grid file format v1 written by the reference (PackForSave), expanded on the device (or its CPU emulation):
+    every block must come back exactly, and the surface must be the reference's."""
+    n = d.shape[0]
+    g = port.grid_from_dense(d, m, b)
+    blob = g.pack()
+    p = poly_factory()
+    p.upload_packed(blob)
+    flags = g.block_flags()
+    nb = n // 16
+    ids = np.unique(np.concatenate([np.arange(min(nb ** 3, 40)), np.random.RandomState(1).randint(0, nb ** 3, 60)]))
+    for bid in ids:
+        bx, by, bz = bid % nb, (bid // nb) % nb, bid // (nb * nb)
+        sl = (slice(bz * 16, bz * 16 + 16), slice(by * 16, by * 16 + 16), slice(bx * 16, bx * 16 + 16))
+        bd, bm, bb, fl = p.read_block(bid)
+        assert np.array_equal(bd, d[sl]) and np.array_equal(bm, m[sl]) and np.array_equal(bb, b[sl]), "%s: block %d differs" % (label, bid)
+        assert fl == flags[bid], "%s: BF_Empty of block %d" % (label, bid)
+    p.execute()
+    s = port.execute(g)
+    ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+    assert ok, label + ": " + msg
+    assert np.array_equal(p.stats(), s.stats()), label
+    return len(blob)
+
+
+@pytest.mark.parametrize("noisy", [False, True])
+def test_emu_upload_packed_grid(emu, port, noisy):
+    d, m, b = _packed_case(64, 21, noisy)
+    check_packed(lambda: make_poly(emu), port, d, m, b, "packed noisy=%s" % noisy)
+
+
+def test_emu_upload_packed_rejects_garbage(emu):
+    p = make_poly(emu)
+    with pytest.raises(Exception):
+        p.upload_packed(np.zeros(64, np.uint8))
+    hdr = np.array([1, 32, 32, 32], np.uint32).view(np.uint8)
+    with pytest.raises(Exception):
+        p.upload_packed(np.concatenate([hdr, np.zeros(10, np.uint8)]))  # size table cut short

@@ -356,3 +356,33 @@ def test_hip_slab_attach_matches_full_run(poly, port, world):
     # only the first `levels` levels are compared; the reference ran all of them
     ok, msg = fields.surface_equal(merged, want, nrm_tol=NRM_TOL)
     assert ok, msg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,noisy", [(128, False), (64, True)])
+def test_hip_upload_packed_grid(poly, port, n, noisy):
+    """§8(f) row 1: the reference's grid file (PackForSave) expanded on the device — blocks byte for byte, flags, and
+    the surface polygonized from it."""
+    from test_emu import _packed_case, check_packed
+    d, m, b = _packed_case(n, 33, noisy)
+    check_packed_hip(poly, port, d, m, b, "packed n=%d noisy=%s" % (n, noisy))
+
+
+def check_packed_hip(poly, port, d, m, b, label):
+    n = d.shape[0]
+    g = port.grid_from_dense(d, m, b)
+    blob = g.pack()
+    poly.upload_packed(blob)
+    flags = g.block_flags()
+    nb = n // 16
+    for bid in np.unique(np.random.RandomState(2).randint(0, nb ** 3, 80)):
+        bx, by, bz = bid % nb, (bid // nb) % nb, bid // (nb * nb)
+        sl = (slice(bz * 16, bz * 16 + 16), slice(by * 16, by * 16 + 16), slice(bx * 16, bx * 16 + 16))
+        bd, bm, bb, fl = poly.read_block(bid)
+        assert np.array_equal(bd, d[sl]) and np.array_equal(bm, m[sl]) and np.array_equal(bb, b[sl]), "%s: block %d differs" % (label, bid)
+        assert fl == flags[bid]
+    poly.execute()
+    s = port.execute(g)
+    ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+    assert ok, label + ": " + msg
+    assert np.array_equal(poly.stats(), s.stats()), label

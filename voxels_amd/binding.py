@@ -48,6 +48,8 @@ class HipLibrary:
         lib.vx_last_error.argtypes = [vp]
         lib.vx_set_stream.argtypes = [vp, vp]
         lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
+        lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
+        lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         lib.vx_material_lut.argtypes = [vp, vp, vp]
@@ -121,6 +123,21 @@ class Polygonizer:
         self._keep = (dist, mat, blend, empty_flags)
         self._check(self._lib.vx_grid_upload(self._h, n, _ptr(dist), _ptr(mat), _ptr(blend), _ptr(empty_flags)), "vx_grid_upload")
         self.n = n
+
+    def upload_packed(self, blob):
+        """Grid file format v1 (Grid::PackForSave) straight to the device; expanded there."""
+        blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob.view(np.uint8))
+        self._check(self._lib.vx_grid_upload_packed(self._h, _ptr(blob), blob.size), "vx_grid_upload_packed")
+        self.n = int(np.frombuffer(blob[4:8].tobytes(), np.uint32)[0])
+
+    def read_block(self, block_id):
+        """(dist int8[16,16,16] (z,y,x), mat, blend, BF_Empty) of one resident block."""
+        d = np.zeros((16, 16, 16), np.int8)
+        m = np.zeros((16, 16, 16), np.uint8)
+        b = np.zeros((16, 16, 16), np.uint8)
+        f = np.zeros(1, np.uint8)
+        self._check(self._lib.vx_grid_read_block(self._h, int(block_id), _ptr(d), _ptr(m), _ptr(b), _ptr(f)), "vx_grid_read_block")
+        return d, m, b, int(f[0])
 
     def attach(self, n, z_begin, z_end, d_dist, dist_z0, d_mat, d_blend, mat_z0, d_flags):
         """Device pointers (ints), e.g. torch tensors' data_ptr()."""

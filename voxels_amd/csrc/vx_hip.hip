@@ -153,6 +153,68 @@ __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockC
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >> 7) * 0x01020408u) >> 24; }
 
+// ------------------------------------------------------------------------------------------------------
+// k_decode_grid: Grid file format v1 -> dense fields (DecompressBlock, src/VoxelGrid.cpp:674-694, for all blocks at
+// once).  One workgroup per 16^3 block, one stream (distance, material, blend) after the other: run lengths ->
+// exclusive scan = run starts; lane t owns the 16-byte voxel row t of the block (y = t & 15, z = t >> 4), finds the
+// run that covers its first voxel by binary search and walks on from there; one 16-byte store per lane and stream.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_decode_grid(const u8* blob, const unsigned long long* where, u32 n, i8* dist, u8* mat, u8* blend, u8* flags)
+{
+	__shared__ u16 starts[2048 + 8];
+	__shared__ u8 vals[2048];
+	__shared__ u32 scanScratch[8];
+	const u32 id = blockIdx.x, nb = n >> 4, tid = threadIdx.x;
+	const u8* rec = blob + where[2 * (size_t)id];
+	const unsigned long long sizes = where[2 * (size_t)id + 1];
+	const u32 fl = (u32)rec[0] | ((u32)rec[1] << 8) | ((u32)rec[2] << 16) | ((u32)rec[3] << 24);
+	if (tid == 0) flags[id] = (u8)(fl & 1u);
+	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+	const size_t rowOff = ((size_t)(bz * 16 + (tid >> 4)) * n + by * 16 + (tid & 15)) * n + bx * 16;
+	const u8* src = rec + 4;
+#pragma unroll 1
+	for (u32 s = 0; s < 3; ++s) {
+		const u32 sz = (u32)((sizes >> (16 * s)) & 0xFFFFu);
+		u8* out = (s == 0 ? (u8*)dist : (s == 1 ? mat : blend)) + rowOff;
+		u32 b[4] = { 0, 0, 0, 0 };
+		if ((fl >> (s + 1)) & 1u) {
+			// raw: 4096 bytes, row t at offset 16 t (the stream itself is not aligned)
+#pragma unroll
+			for (u32 i = 0; i < 16; ++i) if (tid * 16 + i < sz) b[i >> 2] |= (u32)src[tid * 16 + i] << ((i & 3) * 8);
+		} else {
+			const u32 pairs = sz >> 1; // <= 2048
+#pragma unroll
+			for (u32 i = 0; i < 8; ++i) {
+				const u32 q = tid * 8 + i;
+				u32 len = 0, val = 0;
+				if (q < pairs) { len = src[2 * q]; val = src[2 * q + 1]; }
+				starts[q] = (u16)len;
+				vals[q] = (u8)val;
+			}
+			__syncthreads();
+			const u32 total = block_exclusive_scan_u16(starts, pairs, scanScratch);
+			// last run whose start is <= the row's first voxel
+			const u32 q0 = tid * 16;
+			u32 lo = 0, hi = pairs; // invariant: starts[lo] <= q0 (starts[0] == 0), answer in [lo, hi)
+			while (hi - lo > 1) {
+				const u32 mid = (lo + hi) >> 1;
+				if (starts[mid] <= q0) lo = mid; else hi = mid;
+			}
+			u32 r = lo;
+#pragma unroll
+			for (u32 i = 0; i < 16; ++i) {
+				const u32 pos = q0 + i;
+				while (r + 1 < pairs && starts[r + 1] <= pos) ++r;
+				const u32 v = (pairs && pos < total) ? vals[r] : 0u;
+				b[i >> 2] |= v << ((i & 3) * 8);
+			}
+			__syncthreads(); // the run tables are reused by the next stream
+		}
+		*(uint4*)out = make_uint4(b[0], b[1], b[2], b[3]);
+		src += sz;
+	}
+}
+
 // ---- start of a full run: header = 0, block -> slot maps = -1 (one launch instead of a memset per array) -------------
 struct ResetRanges {
 	u32* header;
@@ -1024,6 +1086,12 @@ struct Backend {
 		float ms = 0.f;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
 		return ms;
+	}
+	void run_decode_grid(const u8* blob, const uint64_t* where, u32 n, i8* dist, u8* mat, u8* blend, u8* flags)
+	{
+		const u32 nb = n / 16;
+		hipLaunchKernelGGL(k_decode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, blob, (const unsigned long long*)where, n, dist, mat, blend, flags);
+		check(hipGetLastError(), "k_decode_grid launch");
 	}
 	void end_timing_record() { (void)hipEventRecord(ev1, stream); }
 	float elapsed_ms() // after the stream was synchronised

@@ -414,6 +414,70 @@ int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload: copy failed: " + c->be.error());
 }
 
+int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
+{
+	if (!c || !blobPtr || size < 16) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: null or truncated blob");
+	const u8* blob = (const u8*)blobPtr;
+	auto rd32 = [&](uint64_t off) { u32 v; memcpy(&v, blob + off, 4); return v; };
+	if (rd32(0) != 1) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: not a version-1 grid file");
+	const u32 n = rd32(4);
+	if (n < 16 || (n & 15) || rd32(8) != n || rd32(12) != n) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: the grid must be a cube with an edge that is a multiple of 16");
+	const u32 nb = n / 16;
+	const size_t blocks = (size_t)nb * nb * nb, tot = (size_t)n * n * n;
+	const uint64_t tableEnd = 16 + (uint64_t)blocks * 12;
+	if (size < tableEnd) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: truncated size table");
+	// per block: offset of its record {flags, 3 streams} and the three stream sizes
+	std::vector<uint64_t> where(blocks * 2);
+	uint64_t off = tableEnd;
+	for (size_t i = 0; i < blocks; ++i) {
+		const u32 sd = rd32(16 + i * 12), sm = rd32(16 + i * 12 + 4), sb = rd32(16 + i * 12 + 8);
+		if (sd > 4096 || sm > 4096 || sb > 4096 || (sd & 1) || (sm & 1) || (sb & 1)) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: corrupt stream size");
+		where[i * 2] = off;
+		where[i * 2 + 1] = (uint64_t)sd | ((uint64_t)sm << 16) | ((uint64_t)sb << 32);
+		off += 4 + (uint64_t)sd + sm + sb;
+		if (off > size) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: truncated block data");
+	}
+	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n)) {
+		release_grid(c);
+		c->dDist = c->be.alloc(tot); c->dMat = c->be.alloc(tot); c->dBlend = c->be.alloc(tot); c->dFlags = c->be.alloc(blocks);
+		c->ownsGrid = true;
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device allocation failed: " + c->be.error()); }
+	}
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->haveSurface = false;
+	void* dBlob = c->be.alloc(off + 16);
+	void* dWhere = c->be.alloc(where.size() * 8);
+	bool ok = dBlob && dWhere && c->be.h2d(dBlob, blob, off) && c->be.h2d(dWhere, where.data(), where.size() * 8);
+	if (ok) {
+		c->be.run_decode_grid((const u8*)dBlob, (const uint64_t*)dWhere, n, (i8*)c->dDist, (u8*)c->dMat, (u8*)c->dBlend, (u8*)c->dFlags);
+		ok = c->be.sync_ok();
+	}
+	c->be.free(dBlob); c->be.free(dWhere);
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device decode failed: " + c->be.error());
+}
+
+int vx_grid_read_block(vx_ctx* c, uint32_t id, int8_t* dist, uint8_t* mat, uint8_t* blend, uint8_t* emptyFlag)
+{
+	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: no grid resident");
+	const u32 n = c->n, nb = n / 16;
+	if (id >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block id out of range");
+	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+	if (bz * 16 < c->zBegin || bz * 16 >= c->zEnd) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block outside the resident slab");
+	bool ok = true;
+	for (u32 z = 0; z < 16 && ok; ++z)
+	for (u32 y = 0; y < 16 && ok; ++y) {
+		const size_t dst = (size_t)z * 256 + y * 16;
+		const size_t srcD = ((size_t)((int)(bz * 16 + z) - c->distZ0) * n + (by * 16 + y)) * n + bx * 16;
+		const size_t srcM = ((size_t)((int)(bz * 16 + z) - c->matZ0) * n + (by * 16 + y)) * n + bx * 16;
+		if (dist) ok = ok && c->be.d2h_async(dist + dst, (const u8*)c->dDist + srcD, 16);
+		if (mat) ok = ok && c->be.d2h_async(mat + dst, (const u8*)c->dMat + srcM, 16);
+		if (blend) ok = ok && c->be.d2h_async(blend + dst, (const u8*)c->dBlend + srcM, 16);
+	}
+	if (emptyFlag) ok = ok && c->be.d2h_async(emptyFlag, (const u8*)c->dFlags + id, 1);
+	ok = ok && c->be.sync_ok();
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_read_block: copy failed: " + c->be.error());
+}
+
 int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, const void* d_dist, int32_t dist_z0,
                    const void* d_mat, const void* d_blend, int32_t mat_z0, const void* d_flags)
 {
