@@ -110,6 +110,16 @@ int vx_level_counts(vx_ctx* ctx, uint32_t level, uint32_t* n_blocks, uint64_t to
  * transition vertices/indices of faces 0..5.  Any output pointer may be NULL. */
 int vx_download_level(vx_ctx* ctx, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx,
                       vx_vertex* tverts, uint32_t* tidx);
+/* Device-resident hand-off (renderer interop): the meshes of the last FULL run stay in two device pools; a block's
+ * meshes are contiguous ranges of them.  d_verts / d_indices are device pointers valid until the next run on this
+ * context; indices are relative to the start of their own mesh, exactly as downloaded.  After an incremental run the
+ * untouched blocks live in host copies (the pools are reused), so vx_level_ranges then fails with VX_ERR_INVALID. */
+typedef struct vx_block_ranges {
+	uint32_t v_off, i_off;        /* first vertex / first index of the regular mesh in the pools */
+	uint32_t tv_off[6], ti_off[6]; /* the same for the six transition meshes */
+} vx_block_ranges;
+int vx_device_meshes(vx_ctx* ctx, const vx_vertex** d_verts, const uint32_t** d_indices, uint64_t* n_verts, uint64_t* n_indices);
+int vx_level_ranges(vx_ctx* ctx, uint32_t level, vx_block_ranges* ranges /* one per block, vx_download_level order */);
 /* stats[0..3] = BlocksCalculated, TrivialCells, NonTrivialCells, DegenerateTrianglesRemoved; stats[4..19] =
  * PerCaseCellsCount (include/Polygonizer.h:110-132) */
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);

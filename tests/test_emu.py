@@ -262,3 +262,29 @@ def test_emu_upload_packed_rejects_garbage(emu):
     hdr = np.array([1, 32, 32, 32], np.uint32).view(np.uint8)
     with pytest.raises(Exception):
         p.upload_packed(np.concatenate([hdr, np.zeros(10, np.uint8)]))  # size table cut short
+
+
+def test_emu_device_resident_meshes(emu):
+    """vx_device_meshes + vx_level_ranges describe exactly what vx_download_level copies (with the emulation backend
+    the "device" pools are host memory, so they can be read in place)."""
+    import ctypes as C
+    gold = Golden("noise64_fullrange_mat")
+    p = make_poly(emu)
+    p.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    p.execute()
+    dv, di, nv, ni = p.device_meshes()
+    vdt = p.level(0).verts.dtype
+    verts = np.frombuffer((C.c_char * (nv * 48)).from_address(dv), vdt)
+    idx = np.frombuffer((C.c_char * (ni * 4)).from_address(di), np.uint32)
+    for l in range(3):
+        lv, rg = p.level(l), p.level_ranges(l)
+        ov = oi = otv = oti = 0
+        for k, info in enumerate(lv.infos):
+            assert np.array_equal(verts[rg["v_off"][k]:rg["v_off"][k] + info["n_verts"]], lv.verts[ov:ov + info["n_verts"]])
+            assert np.array_equal(idx[rg["i_off"][k]:rg["i_off"][k] + info["n_idx"]], lv.idx[oi:oi + info["n_idx"]])
+            ov += info["n_verts"]; oi += info["n_idx"]
+            for f in range(6):
+                a, c = info["n_tverts"][f], info["n_tidx"][f]
+                assert np.array_equal(verts[rg["tv_off"][k][f]:rg["tv_off"][k][f] + a], lv.tverts[otv:otv + a])
+                assert np.array_equal(idx[rg["ti_off"][k][f]:rg["ti_off"][k][f] + c], lv.tidx[oti:oti + c])
+                otv += a; oti += c

@@ -386,3 +386,33 @@ def check_packed_hip(poly, port, d, m, b, label):
     ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
     assert ok, label + ": " + msg
     assert np.array_equal(poly.stats(), s.stats()), label
+
+
+@pytest.mark.gpu
+def test_hip_device_resident_meshes(poly):
+    """§8(f) row 4 (first half): the pools stay on the device; vx_device_meshes + vx_level_ranges must describe exactly
+    what vx_download_level copies.  The pools are read back here with a plain hipMemcpy on the raw pointers."""
+    import ctypes as C
+    gold = Golden("noise64_fullrange_mat")
+    poly.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    poly.execute()
+    dv, di, nv, ni = poly.device_meshes()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    vdt = poly.level(0).verts.dtype
+    verts = np.zeros(nv, vdt)
+    idx = np.zeros(ni, np.uint32)
+    assert hip.hipMemcpy(verts.ctypes.data_as(C.c_void_p), C.c_void_p(dv), nv * 48, 2) == 0
+    assert hip.hipMemcpy(idx.ctypes.data_as(C.c_void_p), C.c_void_p(di), ni * 4, 2) == 0
+    for l in range(3):
+        lv, rg = poly.level(l), poly.level_ranges(l)
+        ov = oi = otv = oti = 0
+        for k, info in enumerate(lv.infos):
+            assert np.array_equal(verts[rg["v_off"][k]:rg["v_off"][k] + info["n_verts"]], lv.verts[ov:ov + info["n_verts"]])
+            assert np.array_equal(idx[rg["i_off"][k]:rg["i_off"][k] + info["n_idx"]], lv.idx[oi:oi + info["n_idx"]])
+            ov += info["n_verts"]; oi += info["n_idx"]
+            for f in range(6):
+                a, c = info["n_tverts"][f], info["n_tidx"][f]
+                assert np.array_equal(verts[rg["tv_off"][k][f]:rg["tv_off"][k][f] + a], lv.tverts[otv:otv + a])
+                assert np.array_equal(idx[rg["ti_off"][k][f]:rg["ti_off"][k][f] + c], lv.tidx[oti:oti + c])
+                otv += a; oti += c

@@ -49,6 +49,8 @@ class HipLibrary:
         lib.vx_set_stream.argtypes = [vp, vp]
         lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
+        lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
+        lib.vx_level_ranges.argtypes = [vp, u32, vp]
         lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -138,6 +140,21 @@ class Polygonizer:
         f = np.zeros(1, np.uint8)
         self._check(self._lib.vx_grid_read_block(self._h, int(block_id), _ptr(d), _ptr(m), _ptr(b), _ptr(f)), "vx_grid_read_block")
         return d, m, b, int(f[0])
+
+    def device_meshes(self):
+        """(device pointer of the vertex pool, of the index pool, vertices, indices) of the last full run."""
+        dv, di = C.c_void_p(), C.c_void_p()
+        nv, ni = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
+        return dv.value, di.value, nv.value, ni.value
+
+    def level_ranges(self, lvl):
+        """Per block (download order): offsets of its meshes in the device pools."""
+        nb = self.level(lvl, with_data=False).infos.size
+        dt = np.dtype([("v_off", np.uint32), ("i_off", np.uint32), ("tv_off", np.uint32, 6), ("ti_off", np.uint32, 6)])
+        r = np.zeros(nb, dt)
+        self._check(self._lib.vx_level_ranges(self._h, int(lvl), _ptr(r)), "vx_level_ranges")
+        return r
 
     def attach(self, n, z_begin, z_end, d_dist, dist_z0, d_mat, d_blend, mat_z0, d_flags):
         """Device pointers (ints), e.g. torch tensors' data_ptr()."""

@@ -789,6 +789,30 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 	return VX_OK;
 }
 
+int vx_device_meshes(vx_ctx* c, const vx_vertex** dVerts, const uint32_t** dIdx, uint64_t* nVerts, uint64_t* nIdx)
+{
+	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_device_meshes: no surface");
+	if (dVerts) *dVerts = (const vx_vertex*)c->dVerts;
+	if (dIdx) *dIdx = (const uint32_t*)c->dIdx;
+	if (nVerts) *nVerts = c->poolVerts;
+	if (nIdx) *nIdx = c->poolIdx;
+	return VX_OK;
+}
+
+int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
+{
+	if (!c || !c->haveSurface || level >= c->levelsRun || !ranges) return fail(c, VX_ERR_INVALID, "vx_level_ranges: no such level");
+	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
+	size_t k = 0;
+	for (const EmittedBlock& e : c->blocks[level]) {
+		if (e.own) return fail(c, VX_ERR_INVALID, "vx_level_ranges: blocks kept from before an incremental run are no longer in the device pools");
+		vx_block_ranges& r = ranges[k++];
+		r.v_off = e.rec.vOff; r.i_off = e.rec.iOff;
+		for (int f = 0; f < 6; ++f) { r.tv_off[f] = e.rec.tvOff[f]; r.ti_off[f] = e.rec.tiOff[f]; }
+	}
+	return VX_OK;
+}
+
 int vx_set_stage_timing(vx_ctx* c, int enable)
 {
 	if (!c) return VX_ERR_INVALID;
