@@ -733,7 +733,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
 
 	if (threadIdx.x < 20) wgStats[threadIdx.x] = 0;
-	const Tables T = stage_regular_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
 		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; if (l >= levelBegin) run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive; }
@@ -741,6 +740,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	}
 	__syncthreads();
 	const u32 total = wl.start[MAX_LEVELS];
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	const Tables T = stage_regular_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
 	const u32 lim = p.G.debugPhaseLimit & 0xFFu;
 
@@ -822,7 +823,6 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 	__shared__ WorkList wl;
 	__shared__ u32 scanScratch[8];
 
-	const Tables T = stage_transition_tables(tab, p.tables);
 	if (threadIdx.x == 0) {
 		u32 run = 0;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
@@ -833,6 +833,8 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 	}
 	__syncthreads();
 	const u32 total = wl.start[MAX_LEVELS];
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return;
+	const Tables T = stage_transition_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
 
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
@@ -1186,19 +1188,22 @@ struct Backend {
 	{
 		const u32 cap = p.levels[level].cap;
 		if (!cap) return;
-		const u32 grid = std::min<u32>(cap, (u32)cus * 8);
+		const char* mgEnv = getenv("VX_MAT_GRID"); // tuning aid
+		const u32 grid = std::min<u32>(cap, mgEnv ? (u32)atoi(mgEnv) : (u32)cus * 8);
 		hipLaunchKernelGGL(k_material, dim3(grid), dim3(WG), 0, stream, dev(p), level);
 		check(hipGetLastError(), "k_material launch");
 	}
 	template <typename P>
-	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 5)
+	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 20)
 	{
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
 		if (!cap) return;
 		const char* wgEnv = getenv("VX_REG_WGS_PER_CU"); // tuning aid
 		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : defaultPerCu;
-		const u32 gridS = std::min<u32>(cap, (u32)cus * perCu), gridL = std::min<u32>(cap, (u32)cus * 1);
+		u32 gridS = std::min<u32>(cap, (u32)cus * perCu);
+		const u32 gridL = std::min<u32>(cap, (u32)cus * 1);
+		if (const char* gEnv = getenv("VX_REG_GRID")) gridS = std::min<u32>(cap, (u32)atoi(gEnv) & ~7u); // experiment: one block per workgroup
 		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
 		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
 		check(hipGetLastError(), "k_regular launch");
@@ -1218,7 +1223,7 @@ struct Backend {
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
 		{
 			const char* l0Env = getenv("VX_REG_WGS_L0"); // tuning aid
-			launch_regular(p, 0, 1, sideA, l0Env ? (u32)atoi(l0Env) : 5u);
+			launch_regular(p, 0, 1, sideA, l0Env ? (u32)atoi(l0Env) : 20u);
 		}
 		(void)hipEventRecord(evSideA, sideA);
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
@@ -1243,7 +1248,8 @@ struct Backend {
 		u32 cap = 0;
 		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
 		if (!cap) return;
-		const u32 grid = std::min<u32>(cap, (u32)cus * 5);
+		const char* tgEnv = getenv("VX_TR_GRID"); // tuning aid
+		const u32 grid = std::min<u32>(cap, tgEnv ? ((u32)atoi(tgEnv) & ~7u) : (u32)cus * 12);
 		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		check(hipGetLastError(), "k_transition launch");
 	}
