@@ -404,13 +404,21 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	}
 	__syncthreads();
 
-	// ---- one lane per block: emptiness rule, slot allocation ------------------------------------------
-	if (tid < TB && tid * 16 < validCells) {
-		const u32 bx = tx * TB + tid;
-		const bool skipped = (blockCls[tid] & BC_SKIPPED) != 0;
-		if (!skipped) atomicAdd(&p.G.stats[2], 1u);
-		if (blockAny[tid]) {
-			const u32 slot = atomicAdd(L.nActive, 1u);
+	// ---- one lane per block: emptiness rule, slot allocation (one reservation per tile) -------------------
+	if (tid < 64) { // the first wave; lanes >= TB only take part in the ballots
+		const bool mine = tid < TB && tid * 16 < validCells;
+		const u32 bx = tx * TB + (u32)tid;
+		const bool skipped = mine && (blockCls[tid] & BC_SKIPPED) != 0;
+		const bool active = mine && blockAny[tid] != 0;
+		const unsigned long long calcMask = __ballot(mine && !skipped), actMask = __ballot(active);
+		u32 base = 0;
+		if (tid == 0) {
+			if (calcMask) atomicAdd(&p.G.stats[2], (u32)__popcll(calcMask));
+			if (actMask) base = atomicAdd(L.nActive, (u32)__popcll(actMask));
+		}
+		base = __shfl(base, 0);
+		if (active) {
+			const u32 slot = base + (u32)__popcll(actMask & ((1ull << tid) - 1ull));
 			const u32 id = block_coord_id(bx, by, bz, L.cnt);
 			L.slotOf[id] = (int)slot;
 			L.slotCoord[slot] = id;
@@ -816,6 +824,40 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	if (threadIdx.x < 20 && wgStats[threadIdx.x]) atomicAdd(&p.G.stats[threadIdx.x], wgStats[threadIdx.x]);
 }
 
+// Samples of one boundary plane of a block (tr_phase_load of tv_block.h for a compile-time face): the plane is an
+// affine image of (u,v), so a lane adds two scaled 32-bit terms to one base address per face.  Faces are only staged
+// where a neighbour block exists, so the plane itself is inside the grid; in-plane coordinates clamp at the far edge.
+template <int F>
+__device__ __forceinline__ void tr_face_request(const GridView& g, const RegBlockCtx& b, u32 on, int tid, i8 (&v)[5])
+{
+#pragma unroll
+	for (int q = 0; q < 5; ++q) v[q] = 0;
+	if (!((on >> F) & 1u)) return;
+	const FaceGeom fg = face_geom(F);
+	const int n = g.n, mult = (int)b.mult, half = mult >> 1;
+	int o[3] = { (int)(b.bx * 16) * mult, (int)(b.by * 16) * mult, (int)(b.bz * 16) * mult };
+	const int maxU = n - 1 - o[fg.ua], maxV = n - 1 - o[fg.va];
+	if (fg.positive) o[fg.axis] += 16 * mult;
+	const i8* base = g.dist + ((size_t)(o[2] - g.zOrigin) * n + o[1]) * n + o[0];
+	const u32 stride[3] = { 1u, (u32)n, (u32)n * (u32)n };
+	const u32 su = stride[fg.ua], sv = stride[fg.va];
+#pragma unroll
+	for (int q = 0; q < 5; ++q) {
+		const int r = tid + q * WG;
+		if (r < PLANE) {
+			const int vv = r / 33, uu = r - vv * 33;
+			const u32 off = (u32)min(uu * half, maxU) * su + (u32)min(vv * half, maxV) * sv;
+			v[q] = base[off];
+		}
+	}
+}
+
+__device__ __forceinline__ void tr_face_store(i8* plane, int tid, const i8 (&v)[5])
+{
+#pragma unroll
+	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) plane[r] = v[q]; }
+}
+
 __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 {
 	u8* tab = smem;
@@ -859,20 +901,12 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 			__syncthreads();
 			if (tid == 0) st.faceOn = on;
 			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
-			const int half = (int)b.mult >> 1;
-			const GridView& g = p.G.grid;
-			batched_gather<6 * PLANE, i8, 13>(
-				[&](int s) -> i8 {
-					const int f = s / PLANE, r = s - f * PLANE;
-					if (!((on >> f) & 1u)) return 0;
-					const FaceGeom fg = face_geom(f);
-					int q[3];
-					q[fg.ua] = (int)(bc[fg.ua] * 16 * b.mult) + (r % 33) * half;
-					q[fg.va] = (int)(bc[fg.va] * 16 * b.mult) + (r / 33) * half;
-					q[fg.axis] = (int)((bc[fg.axis] * 16 + (fg.positive ? 16 : 0)) * b.mult);
-					return (i8)dist_at(g, q[0], q[1], q[2]);
-				},
-				[&](int s, i8 v) { const int f = s / PLANE, r = s - f * PLANE; st.plane[f][r] = v; });
+			// 33 x 33 samples per face; three faces (15 loads per lane) are in flight together
+			i8 v[3][5];
+			tr_face_request<0>(p.G.grid, b, on, tid, v[0]); tr_face_request<1>(p.G.grid, b, on, tid, v[1]); tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
+			tr_face_store(st.plane[0], tid, v[0]); tr_face_store(st.plane[1], tid, v[1]); tr_face_store(st.plane[2], tid, v[2]);
+			tr_face_request<3>(p.G.grid, b, on, tid, v[0]); tr_face_request<4>(p.G.grid, b, on, tid, v[1]); tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
+			tr_face_store(st.plane[3], tid, v[0]); tr_face_store(st.plane[4], tid, v[1]); tr_face_store(st.plane[5], tid, v[2]);
 		}
 		__syncthreads();
 		tr_phase_classify(st, tid, WG);
