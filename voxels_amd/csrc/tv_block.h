@@ -1,6 +1,6 @@
 // tv_block.h — per-block phases of the polygonizer, written as "for (i = tid; i < count; i += nthreads)" loops
 // over workgroup-shared state.  On the GPU the state lives in LDS, tid = threadIdx.x and the kernels in
-// tv_kernels.hip put __syncthreads() + wavefront scans between the phases; tests/emu runs the same phases with
+// vx_hip.hip put __syncthreads() + wavefront scans between the phases; tests/emu runs the same phases with
 // tid = 0, nthreads = 1 on a CPU to check the parallel formulation against the oracle.
 //
 // Pipeline (one polygonization):

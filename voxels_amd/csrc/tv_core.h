@@ -2,7 +2,7 @@
 //
 // Everything here is a pure function of grid samples, Lengyel's tables and per-cell facts of the SAME block,
 // so thousands of cells can be evaluated concurrently and still reproduce the reference's strictly sequential
-// vertex numbering.  The functions are __host__ __device__: the HIP kernels (tv_kernels.hip) call them from
+// vertex numbering.  The functions are __host__ __device__: the HIP kernels (vx_hip.hip) call them from
 // LDS-resident state, and tests/emu compiles the very same code with g++ to check the formulation on a CPU.
 //
 // Reference behaviour restated (all file:line into /root/reference/src/TransVoxelImpl.cpp):

@@ -1,16 +1,20 @@
 // vx_hip.hip — gfx950 (MI355X / CDNA4) kernels and HIP backend of libvoxels_hip.so.
 //
-// Five kernels per polygonization, all on one stream, no host round trip in between (work lists and output
-// offsets live in device memory):
-//   k_classify    HBM-bound stream over the whole density field: 16-byte coalesced loads, sign bits packed to
-//                 bit-masks in LDS, cell classification done bit-parallel (128 cells per lane-op); emits the
+// One polygonization = a handful of kernels on three streams of one context, no host round trip in between (work
+// lists and output offsets live in device memory):
+//   k_reset, k_block_summary, k_block_class   counters / slot maps; what the BF_Empty flags already say about a block
+//   k_classify    stream over the density field, skipping blocks the flags prove quiet: 16-byte coalesced loads, sign
+//                 bits packed to bit-masks in LDS, cells classified bit-parallel (256 per lane); emits the
 //                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block.
 //   k_hierarchy   marks the ancestors of active blocks on the coarser LOD levels.
 //   k_material    (per level >= 1, serial) per-cell material vote over the 8 children -> material cache.
-//   k_regular     persistent workgroups, one surface-bearing block at a time: 17^3 corner samples + Transvoxel
-//                 tables staged in LDS, reuse resolution, wavefront prefix sums for vertex/index offsets, one
-//                 atomicAdd per block to reserve its range of the output pools (per-block stream compaction).
-//   k_transition  same for the 6 x 16 x 16 transition cells of the blocks of levels 1..last-1.
+//   k_regular     one surface-bearing block per workgroup pass (grid oversubscribed, the dispatcher balances):
+//                 19^3 samples + Transvoxel tables in LDS, reuse resolution, wavefront prefix sums for vertex/index
+//                 offsets, one atomicAdd per mesh to reserve its range of the output pools (per-block stream
+//                 compaction), one lane per new vertex.  Level 0 runs beside the material chain on a side stream.
+//   k_transition  same for the 6 x 16 x 16 transition cells of the blocks of levels 1..last-1 (third stream).
+//   k_classify_blocks, k_build_worklist, k_gather_records   incremental (Modification) runs.
+//   k_decode_grid Grid file format v1 -> dense fields (vx_grid_upload_packed).
 // The per-cell logic is tv_core.h / tv_block.h (shared with the CPU emulation used by the tests).
 //
 // No MFMA: this is table-driven integer/byte work bound by HBM bandwidth and latency.
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8))) void k_
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_regular / k_transition: persistent workgroups over (level, slot) work items
+// k_regular / k_transition: workgroups striding over (level, slot) work items
 // ------------------------------------------------------------------------------------------------------
 struct WorkList {
 	u32 start[MAX_LEVELS + 1];
@@ -1030,15 +1034,8 @@ struct Backend {
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
 		stream = ownStream;
-		{
-			// the transition pass is the short-handed one (LDS-heavy workgroups): let it win the dispatch race
-			int prLow = 0, prHigh = 0;
-			(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
-			const char* prEnv = getenv("VX_STREAM_PRIORITIES"); // tuning aid: 0 = all default
-			const bool usePr = !prEnv || atoi(prEnv) != 0;
-			(void)hipStreamCreateWithPriority(&sideA, hipStreamNonBlocking, usePr ? prLow : 0);
-			(void)hipStreamCreateWithPriority(&sideB, hipStreamNonBlocking, usePr ? prHigh : 0);
-		}
+		(void)hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking);
+		(void)hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking);
 		(void)hipEventCreateWithFlags(&evClassified, hipEventDisableTiming);
 		(void)hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming);
 		(void)hipEventCreateWithFlags(&evSideA, hipEventDisableTiming);
