@@ -413,8 +413,9 @@ TV_HD void reg_phase_cells(ST& st, const Tables& T, const Globals& G, const Leve
 		i8 V[8];
 		reg_cell_values(st.samp, cx, cy, cz, V);
 		const u32 code = reg_case_code(V);
-		st.cellBits[k] = (u16)(code | (reg_zero_mask(V) << 8));
-		st.info[k] = reg_slot_valid(T, V, code) << 16;
+		const u32 zeroMask = reg_zero_mask(V);
+		st.cellBits[k] = (u16)(code | (zeroMask << 8));
+		st.info[k] = reg_slot_valid(T, zeroMask, code) << 16;
 		u32 m;
 		if (b.level == 0) m = mat_at(G.grid, (int)(b.bx * 16 + cx), (int)(b.by * 16 + cy), (int)(b.bz * 16 + cz));
 		else m = L.cache[(size_t)b.slot * BLOCK_CELLS + c];

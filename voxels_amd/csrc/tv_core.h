@@ -69,7 +69,8 @@ enum : u32 {
 	TAB_TR_EDGE = 3312,      // 16 x u16: the same for the transition cell edges
 	TAB_REG_VERT = 3344,     // 256 x 12 nibbles = 1536 -> 4880
 	TAB_TR_VERT = 4880,      // 512 x 12 nibbles = 3072 -> 7952
-	TAB_BYTES = 7952
+	TAB_REG_OWN = 7952,      // 256 B: reuse slots (bits 1..3) a regular case stores when none of its samples is 0
+	TAB_BYTES = 8208
 };
 
 struct Tables {
@@ -77,6 +78,7 @@ struct Tables {
 	const u8* regCellP;    // 16 x 16
 	const u8* regVertP;    // 256 x 6: twelve edge indices per case
 	const u16* regEdgeP;   // 16
+	const u8* regOwnP;     // 256
 	const u8* trClassP;    // 512
 	const u8* trCornerP;   // 16
 	const u8* trCellP;     // 56 x 40
@@ -84,6 +86,7 @@ struct Tables {
 	const u16* trEdgeP;    // 16
 	TV_HD u32 regClass(u32 code) const { return regClassP[code]; }
 	TV_HD const u8* regCell(u32 cls) const { return regCellP + cls * 16; }
+	TV_HD u32 regOwn(u32 code) const { return regOwnP[code]; }
 	TV_HD u32 regVert(u32 code, u32 i) const { return regEdgeP[(regVertP[code * 6 + (i >> 1)] >> ((i & 1u) * 4u)) & 15u]; }
 	TV_HD u32 trClass(u32 code) const { return trClassP[code]; }
 	TV_HD const u8* trCell(u32 cls) const { return trCellP + cls * 40; }
@@ -96,7 +99,7 @@ TV_HD Tables tables_from_image(const u8* base)
 {
 	Tables T;
 	T.regClassP = base + TAB_REG_CLASS; T.regCellP = base + TAB_REG_CELL; T.regVertP = base + TAB_REG_VERT;
-	T.regEdgeP = (const u16*)(base + TAB_REG_EDGE);
+	T.regEdgeP = (const u16*)(base + TAB_REG_EDGE); T.regOwnP = base + TAB_REG_OWN;
 	T.trClassP = base + TAB_TR_CLASS; T.trCornerP = base + TAB_TR_CORNER; T.trCellP = base + TAB_TR_CELL;
 	T.trVertP = base + TAB_TR_VERT; T.trEdgeP = (const u16*)(base + TAB_TR_EDGE);
 	return T;
@@ -307,15 +310,17 @@ TV_HD u32 reg_case_code(const i8 V[8])
 	return c;
 }
 
-// bit s set <=> this cell itself creates and stores a vertex in reuse slot s (s = 0: the corner-7 vertex)
-TV_HD u32 reg_slot_valid(const Tables& T, const i8 V[8], u32 code)
+// bit s set <=> this cell itself creates and stores a vertex in reuse slot s (s = 0: the corner-7 vertex).
+// Without a zero sample no vertex sits on a corner and the mask is a property of the case (table regOwn).
+TV_HD u32 reg_slot_valid(const Tables& T, u32 zeroMask, u32 code)
 {
+	if (!zeroMask) return T.regOwn(code);
 	const u32 nv = T.regCell(T.regClass(code))[0] >> 4;
 	u32 m = 0;
 	for (u32 vi = 0; vi < nv; ++vi) {
 		const u32 w = T.regVert(code, vi);
 		const int v0 = (w >> 4) & 15, v1 = w & 15;
-		const int t = edge_end(V[v0], V[v1]);
+		const int t = edge_end_bits(zeroMask, v0, v1);
 		if ((t & 0xFF) == 0) { if (t == 0 && v1 == 7) m |= 1u; }
 		else if ((w >> 12) == 8u) m |= 1u << ((w >> 8) & 15);
 	}

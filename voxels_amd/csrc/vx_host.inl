@@ -233,6 +233,12 @@ void build_table_image(std::vector<u8>& img)
 		memcpy(&img[edgeOff], distinct, nDistinct * 2);
 	};
 	pack(TVT_REG_VERT, 256, TAB_REG_EDGE, TAB_REG_VERT);
+	for (u32 code = 0; code < 256; ++code) { // reuse slots a case owns: its vertices with reuse direction 8
+		const u32 nv = TVT_REG_CELL[TVT_REG_CLASS[code] * 16] >> 4;
+		u8 m = 0;
+		for (u32 vi = 0; vi < nv; ++vi) { const u32 w = TVT_REG_VERT[code * 12 + vi]; if ((w >> 12) == 8u) m |= (u8)(1u << ((w >> 8) & 15)); }
+		img[TAB_REG_OWN + code] = m;
+	}
 	pack(TVT_TR_VERT, 512, TAB_TR_EDGE, TAB_TR_VERT);
 }
 
