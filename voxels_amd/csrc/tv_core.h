@@ -70,7 +70,8 @@ enum : u32 {
 	TAB_REG_VERT = 3344,     // 256 x 12 nibbles = 1536 -> 4880
 	TAB_TR_VERT = 4880,      // 512 x 12 nibbles = 3072 -> 7952
 	TAB_REG_OWN = 7952,      // 256 B: reuse slots (bits 1..3) a regular case stores when none of its samples is 0
-	TAB_BYTES = 8208
+	TAB_TR_OWN = 8208,       // 512 x u16: the same for the transition cases (slots 0..9)
+	TAB_BYTES = 9232
 };
 
 struct Tables {
@@ -84,6 +85,7 @@ struct Tables {
 	const u8* trCellP;     // 56 x 40
 	const u8* trVertP;     // 512 x 6
 	const u16* trEdgeP;    // 16
+	const u16* trOwnP;     // 512
 	TV_HD u32 regClass(u32 code) const { return regClassP[code]; }
 	TV_HD const u8* regCell(u32 cls) const { return regCellP + cls * 16; }
 	TV_HD u32 regOwn(u32 code) const { return regOwnP[code]; }
@@ -91,6 +93,7 @@ struct Tables {
 	TV_HD u32 trClass(u32 code) const { return trClassP[code]; }
 	TV_HD const u8* trCell(u32 cls) const { return trCellP + cls * 40; }
 	TV_HD u32 trCorner(u32 c) const { return trCornerP[c]; }
+	TV_HD u32 trOwn(u32 code) const { return trOwnP[code]; }
 	TV_HD u32 trVert(u32 code, u32 i) const { return trEdgeP[(trVertP[code * 6 + (i >> 1)] >> ((i & 1u) * 4u)) & 15u]; }
 };
 
@@ -101,7 +104,7 @@ TV_HD Tables tables_from_image(const u8* base)
 	T.regClassP = base + TAB_REG_CLASS; T.regCellP = base + TAB_REG_CELL; T.regVertP = base + TAB_REG_VERT;
 	T.regEdgeP = (const u16*)(base + TAB_REG_EDGE); T.regOwnP = base + TAB_REG_OWN;
 	T.trClassP = base + TAB_TR_CLASS; T.trCornerP = base + TAB_TR_CORNER; T.trCellP = base + TAB_TR_CELL;
-	T.trVertP = base + TAB_TR_VERT; T.trEdgeP = (const u16*)(base + TAB_TR_EDGE);
+	T.trVertP = base + TAB_TR_VERT; T.trEdgeP = (const u16*)(base + TAB_TR_EDGE); T.trOwnP = (const u16*)(base + TAB_TR_OWN);
 	return T;
 }
 
@@ -592,6 +595,10 @@ TV_HD void tr_vertex_dir_slot(const Tables& T, const i8 v[13], u32 w, int& t, u3
 // bit s set <=> the cell creates and stores a vertex in reuse slot s (0..9)
 TV_HD u32 tr_slot_valid(const Tables& T, const i8 v[13], u32 code)
 {
+	bool anyZero = false;
+#pragma unroll
+	for (int i = 0; i < 9; ++i) anyZero = anyZero || v[i] == 0;
+	if (!anyZero) return T.trOwn(code); // no vertex on a sample point: the mask is a property of the case
 	const u32 nv = (u32)(T.trCell(T.trClass(code) & 0x7F)[0]) >> 4;
 	u32 m = 0;
 	for (u32 vi = 0; vi < nv; ++vi) {

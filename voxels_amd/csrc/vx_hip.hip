@@ -703,7 +703,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 // LDS images of the table subsets each kernel needs
 constexpr u32 REG_TAB_LDS = 512 + 1600 + 256;           // regClass + regCell | edge words + regVert rows | regOwn
-constexpr u32 TR_TAB_LDS = 2832 + 3072;                 // trClass + trCorner + trCell + edge words | trVert rows
+constexpr u32 TR_TAB_LDS = 2832 + 3072 + 1024;          // trClass + trCorner + trCell + edge words | trVert rows | trOwn
 
 __device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes)
 {
@@ -719,7 +719,7 @@ __device__ __forceinline__ Tables stage_regular_tables(u8* lds, const u8* image)
 	copy16(lds + 2112, image + TAB_REG_OWN, 256);
 	Tables T;
 	T.regClassP = lds; T.regCellP = lds + 256; T.regEdgeP = (const u16*)(lds + 512); T.regVertP = lds + 512 + 64; T.regOwnP = lds + 2112;
-	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr; T.trEdgeP = nullptr;
+	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr; T.trEdgeP = nullptr; T.trOwnP = nullptr;
 	return T;
 }
 
@@ -727,9 +727,10 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 {
 	copy16(lds, image + TAB_TR_CLASS, 2832);       // class, corner, cell tables + both edge word tables
 	copy16(lds + 2832, image + TAB_TR_VERT, 3072);
+	copy16(lds + 5904, image + TAB_TR_OWN, 1024);
 	Tables T;
 	T.regClassP = nullptr; T.regCellP = nullptr; T.regVertP = nullptr; T.regEdgeP = nullptr; T.regOwnP = nullptr;
-	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trEdgeP = (const u16*)(lds + 2768 + 32); T.trVertP = lds + 2832;
+	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trEdgeP = (const u16*)(lds + 2768 + 32); T.trVertP = lds + 2832; T.trOwnP = (const u16*)(lds + 5904);
 	return T;
 }
 

@@ -239,6 +239,12 @@ void build_table_image(std::vector<u8>& img)
 		for (u32 vi = 0; vi < nv; ++vi) { const u32 w = TVT_REG_VERT[code * 12 + vi]; if ((w >> 12) == 8u) m |= (u8)(1u << ((w >> 8) & 15)); }
 		img[TAB_REG_OWN + code] = m;
 	}
+	for (u32 code = 0; code < 512; ++code) {
+		const u32 nv = TVT_TR_CELL[(TVT_TR_CLASS[code] & 0x7F) * 40] >> 4;
+		u16 m = 0;
+		for (u32 vi = 0; vi < nv; ++vi) { const u32 w = TVT_TR_VERT[code * 12 + vi]; if ((w >> 12) == 8u) m |= (u16)(1u << ((w >> 8) & 15)); }
+		memcpy(&img[TAB_TR_OWN + code * 2], &m, 2);
+	}
 	pack(TVT_TR_VERT, 512, TAB_TR_EDGE, TAB_TR_VERT);
 }
 
