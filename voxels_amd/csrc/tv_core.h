@@ -139,7 +139,20 @@ TV_HD u32 mat_at(const GridView& g, int x, int y, int z)
 TV_HD void normalize_fix_zero(float v[3])
 {
 	const float len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+	// Correctly rounded square root = the hardware's 1-ulp v_sqrt_f32 nudged by the sign of the two residuals, which is
+	// what the compiler emits for sqrtf minus its input scaling and class test: len2 is 0 or in [1e-16, 2e5] here,
+	// never a denormal, infinity or NaN (0 passes through: the neighbours of 0 give NaN residuals, both tests fail).
+	float len = __builtin_amdgcn_sqrtf(len2);
+	{
+		const float down = __builtin_bit_cast(float, __builtin_bit_cast(int, len) - 1), up = __builtin_bit_cast(float, __builtin_bit_cast(int, len) + 1);
+		const float rDown = __builtin_fmaf(-down, len, len2), rUp = __builtin_fmaf(-up, len, len2);
+		len = (rDown <= 0.f) ? down : len;
+		len = (rUp > 0.f) ? up : len;
+	}
+#else
 	const float len = sqrtf(len2);
+#endif
 	if (len <= 1.1920929e-07f) { v[0] = v[1] = v[2] = 0.f; return; }
 #if defined(__HIP_DEVICE_COMPILE__)
 	// Three IEEE divisions by the same denominator: the compiler's fp32 division (reciprocal, two Newton steps on the
