@@ -208,7 +208,7 @@ struct Backend {
 				st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
 				for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
 					reg_phase_stage_indices(*st, T, chunk, 0, 1);
-					reg_phase_flush_indices(*st, p.P, chunk, 0, 1);
+					reg_phase_flush_indices(*st, T, p.P, chunk, 0, 1);
 				}
 				reg_phase_record(*st, p.G.stats, L, b, p.P, 0);
 			}

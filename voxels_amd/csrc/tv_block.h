@@ -691,64 +691,56 @@ TV_HD void reg_phase_keep(ST& st, const Tables& T, const Globals& G, const RegBl
 	}
 }
 
-// indices of one chunk of the block's index list into the LDS staging buffer (st.vdesc, free after vertex emission);
-// requires ibase scanned.  Nothing is re-resolved: created vertices count up from the cell's vbase, reused ones come
-// from the stored (direction, slot) of the owner cell.  Local indices (< 49152) fit 16 bits, 0xFFFF = INVALID_INDEX.
+// Index list, one lane per index.  Phase 1 (per cell, cheap): a descriptor for every kept triangle corner of the chunk
+// goes to st.vdesc (free after vertex emission) at its position in the block's index list (ibase scanned):
+// compact cell | (triangle * 3 + corner) << 12.
 template <typename ST>
 TV_HD void reg_phase_stage_indices(ST& st, const Tables& T, u32 chunkBase, int tid, int nth)
 {
 	const int nt = st.wordPrefix[128];
 	for (int k = tid; k < nt; k += nth) {
-		const u32 keepMask = st.info[k] >> 24;
-		const u32 first = st.ibase[k], count = 3u * (u32)TV_POPC(keepMask);
-		if (first >= chunkBase + VDESC_CAP || first + count <= chunkBase) continue;
-		const u32 c = st.cellOf[k];
-		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
-		const u32 bits = st.cellBits[k], code = bits & 0xFFu, zeroMask = bits >> 8;
-		const u8* cd = T.regCell(T.regClass(code));
-		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
-		const u32 newMask = st.newMask[k], invalidMask = st.invalidMask[k];
-		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0; // 4 x u16 per register
-		u32 ord = 0;
-		for (u32 vi = 0; vi < nv; ++vi) {
-			u32 id;
-			if ((newMask >> vi) & 1u) {
-				id = (u32)st.vbase[k] + ord; ++ord;
-			} else if ((invalidMask >> vi) & 1u) {
-				id = 0xFFFFu;
-			} else {
-				u32 dir, slot;
-				reg_reuse_source(zeroMask, T.regVert(code, vi), dir, slot);
-				const u32 c2 = (u32)(((cz - (int)((dir >> 2) & 1)) << 8) | ((cy - (int)((dir >> 1) & 1)) << 4) | (cx - (int)(dir & 1)));
-				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-				id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);
-			}
-			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
-			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
-		}
-		u32 pos = first;
-		for (u32 tr = 0; tr < ntri; ++tr) {
-			if (!((keepMask >> tr) & 1u)) continue;
-			for (u32 e = 0; e < 3; ++e, ++pos) {
-				if (pos < chunkBase || pos >= chunkBase + VDESC_CAP) continue;
-				const u32 vi = cd[1 + tr * 3 + e];
-				const unsigned long long pk = (vi < 4) ? pk0 : ((vi < 8) ? pk1 : pk2);
-				st.vdesc[pos - chunkBase] = (u16)((u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu);
-			}
+		u32 keepMask = st.info[k] >> 24;
+		u32 pos = st.ibase[k];
+		const u32 count = 3u * (u32)TV_POPC(keepMask);
+		if (pos >= chunkBase + VDESC_CAP || pos + count <= chunkBase) continue;
+		while (keepMask) {
+			const u32 tr = (u32)__builtin_ctz(keepMask);
+			keepMask &= keepMask - 1;
+			for (u32 e = 0; e < 3; ++e, ++pos)
+				if (pos >= chunkBase && pos < chunkBase + VDESC_CAP) st.vdesc[pos - chunkBase] = (u16)((u32)k | ((tr * 3 + e) << 12));
 		}
 	}
 }
 
-// staged chunk -> index pool: consecutive lanes write consecutive dwords
+// Phase 2: every lane resolves its own index — nothing is re-resolved: a created vertex is the cell's vbase plus its
+// rank among the cell's created vertices, a reused one comes from the stored slot ordinal of the owner cell — and
+// stores it: consecutive lanes write consecutive dwords of the index pool.
 template <typename ST>
-TV_HD void reg_phase_flush_indices(const ST& st, const Pools& P, u32 chunkBase, int tid, int nth)
+TV_HD void reg_phase_flush_indices(const ST& st, const Tables& T, const Pools& P, u32 chunkBase, int tid, int nth)
 {
 	if (st.iOff + st.iTotal > P.idxCap) return;
 	const u32 end = (st.iTotal - chunkBase < (u32)VDESC_CAP) ? st.iTotal - chunkBase : (u32)VDESC_CAP;
 	u32* out = P.idx + st.iOff + chunkBase;
 	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
-		const u32 id = st.vdesc[j];
-		out[j] = (id == 0xFFFFu) ? INVALID_INDEX : id;
+		const u32 desc = st.vdesc[j];
+		const u32 k = desc & 0xFFFu, corner = desc >> 12;
+		const u32 bits = st.cellBits[k], code = bits & 0xFFu;
+		const u32 vi = T.regCell(T.regClass(code))[1 + corner];
+		const u32 newMask = st.newMask[k];
+		u32 id;
+		if ((newMask >> vi) & 1u) {
+			id = (u32)st.vbase[k] + (u32)TV_POPC(newMask & ((1u << vi) - 1u));
+		} else if ((st.invalidMask[k] >> vi) & 1u) {
+			id = INVALID_INDEX;
+		} else {
+			u32 dir, slot;
+			reg_reuse_source(bits >> 8, T.regVert(code, vi), dir, slot);
+			const u32 c = st.cellOf[k];
+			const u32 c2 = c - ((dir & 1u) + (((dir >> 1) & 1u) << 4) + (((dir >> 2) & 1u) << 8));
+			const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+			id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);
+		}
+		out[j] = id;
 	}
 }
 

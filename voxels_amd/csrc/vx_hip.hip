@@ -822,7 +822,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			if (chunk) __syncthreads();
 			reg_phase_stage_indices(st, T, chunk, tid, WG);
 			__syncthreads();
-			reg_phase_flush_indices(st, p.P, chunk, tid, WG);
+			reg_phase_flush_indices(st, T, p.P, chunk, tid, WG);
 		}
 		reg_phase_record(st, wgStats, L, b, p.P, tid);
 	}
