@@ -254,7 +254,10 @@ struct Backend {
 							tr_phase_describe(*st, chunk, 0, 1);
 							tr_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
 						}
-						tr_phase_emit_indices(*st, T, p.P, 0, 1);
+						for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
+							tr_phase_stage_indices(*st, T, chunk, 0, 1);
+							tr_phase_flush_indices(*st, T, p.P, chunk, 0, 1);
+						}
 					}
 					tr_phase_record(*st, L, b, p.P, f0, f1, 0);
 					f0 = f1;

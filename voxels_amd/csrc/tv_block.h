@@ -790,6 +790,7 @@ struct TrState {
 	u16 cellOf[TR_CAP];       // compact -> cell id
 	u16 cellMat[TR_CAP];      // compact: low-res cell material
 	u16 valid[TR_CAP];        // compact: slot valid mask (10 bits)
+	u32 cellBits[TR_CAP];     // compact: case code (9 bits) | (expanded sample == 0) mask << 9 — what the index logic needs of the samples
 	unsigned long long ords[TR_CAP]; // compact: ordinal (4 bits) of the vertex stored in each of the 10 slots
 	u16 vbase[TR_CAP];        // compact: exclusive scan of new vertex counts (flat over the batch's faces)
 	u16 ibase[TR_CAP];        // compact: exclusive scan of index counts (flat over the batch's faces)
@@ -883,7 +884,9 @@ TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const
 		tr_cell_values(st, f, row, col, v9);
 		tr_expand_values(v9, v);
 		st.cellOf[k] = (u16)c;
-		st.valid[k] = (u16)tr_slot_valid(T, v, tr_case_code(v9));
+		const u32 code = tr_case_code(v9);
+		st.cellBits[k] = code | (tr_zero_mask(v) << 9);
+		st.valid[k] = (u16)tr_slot_valid(T, v, code);
 		int local[3];
 		tr_low_local(face_geom(f), row, col, local);
 		st.cellMat[k] = L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])];
@@ -919,10 +922,7 @@ TV_HD void tr_phase_count(TrState& st, const Tables& T, int tid, int nth)
 	for (int k = tid; k < nt; k += nth) {
 		const u32 c = st.cellOf[k];
 		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
-		i8 v9[9], v[13];
-		tr_cell_values(st, f, row, col, v9);
-		tr_expand_values(v9, v);
-		const u32 code = tr_case_code(v9);
+		const u32 bits = st.cellBits[k], code = bits & 0x1FFu, zeroMask = bits >> 9;
 		const u8* cd = T.trCell(T.trClass(code) & 0x7F);
 		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
 		const u32 mask2 = tr_mask2(st, f, row, col);
@@ -930,7 +930,7 @@ TV_HD void tr_phase_count(TrState& st, const Tables& T, int tid, int nth)
 		u32 count = 0, newMask = 0;
 		unsigned long long ords = 0;
 		for (u32 vi = 0; vi < nv; ++vi) {
-			const TrResolution r = tr_resolve(T, v, T.trVert(code, vi), mask2, st.cellMat[k] & 0xFFu, nb);
+			const TrResolution r = tr_resolve(T, zeroMask, T.trVert(code, vi), mask2, st.cellMat[k] & 0xFFu, nb);
 			if (r.kind == RK_NEW_EDGE) {
 				if (r.store != NO_SLOT) ords = (ords & ~(0xFull << (r.store * 4))) | ((unsigned long long)count << (r.store * 4));
 				++count;
@@ -997,51 +997,52 @@ TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G
 	}
 }
 
-// indices of all transition cells; requires vbase/ibase scanned, vOff/iOff set
-TV_HD void tr_phase_emit_indices(TrState& st, const Tables& T, const Pools& P, int tid, int nth)
+// Index lists of the batch's faces, one lane per index (same scheme as the regular pass).  Phase 1, per cell: a
+// descriptor for every triangle corner of the chunk at its position in the flat index list: compact cell | corner << 9.
+TV_HD void tr_phase_stage_indices(TrState& st, const Tables& T, u32 chunkBase, int tid, int nth)
 {
 	const int nt = st.wordPrefix[48];
-	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
 	for (int k = tid; k < nt; k += nth) {
+		const u32 first = st.ibase[k];
+		const u32 count = 3u * ((u32)T.trCell(T.trClass(st.cellBits[k] & 0x1FFu) & 0x7F)[0] & 15u);
+		if (first >= chunkBase + VDESC_CAP || first + count <= chunkBase) continue;
+		for (u32 i = 0; i < count; ++i) {
+			const u32 pos = first + i;
+			if (pos >= chunkBase && pos < chunkBase + VDESC_CAP) st.vdesc[pos - chunkBase] = (u16)((u32)k | (i << 9));
+		}
+	}
+}
+
+// Phase 2: each lane resolves and stores its index (relative to its face's first vertex; winding flipped per class/face)
+TV_HD void tr_phase_flush_indices(const TrState& st, const Tables& T, const Pools& P, u32 chunkBase, int tid, int nth)
+{
+	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
+	const u32 end = (st.iTotal - chunkBase < (u32)VDESC_CAP) ? st.iTotal - chunkBase : (u32)VDESC_CAP;
+	u32* out = P.idx + st.iOff + chunkBase;
+	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
+		const u32 desc = st.vdesc[j];
+		const u32 k = desc & 0x1FFu, i = desc >> 9;
 		const u32 c = st.cellOf[k];
-		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
-		i8 v9[9], v[13];
-		tr_cell_values(st, f, row, col, v9);
-		tr_expand_values(v9, v);
-		const u32 code = tr_case_code(v9);
+		const u32 f = c >> 8;
+		const u32 bits = st.cellBits[k], code = bits & 0x1FFu;
 		const u32 cls = T.trClass(code);
 		const u8* cd = T.trCell(cls & 0x7F);
-		const u32 nv = (u32)cd[0] >> 4, ntri = (u32)cd[0] & 15;
+		const bool flip = ((cls >> 7) ^ (f & 1u)) != 0; // reverseWinding = {0,1,0,1,0,1}
+		const u32 tr = i / 3, e = i - tr * 3;
+		const u32 vi = cd[1 + tr * 3 + ((flip && e) ? 3 - e : e)];
+		const u32 faceVBase = st.vbase[st.wordPrefix[f * 8]]; // the face's first cell exists: cell k is in it
 		const u32 newMask = st.newMask[k];
-		const u32 faceVBase = st.vbase[st.wordPrefix[f * 8]]; // compact index of the face's first cell exists: cell k is in it
-		unsigned long long pk0 = 0, pk1 = 0, pk2 = 0;          // per-face local indices (< 3072), 4 x u16 per register
-		u32 ord = 0;
-		for (u32 vi = 0; vi < nv; ++vi) {
-			u32 id;
-			if ((newMask >> vi) & 1u) {
-				id = (u32)st.vbase[k] - faceVBase + ord; ++ord;
-			} else {
-				int t, corner; u32 dir, slot; bool endpoint;
-				tr_vertex_dir_slot(T, v, T.trVert(code, vi), t, dir, slot, endpoint, corner);
-				const u32 c2 = (u32)((f << 8) | ((row - (int)((dir >> 1) & 1)) << 4) | (col - (int)(dir & 1)));
-				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-				id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
-			}
-			const unsigned long long sh = (unsigned long long)id << ((vi & 3) * 16);
-			if (vi < 4) pk0 |= sh; else if (vi < 8) pk1 |= sh; else pk2 |= sh;
+		u32 id;
+		if ((newMask >> vi) & 1u) {
+			id = (u32)st.vbase[k] - faceVBase + (u32)TV_POPC(newMask & ((1u << vi) - 1u));
+		} else {
+			int t, corner; u32 dir, slot; bool endpoint;
+			tr_vertex_dir_slot_z(T, bits >> 9, T.trVert(code, vi), t, dir, slot, endpoint, corner);
+			const u32 c2 = c - ((dir & 1u) + (((dir >> 1) & 1u) << 4));
+			const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+			id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
 		}
-		u32* out = P.idx + st.iOff + st.ibase[k];
-		const bool flip = ((cls >> 7) ^ (u32)(f & 1)) != 0; // reverseWinding = {0,1,0,1,0,1}
-		for (u32 tr = 0; tr < ntri; ++tr) {
-			u32 id3[3];
-			for (u32 e = 0; e < 3; ++e) {
-				const u32 vi = cd[1 + tr * 3 + e];
-				const unsigned long long pk = (vi < 4) ? pk0 : ((vi < 8) ? pk1 : pk2);
-				id3[e] = (u32)(pk >> ((vi & 3) * 16)) & 0xFFFFu;
-			}
-			out[0] = id3[0]; out[1] = flip ? id3[2] : id3[1]; out[2] = flip ? id3[1] : id3[2];
-			out += 3;
-		}
+		out[j] = id;
 	}
 }
 

@@ -595,14 +595,28 @@ TV_HD void tr_expand_values(const i8 v9[9], i8 v13[13])
 	v13[9] = v9[0]; v13[10] = v9[2]; v13[11] = v9[6]; v13[12] = v9[8];
 }
 
-TV_HD void tr_vertex_dir_slot(const Tables& T, const i8 v[13], u32 w, int& t, u32& dir, u32& slot, bool& endpoint, int& corner)
+// zeroMask: bit i = transition sample i (0..12, expanded) is exactly 0 — all these decisions need of the values
+TV_HD void tr_vertex_dir_slot_z(const Tables& T, u32 zeroMask, u32 w, int& t, u32& dir, u32& slot, bool& endpoint, int& corner)
 {
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
 	dir = w >> 12; slot = (w >> 8) & 15;
-	t = edge_end(v[v0], v[v1]); // 0 / 256 / 1 = inside
+	t = edge_end_bits(zeroMask, v0, v1); // 0 / 256 / 1 = inside
 	corner = (t == 0) ? v1 : v0;
 	endpoint = (t & 0xFF) == 0;
 	if (endpoint) { const u32 cd = T.trCorner(corner); dir = cd >> 4; slot = cd & 15; }
+}
+
+TV_HD u32 tr_zero_mask(const i8 v[13])
+{
+	u32 m = 0;
+#pragma unroll
+	for (int i = 0; i < 13; ++i) m |= (v[i] == 0 ? 1u : 0u) << i;
+	return m;
+}
+
+TV_HD void tr_vertex_dir_slot(const Tables& T, const i8 v[13], u32 w, int& t, u32& dir, u32& slot, bool& endpoint, int& corner)
+{
+	tr_vertex_dir_slot_z(T, tr_zero_mask(v), w, t, dir, slot, endpoint, corner);
 }
 
 // bit s set <=> the cell creates and stores a vertex in reuse slot s (0..9)
@@ -633,11 +647,11 @@ struct TrResolution {
 //   mask2 : bit0 = a non-trivial transition cell exists earlier in this row, bit1 = row > 0
 //   nb(dcol, drow, slot, &valid, &mat): reuse slot of the cell at (col - dcol, row - drow) of this face
 template <typename NB>
-TV_HD TrResolution tr_resolve(const Tables& T, const i8 v[13], u32 w, u32 mask2, u32 myMatId, const NB& nb)
+TV_HD TrResolution tr_resolve(const Tables& T, u32 zeroMask, u32 w, u32 mask2, u32 myMatId, const NB& nb)
 {
 	TrResolution r;
 	int t, corner; u32 dir, slot; bool endpoint;
-	tr_vertex_dir_slot(T, v, w, t, dir, slot, endpoint, corner);
+	tr_vertex_dir_slot_z(T, zeroMask, w, t, dir, slot, endpoint, corner);
 	r.t = t; r.dir = (u8)dir; r.slot = (u8)slot; r.endpoint = endpoint ? 1 : 0;
 	bool addForReuse = true;
 	if ((dir & mask2) == dir) {

@@ -949,7 +949,12 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 					__syncthreads();
 					tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
 				}
-				tr_phase_emit_indices(st, T, p.P, tid, WG);
+				for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
+					__syncthreads();
+					tr_phase_stage_indices(st, T, chunk, tid, WG);
+					__syncthreads();
+					tr_phase_flush_indices(st, T, p.P, chunk, tid, WG);
+				}
 			}
 			tr_phase_record(st, L, b, p.P, f0, f1, tid);
 			f0 = f1;
