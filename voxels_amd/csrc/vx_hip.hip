@@ -226,11 +226,11 @@ struct ResetRanges {
 	u32 start[MAX_LEVELS + 1]; // word ranges of the flat index space: [0, headerWords) header, then slotOf of level 0, 1, ...
 };
 
-__global__ __launch_bounds__(WG) void k_reset(ExecParamsDev p, ResetRanges r)
+__device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetRanges& r, u32 lane)
 {
 	const u32 total = r.start[MAX_LEVELS];
 	// four consecutive words per lane; ranges are multiples of 4 words except possibly tiny coarse levels
-	const u32 first = (blockIdx.x * WG + threadIdx.x) * 4;
+	const u32 first = lane * 4;
 #pragma unroll
 	for (u32 k = 0; k < 4; ++k) {
 		const u32 i = first + k;
@@ -244,12 +244,14 @@ __global__ __launch_bounds__(WG) void k_reset(ExecParamsDev p, ResetRanges r)
 }
 
 // ---- what the emptiness flags already say about a block (two tiny launches ahead of k_classify) ------------
-// summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign)
-__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi)
+// summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign).  The same launch
+// resets the run's counters and slot maps (independent work, one launch fewer at the head of every run).
+__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi, ResetRanges r)
 {
 	const LevelDesc& L = p.levels[0];
 	const u32 per = L.cnt * L.cnt;
 	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (r.header) reset_words(p, r, i);
 	if (i >= per * (zbHi - zbLo)) return;
 	const u32 id = zbLo * per + i;
 	u32 s = 0;
@@ -1141,7 +1143,8 @@ struct Backend {
 		return ms;
 	}
 
-	// header words = 0 and every level's block -> slot map = -1, in one launch
+	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_block_summary)
+	ResetRanges pendingReset = {};
 	template <typename P>
 	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
 	{
@@ -1153,8 +1156,7 @@ struct Backend {
 			if (l < levels) run += p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt;
 		}
 		r.start[MAX_LEVELS] = run;
-		hipLaunchKernelGGL(k_reset, dim3((run / 4 + WG) / WG), dim3(WG), 0, stream, dev(p), r);
-		check(hipGetLastError(), "k_reset launch");
+		pendingReset = r;
 	}
 
 	template <typename P>
@@ -1175,7 +1177,12 @@ struct Backend {
 		if (!grid) return;
 		const u32 per = L.cnt * L.cnt;
 		const u32 zbLo = L.zb0 ? L.zb0 - 1 : 0, zbHi = std::min<u32>(L.zb1 + 1, L.cnt);
-		hipLaunchKernelGGL(k_block_summary, dim3((per * (zbHi - zbLo) + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi);
+		{
+			const ResetRanges r = pendingReset;
+			pendingReset.header = nullptr;
+			const u32 lanes = std::max<u32>(per * (zbHi - zbLo), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
+			hipLaunchKernelGGL(k_block_summary, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi, r);
+		}
 		hipLaunchKernelGGL(k_block_class, dim3((per * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
 		const u32 rows = L.cnt * (L.zb1 - L.zb0);
 		u32 rowGroup = 0; // 0 = no remap
