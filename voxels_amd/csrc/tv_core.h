@@ -288,6 +288,19 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	if (f) f = (f >> 3) | ((f & 7u) << 3);
 	o.secW = f;
 	o.nrm[0] = r.n[0]; o.nrm[1] = r.n[1]; o.nrm[2] = r.n[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+	{
+		// texture bytes {0, blend, Ids1[1], Ids0[1] | Ids1[2], Ids1[0], Ids0[2], Ids0[0]} picked out of the row with two
+		// byte permutes (selector 0..3 = low dword, 4..7 = high dword, 0x0C = constant 0)
+		const u32 lo = (u32)row, hi = (u32)(row >> 32);
+		const bool ok = ((hi >> 16) & 0xFFu) != 0;
+		u32 t0 = __builtin_amdgcn_perm(hi, lo, 0x01040C0Cu) | (((r.mat >> 8) & 0xFFu) << 8);
+		u32 t1 = __builtin_amdgcn_perm(hi, lo, 0x00020305u);
+		if (!ok) { t0 = 0; t1 = 0; }
+		memcpy(&o.tex[0], &t0, 4);
+		memcpy(&o.tex[4], &t1, 4);
+	}
+#else
 	u8 e[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) e[i] = (u8)(row >> (8 * i));
@@ -300,6 +313,7 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	o.tex[5] = ok ? e[3] : 0; // Upy = Ids1[0]
 	o.tex[6] = ok ? e[2] : 0; // Tny = Ids0[2]
 	o.tex[7] = ok ? e[0] : 0; // Tpy = Ids0[0]
+#endif
 	*out = o;
 }
 
