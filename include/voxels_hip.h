@@ -91,6 +91,19 @@ int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
 /* Re-upload `count` edited 16^3 blocks (block ids, x-fastest 4096-byte blocks) + the full flag array. */
 int vx_grid_update_blocks(vx_ctx* ctx, uint32_t count, const uint32_t* block_ids, const int8_t* dist,
                           const uint8_t* mat, const uint8_t* blend, const uint8_t* empty_flags);
+/* ---- edits on the device (Grid::InjectSurface / Grid::InjectMaterial, src/VoxelGrid.cpp:388-584) -------------------
+ * For a grid that lives on the device only (vx_grid_upload / vx_grid_upload_packed): the same arithmetic per voxel, the
+ * same per-block sections and the same "touched block" rule as the reference, BF_Empty of every touched block
+ * recomputed by the codec's rule (CompressBlock, :610-672).  out_min / out_max receive the modified box exactly as
+ * Grid::Inject* returns it (output, Y-up, order) — feed it to vx_polygonize_dirty.
+ * vx_grid_inject_ball: InjectSurface with the analytic VoxelSurface  f(x,y,z) = sqrt(x^2 + y^2 + z^2) - radius  sampled
+ * relative to `position` (the sphere brush of doc_source/Modification.md); type = InjectionType (0 IT_Add,
+ * 1 IT_SubtractAddInner, 2 IT_Subtract). */
+int vx_grid_inject_ball(vx_ctx* ctx, const float position[3], const float extents[3], float radius, int type,
+                        float out_min[3], float out_max[3]);
+int vx_grid_inject_material(vx_ctx* ctx, const float position[3], const float extents[3], uint8_t material,
+                            int add_subtract_blend, float out_min[3], float out_max[3]);
+
 /* MaterialMap::GetMaterial resolved on the host (include/MaterialMap.h:19-30): lut[id] = {DiffuseIds0[3],
  * DiffuseIds1[3]}, valid[id] == 0 means GetMaterial returned NULL (texture bytes stay 0). */
 int vx_material_lut(vx_ctx* ctx, const uint8_t* lut /*256*6*/, const uint8_t* valid /*256*/);
@@ -110,10 +123,11 @@ int vx_level_counts(vx_ctx* ctx, uint32_t level, uint32_t* n_blocks, uint64_t to
  * transition vertices/indices of faces 0..5.  Any output pointer may be NULL. */
 int vx_download_level(vx_ctx* ctx, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx,
                       vx_vertex* tverts, uint32_t* tidx);
-/* Device-resident hand-off (renderer interop): the meshes of the last FULL run stay in two device pools; a block's
- * meshes are contiguous ranges of them.  d_verts / d_indices are device pointers valid until the next run on this
- * context; indices are relative to the start of their own mesh, exactly as downloaded.  After an incremental run the
- * untouched blocks live in host copies (the pools are reused), so vx_level_ranges then fails with VX_ERR_INVALID. */
+/* Device-resident hand-off (renderer interop): the meshes stay in two device pools; a block's meshes are contiguous
+ * ranges of them.  A full run rewrites the pools; an incremental run appends the rebuilt blocks behind what is there
+ * (ranges of kept blocks stay valid, ranges of replaced blocks become garbage until the next full run).  d_verts /
+ * d_indices are valid until the next run on this context (an incremental run may move the pools when it has to grow
+ * them); indices are relative to the start of their own mesh, exactly as downloaded. */
 typedef struct vx_block_ranges {
 	uint32_t v_off, i_off;        /* first vertex / first index of the regular mesh in the pools */
 	uint32_t tv_off[6], ti_off[6]; /* the same for the six transition meshes */

@@ -55,6 +55,31 @@ struct Backend {
 			}
 		}
 	}
+	void run_edit(const GridView& g, u8* flags, const u32* ids, u32 count, const EditParams& e)
+	{
+		const u32 nb = (u32)g.n / 16;
+		for (u32 t = 0; t < count; ++t) {
+			const u32 id = ids[t], bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+			const EditSection s = edit_section(e, bx, by, bz);
+			for (int iz = 0; iz < s.count[2]; ++iz) for (int iy = 0; iy < s.count[1]; ++iy) for (int ix = 0; ix < s.count[0]; ++ix) edit_voxel(g, e, s, ix, iy, iz);
+			if (e.kind == EDIT_BALL) flags[id] = edit_block_empty(g, bx, by, bz);
+		}
+	}
+	bool d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	void run_scatter_blocks(const u32* ids, u32 count, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
+	{
+		const u32 nb = n / 16;
+		const u8* src[3] = { sd, sm, sb };
+		u8* dst[3] = { dist, mat, blend };
+		for (u32 i = 0; i < count; ++i) {
+			const u32 id = ids[i], bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+			for (int k = 0; k < 3; ++k) {
+				if (!src[k]) continue;
+				for (u32 z = 0; z < 16; ++z) for (u32 y = 0; y < 16; ++y)
+					memcpy(dst[k] + ((size_t)(bz * 16 + z) * n + by * 16 + y) * n + bx * 16, src[k] + (size_t)i * 4096 + z * 256 + y * 16, 16);
+			}
+		}
+	}
 	void end_timing_record() {}
 	float elapsed_ms() { return 0.f; }
 	template <typename P>

@@ -288,3 +288,54 @@ def test_emu_device_resident_meshes(emu):
                 assert np.array_equal(verts[rg["tv_off"][k][f]:rg["tv_off"][k][f] + a], lv.tverts[otv:otv + a])
                 assert np.array_equal(idx[rg["ti_off"][k][f]:rg["ti_off"][k][f] + c], lv.tidx[oti:oti + c])
                 otv += a; oti += c
+
+
+def check_device_edits(p, port, n, seed, surface_tol=0.0):
+    """§8(f) row 2: a chain of ball / material edits applied to the resident grid by the library itself, compared after
+    every edit with the reference doing the same Grid::InjectSurface / InjectMaterial + incremental Execute."""
+    from voxels_amd import synth
+    d0, m0, b0 = synth.terrain(n, seed=seed)
+    g = port.grid_from_dense(d0, m0, b0)
+    s = port.execute(g)
+    p.upload_packed(g.pack())
+    p.execute()
+    c = n / 2.0
+    nb = n // 16
+    edits = (("ball", 2, (c - 2.0, c + 1.5, c - 0.75), (20, 20, 20), 7.0), ("ball", 0, (c + 8, c - 12, c - 7), (16, 16, 16), 6.0),
+             ("mat", 3, (c - 3.0, c + 2.0, c - 2.0), (14, 14, 14), 1), ("ball", 2, (3.0, n - 4.0, c - 2), (12, 12, 12), 5.0),
+             ("ball", 1, (c + 0.5, c + 0.25, c - 4.5), (9, 9, 9), 3.5), ("mat", 3, (c - 1.0, c + 1.0, c - 1.0), (10, 10, 10), 0))
+    for kind, a, pos, ext, r in edits:
+        pre = g.read_dense()
+        if kind == "ball":
+            mn, mx = g.inject_ball(pos, ext, r, a)
+            mn2, mx2 = p.inject_ball(pos, ext, r, a)
+        else:
+            mn, mx = g.inject_material(pos, ext, a, bool(r))
+            mn2, mx2 = p.inject_material(pos, ext, a, bool(r))
+        assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2)
+        post = g.read_dense()
+        ids, _ = fields.edited_blocks(pre, post)
+        assert ids.size, "the edit must change something"
+        flags = g.block_flags()
+        # every block around the edit: data and BF_Empty
+        lo = np.maximum(np.floor((np.array(pos) - np.array(ext)) / 16).astype(int) - 1, 0)
+        hi = np.minimum(np.ceil((np.array(pos) + np.array(ext)) / 16).astype(int) + 1, nb)
+        for bz in range(lo[2], hi[2]):
+            for by in range(lo[1], hi[1]):
+                for bx in range(lo[0], hi[0]):
+                    bid = (bz * nb + by) * nb + bx
+                    sl = (slice(bz * 16, bz * 16 + 16), slice(by * 16, by * 16 + 16), slice(bx * 16, bx * 16 + 16))
+                    bd, bm, bb, fl = p.read_block(bid)
+                    assert np.array_equal(bd, post[0][sl]), "distances of block %d after %s" % (bid, kind)
+                    assert np.array_equal(bm, post[1][sl]) and np.array_equal(bb, post[2][sl]), "materials of block %d after %s" % (bid, kind)
+                    assert fl == flags[bid], "BF_Empty of block %d after %s" % (bid, kind)
+        ref_ids = port.execute_modify(g, s, mn, mx)
+        got = p.execute_dirty(mn2, mx2)
+        assert np.array_equal(got, ref_ids)
+        ok, msg = fields.surface_equal(p.all_levels(), s.all_levels(), nrm_tol=surface_tol)
+        assert ok, msg
+        assert np.array_equal(p.stats(), s.stats())
+
+
+def test_emu_device_edits(emu, port):
+    check_device_edits(make_poly(emu), port, 64, 23)

@@ -416,3 +416,12 @@ def test_hip_device_resident_meshes(poly):
                 assert np.array_equal(verts[rg["tv_off"][k][f]:rg["tv_off"][k][f] + a], lv.tverts[otv:otv + a])
                 assert np.array_equal(idx[rg["ti_off"][k][f]:rg["ti_off"][k][f] + c], lv.tidx[oti:oti + c])
                 otv += a; oti += c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 256])
+def test_hip_device_edits(poly, port, n):
+    """§8(f) row 2: Grid::InjectSurface (ball brush) / InjectMaterial executed on the resident grid by k_edit, BF_Empty by
+    k_edit_flags — voxel data, flags, modified box, rebuilt block ids and the surface after every edit of a chain."""
+    from test_emu import check_device_edits
+    check_device_edits(poly, port, n, 23, surface_tol=NRM_TOL)

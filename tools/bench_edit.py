@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""§8(f) row 2 measurement (BASELINE config 5 shape): 512^3 terrain, sphere carve of radius 20 at the surface, then the
+incremental re-polygonization.  Compares the edit done on the device (vx_grid_inject_ball) with the host path
+(reference Grid::InjectSurface on the host + vx_grid_update_blocks).  Usage (GPU box): python tools/bench_edit.py [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fields  # noqa: E402
+import vxo  # noqa: E402
+from voxels_amd import Polygonizer, synth  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    d, m, b = synth.terrain(n, 0, n, 1337)
+    oracle = vxo.load_ref() or vxo.load_port()
+    g = oracle.grid_from_dense(d, m, b)
+    p = Polygonizer()
+    p.set_materials(vxo.default_lut())
+    p.upload_packed(g.pack())
+    p.execute(0)
+    col = d[:, n // 2, n // 2]
+    zs = int(np.argmax(col >= 0)) if (col >= 0).any() else n // 2  # a point on the surface
+    pos, ext, r = (n / 2.0, n / 2.0, float(zs)), (44.0, 44.0, 44.0), 20.0
+    t = time.perf_counter(); mn, mx = p.inject_ball(pos, ext, r, 2); t_dev = time.perf_counter() - t
+    t = time.perf_counter(); ids = p.execute_dirty(mn, mx); t_poly = time.perf_counter() - t
+    dev1 = p.info.device_ms
+    # steady state: a second, smaller edit next to the first (block lists, scratch buffers and pools are in place now)
+    pos2 = (pos[0] + 9.0, pos[1] - 7.0, pos[2] + 3.0)
+    t = time.perf_counter(); mnb, mxb = p.inject_ball(pos2, (30.0, 30.0, 30.0), 12.0, 2); t_dev2 = time.perf_counter() - t
+    t = time.perf_counter(); idsb = p.execute_dirty(mnb, mxb); t_poly2 = time.perf_counter() - t
+    dev2 = p.info.device_ms
+    # host path for the same edit on a second context
+    q = Polygonizer()
+    q.set_materials(vxo.default_lut())
+    pre = g.read_dense()
+    q.upload(*pre, g.block_flags())
+    q.execute(0)
+    t = time.perf_counter()
+    mn2, mx2 = g.inject_ball(pos, ext, r, 2)
+    t_host_edit = time.perf_counter() - t
+    post = g.read_dense()
+    bids, (dd, mm, bb) = fields.edited_blocks(pre, post)
+    t = time.perf_counter(); q.update_blocks(bids, dd.view(np.int8), mm, bb, g.block_flags()); t_up = time.perf_counter() - t
+    ids2 = q.execute_dirty(mn2, mx2)
+    assert np.array_equal(ids, ids2) and np.array_equal(mn, mn2)
+    g.inject_ball(pos2, (30.0, 30.0, 30.0), 12.0, 2)
+    print("grid %d^3, IT_Subtract ball r=%g, extents %s: %d blocks changed, %d blocks rebuilt" % (n, r, ext, bids.size, ids.size))
+    print("  device edit (vx_grid_inject_ball, incl. BF_Empty refresh): %7.3f ms" % (t_dev * 1e3))
+    print("  incremental polygonization (vx_polygonize_dirty)          : %7.3f ms (device %.3f ms)" % (t_poly * 1e3, dev1))
+    print("  second edit (r=12): device edit %.3f ms, vx_polygonize_dirty %.3f ms (device %.3f ms), %d blocks rebuilt" % (t_dev2 * 1e3, t_poly2 * 1e3, dev2, idsb.size))
+    print("  host path: reference Grid::InjectSurface %7.3f ms + vx_grid_update_blocks %7.3f ms" % (t_host_edit * 1e3, t_up * 1e3))
+
+
+if __name__ == "__main__":
+    main()

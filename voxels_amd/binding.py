@@ -50,6 +50,8 @@ class HipLibrary:
         lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
+        lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
+        lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
         lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
@@ -140,6 +142,19 @@ class Polygonizer:
         f = np.zeros(1, np.uint8)
         self._check(self._lib.vx_grid_read_block(self._h, int(block_id), _ptr(d), _ptr(m), _ptr(b), _ptr(f)), "vx_grid_read_block")
         return d, m, b, int(f[0])
+
+    def inject_ball(self, pos, ext, radius, inj_type):
+        """Grid::InjectSurface with the analytic ball brush, on the device; returns the modified box (output order)."""
+        pos = np.ascontiguousarray(pos, np.float32); ext = np.ascontiguousarray(ext, np.float32)
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._check(self._lib.vx_grid_inject_ball(self._h, _ptr(pos), _ptr(ext), C.c_float(radius), int(inj_type), _ptr(mn), _ptr(mx)), "vx_grid_inject_ball")
+        return mn, mx
+
+    def inject_material(self, pos, ext, material, add):
+        pos = np.ascontiguousarray(pos, np.float32); ext = np.ascontiguousarray(ext, np.float32)
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._check(self._lib.vx_grid_inject_material(self._h, _ptr(pos), _ptr(ext), int(material), int(bool(add)), _ptr(mn), _ptr(mx)), "vx_grid_inject_material")
+        return mn, mx
 
     def device_meshes(self):
         """(device pointer of the vertex pool, of the index pool, vertices, indices) of the last full run."""

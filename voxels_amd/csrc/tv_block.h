@@ -1071,4 +1071,122 @@ TV_HD void tr_phase_record(const TrState& st, const LevelDesc& L, const RegBlock
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Edits on the resident grid: Grid::InjectSurface with the analytic ball brush, Grid::InjectMaterial
+// (src/VoxelGrid.cpp:388-584), and the codec's BF_Empty rule for the touched blocks (:610-672)
+// ---------------------------------------------------------------------------------------------------------
+enum { EDIT_BALL = 0, EDIT_MATERIAL = 1 };
+
+struct EditParams {
+	float pos[3], ext[3];
+	int kind, type;     // type = InjectionType for EDIT_BALL
+	float radius;
+	u32 material, add;
+};
+
+// the section of block (bx,by,bz) an edit rewrites: per axis first local coordinate and iteration count of the
+// reference's `for (x = start; x < end; ++x)` loops (:368-386; coordinates may be fractional, the voxel is (unsigned)x)
+struct EditSection {
+	float start[3];
+	int count[3];
+	float bmin[3];
+};
+
+TV_HD float edit_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+TV_HD EditSection edit_section(const EditParams& e, u32 bx, u32 by, u32 bz)
+{
+	EditSection s;
+	const u32 bc[3] = { bx, by, bz };
+	for (int k = 0; k < 3; ++k) {
+		s.bmin[k] = (float)(bc[k] * 16);
+		const float p = e.pos[k] - e.ext[k] / 2;
+		const float b0 = edit_clampf(p, s.bmin[k], s.bmin[k] + 16.f) - s.bmin[k];
+		const float b1 = edit_clampf(p + e.ext[k], s.bmin[k], s.bmin[k] + 16.f) - s.bmin[k];
+		s.start[k] = b0;
+		int cnt = 0;
+		for (float x = b0; x < b1; ++x) ++cnt; // at most 17 steps; the loop itself is the specification
+		s.count[k] = cnt;
+	}
+	return s;
+}
+
+// :37-50
+TV_HD i8 edit_round_distance(float v)
+{
+	const float a = ceilf(fabsf(v));
+	float b = a * (float)(v > 0 ? 1 : -1);
+	if (b > 127.f) b = 127.f;
+	return (i8)(int)b;
+}
+
+// value of a float loop variable after k steps of `+= 1` (the reference iterates floats; start + k may round differently)
+TV_HD float edit_step(float start, int k)
+{
+	float x = start;
+	for (int q = 0; q < k; ++q) x += 1.0f;
+	return x;
+}
+
+// one voxel of the section: (ix,iy,iz) = loop indices along x,y,z
+TV_HD void edit_voxel(const GridView& g, const EditParams& e, const EditSection& s, int ix, int iy, int iz)
+{
+	const float x = edit_step(s.start[0], ix), y = edit_step(s.start[1], iy), z = edit_step(s.start[2], iz);
+	const size_t i = ((size_t)((u32)s.bmin[2] + (u32)z) * g.n + ((u32)s.bmin[1] + (u32)y)) * g.n + ((u32)s.bmin[0] + (u32)x);
+	if (e.kind == EDIT_BALL) {
+		// the brush is sampled from (block corner + section start - position) in steps of 1, like the GetSurface call (:405-420)
+		const float sx = edit_step((s.bmin[0] + s.start[0]) - e.pos[0], ix);
+		const float sy = edit_step((s.bmin[1] + s.start[1]) - e.pos[1], iy);
+		const float sz = edit_step((s.bmin[2] + s.start[2]) - e.pos[2], iz);
+		const float sv = sqrtf((sx * sx + sy * sy) + sz * sz) - e.radius;
+		i8* dist = const_cast<i8*>(g.dist);
+		const float value = (float)dist[i];
+		float r;
+		if (e.type == 0) r = value < sv ? value : sv;        // IT_Add: min
+		else if (e.type == 1) r = value > sv ? value : sv;   // IT_SubtractAddInner: max
+		else r = (-sv > value) ? -sv : value;                // IT_Subtract: max(-surface, value)
+		dist[i] = edit_round_distance(r);
+	} else {
+		u8* mat = const_cast<u8*>(g.mat);
+		u8* blend = const_cast<u8*>(g.blend);
+		const float coeff = (e.ext[0] / 2.0f) * 0.75f;
+		const float cx = (x + s.bmin[0]) - e.pos[0], cy = (y + s.bmin[1]) - e.pos[1], cz = (z + s.bmin[2]) - e.pos[2];
+		const float d = sqrtf((cx * cx + cy * cy) + cz * cz) / coeff;
+		float w = 1 - d;
+		w = w > 0.f ? w : 0.f; w = w < 1.f ? w : 1.f;
+		const u8 outBlend = (u8)(w * 255.f);
+		if (mat[i] == (u8)e.material) {
+			int v = (e.add ? 1 : -1) * (int)outBlend + (int)blend[i];
+			v = v < 255 ? v : 255; v = v > 0 ? v : 0;
+			blend[i] = (u8)v;
+		} else {
+			mat[i] = (u8)e.material;
+			blend[i] = outBlend;
+		}
+	}
+}
+
+// BF_Empty of a block by the codec's rule: the RLE (runs of at most 255) fits 4096 bytes, and every run value has
+// strictly the sign of the first sample (walk in codec order: x, then y, then z)
+TV_HD u8 edit_block_empty(const GridView& g, u32 bx, u32 by, u32 bz)
+{
+	const i8* base = g.dist + ((size_t)(bz * 16) * g.n + by * 16) * g.n + bx * 16;
+	const i8 first = base[0];
+	i8 last = first;
+	u32 counter = 0, size = 1;
+	bool empty = true;
+	for (u32 z = 0; z < 16; ++z)
+	for (u32 y = 0; y < 16; ++y) {
+		const i8* row = base + ((size_t)z * g.n + y) * g.n;
+		for (u32 x = 0; x < 16; ++x) {
+			const i8 cur = row[x];
+			if (last == cur && counter < 0xFF) { ++counter; continue; }
+			size += 2; counter = 1; last = cur;
+			if ((int)first * (int)last <= 0) empty = false;
+			if (size > 4096) return 0;
+		}
+	}
+	return empty ? 1 : 0;
+}
+
 } // namespace tv

@@ -219,6 +219,84 @@ __global__ __launch_bounds__(WG) void k_decode_grid(const u8* blob, const unsign
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_edit / k_edit_flags: Grid::InjectSurface (analytic ball) and Grid::InjectMaterial on the resident grid, one
+// workgroup per touched block; then BF_Empty of the touched blocks, one lane per block (the codec walk is serial).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_edit(GridView g, const u32* ids, EditParams e)
+{
+	const u32 nb = (u32)g.n / 16, id = ids[blockIdx.x];
+	const EditSection s = edit_section(e, id % nb, (id / nb) % nb, id / (nb * nb));
+	const int total = s.count[0] * s.count[1] * s.count[2];
+	for (int v = threadIdx.x; v < total; v += WG) {
+		const int ix = v % s.count[0], iy = (v / s.count[0]) % s.count[1], iz = v / (s.count[0] * s.count[1]);
+		edit_voxel(g, e, s, ix, iy, iz);
+	}
+}
+
+// BF_Empty by the codec's rule (edit_block_empty of tv_block.h walks the block serially), one workgroup per block.
+// A run starts where the value changes and every 255 voxels inside a constant stretch; the RLE stays "effective"
+// while it has at most 2048 runs; empty <=> effective and every sample has strictly the sign of the first.
+__global__ __launch_bounds__(WG) void k_edit_flags(GridView g, u8* flags, const u32* ids, u32 count)
+{
+	__shared__ i8 lastOfRow[WG];
+	__shared__ int waveMax[WG / 64];
+	__shared__ u32 runs;
+	const u32 nb = (u32)g.n / 16, id = ids[blockIdx.x], t = threadIdx.x;
+	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+	const i8* base = g.dist + ((size_t)(bz * 16) * g.n + by * 16) * g.n + bx * 16;
+	const uint4 raw = *(const uint4*)(base + ((size_t)(t >> 4) * g.n + (t & 15)) * g.n); // row t = (y = t & 15, z = t >> 4): codec order
+	i8 v[16];
+	memcpy(v, &raw, 16);
+	lastOfRow[t] = v[15];
+	if (t == 0) runs = 0;
+	__syncthreads();
+	const i8 first = base[0];
+	i8 prev = t ? lastOfRow[t - 1] : (i8)~v[0]; // voxel 0 always starts a run
+	int lastStart = -1;                         // last position in this row where the value changes
+	bool sameSign = true;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		if (v[j] != prev) lastStart = (int)t * 16 + j;
+		prev = v[j];
+		sameSign = sameSign && ((int)first * (int)v[j] > 0);
+	}
+	// start of the stretch that is open when this row begins = max of lastStart over the earlier rows
+	int incl = lastStart;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((int)(t & 63) >= d) incl = max(incl, o); }
+	if ((t & 63) == 63) waveMax[t >> 6] = incl;
+	__syncthreads();
+	int carry = __shfl_up(incl, 1);
+	if ((t & 63) == 0) carry = -1;
+	for (u32 w = 0; w < (t >> 6); ++w) carry = max(carry, waveMax[w]);
+	u32 myRuns = 0;
+	int start = carry;
+	prev = t ? lastOfRow[t - 1] : (i8)~v[0];
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		const int pos = (int)t * 16 + j;
+		if (v[j] != prev) start = pos;
+		prev = v[j];
+		if ((pos - start) % 255 == 0) ++myRuns;
+	}
+	if (myRuns) atomicAdd(&runs, myRuns);
+	const int allSame = __syncthreads_and(sameSign ? 1 : 0);
+	if (t == 0) flags[id] = (allSame && runs <= 2048u) ? 1 : 0;
+}
+
+// k_scatter_blocks: edited 16^3 blocks (4096 contiguous bytes each) into the dense fields; lane t owns voxel row t
+__global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
+{
+	const u32 nb = n >> 4, id = ids[blockIdx.x], t = threadIdx.x;
+	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+	const size_t rowOff = ((size_t)(bz * 16 + (t >> 4)) * n + by * 16 + (t & 15)) * n + bx * 16;
+	const size_t srcOff = (size_t)blockIdx.x * 4096 + t * 16;
+	if (sd) *(uint4*)(dist + rowOff) = *(const uint4*)(sd + srcOff);
+	if (sm) *(uint4*)(mat + rowOff) = *(const uint4*)(sm + srcOff);
+	if (sb) *(uint4*)(blend + rowOff) = *(const uint4*)(sb + srcOff);
+}
+
 // ---- start of a full run: header = 0, block -> slot maps = -1 (one launch instead of a memset per array) -------------
 struct ResetRanges {
 	u32* header;
@@ -1134,6 +1212,18 @@ struct Backend {
 		const u32 nb = n / 16;
 		hipLaunchKernelGGL(k_decode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, blob, (const unsigned long long*)where, n, dist, mat, blend, flags);
 		check(hipGetLastError(), "k_decode_grid launch");
+	}
+	bool d2d(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(D2D)"); }
+	void run_scatter_blocks(const u32* ids, u32 count, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
+	{
+		hipLaunchKernelGGL(k_scatter_blocks, dim3(count), dim3(WG), 0, stream, ids, n, sd, sm, sb, dist, mat, blend);
+		check(hipGetLastError(), "k_scatter_blocks launch");
+	}
+	void run_edit(const GridView& g, u8* flags, const u32* ids, u32 count, const EditParams& e)
+	{
+		hipLaunchKernelGGL(k_edit, dim3(count), dim3(WG), 0, stream, g, ids, e);
+		if (e.kind == EDIT_BALL) hipLaunchKernelGGL(k_edit_flags, dim3(count), dim3(WG), 0, stream, g, flags, ids, count);
+		check(hipGetLastError(), "k_edit launch");
 	}
 	void end_timing_record() { (void)hipEventRecord(ev1, stream); }
 	float elapsed_ms() // after the stream was synchronised

@@ -37,13 +37,7 @@ struct EmittedBlock {
 	BlockRecord rec;
 	u32 id;
 	float minc[3], maxc[3];
-	// meshes live in the downloaded pools (offsets in rec) until an incremental run needs the pools again; then
-	// every block takes ownership of a host copy
-	struct Meshes {
-		std::vector<PolyVertex> v, tv[6];
-		std::vector<u32> i, ti[6];
-	};
-	std::shared_ptr<Meshes> own;
+	// the meshes live in the output pools (offsets in rec): full runs rewrite the pools, incremental runs append to them
 };
 
 enum { HDR_WORDS = 192, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
@@ -78,12 +72,14 @@ struct vx_ctx {
 	std::vector<EmittedBlock> blocks[MAX_LEVELS];
 	std::vector<PolyVertex> hVerts;
 	std::vector<u32> hIdx;
-	bool poolsOnHost = false;
+	u32 hostVerts = 0, hostIdx = 0; // how much of the (append-only between full runs) pools the host mirror already holds
 	bool listsReady = false;
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
 	u32 hdr[HDR_WORDS];
 	u32* hdrPinned = nullptr; // pinned landing buffer of the header read-back
+	void* dScratch = nullptr;  // small reusable device buffer (block id lists of edits)
+	size_t scratchCap = 0;
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
 	size_t hRecCap = 0;
 	u32 debugPhaseLimit = 0;
@@ -278,29 +274,40 @@ void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
 	mx[0] = mn[0] + ext; mx[1] = mn[1] + ext; mx[2] = mn[2] + ext;
 }
 
+// host mirror of the output pools; between full runs the pools only grow, so only the new tail is copied
 bool fetch_pools(vx_ctx* c)
 {
-	if (c->poolsOnHost) return true;
-	c->hVerts.resize(c->poolVerts);
-	c->hIdx.resize(c->poolIdx);
-	if (c->poolVerts && !c->be.d2h(c->hVerts.data(), c->dVerts, (size_t)c->poolVerts * sizeof(PolyVertex))) return false;
-	if (c->poolIdx && !c->be.d2h(c->hIdx.data(), c->dIdx, (size_t)c->poolIdx * 4)) return false;
-	c->poolsOnHost = true;
+	if (c->hostVerts < c->poolVerts) {
+		c->hVerts.resize(c->poolVerts);
+		if (!c->be.d2h(c->hVerts.data() + c->hostVerts, (const PolyVertex*)c->dVerts + c->hostVerts, (size_t)(c->poolVerts - c->hostVerts) * sizeof(PolyVertex))) return false;
+		c->hostVerts = c->poolVerts;
+	}
+	if (c->hostIdx < c->poolIdx) {
+		c->hIdx.resize(c->poolIdx);
+		if (!c->be.d2h(c->hIdx.data() + c->hostIdx, (const u32*)c->dIdx + c->hostIdx, (size_t)(c->poolIdx - c->hostIdx) * 4)) return false;
+		c->hostIdx = c->poolIdx;
+	}
 	return true;
 }
 
-// copy a block's meshes out of the host pool image into the block itself
-void own_block(const vx_ctx* c, EmittedBlock& e)
+// grow the pools of an incremental run: what earlier runs wrote stays valid
+bool grow_pools_keeping(vx_ctx* c, u32 needVerts, u32 needIdx)
 {
-	if (e.own) return;
-	const BlockRecord& r = e.rec;
-	e.own = std::make_shared<EmittedBlock::Meshes>();
-	e.own->v.assign(c->hVerts.begin() + r.vOff, c->hVerts.begin() + r.vOff + r.vCount);
-	e.own->i.assign(c->hIdx.begin() + r.iOff, c->hIdx.begin() + r.iOff + r.iCount);
-	for (int f = 0; f < 6; ++f) {
-		e.own->tv[f].assign(c->hVerts.begin() + r.tvOff[f], c->hVerts.begin() + r.tvOff[f] + r.tvCount[f]);
-		e.own->ti[f].assign(c->hIdx.begin() + r.tiOff[f], c->hIdx.begin() + r.tiOff[f] + r.tiCount[f]);
+	if (needVerts > c->vertCap) {
+		void* nv = c->be.alloc((size_t)needVerts * sizeof(PolyVertex));
+		if (!nv) return false;
+		if (c->poolVerts && !c->be.d2d(nv, c->dVerts, (size_t)c->poolVerts * sizeof(PolyVertex))) { c->be.free(nv); return false; }
+		c->be.free(c->dVerts);
+		c->dVerts = nv; c->vertCap = needVerts;
 	}
+	if (needIdx > c->idxCap) {
+		void* ni = c->be.alloc((size_t)needIdx * 4);
+		if (!ni) return false;
+		if (c->poolIdx && !c->be.d2d(ni, c->dIdx, (size_t)c->poolIdx * 4)) { c->be.free(ni); return false; }
+		c->be.free(c->dIdx);
+		c->dIdx = ni; c->idxCap = needIdx;
+	}
+	return true;
 }
 
 // Block lists of a full run: every surface-bearing block with at least one regular vertex, in coordinate order; ids
@@ -395,6 +402,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
 	c->be.free_pinned(c->hdrPinned);
+	c->be.free(c->dScratch);
 	c->be.shutdown();
 	delete c;
 }
@@ -509,21 +517,98 @@ int vx_grid_update_blocks(vx_ctx* c, uint32_t count, const uint32_t* ids, const 
 	if (!c || !c->ownsGrid || !c->n) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: needs a grid uploaded with vx_grid_upload");
 	const u32 n = c->n, nb = n / 16;
 	bool ok = true;
-	for (u32 i = 0; i < count && ok; ++i) {
-		const u32 id = ids[i];
-		if (id >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: block id out of range");
-		const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
-		for (u32 z = 0; z < 16 && ok; ++z)
-		for (u32 y = 0; y < 16 && ok; ++y) {
-			const size_t dst = ((size_t)(bz * 16 + z) * n + (by * 16 + y)) * n + bx * 16;
-			const size_t src = (size_t)i * 4096 + z * 256 + y * 16;
-			if (dist) ok = ok && c->be.h2d((u8*)c->dDist + dst, dist + src, 16);
-			if (mat) ok = ok && c->be.h2d((u8*)c->dMat + dst, mat + src, 16);
-			if (blend) ok = ok && c->be.h2d((u8*)c->dBlend + dst, blend + src, 16);
+	for (u32 i = 0; i < count; ++i) if (ids[i] >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: block id out of range");
+	if (count && (dist || mat || blend)) {
+		// the blocks travel as they are (4096 contiguous bytes each) and are scattered into the dense fields on the device
+		const size_t bytes = (size_t)count * 4096;
+		void* dIds = c->be.alloc((size_t)count * 4);
+		void* stage[3] = { dist ? c->be.alloc(bytes) : nullptr, mat ? c->be.alloc(bytes) : nullptr, blend ? c->be.alloc(bytes) : nullptr };
+		const void* src[3] = { dist, mat, blend };
+		ok = dIds && c->be.h2d(dIds, ids, (size_t)count * 4);
+		for (int k = 0; k < 3 && ok; ++k) if (src[k]) ok = stage[k] && c->be.h2d(stage[k], src[k], bytes);
+		if (ok) {
+			c->be.run_scatter_blocks((const u32*)dIds, count, n, (const u8*)stage[0], (const u8*)stage[1], (const u8*)stage[2], (u8*)c->dDist, (u8*)c->dMat, (u8*)c->dBlend);
+			ok = c->be.sync_ok();
 		}
+		c->be.free(dIds);
+		for (int k = 0; k < 3; ++k) c->be.free(stage[k]);
 	}
 	if (flags) ok = ok && c->be.h2d(c->dFlags, flags, (size_t)nb * nb * nb);
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_update_blocks: copy failed: " + c->be.error());
+}
+
+namespace {
+
+// blocks the reference refreshes for an edit at pos +- ext (VoxelGrid.cpp:341-366: the test uses the FULL extents on
+// both sides, twice the edited box) and the box it reports (:477-487, output order)
+void edit_touched_blocks(u32 n, const float pos[3], const float ext[3], std::vector<u32>& out)
+{
+	const u32 nb = n / 16;
+	for (u32 z = 0; z < nb; ++z) for (u32 y = 0; y < nb; ++y) for (u32 x = 0; x < nb; ++x) {
+		const float bmin[3] = { (float)(x * 16), (float)(y * 16), (float)(z * 16) };
+		bool hit = true;
+		for (int k = 0; k < 3; ++k) {
+			const float bmax = (bmin[k] + 8.f) + 8.f;
+			if (pos[k] - ext[k] > bmax || bmin[k] > pos[k] + ext[k]) hit = false;
+		}
+		if (hit) out.push_back((z * nb + y) * nb + x);
+	}
+}
+
+void edit_modified_box(u32 n, const float pos[3], const float ext[3], float outMin[3], float outMax[3])
+{
+	const float p[3] = { pos[0] - ext[0] / 2.0f, pos[1] - ext[1] / 2.0f, pos[2] - ext[2] / 2.0f };
+	outMin[0] = std::max(0.f, p[0]); outMin[1] = std::max(0.f, p[2]); outMin[2] = std::max(0.f, p[1]);
+	outMax[0] = std::min((float)n, outMin[0] + ext[0]);
+	outMax[1] = std::min((float)n, outMin[1] + ext[2]);
+	outMax[2] = std::min((float)n, outMin[2] + ext[1]);
+}
+
+int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3], const EditParams& e, float outMin[3], float outMax[3])
+{
+	if (!c || !pos || !ext || !outMin || !outMax) return fail(c, VX_ERR_INVALID, std::string(what) + ": null argument");
+	if (!c->ownsGrid || !c->n || c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, std::string(what) + ": needs a whole grid owned by the context (vx_grid_upload / vx_grid_upload_packed)");
+	std::vector<u32> touched;
+	edit_touched_blocks(c->n, pos, ext, touched);
+	edit_modified_box(c->n, pos, ext, outMin, outMax);
+	if (touched.empty()) return VX_OK;
+	if (touched.size() * 4 > c->scratchCap) {
+		c->be.free(c->dScratch);
+		c->scratchCap = touched.size() * 4 + 4096;
+		c->dScratch = c->be.alloc(c->scratchCap);
+		if (!c->dScratch) { c->scratchCap = 0; return fail(c, VX_ERR_DEVICE, std::string(what) + ": allocation failed"); }
+	}
+	void* dIds = c->dScratch;
+	bool ok = c->be.h2d(dIds, touched.data(), touched.size() * 4);
+	if (ok) {
+		GridView g;
+		g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
+		g.n = (int)c->n; g.zOrigin = 0; g.zOriginMat = 0;
+		c->be.run_edit(g, (u8*)c->dFlags, (const u32*)dIds, (u32)touched.size(), e);
+		ok = c->be.sync_ok();
+	}
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device edit failed: " + c->be.error());
+}
+
+} // namespace
+
+int vx_grid_inject_ball(vx_ctx* c, const float pos[3], const float ext[3], float radius, int type, float outMin[3], float outMax[3])
+{
+	if (type < 0 || type > 2) return fail(c, VX_ERR_INVALID, "vx_grid_inject_ball: unknown injection type");
+	EditParams e;
+	memset(&e, 0, sizeof(e));
+	if (pos && ext) for (int k = 0; k < 3; ++k) { e.pos[k] = pos[k]; e.ext[k] = ext[k]; }
+	e.kind = EDIT_BALL; e.type = type; e.radius = radius;
+	return run_edit(c, "vx_grid_inject_ball", pos, ext, e, outMin, outMax);
+}
+
+int vx_grid_inject_material(vx_ctx* c, const float pos[3], const float ext[3], uint8_t material, int add, float outMin[3], float outMax[3])
+{
+	EditParams e;
+	memset(&e, 0, sizeof(e));
+	if (pos && ext) for (int k = 0; k < 3; ++k) { e.pos[k] = pos[k]; e.ext[k] = ext[k]; }
+	e.kind = EDIT_MATERIAL; e.material = material; e.add = add ? 1 : 0;
+	return run_edit(c, "vx_grid_inject_material", pos, ext, e, outMin, outMax);
 }
 
 int vx_material_lut(vx_ctx* c, const uint8_t* lut, const uint8_t* valid)
@@ -583,7 +668,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	}
 	c->levelsRun = levels;
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
-	c->poolsOnHost = false;
+	c->hostVerts = 0; c->hostIdx = 0; // the pools were rewritten
 	c->haveSurface = true;
 	c->listsReady = false; // block lists (record read-back + ordering) are materialised on first access
 	u32 idBase = 0;
@@ -629,13 +714,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on z-slabs");
 	const u32 levels = c->levelsRun;
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
-	// the pools are about to be reused: every existing block takes a host copy of its meshes
-	bool anyInPool = false;
-	for (u32 L = 0; L < levels; ++L) for (const EmittedBlock& e : c->blocks[L]) if (!e.own) anyInPool = true;
-	if (anyInPool) {
-		if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
-		for (u32 L = 0; L < levels; ++L) for (EmittedBlock& e : c->blocks[L]) own_block(c, e);
-	}
+	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is
 	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
 	std::vector<u32> coords, ids;
 	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
@@ -687,7 +766,13 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		for (u32 L = 0; L < levels; ++L) { p.G.workItems[L] = (const u32*)c->dWork + start[L]; p.G.prevActive[L] = prevActive[L]; }
 		c->be.begin_timing();
 		c->be.stage_mark(0);
-		c->be.fill((u32*)c->dHeader + HDR_CURSORS, 0, (HDR_WORDS - HDR_CURSORS) * 4); // cursors, stats, work counts — NOT the slot counts
+		{
+			// cursors (continuing at the pools' current ends), stats, work counts — NOT the slot counts
+			u32 tail[HDR_WORDS - HDR_CURSORS];
+			memset(tail, 0, sizeof(tail));
+			tail[CUR_V] = c->poolVerts; tail[CUR_I] = c->poolIdx;
+			if (!c->be.h2d((u32*)c->dHeader + HDR_CURSORS, tail, sizeof(tail))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: header upload failed");
+		}
 		c->be.stage_mark(1);
 		c->be.run_classify_blocks(p, (const u32*)c->dDirty + start[0], cnt[0]);
 		c->be.stage_mark(2);
@@ -706,12 +791,10 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
-		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+		if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
-	c->poolsOnHost = false;
-	if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pool download failed: " + c->be.error());
 	std::vector<BlockRecord> recs(total);
 	if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
 	u32 trivialBlocks = c->hdr[HDR_STATS + 2];
@@ -733,7 +816,6 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			e.rec = r;
 			e.id = ids[start[L] + k];
 			block_corners(d, coord, e.minc, e.maxc);
-			own_block(c, e);
 			c->blocks[L].push_back(std::move(e));
 		}
 		if (L) trivialBlocks += cnt[L];
@@ -774,9 +856,7 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 {
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
-	bool needPools = false;
-	for (const EmittedBlock& e : c->blocks[level]) if (!e.own) needPools = true;
-	if ((verts || idx || tverts || tidx) && needPools && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
+	if ((verts || idx || tverts || tidx) && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
 	size_t ov = 0, oi = 0, otv = 0, oti = 0, k = 0;
 	for (const EmittedBlock& e : c->blocks[level]) {
 		const BlockRecord& r = e.rec;
@@ -787,14 +867,14 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 			memcpy(b.min_corner, e.minc, 12); memcpy(b.max_corner, e.maxc, 12);
 		}
 		++k;
-		if (verts && r.vCount) memcpy(verts + ov, e.own ? e.own->v.data() : c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
+		if (verts && r.vCount) memcpy(verts + ov, c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
 		ov += r.vCount;
-		if (idx && r.iCount) memcpy(idx + oi, e.own ? e.own->i.data() : c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
+		if (idx && r.iCount) memcpy(idx + oi, c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
 		oi += r.iCount;
 		for (int f = 0; f < 6; ++f) {
-			if (tverts && r.tvCount[f]) memcpy(tverts + otv, e.own ? e.own->tv[f].data() : c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
+			if (tverts && r.tvCount[f]) memcpy(tverts + otv, c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
 			otv += r.tvCount[f];
-			if (tidx && r.tiCount[f]) memcpy(tidx + oti, e.own ? e.own->ti[f].data() : c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
+			if (tidx && r.tiCount[f]) memcpy(tidx + oti, c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
 			oti += r.tiCount[f];
 		}
 	}
@@ -817,7 +897,6 @@ int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	size_t k = 0;
 	for (const EmittedBlock& e : c->blocks[level]) {
-		if (e.own) return fail(c, VX_ERR_INVALID, "vx_level_ranges: blocks kept from before an incremental run are no longer in the device pools");
 		vx_block_ranges& r = ranges[k++];
 		r.v_off = e.rec.vOff; r.i_off = e.rec.iOff;
 		for (int f = 0; f < 6; ++f) { r.tv_off[f] = e.rec.tvOff[f]; r.ti_off[f] = e.rec.tiOff[f]; }
