@@ -117,6 +117,12 @@ int vx_polygonize(vx_ctx* ctx, uint32_t num_levels, vx_exec_info* info);
 int vx_polygonize_dirty(vx_ctx* ctx, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
                         uint32_t* modified_ids, uint32_t cap, uint32_t* count);
 
+/* Incremental runs append rebuilt blocks to the output pools and leave the replaced blocks' ranges behind.  This packs
+ * the live meshes to the front of fresh pools on the device (offsets reported by vx_level_ranges change, contents and
+ * order of everything downloaded do not).  vx_polygonize_dirty calls it by itself once more than half of the pools is
+ * dead; applications holding device pointers may call it at a time of their choosing. */
+int vx_compact_pools(vx_ctx* ctx);
+
 /* ---- results (PolygonSurface accessors, include/Polygonizer.h:136-178) ------------------------------- */
 int vx_level_counts(vx_ctx* ctx, uint32_t level, uint32_t* n_blocks, uint64_t totals[4] /* verts, idx, tverts, tidx */);
 /* Blocks of one level in GetBlockForLevel order, concatenated: regular vertices/indices, then per block the

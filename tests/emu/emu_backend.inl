@@ -66,6 +66,11 @@ struct Backend {
 		}
 	}
 	bool d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
+	{
+		for (u32 i = 0; i < count; ++i)
+			memcpy((u8*)dst + (size_t)seg[i * 3 + 1] * elemBytes, (const u8*)src + (size_t)seg[i * 3] * elemBytes, (size_t)seg[i * 3 + 2] * elemBytes);
+	}
 	void run_scatter_blocks(const u32* ids, u32 count, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
 	{
 		const u32 nb = n / 16;

@@ -339,3 +339,32 @@ def check_device_edits(p, port, n, seed, surface_tol=0.0):
 
 def test_emu_device_edits(emu, port):
     check_device_edits(make_poly(emu), port, 64, 23)
+
+
+def check_compaction(p, port, n):
+    """Pools after a chain of edits hold dead ranges; vx_compact_pools packs the live meshes into fresh pools without
+    changing anything a caller can download, and further incremental runs keep working."""
+    from voxels_amd import synth
+    d0, m0, b0 = synth.terrain(n, seed=31)
+    g = port.grid_from_dense(d0, m0, b0)
+    s = port.execute(g)
+    p.upload_packed(g.pack())
+    p.execute()
+    c = n / 2.0
+    for i, (pos, r) in enumerate((((c, c, c), 6.0), ((c + 5, c - 3, c + 2), 5.0), ((c - 6, c + 4, c - 1), 7.0))):
+        mn, mx = g.inject_ball(pos, (2 * r + 4,) * 3, r, 2)
+        p.inject_ball(pos, (2 * r + 4,) * 3, r, 2)
+        port.execute_modify(g, s, mn, mx)
+        p.execute_dirty(mn, mx)
+        before = p.device_meshes()
+        p.compact_pools()
+        after = p.device_meshes()
+        assert after[2] <= before[2] and after[3] <= before[3]
+        live_v = sum(int(p.level(l, with_data=False).infos["n_verts"].sum() + p.level(l, with_data=False).infos["n_tverts"].sum()) for l in range(len(s.all_levels())))
+        assert after[2] == live_v, "compaction leaves exactly the live vertices"
+        ok, msg = fields.surface_equal(p.all_levels(), s.all_levels(), nrm_tol=1e-5)
+        assert ok, "after compaction %d: %s" % (i, msg)
+
+
+def test_emu_pool_compaction(emu, port):
+    check_compaction(make_poly(emu), port, 64)

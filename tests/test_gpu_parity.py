@@ -425,3 +425,10 @@ def test_hip_device_edits(poly, port, n):
     k_edit_flags — voxel data, flags, modified box, rebuilt block ids and the surface after every edit of a chain."""
     from test_emu import check_device_edits
     check_device_edits(poly, port, n, 23, surface_tol=NRM_TOL)
+
+
+@pytest.mark.gpu
+def test_hip_pool_compaction(poly, port):
+    """vx_compact_pools after incremental runs: live meshes packed on the device, downloads unchanged."""
+    from test_emu import check_compaction
+    check_compaction(poly, port, 128)

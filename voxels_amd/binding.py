@@ -50,6 +50,7 @@ class HipLibrary:
         lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
+        lib.vx_compact_pools.argtypes = [vp]
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
@@ -155,6 +156,9 @@ class Polygonizer:
         mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
         self._check(self._lib.vx_grid_inject_material(self._h, _ptr(pos), _ptr(ext), int(material), int(bool(add)), _ptr(mn), _ptr(mx)), "vx_grid_inject_material")
         return mn, mx
+
+    def compact_pools(self):
+        self._check(self._lib.vx_compact_pools(self._h), "vx_compact_pools")
 
     def device_meshes(self):
         """(device pointer of the vertex pool, of the index pool, vertices, indices) of the last full run."""

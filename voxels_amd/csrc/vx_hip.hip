@@ -285,6 +285,14 @@ __global__ __launch_bounds__(WG) void k_edit_flags(GridView g, u8* flags, const 
 	if (t == 0) flags[id] = (allSame && runs <= 2048u) ? 1 : 0;
 }
 
+// k_copy_segments: pool compaction — segment i moves `count` elements from src[srcOff] to dst[dstOff]; elements are
+// 48-byte vertices or 4-byte indices, moved as dwords (both pools are at least 4-byte aligned at any element)
+__global__ __launch_bounds__(WG) void k_copy_segments(const u32* seg, const u32* src, u32* dst, u32 dwordsPerElem)
+{
+	const u32 s = seg[blockIdx.x * 3] * dwordsPerElem, d = seg[blockIdx.x * 3 + 1] * dwordsPerElem, n = seg[blockIdx.x * 3 + 2] * dwordsPerElem;
+	for (u32 i = threadIdx.x; i < n; i += WG) dst[d + i] = src[s + i];
+}
+
 // k_scatter_blocks: edited 16^3 blocks (4096 contiguous bytes each) into the dense fields; lane t owns voxel row t
 __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
 {
@@ -1214,6 +1222,12 @@ struct Backend {
 		check(hipGetLastError(), "k_decode_grid launch");
 	}
 	bool d2d(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(D2D)"); }
+	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
+	{
+		if (!count) return;
+		hipLaunchKernelGGL(k_copy_segments, dim3(count), dim3(WG), 0, stream, seg, (const u32*)src, (u32*)dst, elemBytes / 4);
+		check(hipGetLastError(), "k_copy_segments launch");
+	}
 	void run_scatter_blocks(const u32* ids, u32 count, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
 	{
 		hipLaunchKernelGGL(k_scatter_blocks, dim3(count), dim3(WG), 0, stream, ids, n, sd, sm, sb, dist, mat, blend);

@@ -706,6 +706,62 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 
 // Incremental re-polygonization (TransVoxelRun::Execute with a Modification, TransVoxelImpl.cpp:429-465): per level the
 // blocks of the dirty box plus one ring are dropped and rebuilt; the material caches keep their old contents.
+namespace {
+
+// live vertices / indices according to the block lists
+void live_totals(const vx_ctx* c, uint64_t& verts, uint64_t& idx)
+{
+	verts = idx = 0;
+	for (u32 L = 0; L < c->levelsRun; ++L) for (const EmittedBlock& e : c->blocks[L]) {
+		verts += e.rec.vCount; idx += e.rec.iCount;
+		for (int f = 0; f < 6; ++f) { verts += e.rec.tvCount[f]; idx += e.rec.tiCount[f]; }
+	}
+}
+
+} // namespace
+
+int vx_compact_pools(vx_ctx* c)
+{
+	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_compact_pools: no surface");
+	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
+	uint64_t liveV, liveI;
+	live_totals(c, liveV, liveI);
+	if (liveV == c->poolVerts && liveI == c->poolIdx) return VX_OK; // nothing dead
+	// copy list: (source offset, destination offset, count) per mesh, vertices first then indices
+	std::vector<u32> segV, segI;
+	u32 nv = 0, ni = 0;
+	auto moveV = [&](u32& off, u32 count) { if (count) { segV.push_back(off); segV.push_back(nv); segV.push_back(count); } off = nv; nv += count; };
+	auto moveI = [&](u32& off, u32 count) { if (count) { segI.push_back(off); segI.push_back(ni); segI.push_back(count); } off = ni; ni += count; };
+	std::vector<EmittedBlock> moved[MAX_LEVELS];
+	for (u32 L = 0; L < c->levelsRun; ++L) {
+		moved[L] = c->blocks[L];
+		for (EmittedBlock& e : moved[L]) {
+			moveV(e.rec.vOff, e.rec.vCount); moveI(e.rec.iOff, e.rec.iCount);
+			for (int f = 0; f < 6; ++f) { moveV(e.rec.tvOff[f], e.rec.tvCount[f]); moveI(e.rec.tiOff[f], e.rec.tiCount[f]); }
+		}
+	}
+	const u32 capV = std::max<u32>(nv + nv / 8 + 1024, 1u << 16), capI = std::max<u32>(ni + ni / 8 + 4096, 1u << 18);
+	void* newV = c->be.alloc((size_t)capV * sizeof(PolyVertex));
+	void* newI = c->be.alloc((size_t)capI * 4);
+	void* dSeg = c->be.alloc((segV.size() + segI.size() + 4) * 4);
+	bool ok = newV && newI && dSeg;
+	if (ok && !segV.empty()) ok = c->be.h2d(dSeg, segV.data(), segV.size() * 4);
+	if (ok && !segI.empty()) ok = c->be.h2d((u32*)dSeg + segV.size(), segI.data(), segI.size() * 4);
+	if (ok) {
+		c->be.run_copy_segments((const u32*)dSeg, (u32)(segV.size() / 3), c->dVerts, newV, (u32)sizeof(PolyVertex));
+		c->be.run_copy_segments((const u32*)dSeg + segV.size(), (u32)(segI.size() / 3), c->dIdx, newI, 4u);
+		ok = c->be.sync_ok();
+	}
+	c->be.free(dSeg);
+	if (!ok) { c->be.free(newV); c->be.free(newI); return fail(c, VX_ERR_DEVICE, "vx_compact_pools: device copy failed: " + c->be.error()); }
+	c->be.free(c->dVerts); c->be.free(c->dIdx);
+	c->dVerts = newV; c->dIdx = newI; c->vertCap = capV; c->idxCap = capI;
+	c->poolVerts = nv; c->poolIdx = ni;
+	c->hostVerts = 0; c->hostIdx = 0; // the host mirror describes the old layout
+	for (u32 L = 0; L < c->levelsRun; ++L) c->blocks[L].swap(moved[L]);
+	return VX_OK;
+}
+
 int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
                         uint32_t* modified_ids, uint32_t cap, uint32_t* count)
 {
@@ -714,7 +770,16 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on z-slabs");
 	const u32 levels = c->levelsRun;
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
-	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is
+	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;
+	// once more than half of the pools is dead they are packed first
+	{
+		uint64_t liveV, liveI;
+		live_totals(c, liveV, liveI);
+		if ((uint64_t)c->poolVerts > 2 * liveV + (1u << 16) || (uint64_t)c->poolIdx > 2 * liveI + (1u << 18)) {
+			const int rc = vx_compact_pools(c);
+			if (rc != VX_OK) return rc;
+		}
+	}
 	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
 	std::vector<u32> coords, ids;
 	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
