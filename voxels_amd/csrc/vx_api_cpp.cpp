@@ -67,9 +67,9 @@ Grid* Grid::Create(unsigned w, const char* heightmap)
 	return new Grid(VoxelGrid::FromHeightmap(w, heightmap));
 }
 
-Grid* Grid::Load(const char* blob, unsigned)
+Grid* Grid::Load(const char* blob, unsigned size)
 {
-	VoxelGrid* g = blob ? VoxelGrid::Load(blob) : nullptr;
+	VoxelGrid* g = blob ? VoxelGrid::Load(blob, size) : nullptr;
 	if (!g) { Log(LS_Error, "Voxel grid file version not supported!"); return nullptr; }
 	return new Grid(g);
 }
@@ -304,7 +304,13 @@ public:
 		std::vector<uint8_t> flags;
 		g.EmptyFlags(flags);
 		if (ResidentGrid != &g) {
-			if (vx_grid_upload(Ctx, g.Size(), g.Distances(), g.Materials(), g.Blends(), flags.data()) != VX_OK) return false;
+			// a grid that came from Grid::Load and was not edited since travels as its (much smaller) file and is
+			// expanded on the device; anything else as dense fields
+			const std::vector<char>* file = g.PristineFile();
+			const int rc = file ? vx_grid_upload_packed(Ctx, file->data(), file->size())
+			                    : vx_grid_upload(Ctx, g.Size(), g.Distances(), g.Materials(), g.Blends(), flags.data());
+			if (rc != VX_OK) return false;
+			g.DropFile();
 			ResidentGrid = &g;
 		} else if (ResidentGeneration != g.Generation()) {
 			std::vector<uint32_t> ids = g.DirtyBlocks();

@@ -169,7 +169,7 @@ VoxelGrid* VoxelGrid::FromHeightmap(uint32_t n, const char* heightmap)
 }
 
 // :215-267 (file format v1)
-VoxelGrid* VoxelGrid::Load(const char* blob)
+VoxelGrid* VoxelGrid::Load(const char* blob, size_t size)
 {
 	const char* p = blob;
 	auto get32 = [&p]() { uint32_t v; memcpy(&v, p, 4); p += 4; return v; };
@@ -188,6 +188,10 @@ VoxelGrid* VoxelGrid::Load(const char* blob)
 		g->Scatter(g->m_Mat.data(), bx, by, bz, tmp);
 		Decode<uint8_t>((const uint8_t*)p, m.sizeBlend, (m.flags & BF_BlendUncompressed) != 0, tmp); p += m.sizeBlend;
 		g->Scatter(g->m_Blend.data(), bx, by, bz, tmp);
+	}
+	if (size >= (size_t)(p - blob)) { // keep the file: the polygonizer's first upload sends it instead of the dense fields
+		g->m_File.assign(blob, p);
+		g->m_FileGeneration = g->m_Generation;
 	}
 	return g;
 }

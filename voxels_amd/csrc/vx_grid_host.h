@@ -25,7 +25,7 @@ public:
 
 	static VoxelGrid* FromSurface(uint32_t n, float sx, float sy, float sz, float step, VoxelSurface* surface);
 	static VoxelGrid* FromHeightmap(uint32_t n, const char* heightmap);
-	static VoxelGrid* Load(const char* blob);
+	static VoxelGrid* Load(const char* blob, size_t size = 0);
 	void Pack(std::vector<char>& out) const;
 
 	uint32_t Size() const { return m_N; }
@@ -50,6 +50,10 @@ public:
 	uint64_t Generation() const { return m_Generation; }
 	const std::vector<uint32_t>& DirtyBlocks() const { return m_Dirty; }
 	void ClearDirty() { m_Dirty.clear(); }
+	// the file a grid was loaded from, kept until the first upload so that the device can expand it itself
+	// (valid only while nothing was edited since the load)
+	const std::vector<char>* PristineFile() const { return (m_FileGeneration == m_Generation && !m_File.empty()) ? &m_File : nullptr; }
+	void DropFile() { std::vector<char>().swap(m_File); }
 
 private:
 	void Gather(const uint8_t* src, uint32_t bx, uint32_t by, uint32_t bz, uint8_t* out) const;
@@ -65,6 +69,8 @@ private:
 	std::vector<BlockMeta> m_Meta;
 	uint64_t m_Generation;
 	std::vector<uint32_t> m_Dirty;
+	std::vector<char> m_File;
+	uint64_t m_FileGeneration = 0;
 };
 
 } // namespace Voxels
