@@ -28,8 +28,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("VOXELS_BENCH_N", "1024")))
     ap.add_argument("--levels", type=int, default=int(os.environ.get("VOXELS_BENCH_LEVELS", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
