@@ -78,6 +78,11 @@ int vx_grid_upload(vx_ctx* ctx, uint32_t n, const int8_t* dist, const uint8_t* m
  * (CompressBlock / DecompressBlock, :610-694).  The blob goes to the device as it is and is expanded there; BF_Empty
  * comes from the per-block flags.  Replaces Grid::Load + vx_grid_upload (no host decode, no 3 bytes/voxel transfer). */
 int vx_grid_upload_packed(vx_ctx* ctx, const void* blob, uint64_t size);
+/* The resident grid as a Grid file (Grid::PackForSave, src/VoxelGrid.cpp:269-315): every block is run-length encoded on
+ * the device by the codec's rules (runs of at most 255; a stream whose code would exceed 4096 bytes is stored raw and
+ * flagged), the file is assembled in `out`.  Byte-identical to what the reference writes for the same grid.
+ * *size receives the file size; with out == NULL (or capacity too small: VX_ERR_INVALID) nothing is written. */
+int vx_grid_pack(vx_ctx* ctx, void* out, uint64_t capacity, uint64_t* size);
 /* One 16^3 block of the resident grid back to the host, x fastest (Grid::GetBlockDistanceData / GetBlockMaterialData,
  * src/VoxelGrid.cpp:586-608); any output may be NULL.  empty_flag receives BF_Empty. */
 int vx_grid_read_block(vx_ctx* ctx, uint32_t block_id, int8_t* dist, uint8_t* mat, uint8_t* blend, uint8_t* empty_flag);

@@ -65,6 +65,26 @@ struct Backend {
 			if (e.kind == EDIT_BALL) flags[id] = edit_block_empty(g, bx, by, bz);
 		}
 	}
+	// Grid file format v1 written block by block (the HIP backend does this in k_encode_grid)
+	void run_encode_grid(const GridView& g, u32* meta, const uint64_t* where, u8* blob)
+	{
+		const u32 n = (u32)g.n, nb = n / 16;
+		const u8* arrays[3] = { (const u8*)g.dist, g.mat, g.blend };
+		for (u32 id = 0; id < nb * nb * nb; ++id) {
+			const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+			u32 flags = edit_block_empty(g, bx, by, bz) ? 1u : 0u;
+			u8* dst = blob ? blob + where[id] + 4 : nullptr;
+			for (int s = 0; s < 3; ++s) {
+				const u8* a = arrays[s];
+				bool raw;
+				const u32 sz = encode_stream_serial([&](u32 r) { return a + ((size_t)(bz * 16 + (r >> 4)) * n + by * 16 + (r & 15)) * n + bx * 16; }, dst, raw);
+				if (raw) flags |= 2u << s;
+				if (!blob) meta[id * 4 + s] = sz;
+				if (dst) dst += sz;
+			}
+			if (!blob) meta[id * 4 + 3] = flags; else memcpy(blob + where[id], &flags, 4);
+		}
+	}
 	bool d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
 	{

@@ -368,3 +368,27 @@ def check_compaction(p, port, n):
 
 def test_emu_pool_compaction(emu, port):
     check_compaction(make_poly(emu), port, 64)
+
+
+def check_pack(p, port, n, seed, noisy):
+    """vx_grid_pack (device RLE encode) writes byte for byte the file the reference's PackForSave writes — for a
+    grid uploaded dense, after a round trip through the packed upload, and after edits made on the device."""
+    d, m, b = _packed_case(n, seed, noisy)
+    g = port.grid_from_dense(d, m, b)
+    want = g.pack()
+    p.upload(d, m, b, g.block_flags())
+    got = p.pack()
+    assert got.size == want.size and np.array_equal(got, want), "dense upload -> pack"
+    p.upload_packed(want)
+    assert np.array_equal(p.pack(), want), "packed upload -> pack"
+    c = n / 2.0
+    g.inject_ball((c, c - 1.5, c + 2.0), (18, 18, 18), 6.0, 2)
+    p.inject_ball((c, c - 1.5, c + 2.0), (18, 18, 18), 6.0, 2)
+    g.inject_material((c + 1, c, c - 2.0), (12, 12, 12), 2, True)
+    p.inject_material((c + 1, c, c - 2.0), (12, 12, 12), 2, True)
+    assert np.array_equal(p.pack(), g.pack()), "after device edits"
+
+
+@pytest.mark.parametrize("noisy", [False, True])
+def test_emu_grid_pack(emu, port, noisy):
+    check_pack(make_poly(emu), port, 64, 41, noisy)

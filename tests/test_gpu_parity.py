@@ -432,3 +432,11 @@ def test_hip_pool_compaction(poly, port):
     """vx_compact_pools after incremental runs: live meshes packed on the device, downloads unchanged."""
     from test_emu import check_compaction
     check_compaction(poly, port, 128)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,noisy", [(128, False), (64, True)])
+def test_hip_grid_pack(poly, port, n, noisy):
+    """§8(f) row 1, encode half: k_encode_grid writes the reference's file byte for byte."""
+    from test_emu import check_pack
+    check_pack(poly, port, n, 43, noisy)

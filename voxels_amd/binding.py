@@ -51,6 +51,7 @@ class HipLibrary:
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
         lib.vx_compact_pools.argtypes = [vp]
+        lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
@@ -134,6 +135,14 @@ class Polygonizer:
         blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob.view(np.uint8))
         self._check(self._lib.vx_grid_upload_packed(self._h, _ptr(blob), blob.size), "vx_grid_upload_packed")
         self.n = int(np.frombuffer(blob[4:8].tobytes(), np.uint32)[0])
+
+    def pack(self):
+        """Grid::PackForSave of the resident grid (encoded on the device) -> uint8 array."""
+        size = C.c_uint64()
+        self._check(self._lib.vx_grid_pack(self._h, None, 0, C.byref(size)), "vx_grid_pack")
+        out = np.zeros(size.value, np.uint8)
+        self._check(self._lib.vx_grid_pack(self._h, _ptr(out), out.size, C.byref(size)), "vx_grid_pack")
+        return out
 
     def read_block(self, block_id):
         """(dist int8[16,16,16] (z,y,x), mat, blend, BF_Empty) of one resident block."""

@@ -1189,4 +1189,31 @@ TV_HD u8 edit_block_empty(const GridView& g, u32 bx, u32 by, u32 bz)
 	return empty ? 1 : 0;
 }
 
+// CompressBlock (src/VoxelGrid.cpp:610-672) on one 4096-byte stream given as 256 rows of 16 bytes with stride
+// `rowStride(row)`: returns the coded size (2 bytes per run, runs of at most 255) or 4096 when the code would not fit
+// (then the stream is stored raw); with `out` the bytes are written too.
+template <typename RowFn>
+TV_HD u32 encode_stream_serial(const RowFn& rowPtr, u8* out, bool& raw)
+{
+	u32 runs = 1;
+	{
+		u8 last = rowPtr(0)[0];
+		u32 counter = 0;
+		for (u32 r = 0; r < 256; ++r) { const u8* row = rowPtr(r); for (u32 x = 0; x < 16; ++x) { const u8 cur = row[x]; if (last == cur && counter < 0xFF) { ++counter; continue; } ++runs; counter = 1; last = cur; } }
+	}
+	raw = runs > 2048;
+	if (!out) return raw ? 4096u : 2u * runs;
+	if (raw) { for (u32 r = 0; r < 256; ++r) { const u8* row = rowPtr(r); for (u32 x = 0; x < 16; ++x) out[r * 16 + x] = row[x]; } return 4096u; }
+	u8 last = rowPtr(0)[0];
+	u32 counter = 0, w = 0;
+	for (u32 r = 0; r < 256; ++r) { const u8* row = rowPtr(r); for (u32 x = 0; x < 16; ++x) {
+		const u8 cur = row[x];
+		if (last == cur && counter < 0xFF) { ++counter; continue; }
+		out[w++] = (u8)counter; out[w++] = last;
+		counter = 1; last = cur;
+	} }
+	out[w++] = (u8)counter; out[w++] = last;
+	return w;
+}
+
 } // namespace tv

@@ -293,6 +293,104 @@ __global__ __launch_bounds__(WG) void k_copy_segments(const u32* seg, const u32*
 	for (u32 i = threadIdx.x; i < n; i += WG) dst[d + i] = src[s + i];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_encode_grid: dense fields -> Grid file format v1 (CompressBlock for every stream of every block).  One workgroup
+// per block; lane t owns the 16-byte row t (codec order).  Run starts = value changes and every 255 voxels inside a
+// constant stretch (start of the stretch by a workgroup-wide max-scan); run ids by an exclusive scan of the start
+// counts; a run's length is the distance to the next start.  Pass 1 (blob == nullptr) writes sizes + flags, pass 2
+// writes the records at the offsets the host derived from them.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_encode_grid(GridView g, u32* meta, const unsigned long long* where, u8* blob)
+{
+	__shared__ u8 lastOfRow[WG];
+	__shared__ int waveMax[WG / 64];
+	__shared__ u32 waveSum[WG / 64];
+	__shared__ u16 startPos[2048 + 2];
+	__shared__ u8 vals[2048];
+	const u32 n = (u32)g.n, nb = n >> 4, id = blockIdx.x, t = threadIdx.x;
+	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
+	const size_t rowOff = ((size_t)(bz * 16 + (t >> 4)) * n + by * 16 + (t & 15)) * n + bx * 16;
+	u8* dst = blob ? blob + where[id] + 4 : nullptr;
+	u32 flags = 0;
+#pragma unroll 1
+	for (u32 s = 0; s < 3; ++s) {
+		const u8* src = (s == 0 ? (const u8*)g.dist : (s == 1 ? g.mat : g.blend)) + rowOff;
+		const uint4 rawRow = *(const uint4*)src;
+		u8 v[16];
+		memcpy(v, &rawRow, 16);
+		__syncthreads(); // LDS of the previous stream is free
+		lastOfRow[t] = v[15];
+		__syncthreads();
+		u8 prev = t ? lastOfRow[t - 1] : (u8)~v[0]; // voxel 0 always starts a run
+		int lastStart = -1;
+#pragma unroll
+		for (int j = 0; j < 16; ++j) { if (v[j] != prev) lastStart = (int)t * 16 + j; prev = v[j]; }
+		int incl = lastStart;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((int)(t & 63) >= d) incl = max(incl, o); }
+		if ((t & 63) == 63) waveMax[t >> 6] = incl;
+		__syncthreads();
+		int start = __shfl_up(incl, 1);
+		if ((t & 63) == 0) start = -1;
+		for (u32 w = 0; w < (t >> 6); ++w) start = max(start, waveMax[w]);
+		u32 startMask = 0; // which of this row's voxels start a run
+		prev = t ? lastOfRow[t - 1] : (u8)~v[0];
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			const int pos = (int)t * 16 + j;
+			if (v[j] != prev) start = pos;
+			prev = v[j];
+			if ((pos - start) % 255 == 0) startMask |= 1u << j;
+		}
+		// exclusive scan of the start counts -> id of this row's first run; total = number of runs
+		const u32 mine = (u32)__popc(startMask);
+		u32 inclSum = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inclSum, d); if ((int)(t & 63) >= d) inclSum += o; }
+		if ((t & 63) == 63) waveSum[t >> 6] = inclSum;
+		__syncthreads();
+		u32 base = inclSum - mine, runs = 0;
+		for (u32 w = 0; w < WG / 64; ++w) { if (w < (t >> 6)) base += waveSum[w]; runs += waveSum[w]; }
+		const bool raw = runs > 2048u;
+		const u32 sz = raw ? 4096u : 2u * runs;
+		if (raw) flags |= 2u << s;
+		if (!blob) {
+			if (t == 0) meta[id * 4 + s] = sz;
+		} else if (raw) {
+#pragma unroll
+			for (int j = 0; j < 16; ++j) dst[t * 16 + j] = v[j];
+		} else {
+			u32 r = base;
+			u32 m = startMask;
+			while (m) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1;
+				startPos[r] = (u16)(t * 16 + j);
+				vals[r] = v[j];
+				++r;
+			}
+			if (t == 0) startPos[runs] = 4096;
+			__syncthreads();
+			for (u32 q = t; q < runs; q += WG) {
+				dst[2 * q] = (u8)(startPos[q + 1] - startPos[q]);
+				dst[2 * q + 1] = vals[q];
+			}
+		}
+		if (s == 0) {
+			const i8 firstSample = *(const i8*)((const u8*)g.dist + ((size_t)(bz * 16) * n + by * 16) * n + bx * 16);
+			bool same = true;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) same = same && ((int)firstSample * (int)(i8)v[j] > 0);
+			if (__syncthreads_and(same ? 1 : 0) && !raw) flags |= 1u;
+		}
+		if (dst) dst += sz;
+	}
+	if (t == 0) {
+		if (!blob) meta[id * 4 + 3] = flags;
+		else { u8* rec = blob + where[id]; rec[0] = (u8)flags; rec[1] = 0; rec[2] = 0; rec[3] = 0; }
+	}
+}
+
 // k_scatter_blocks: edited 16^3 blocks (4096 contiguous bytes each) into the dense fields; lane t owns voxel row t
 __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, const u8* sd, const u8* sm, const u8* sb, u8* dist, u8* mat, u8* blend)
 {
@@ -596,7 +694,7 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 	return bestId | ((avg & 0xFFu) << 8);
 }
 
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8))) void k_material(ExecParamsDev p, u32 level)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_material(ExecParamsDev p, u32 level)
 {
 	__shared__ MatLds st;
 	const LevelDesc& L = p.levels[level];
@@ -1222,6 +1320,12 @@ struct Backend {
 		check(hipGetLastError(), "k_decode_grid launch");
 	}
 	bool d2d(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(D2D)"); }
+	void run_encode_grid(const GridView& g, u32* meta, const uint64_t* where, u8* blob)
+	{
+		const u32 nb = (u32)g.n / 16;
+		hipLaunchKernelGGL(k_encode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, g, meta, (const unsigned long long*)where, blob);
+		check(hipGetLastError(), "k_encode_grid launch");
+	}
 	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
 	{
 		if (!count) return;

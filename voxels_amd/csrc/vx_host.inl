@@ -476,6 +476,48 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device decode failed: " + c->be.error());
 }
 
+int vx_grid_pack(vx_ctx* c, void* out, uint64_t capacity, uint64_t* size)
+{
+	if (!c || !size) return fail(c, VX_ERR_INVALID, "vx_grid_pack: null argument");
+	if (!c->n || !c->dDist || c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_grid_pack: needs a whole grid resident");
+	const u32 n = c->n, nb = n / 16;
+	const size_t blocks = (size_t)nb * nb * nb;
+	GridView g;
+	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
+	g.n = (int)n; g.zOrigin = c->distZ0; g.zOriginMat = c->matZ0;
+	// pass 1: stream sizes + flags of every block
+	void* dMeta = c->be.alloc(blocks * 16);
+	std::vector<u32> meta(blocks * 4);
+	bool ok = dMeta != nullptr;
+	if (ok) {
+		c->be.run_encode_grid(g, (u32*)dMeta, nullptr, nullptr);
+		ok = c->be.d2h(meta.data(), dMeta, blocks * 16);
+	}
+	const uint64_t tableEnd = 16 + (uint64_t)blocks * 12;
+	std::vector<uint64_t> where(blocks);
+	uint64_t off = 0; // relative to the end of the size table
+	for (size_t i = 0; ok && i < blocks; ++i) { where[i] = off; off += 4 + (uint64_t)meta[i * 4] + meta[i * 4 + 1] + meta[i * 4 + 2]; }
+	*size = tableEnd + off;
+	if (!ok) { c->be.free(dMeta); return fail(c, VX_ERR_DEVICE, "vx_grid_pack: device pass failed: " + c->be.error()); }
+	if (!out) { c->be.free(dMeta); return VX_OK; }
+	if (capacity < *size) { c->be.free(dMeta); return fail(c, VX_ERR_INVALID, "vx_grid_pack: output buffer too small"); }
+	// pass 2: the block records {flags, distance, material, blend streams} at their offsets
+	void* dWhere = c->be.alloc(blocks * 8);
+	void* dBlob = c->be.alloc(off + 16);
+	ok = dWhere && dBlob && c->be.h2d(dWhere, where.data(), blocks * 8);
+	if (ok) {
+		c->be.run_encode_grid(g, (u32*)dMeta, (const uint64_t*)dWhere, (u8*)dBlob);
+		ok = c->be.d2h((u8*)out + tableEnd, dBlob, off);
+	}
+	c->be.free(dMeta); c->be.free(dWhere); c->be.free(dBlob);
+	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_grid_pack: device pass failed: " + c->be.error());
+	u8* o = (u8*)out;
+	const u32 header[4] = { 1u, n, n, n };
+	memcpy(o, header, 16);
+	for (size_t i = 0; i < blocks; ++i) memcpy(o + 16 + i * 12, &meta[i * 4], 12);
+	return VX_OK;
+}
+
 int vx_grid_read_block(vx_ctx* c, uint32_t id, int8_t* dist, uint8_t* mat, uint8_t* blend, uint8_t* emptyFlag)
 {
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: no grid resident");
