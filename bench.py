@@ -7,9 +7,10 @@ terrain, LOD levels 0..3 with transition cells and materials, on N MI355X GPUs o
          bench.py --gpus N --steps K --warmup W
 
 A step = one vx_polygonize over the resident grid (classify -> hierarchy -> material -> regular -> transition
-kernels + the small header read-back that tells the host the counts).  With N > 1 the grid is sharded in z-slabs
-(strong scaling: the 1024^3 grid is fixed), and every step also re-exchanges the slab halo (1 distance plane
-down, 2 distance + 1 material + 1 blend plane up) over RCCL, as the path does after an edit.  Inputs are generated
+kernels + the small header read-back that tells the host the counts).  With N > 1 the grid is sharded in slabs
+(along y by default: a terrain's surface lives in a few z-layers; strong scaling: the 1024^3 grid is fixed), and every
+step also re-exchanges the slab halo (1 distance layer down, 2 distance + 1 material + 1 blend layer up) over RCCL,
+as the path does after an edit.  Inputs are generated
 on the host (voxels_synth) and are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -33,6 +34,7 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("VOXELS_BENCH_N", "1024")))
     ap.add_argument("--levels", type=int, default=int(os.environ.get("VOXELS_BENCH_LEVELS", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-axis", choices=["y", "z"], default="y", help="axis along which the grid is cut into one slab per GPU (y balances height-field terrains, whose surface sits in a few z-layers)")
     ap.add_argument("--serialize", action="store_true", help="run the timed steps with the library's streams serialised (one kernel at a time), for per-kernel profiling")
     return ap.parse_args()
 
@@ -87,13 +89,23 @@ def main():
     z0, z1 = rank * planes, (rank + 1) * planes
 
     # ---- host generation of this rank's slab + residency ----------------------------------------------
+    axis = args.slab_axis if world > 1 else "z"  # one rank: the whole grid in its natural layout
     t_gen = time.perf_counter()
-    d, m, b = synth.terrain(n, z0, z1, seed)
-    flags_own = synth.block_empty_flags(d)
-    t_gen = time.perf_counter() - t_gen
     from voxels_amd.slab import SlabBuffers
-    slab = SlabBuffers(torch, n, rank, world, dev)
-    slab.fill_own(d, m, b, flags_own)
+    slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
+    if axis == "z":
+        d, m, b = synth.terrain(n, z0, z1, seed)
+        flags_own = synth.block_empty_flags(d)
+        t_gen = time.perf_counter() - t_gen
+        slab.fill_own(d, m, b, flags_own)
+    else:
+        # rows [z0, z1) of every plane; the generator works plane-wise, so the whole field is produced and sliced (host
+        # work outside the timed region), and the flags of all blocks are derived locally
+        d, m, b = synth.terrain(n, 0, n, seed)
+        flags_all = synth.block_empty_flags(d)
+        t_gen = time.perf_counter() - t_gen
+        sl = slice(z0, z1)
+        slab.fill_own(np.ascontiguousarray(d[:, sl]), np.ascontiguousarray(m[:, sl]), np.ascontiguousarray(b[:, sl]), flags_all)
     del d, m, b
     slab.gather_flags(dist_pkg)
 
@@ -196,8 +208,8 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": "%d^3 procedural noise terrain (seed %d), materials, LOD levels 0..%d with transition cells, "
-                                   "z-slab sharded over %d GPU(s)" % (n, seed, levels - 1, world),
-                       "grid": n, "levels": levels, "parallelism": "zslab%d" % world,
+                                   "%s-slab sharded over %d GPU(s)" % (n, seed, levels - 1, axis, world),
+                       "grid": n, "levels": levels, "parallelism": "%sslab%d" % (axis, world),
                        "active_blocks": [int(x) for x in info.active_blocks[:levels]],
                        "verts": int(totals[0]), "indices": int(totals[1]), "tverts": int(totals[2]), "tindices": int(totals[3]),
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "host_gen_s": round(t_gen, 2),

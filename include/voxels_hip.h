@@ -93,6 +93,13 @@ int vx_grid_read_block(vx_ctx* ctx, uint32_t block_id, int8_t* dist, uint8_t* ma
 int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
                    const void* d_dist, int32_t dist_z0, const void* d_mat, const void* d_blend, int32_t mat_z0,
                    const void* d_empty_flags);
+/* The same for a slab cut along y (the usual choice for terrains: a height field puts nearly all of its surface into a
+ * few z-layers, so z-slabs leave most ranks idle): this rank polygonizes the rows [y_begin, y_end) of every z-plane.
+ * d_dist is [n planes][dist_rows rows][n] with row 0 = global y dist_y0 and must cover [y_begin-1, y_end+1] clamped;
+ * d_mat / d_blend are [n][mat_rows][n] with row 0 = global y mat_y0 covering [y_begin, y_end] clamped. */
+int vx_grid_attach_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end,
+                     const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
+                     const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_empty_flags);
 /* Re-upload `count` edited 16^3 blocks (block ids, x-fastest 4096-byte blocks) + the full flag array. */
 int vx_grid_update_blocks(vx_ctx* ctx, uint32_t count, const uint32_t* block_ids, const int8_t* dist,
                           const uint8_t* mat, const uint8_t* blend, const uint8_t* empty_flags);

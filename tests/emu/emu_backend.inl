@@ -142,7 +142,7 @@ struct Backend {
 		const LevelDesc& L = p.levels[0];
 		std::vector<i8> samp(SAMPLES + 7);
 		for (u32 bz = L.zb0; bz < L.zb1; ++bz)
-		for (u32 by = 0; by < L.cnt; ++by)
+		for (u32 by = L.yb0; by < L.yb1; ++by)
 		for (u32 bx = 0; bx < L.cnt; ++bx) classify_block(p, bx, by, bz, false, samp);
 	}
 

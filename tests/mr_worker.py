@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     out_dir, n, levels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    axis = sys.argv[4] if len(sys.argv) > 4 else "z"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from emu_lib import emu_library
@@ -22,9 +23,14 @@ def main():
     from voxels_amd.slab import SlabBuffers
     import vxo
 
-    slab = SlabBuffers(torch, n, rank, world, torch.device("cpu"))
-    d, m, b = synth.terrain(n, slab.z0, slab.z1, seed=5)
-    slab.fill_own(d, m, b, synth.block_empty_flags(d))
+    slab = SlabBuffers(torch, n, rank, world, torch.device("cpu"), axis=axis)
+    if axis == "z":
+        d, m, b = synth.terrain(n, slab.z0, slab.z1, seed=5)
+        slab.fill_own(d, m, b, synth.block_empty_flags(d))
+    else:  # own rows of every plane; the flags of all blocks are derived locally (own blocks interleave in id order)
+        d, m, b = synth.terrain(n, seed=5)
+        sl = slice(slab.z0, slab.z1)
+        slab.fill_own(np.ascontiguousarray(d[:, sl]), np.ascontiguousarray(m[:, sl]), np.ascontiguousarray(b[:, sl]), synth.block_empty_flags(d))
     slab.gather_flags(dist)
     slab.halo_exchange(dist)
     p = Polygonizer(library=emu_library())

@@ -159,6 +159,37 @@ def test_emu_z_slabs_union_equals_whole(emu):
     assert np.array_equal(stats.astype(np.uint32), ref_stats)
 
 
+def test_emu_y_slabs_union_equals_whole(emu):
+    """The same with slabs cut along y (rows of every z-plane): what bench.py uses for terrains, whose surface sits in a few
+    z-layers.  Arrays are [n][rows][n]; the ranks' blocks interleave in block-id order."""
+    from voxels_amd import synth
+    from voxels_amd.slab import merge_rank_levels
+    n, levels = 128, 3
+    d, m, b = synth.terrain(n, seed=6)
+    flags = synth.block_empty_flags(d)
+    whole = make_poly(emu)
+    whole.upload(d, m, b, flags)
+    whole.execute(levels)
+    ref_levels, ref_stats = whole.all_levels(), whole.stats()
+    parts, stats, keep = [], np.zeros(20, np.uint64), []
+    for r in range(2):
+        y0, y1 = r * 64, (r + 1) * 64
+        lo, hi = max(y0 - 1, 0), min(y1 + 2, n)
+        hm = min(y1 + 1, n)
+        dd = np.ascontiguousarray(d[:, lo:hi])
+        mm = np.ascontiguousarray(m[:, y0:hm])
+        bb = np.ascontiguousarray(b[:, y0:hm])
+        keep.append((dd, mm, bb))
+        p = make_poly(emu)
+        p.attach_y(n, y0, y1, dd.ctypes.data, lo, hi - lo, mm.ctypes.data, bb.ctypes.data, y0, hm - y0, flags.ctypes.data)
+        p.execute(levels)
+        parts.append(p.all_levels())
+        stats += p.stats()
+    ok, msg = fields.surface_equal(merge_rank_levels(parts), ref_levels)
+    assert ok, msg
+    assert np.array_equal(stats.astype(np.uint32), ref_stats)
+
+
 def test_emu_carve_modify_matches_reference_fixture(emu):
     """Config 5 in small: full run, sphere carve (Grid::InjectSurface result taken from the fixture), incremental
     re-polygonization of the dirty box — against the reference's own Modification run."""

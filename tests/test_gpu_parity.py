@@ -321,8 +321,8 @@ def test_hip_config5_512_carve_incremental(poly, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_hip_slab_attach_matches_full_run(poly, port, world):
+@pytest.mark.parametrize("world,axis", [(2, "z"), (4, "z"), (2, "y"), (4, "y")])
+def test_hip_slab_attach_matches_full_run(poly, port, world, axis):
     """The multi-GPU data path on one GPU: every rank's slab (own planes + halo planes, attached device tensors) is
     polygonized on its own and the concatenation must equal the reference's surface of the whole grid — including the
     quiet-block shortcut, which samples the halo planes for the neighbouring slabs' signs."""
@@ -338,14 +338,8 @@ def test_hip_slab_attach_matches_full_run(poly, port, world):
     dev = torch.device("cuda", 0)
     per_rank, stats = [], np.zeros(20, np.int64)
     for r in range(world):
-        slab = SlabBuffers(torch, n, r, world, dev)
-        z0, z1 = slab.z0, slab.z1
-        slab.flags.copy_(torch.from_numpy(flags))
-        lo, hi = max(z0 - 1, 0), min(z1 + 2, n)
-        slab.dist[lo - (z0 - 1):hi - (z0 - 1)].copy_(torch.from_numpy(d[lo:hi]))
-        hi_m = min(z1 + 1, n)
-        slab.mat[:hi_m - z0].copy_(torch.from_numpy(m[z0:hi_m]))
-        slab.blend[:hi_m - z0].copy_(torch.from_numpy(b[z0:hi_m]))
+        slab = SlabBuffers(torch, n, r, world, dev, axis=axis)
+        slab.fill_from_full(d, m, b, flags)
         torch.cuda.synchronize()
         slab.attach(poly)
         poly.execute(levels)

@@ -13,16 +13,20 @@ from emu_lib import emu_library
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_equal_one(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("axis,port", [("z", "29611"), ("y", "29613")])
+def test_two_ranks_equal_one(tmp_path, axis, port):
     from voxels_amd import synth
     from voxels_amd.binding import Level, Polygonizer
     from voxels_amd.slab import merge_rank_levels
     n, levels, world = 128, 3, 2
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"), str(tmp_path), str(n), str(levels)], env=e))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"), str(tmp_path), str(n), str(levels), axis], env=e))
     for p in procs:
         assert p.wait(timeout=600) == 0
     parts, stats = [], np.zeros(20, np.uint64)

@@ -49,6 +49,7 @@ class HipLibrary:
         lib.vx_set_stream.argtypes = [vp, vp]
         lib.vx_grid_upload.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
+        lib.vx_grid_attach_y.argtypes = [vp, u32, u32, u32, vp, C.c_int32, u32, vp, vp, C.c_int32, u32, vp]
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
         lib.vx_compact_pools.argtypes = [vp]
         lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
@@ -189,6 +190,13 @@ class Polygonizer:
         self._check(self._lib.vx_grid_attach(self._h, n, z_begin, z_end, C.c_void_p(d_dist), dist_z0,
                                              C.c_void_p(d_mat), C.c_void_p(d_blend), mat_z0, C.c_void_p(d_flags)),
                     "vx_grid_attach")
+        self.n = n
+
+    def attach_y(self, n, y_begin, y_end, d_dist, dist_y0, dist_rows, d_mat, d_blend, mat_y0, mat_rows, d_flags):
+        """Slab cut along y: device arrays [n][rows][n] (see vx_grid_attach_y)."""
+        self._check(self._lib.vx_grid_attach_y(self._h, n, y_begin, y_end, C.c_void_p(d_dist), dist_y0, dist_rows,
+                                               C.c_void_p(d_mat), C.c_void_p(d_blend), mat_y0, mat_rows, C.c_void_p(d_flags)),
+                    "vx_grid_attach_y")
         self.n = n
 
     def update_blocks(self, block_ids, dist, mat, blend, empty_flags):

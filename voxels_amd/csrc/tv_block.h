@@ -47,6 +47,7 @@ struct LevelDesc {
 	u32 cnt;            // blocks per axis of this level (global)
 	u32 mult;           // cell size in voxels
 	u32 zb0, zb1;       // block layers [zb0, zb1) owned by this rank
+	u32 yb0, yb1;       // block rows [yb0, yb1) owned by this rank (slabs are cut along z or along y)
 	int* slotOf;        // [cnt^3] block coordinate id -> active slot, -1 = none
 	u32* slotCoord;     // [cap] slot -> coordinate id
 	u32* nActive;       // number of slots in use
@@ -308,9 +309,9 @@ TV_HD void reg_stage_level0(const GridView& g, u32 bx, u32 by, u32 bz, i8* samp,
 		const int r = q / 6, j = q - r * 6;
 		const int jj = r % 19, kk = r / 19;
 		const int y = clampi((int)by * 16 + jj - 1, 0, n - 1);
-		const int z = clampi((int)bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
+		const int z = clampi((int)bz * 16 + kk - 1, 0, n - 1);
 		const int x = clampi(gx0 + 4 * j, 0, n - 4);
-		const u32 v = *(const u32*)(g.dist + ((size_t)z * n + y) * n + x);
+		const u32 v = *(const u32*)(g.dist + dist_offset(g, x, y, z));
 		*(u32*)(samp + kk * SPLANE + jj * SROW + 4 * j) = v;
 	}
 }
@@ -547,11 +548,11 @@ enum { EMIT_BATCH = 4 };     // vertices per lane whose fetches are in flight to
 struct BlockMaterials {
 	const u8* mat;
 	const u8* blend;
-	int n, maxX, maxY, maxZ;
+	int n, pitch, maxX, maxY, maxZ; // pitch = rows per z-plane of the resident material field
 	TV_HD u32 at(int lx, int ly, int lz) const
 	{
 		lx = lx > maxX ? maxX : lx; ly = ly > maxY ? maxY : ly; lz = lz > maxZ ? maxZ : lz;
-		const u32 off = (u32)((lz * n + ly) * n + lx);
+		const u32 off = (u32)((lz * pitch + ly) * n + lx);
 		return (u32)mat[off] | ((u32)blend[off] << 8);
 	}
 };
@@ -559,8 +560,8 @@ struct BlockMaterials {
 TV_HD BlockMaterials block_materials(const GridView& g, const RegBlockCtx& b)
 {
 	BlockMaterials m;
-	const size_t origin = ((size_t)((int)(b.bz * 16) - g.zOriginMat) * g.n + b.by * 16) * g.n + b.bx * 16;
-	m.mat = g.mat + origin; m.blend = g.blend + origin; m.n = g.n;
+	const size_t origin = mat_offset(g, (int)(b.bx * 16), (int)(b.by * 16), (int)(b.bz * 16));
+	m.mat = g.mat + origin; m.blend = g.blend + origin; m.n = g.n; m.pitch = g.pitchYMat;
 	m.maxX = g.n - 1 - (int)(b.bx * 16); m.maxY = g.n - 1 - (int)(b.by * 16); m.maxZ = g.n - 1 - (int)(b.bz * 16);
 	return m;
 }

@@ -108,9 +108,10 @@ TV_HD Tables tables_from_image(const u8* base)
 	return T;
 }
 
-// Dense voxel field resident in HBM: x fastest, then y, then z.  A rank of a multi-GPU run holds the z-planes
-// [zOrigin, zOrigin + planes) of the global grid (its slab plus halo); coordinates are always global and are
-// clamped to the GLOBAL extent [0, n-1] exactly like the reference clamps every fetch.
+// Dense voxel field resident in HBM: x fastest, then y, then z.  A rank of a multi-GPU run holds a slab of the global
+// grid plus halo: the z-planes [zOrigin, ...) and, within every plane, the rows [yOrigin, yOrigin + pitchY) (a whole
+// grid has zOrigin = yOrigin = 0 and pitchY = n; slabs are cut along z OR along y).  Coordinates are always global
+// and are clamped to the GLOBAL extent [0, n-1] exactly like the reference clamps every fetch.
 struct GridView {
 	const i8* dist;
 	const u8* mat;
@@ -118,21 +119,27 @@ struct GridView {
 	int n;          // global grid edge
 	int zOrigin;    // global z of plane 0 of dist[]
 	int zOriginMat; // global z of plane 0 of mat[] / blend[]
+	int yOrigin, yOriginMat; // global y of row 0 of every plane
+	int pitchY, pitchYMat;   // rows per plane
 };
 
 TV_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// element offsets of global voxel (x,y,z), already clamped to the grid
+TV_HD size_t dist_offset(const GridView& g, int x, int y, int z) { return ((size_t)(z - g.zOrigin) * g.pitchY + (y - g.yOrigin)) * g.n + x; }
+TV_HD size_t mat_offset(const GridView& g, int x, int y, int z) { return ((size_t)(z - g.zOriginMat) * g.pitchYMat + (y - g.yOriginMat)) * g.n + x; }
+
 TV_HD int dist_at(const GridView& g, int x, int y, int z)
 {
-	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1) - g.zOrigin;
-	return g.dist[((size_t)z * g.n + y) * g.n + x];
+	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1);
+	return g.dist[dist_offset(g, x, y, z)];
 }
 
 // material info packed as id | blend << 8
 TV_HD u32 mat_at(const GridView& g, int x, int y, int z)
 {
-	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1) - g.zOriginMat;
-	const size_t i = ((size_t)z * g.n + y) * g.n + x;
+	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1);
+	const size_t i = mat_offset(g, x, y, z);
 	return (u32)g.mat[i] | ((u32)g.blend[i] << 8);
 }
 

@@ -133,8 +133,8 @@ __device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockC
 		for (int r = (int)threadIdx.x; r < 361; r += WG) {
 			const int jj = r % 19, kk = r / 19;
 			const int y = clampi((int)b.by * 16 + jj - 1, 0, n - 1);
-			const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1) - g.zOrigin;
-			const i8* row = g.dist + ((size_t)z * n + y) * n;
+			const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1);
+			const i8* row = g.dist + dist_offset(g, 0, y, z);
 			u32 v[6];
 			v[0] = *(const u32*)(row + xFirst);
 #pragma unroll
@@ -430,22 +430,21 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 // ---- what the emptiness flags already say about a block (two tiny launches ahead of k_classify) ------------
 // summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign).  The same launch
 // resets the run's counters and slot maps (independent work, one launch fewer at the head of every run).
-__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi, ResetRanges r)
+__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi, u32 ybLo, u32 ybHi, ResetRanges r)
 {
 	const LevelDesc& L = p.levels[0];
-	const u32 per = L.cnt * L.cnt;
 	const u32 i = blockIdx.x * WG + threadIdx.x;
 	if (r.header) reset_words(p, r, i);
-	if (i >= per * (zbHi - zbLo)) return;
-	const u32 id = zbLo * per + i;
+	const u32 rowsY = ybHi - ybLo;
+	if (i >= L.cnt * rowsY * (zbHi - zbLo)) return;
+	const u32 bx = i % L.cnt, by = ybLo + (i / L.cnt) % rowsY, bz = zbLo + i / (L.cnt * rowsY);
+	const u32 id = block_coord_id(bx, by, bz, L.cnt);
 	u32 s = 0;
 	if (p.G.emptyFlags[id]) {
-		u32 bx, by, bz;
-		block_coords(id, L.cnt, bx, by, bz);
 		const GridView& g = p.G.grid;
-		int z = (int)bz * 16;
-		if (z < g.zOrigin) z = g.zOrigin; // the slab below: only its top plane is resident (still inside the block)
-		const i8 v = g.dist[((size_t)(z - g.zOrigin) * g.n + by * 16) * g.n + bx * 16];
+		// the neighbour slab below (in z or in y): only its last plane / row is resident, still inside the block
+		const int z = max((int)bz * 16, g.zOrigin), y = max((int)by * 16, g.yOrigin);
+		const i8 v = g.dist[dist_offset(g, (int)bx * 16, y, z)];
 		s = 1u | (((u32)(v >> 7) & 1u) << 1);
 	}
 	p.G.blockSummary[id] = (u8)s;
@@ -454,12 +453,11 @@ __global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo,
 __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 {
 	const LevelDesc& L = p.levels[0];
-	const u32 per = L.cnt * L.cnt;
 	const u32 i = blockIdx.x * WG + threadIdx.x;
-	if (i >= per * (L.zb1 - L.zb0)) return;
-	const u32 id = L.zb0 * per + i;
-	u32 bx, by, bz;
-	block_coords(id, L.cnt, bx, by, bz);
+	const u32 rowsY = L.yb1 - L.yb0;
+	if (i >= L.cnt * rowsY * (L.zb1 - L.zb0)) return;
+	const u32 bx = i % L.cnt, by = L.yb0 + (i / L.cnt) % rowsY, bz = L.zb0 + i / (L.cnt * rowsY);
+	const u32 id = block_coord_id(bx, by, bz, L.cnt);
 	u32 all = 3u, any = 0u; // AND / OR over the 27 summaries (neighbour coordinates clamped like the reference's)
 #pragma unroll
 	for (int k = 0; k < 27; ++k) {
@@ -500,7 +498,6 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	// (all of its channels) and consecutive rows share their halo lines in that L2.
 	u32 tile = blockIdx.x;
 	{
-		const u32 rows = L.cnt * (L.zb1 - L.zb0);
 		if (rowGroup) {
 			// groups of R block rows go round-robin over the XCDs: the surface usually sits in a narrow z band, and
 			// tiles of quiet blocks cost nothing, so contiguous per-XCD ranges would leave most XCDs idle
@@ -510,7 +507,8 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 			tile = (((lr / R) * 8u + xcd) * R + lr % R) * tilesX + m % tilesX;
 		}
 	}
-	const u32 tx = tile % tilesX, by = (tile / tilesX) % L.cnt, bz = L.zb0 + tile / (tilesX * L.cnt);
+	const u32 rowsY = L.yb1 - L.yb0;
+	const u32 tx = tile % tilesX, by = L.yb0 + (tile / tilesX) % rowsY, bz = L.zb0 + tile / (tilesX * rowsY);
 	const int x0 = (int)tx * 16 * TB;
 	const int validCells = (n - x0) < 16 * TB ? (n - x0) : 16 * TB; // multiple of 16
 	const int tid = threadIdx.x;
@@ -536,8 +534,8 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 				if (cls & BC_NEGATIVE) d = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
 			} else if (seg * 16 < validCells) {
 				const int y = clampi((int)by * 16 + ry, 0, n - 1);
-				const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
-				d = *(const uint4*)(g.dist + ((size_t)z * n + y) * n + x0 + seg * 16);
+				const int z = clampi((int)bz * 16 + rz, 0, n - 1);
+				d = *(const uint4*)(g.dist + dist_offset(g, x0 + seg * 16, y, z));
 			}
 			return d;
 		},
@@ -548,9 +546,9 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 		[&](int r) {
 			const int ry = r % 17, rz = r / 17;
 			const int y = clampi((int)by * 16 + ry, 0, n - 1);
-			const int z = clampi((int)bz * 16 + rz, 0, n - 1) - g.zOrigin;
+			const int z = clampi((int)bz * 16 + rz, 0, n - 1);
 			const int x = clampi(x0 + validCells, 0, n - 1);
-			return g.dist[((size_t)z * n + y) * n + x];
+			return g.dist[dist_offset(g, x, y, z)];
 		},
 		[&](int r, i8 v) { halo[r] = (u8)((u32)(v >> 7) & 1u); });
 	__syncthreads();
@@ -723,7 +721,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		uint4 old0, old1;
 		if (!defineAll) { old0 = ((const uint4*)cacheOut)[tid]; old1 = ((const uint4*)cacheOut)[tid + WG]; }
 		const int x0 = (int)(bx * 16) * mult, y0 = (int)(by * 16) * mult, z0 = (int)(bz * 16) * mult;
-		const i8* base = g.dist + ((size_t)(z0 - g.zOrigin) * n + y0) * n + x0; // uniform; lanes add 32-bit offsets
+		const i8* base = g.dist + dist_offset(g, x0, y0, z0); // uniform; lanes add 32-bit offsets
+		const int pitch = g.pitchY;
 		for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
 		if (tid < 8) st.childSlot[tid] = cs;
 		if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
@@ -742,7 +741,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 				if (sIdx < SAMPLES) {
 					const int i = sIdx % 17, j = (sIdx / 17) % 17, k = sIdx / 289;
 					const int dx = min(x0 + i * mult, n - 1) - x0, dy = min(y0 + j * mult, n - 1) - y0, dz = min(z0 + k * mult, n - 1) - z0;
-					v[q] = base[(u32)((dz * n + dy) * n + dx)];
+					v[q] = base[(u32)((dz * pitch + dy) * n + dx)];
 				}
 			}
 #pragma unroll
@@ -827,8 +826,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		// ---- vote: the eight child entries of a cell are requested together --------------------------------
 		{
 			const int nVote = (int)st.voteCount;
-			const u8* matBase = g.mat + ((size_t)((int)(bz * 32) - g.zOriginMat) * n + by * 32) * n + bx * 32;
-			const u8* blendBase = g.blend + ((size_t)((int)(bz * 32) - g.zOriginMat) * n + by * 32) * n + bx * 32;
+			const size_t matOrigin = mat_offset(g, (int)(bx * 32), (int)(by * 32), (int)(bz * 32));
+			const u8* matBase = g.mat + matOrigin;
+			const u8* blendBase = g.blend + matOrigin;
+			const int pitchMat = g.pitchYMat;
 			for (int k = tid; k < nVote; k += WG) {
 				const u32 c = st.voteList[k];
 				const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 						const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
 						m[i] = EMPTY_MATERIAL; bl[i] = 0;
 						if ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) {
-							const u32 off = (u32)((czz * n + cyy) * n + cxx);
+							const u32 off = (u32)((czz * pitchMat + cyy) * n + cxx);
 							m[i] = matBase[off]; bl[i] = blendBase[off];
 						}
 					}
@@ -1030,8 +1031,8 @@ __device__ __forceinline__ void tr_face_request(const GridView& g, const RegBloc
 	int o[3] = { (int)(b.bx * 16) * mult, (int)(b.by * 16) * mult, (int)(b.bz * 16) * mult };
 	const int maxU = n - 1 - o[fg.ua], maxV = n - 1 - o[fg.va];
 	if (fg.positive) o[fg.axis] += 16 * mult;
-	const i8* base = g.dist + ((size_t)(o[2] - g.zOrigin) * n + o[1]) * n + o[0];
-	const u32 stride[3] = { 1u, (u32)n, (u32)n * (u32)n };
+	const i8* base = g.dist + dist_offset(g, o[0], o[1], o[2]);
+	const u32 stride[3] = { 1u, (u32)n, (u32)g.pitchY * (u32)n };
 	const u32 su = stride[fg.ua], sv = stride[fg.va];
 #pragma unroll
 	for (int q = 0; q < 5; ++q) {
@@ -1381,18 +1382,20 @@ struct Backend {
 	{
 		const LevelDesc& L = p.levels[0];
 		const u32 tilesX = (L.cnt + TB - 1) / TB;
-		const u32 grid = tilesX * L.cnt * (L.zb1 - L.zb0);
+		const u32 rowsY = L.yb1 - L.yb0;
+		const u32 grid = tilesX * rowsY * (L.zb1 - L.zb0);
 		if (!grid) return;
-		const u32 per = L.cnt * L.cnt;
+		// summaries also for the neighbour layers of the slab (one block layer beyond it in z and in y)
 		const u32 zbLo = L.zb0 ? L.zb0 - 1 : 0, zbHi = std::min<u32>(L.zb1 + 1, L.cnt);
+		const u32 ybLo = L.yb0 ? L.yb0 - 1 : 0, ybHi = std::min<u32>(L.yb1 + 1, L.cnt);
 		{
 			const ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
-			const u32 lanes = std::max<u32>(per * (zbHi - zbLo), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
-			hipLaunchKernelGGL(k_block_summary, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi, r);
+			const u32 lanes = std::max<u32>(L.cnt * (ybHi - ybLo) * (zbHi - zbLo), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
+			hipLaunchKernelGGL(k_block_summary, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi, ybLo, ybHi, r);
 		}
-		hipLaunchKernelGGL(k_block_class, dim3((per * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
-		const u32 rows = L.cnt * (L.zb1 - L.zb0);
+		hipLaunchKernelGGL(k_block_class, dim3((L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
+		const u32 rows = rowsY * (L.zb1 - L.zb0);
 		u32 rowGroup = 0; // 0 = no remap
 		if ((rows & 7u) == 0) {
 			const char* rgEnv = getenv("VX_CLASSIFY_ROWGROUP"); // tuning aid

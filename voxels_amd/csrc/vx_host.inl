@@ -49,6 +49,9 @@ struct vx_ctx {
 	std::string err;
 	// grid
 	u32 n = 0, zBegin = 0, zEnd = 0;
+	u32 yBegin = 0, yEnd = 0;            // owned rows (slabs cut along y); [0, n) otherwise
+	int distY0 = 0, matY0 = 0;           // global y of row 0 of every resident plane
+	u32 distRows = 0, matRows = 0;       // rows per resident plane (n for a whole grid or a z-slab)
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
@@ -58,7 +61,7 @@ struct vx_ctx {
 	void *dDirty = nullptr, *dWork = nullptr, *dGather = nullptr;  // incremental runs: dirty block coords, work items, gathered records
 	u32 dirtyCap = 0;
 	// level tables
-	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0;
+	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0, tablesYb0 = 0, tablesYb1 = 0;
 	u32 refLevels = 0;
 	LevelDesc lv[MAX_LEVELS];
 	std::vector<void*> levelAllocs;
@@ -118,8 +121,8 @@ void release_grid(vx_ctx* c)
 
 bool ensure_level_tables(vx_ctx* c)
 {
-	const u32 zb0 = c->zBegin / 16, zb1 = c->zEnd / 16;
-	if (c->tablesN == c->n && c->tablesZb0 == zb0 && c->tablesZb1 == zb1) return true;
+	const u32 zb0 = c->zBegin / 16, zb1 = c->zEnd / 16, yb0 = c->yBegin / 16, yb1 = c->yEnd / 16;
+	if (c->tablesN == c->n && c->tablesZb0 == zb0 && c->tablesZb1 == zb1 && c->tablesYb0 == yb0 && c->tablesYb1 == yb1) return true;
 	free_level_tables(c);
 	c->refLevels = ref_levels(c->n);
 	auto alloc = [&](size_t bytes) -> void* {
@@ -135,9 +138,12 @@ bool ensure_level_tables(vx_ctx* c)
 		d.zb0 = zb0 >> L;
 		d.zb1 = (zb1 + d.mult - 1) >> L;
 		if (d.zb1 > d.cnt) d.zb1 = d.cnt;
+		d.yb0 = yb0 >> L;
+		d.yb1 = (yb1 + d.mult - 1) >> L;
+		if (d.yb1 > d.cnt) d.yb1 = d.cnt;
 		d.hasTransitions = (L > 0 && L != c->refLevels - 1) ? 1 : 0;
 		const size_t total = (size_t)d.cnt * d.cnt * d.cnt;
-		const size_t cap = (size_t)d.cnt * d.cnt * (d.zb1 > d.zb0 ? d.zb1 - d.zb0 : 0);
+		const size_t cap = (size_t)d.cnt * (d.yb1 > d.yb0 ? d.yb1 - d.yb0 : 0) * (d.zb1 > d.zb0 ? d.zb1 - d.zb0 : 0);
 		d.cap = (u32)cap;
 		d.slotOf = (int*)alloc(total * 4);
 		d.slotCoord = (u32*)alloc(cap * 4);
@@ -155,7 +161,7 @@ bool ensure_level_tables(vx_ctx* c)
 			if (!c->dBlockSummary || !c->dBlockClass) return false;
 		}
 	}
-	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1;
+	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1; c->tablesYb0 = yb0; c->tablesYb1 = yb1;
 	return true;
 }
 
@@ -183,6 +189,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.grid.n = (int)c->n;
 	p.G.grid.zOrigin = c->distZ0;
 	p.G.grid.zOriginMat = c->matZ0;
+	p.G.grid.yOrigin = c->distY0; p.G.grid.yOriginMat = c->matY0;
+	p.G.grid.pitchY = (int)c->distRows; p.G.grid.pitchYMat = (int)c->matRows;
 	p.G.emptyFlags = (const u8*)c->dFlags;
 	p.G.lut = (const u8*)c->dLut;
 	p.G.stats = (u32*)c->dHeader + HDR_STATS;
@@ -427,6 +435,7 @@ int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat
 		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload: device allocation failed: " + c->be.error()); }
 	}
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	bool ok = c->be.h2d(c->dDist, dist, tot) && c->be.h2d(c->dFlags, flags, nb);
 	ok = ok && (mat ? c->be.h2d(c->dMat, mat, tot) : c->be.fill(c->dMat, 0, tot));
 	ok = ok && (blend ? c->be.h2d(c->dBlend, blend, tot) : c->be.fill(c->dBlend, 0, tot));
@@ -464,6 +473,7 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device allocation failed: " + c->be.error()); }
 	}
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
 	void* dBlob = c->be.alloc(off + 16);
 	void* dWhere = c->be.alloc(where.size() * 8);
@@ -479,12 +489,12 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 int vx_grid_pack(vx_ctx* c, void* out, uint64_t capacity, uint64_t* size)
 {
 	if (!c || !size) return fail(c, VX_ERR_INVALID, "vx_grid_pack: null argument");
-	if (!c->n || !c->dDist || c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_grid_pack: needs a whole grid resident");
+	if (!c->n || !c->dDist || (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n)) return fail(c, VX_ERR_INVALID, "vx_grid_pack: needs a whole grid resident");
 	const u32 n = c->n, nb = n / 16;
 	const size_t blocks = (size_t)nb * nb * nb;
 	GridView g;
 	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-	g.n = (int)n; g.zOrigin = c->distZ0; g.zOriginMat = c->matZ0;
+	g.n = (int)n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)n; g.pitchYMat = (int)n;
 	// pass 1: stream sizes + flags of every block
 	void* dMeta = c->be.alloc(blocks * 16);
 	std::vector<u32> meta(blocks * 4);
@@ -524,13 +534,13 @@ int vx_grid_read_block(vx_ctx* c, uint32_t id, int8_t* dist, uint8_t* mat, uint8
 	const u32 n = c->n, nb = n / 16;
 	if (id >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block id out of range");
 	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
-	if (bz * 16 < c->zBegin || bz * 16 >= c->zEnd) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block outside the resident slab");
+	if (bz * 16 < c->zBegin || bz * 16 >= c->zEnd || by * 16 < c->yBegin || by * 16 >= c->yEnd) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block outside the resident slab");
 	bool ok = true;
 	for (u32 z = 0; z < 16 && ok; ++z)
 	for (u32 y = 0; y < 16 && ok; ++y) {
 		const size_t dst = (size_t)z * 256 + y * 16;
-		const size_t srcD = ((size_t)((int)(bz * 16 + z) - c->distZ0) * n + (by * 16 + y)) * n + bx * 16;
-		const size_t srcM = ((size_t)((int)(bz * 16 + z) - c->matZ0) * n + (by * 16 + y)) * n + bx * 16;
+		const size_t srcD = ((size_t)((int)(bz * 16 + z) - c->distZ0) * c->distRows + ((int)(by * 16 + y) - c->distY0)) * n + bx * 16;
+		const size_t srcM = ((size_t)((int)(bz * 16 + z) - c->matZ0) * c->matRows + ((int)(by * 16 + y) - c->matY0)) * n + bx * 16;
 		if (dist) ok = ok && c->be.d2h_async(dist + dst, (const u8*)c->dDist + srcD, 16);
 		if (mat) ok = ok && c->be.d2h_async(mat + dst, (const u8*)c->dMat + srcM, 16);
 		if (blend) ok = ok && c->be.d2h_async(blend + dst, (const u8*)c->dBlend + srcM, 16);
@@ -549,6 +559,21 @@ int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, cons
 	c->n = n; c->zBegin = z_begin; c->zEnd = z_end;
 	c->dDist = (void*)d_dist; c->dMat = (void*)d_mat; c->dBlend = (void*)d_blend; c->dFlags = (void*)d_flags;
 	c->distZ0 = dist_z0; c->matZ0 = mat_z0;
+	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
+	c->haveSurface = false;
+	return VX_OK;
+}
+
+int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
+                     const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_flags)
+{
+	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || y_begin >= y_end || y_end > n || (y_begin & 15) || (y_end & 15) || !dist_rows || !mat_rows)
+		return fail(c, VX_ERR_INVALID, "vx_grid_attach_y: bad arguments (slab bounds must be multiples of 16)");
+	release_grid(c);
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = y_begin; c->yEnd = y_end;
+	c->dDist = (void*)d_dist; c->dMat = (void*)d_mat; c->dBlend = (void*)d_blend; c->dFlags = (void*)d_flags;
+	c->distY0 = dist_y0; c->matY0 = mat_y0; c->distRows = dist_rows; c->matRows = mat_rows;
 	c->haveSurface = false;
 	return VX_OK;
 }
@@ -609,7 +634,7 @@ void edit_modified_box(u32 n, const float pos[3], const float ext[3], float outM
 int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3], const EditParams& e, float outMin[3], float outMax[3])
 {
 	if (!c || !pos || !ext || !outMin || !outMax) return fail(c, VX_ERR_INVALID, std::string(what) + ": null argument");
-	if (!c->ownsGrid || !c->n || c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, std::string(what) + ": needs a whole grid owned by the context (vx_grid_upload / vx_grid_upload_packed)");
+	if (!c->ownsGrid || !c->n || (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n)) return fail(c, VX_ERR_INVALID, std::string(what) + ": needs a whole grid owned by the context (vx_grid_upload / vx_grid_upload_packed)");
 	std::vector<u32> touched;
 	edit_touched_blocks(c->n, pos, ext, touched);
 	edit_modified_box(c->n, pos, ext, outMin, outMax);
@@ -625,7 +650,7 @@ int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3]
 	if (ok) {
 		GridView g;
 		g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-		g.n = (int)c->n; g.zOrigin = 0; g.zOriginMat = 0;
+		g.n = (int)c->n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)c->n; g.pitchYMat = (int)c->n;
 		c->be.run_edit(g, (u8*)c->dFlags, (const u32*)dIds, (u32)touched.size(), e);
 		ok = c->be.sync_ok();
 	}
@@ -669,8 +694,8 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
 	if (!ensure_level_tables(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: level table allocation failed: " + c->be.error());
 	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
-	const u32 slabPlanes = c->zEnd - c->zBegin;
-	if (levels > 1 && (slabPlanes % (16u << (levels - 1))) && (c->zBegin != 0 || c->zEnd != c->n))
+	const u32 slabPlanes = c->zEnd - c->zBegin, slabRows = c->yEnd - c->yBegin;
+	if (levels > 1 && (((slabPlanes % (16u << (levels - 1))) && (c->zBegin != 0 || c->zEnd != c->n)) || ((slabRows % (16u << (levels - 1))) && (c->yBegin != 0 || c->yEnd != c->n))))
 		return fail(c, VX_ERR_INVALID, "vx_polygonize: slab thickness must be a multiple of the coarsest block size");
 	if (!c->vertCap) {
 		// first guess: ~3 vertices and ~12 indices per surface voxel column; grown on demand (exact need is known after a run)
@@ -717,7 +742,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	u32 blocksCalculated = 0, trivial = 0;
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
-		const u32 owned = d.cnt * d.cnt * (d.zb1 - d.zb0);
+		const u32 owned = d.cnt * (d.yb1 - d.yb0) * (d.zb1 - d.zb0);
 		idBase += d.cnt * d.cnt * d.cnt;
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
@@ -741,7 +766,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		info->total_verts = c->poolVerts;
 		info->total_indices = c->poolIdx;
 		for (u32 L = 0; L < levels && L < 8; ++L) info->active_blocks[L] = c->hdr[L];
-		info->algorithmic_bytes = (uint64_t)c->n * c->n * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
+		info->algorithmic_bytes = (uint64_t)c->n * slabRows * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
 	}
 	return VX_OK;
 }
@@ -809,7 +834,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 {
 	if (!c || !min_corner || !max_corner) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: null argument");
 	if (!c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: run vx_polygonize first");
-	if (c->zBegin != 0 || c->zEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on z-slabs");
+	if (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on slabs");
 	const u32 levels = c->levelsRun;
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;

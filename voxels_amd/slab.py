@@ -11,35 +11,68 @@ import numpy as np
 
 
 class SlabBuffers:
-    """Device (or host) tensors holding a rank's slab plus halo planes.
+    """Device (or host) tensors holding a rank's slab plus halo.
 
-    dist  [planes + 3, n, n]  plane 0 <-> global z0 - 1
-    mat   [planes + 1, n, n]  plane 0 <-> global z0
-    blend [planes + 1, n, n]
+    axis "z" (slabs of whole z-planes):              axis "y" (slabs of rows of every z-plane):
+      dist  [planes + 3, n, n]  plane 0 <-> z0 - 1      dist  [n, planes + 3, n]  row 0 <-> y0 - 1
+      mat   [planes + 1, n, n]  plane 0 <-> z0          mat   [n, planes + 1, n]  row 0 <-> y0
+      blend like mat                                    blend like mat
+    A height-field terrain keeps nearly all of its surface in a few z-layers, so z-slabs give most ranks nothing to do;
+    y-slabs cut across the surface and balance.  The halo requirement is the same along either axis.
     """
 
-    def __init__(self, torch, n, rank, world, device):
-        assert n % world == 0
-        self.torch, self.n, self.rank, self.world = torch, n, rank, world
+    def __init__(self, torch, n, rank, world, device, axis="z"):
+        assert n % world == 0 and axis in ("z", "y")
+        self.torch, self.n, self.rank, self.world, self.axis = torch, n, rank, world, axis
         self.planes = n // world
-        self.z0, self.z1 = rank * self.planes, (rank + 1) * self.planes
-        self.dist = torch.zeros((self.planes + 3, n, n), dtype=torch.int8, device=device)
-        self.mat = torch.zeros((self.planes + 1, n, n), dtype=torch.uint8, device=device)
-        self.blend = torch.zeros((self.planes + 1, n, n), dtype=torch.uint8, device=device)
+        self.z0, self.z1 = rank * self.planes, (rank + 1) * self.planes  # owned range along the slab axis
+        p = self.planes
+        dshape = (p + 3, n, n) if axis == "z" else (n, p + 3, n)
+        mshape = (p + 1, n, n) if axis == "z" else (n, p + 1, n)
+        self.dist = torch.zeros(dshape, dtype=torch.int8, device=device)
+        self.mat = torch.zeros(mshape, dtype=torch.uint8, device=device)
+        self.blend = torch.zeros(mshape, dtype=torch.uint8, device=device)
         self.flags = torch.zeros(((n // 16) ** 3,), dtype=torch.uint8, device=device)
 
+    def _d(self, a, b):
+        """slice [a, b) of the distance tensor along the slab axis"""
+        return self.dist[a:b] if self.axis == "z" else self.dist[:, a:b]
+
+    def _m(self, t, a, b):
+        return t[a:b] if self.axis == "z" else t[:, a:b]
+
     def fill_own(self, d, m, b, flags_own):
+        """d, m, b: this rank's own part ([planes, n, n] for z-slabs, [n, planes, n] for y-slabs); flags_own: the flags of
+        the rank's own blocks in block-id order (z-slabs) or the full flag array (y-slabs, where own blocks interleave)."""
         t = self.torch
-        self.dist[1:self.planes + 1].copy_(t.from_numpy(d))
-        self.mat[:self.planes].copy_(t.from_numpy(m))
-        self.blend[:self.planes].copy_(t.from_numpy(b))
-        per = flags_own.size
-        self.flags[self.rank * per:(self.rank + 1) * per].copy_(t.from_numpy(flags_own))
+        self._d(1, self.planes + 1).copy_(t.from_numpy(d))
+        self._m(self.mat, 0, self.planes).copy_(t.from_numpy(m))
+        self._m(self.blend, 0, self.planes).copy_(t.from_numpy(b))
+        if self.axis == "z":
+            per = flags_own.size
+            self.flags[self.rank * per:(self.rank + 1) * per].copy_(t.from_numpy(flags_own))
+        else:
+            self.flags.copy_(t.from_numpy(np.ascontiguousarray(flags_own)))
+
+    def fill_from_full(self, d, m, b, flags):
+        """everything (own part + halo + all flags) from whole-grid host arrays — no exchange needed afterwards"""
+        t, n, p = self.torch, self.n, self.planes
+        lo, hi = max(self.z0 - 1, 0), min(self.z1 + 2, n)
+        hm = min(self.z1 + 1, n)
+        if self.axis == "z":
+            self.dist[lo - (self.z0 - 1):hi - (self.z0 - 1)].copy_(t.from_numpy(d[lo:hi]))
+            self.mat[:hm - self.z0].copy_(t.from_numpy(m[self.z0:hm]))
+            self.blend[:hm - self.z0].copy_(t.from_numpy(b[self.z0:hm]))
+        else:
+            self.dist[:, lo - (self.z0 - 1):hi - (self.z0 - 1)].copy_(t.from_numpy(np.ascontiguousarray(d[:, lo:hi])))
+            self.mat[:, :hm - self.z0].copy_(t.from_numpy(np.ascontiguousarray(m[:, self.z0:hm])))
+            self.blend[:, :hm - self.z0].copy_(t.from_numpy(np.ascontiguousarray(b[:, self.z0:hm])))
+        self.flags.copy_(t.from_numpy(np.ascontiguousarray(flags, np.uint8)))
 
     def gather_flags(self, dist_pkg):
         """Every rank needs the BF_Empty flags of the neighbouring slabs' boundary block layers; they are tiny, so
-        all ranks simply gather the whole array."""
-        if self.world == 1:
+        all ranks simply gather the whole array (z-slabs; with y-slabs fill_own already takes the full array)."""
+        if self.world == 1 or self.axis != "z":
             return
         per = self.flags.numel() // self.world
         mine = self.flags[self.rank * per:(self.rank + 1) * per].clone()
@@ -48,35 +81,67 @@ class SlabBuffers:
         self.flags.copy_(self.torch.cat(chunks))
 
     def halo_exchange(self, dist_pkg):
+        """1 distance layer from the slab below; 2 distance layers + 1 material + 1 blend layer from the slab above (a layer
+        = a z-plane or a y-row of every plane).  One grouped send/recv batch; strided row slices travel through
+        contiguous staging tensors."""
         if self.world == 1:
             return
         r, w, p = self.rank, self.world, self.planes
-        ops = []
+        contiguous = self.axis == "z"
+        ops, landings = [], []
+
+        def send(x, peer):
+            ops.append(dist_pkg.P2POp(dist_pkg.isend, x if contiguous else x.contiguous(), peer))
+
+        def recv(x, peer):
+            if contiguous:
+                ops.append(dist_pkg.P2POp(dist_pkg.irecv, x, peer))
+            else:
+                tmp = self.torch.empty(x.shape, dtype=x.dtype, device=x.device)
+                landings.append((x, tmp))
+                ops.append(dist_pkg.P2POp(dist_pkg.irecv, tmp, peer))
+
         if r > 0:
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, self.dist[1:3], r - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, self.mat[0:1], r - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, self.blend[0:1], r - 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, self.dist[0:1], r - 1))
+            send(self._d(1, 3), r - 1)
+            send(self._m(self.mat, 0, 1), r - 1)
+            send(self._m(self.blend, 0, 1), r - 1)
+            recv(self._d(0, 1), r - 1)
         if r < w - 1:
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, self.dist[p + 1:p + 3], r + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, self.mat[p:p + 1], r + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.irecv, self.blend[p:p + 1], r + 1))
-            ops.append(dist_pkg.P2POp(dist_pkg.isend, self.dist[p:p + 1], r + 1))
+            recv(self._d(p + 1, p + 3), r + 1)
+            recv(self._m(self.mat, p, p + 1), r + 1)
+            recv(self._m(self.blend, p, p + 1), r + 1)
+            send(self._d(p, p + 1), r + 1)
         for work in dist_pkg.batch_isend_irecv(ops):
             work.wait()
+        for dst, tmp in landings:
+            dst.copy_(tmp)
 
     def attach(self, poly):
-        poly.attach(self.n, self.z0, self.z1, self.dist.data_ptr(), self.z0 - 1, self.mat.data_ptr(),
-                    self.blend.data_ptr(), self.z0, self.flags.data_ptr())
+        if self.axis == "z":
+            poly.attach(self.n, self.z0, self.z1, self.dist.data_ptr(), self.z0 - 1, self.mat.data_ptr(),
+                        self.blend.data_ptr(), self.z0, self.flags.data_ptr())
+        else:
+            poly.attach_y(self.n, self.z0, self.z1, self.dist.data_ptr(), self.z0 - 1, self.planes + 3, self.mat.data_ptr(),
+                          self.blend.data_ptr(), self.z0, self.planes + 1, self.flags.data_ptr())
 
 
 def merge_rank_levels(per_rank_levels):
-    """Concatenate per-rank Level lists (rank order = block-id order because slabs are z-major)."""
+    """One Level list from per-rank Level lists, blocks in block-id order (with z-slabs that is rank order; with
+    y-slabs the ranks' blocks interleave)."""
     from .binding import Level
     out = []
     for l in range(len(per_rank_levels[0])):
-        parts = [r[l] for r in per_rank_levels]
-        out.append(Level(np.concatenate([p.infos for p in parts]), np.concatenate([p.verts for p in parts]),
-                         np.concatenate([p.idx for p in parts]), np.concatenate([p.tverts for p in parts]),
-                         np.concatenate([p.tidx for p in parts])))
+        blocks = []  # (id, info, verts, idx, tverts, tidx)
+        for r in per_rank_levels:
+            lv = r[l]
+            ov = oi = otv = oti = 0
+            for info in lv.infos:
+                nv, ni, ntv, nti = int(info["n_verts"]), int(info["n_idx"]), int(info["n_tverts"].sum()), int(info["n_tidx"].sum())
+                blocks.append((int(info["id"]), info, lv.verts[ov:ov + nv], lv.idx[oi:oi + ni], lv.tverts[otv:otv + ntv], lv.tidx[oti:oti + nti]))
+                ov += nv; oi += ni; otv += ntv; oti += nti
+        blocks.sort(key=lambda t: t[0])
+        first = per_rank_levels[0][l]
+        cat = lambda k, proto: np.concatenate([b[k] for b in blocks]) if blocks else proto[:0]
+        infos = np.array([b[1] for b in blocks], dtype=first.infos.dtype) if blocks else first.infos[:0]
+        out.append(Level(infos, cat(2, first.verts), cat(3, first.idx), cat(4, first.tverts), cat(5, first.tidx)))
     return out
