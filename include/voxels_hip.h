@@ -72,6 +72,10 @@ int vx_set_stream(vx_ctx* ctx, void* hip_stream);
  * (src/VoxelGrid.h:139-144); mat/blend may be NULL (all zero). */
 int vx_grid_upload(vx_ctx* ctx, uint32_t n, const int8_t* dist, const uint8_t* mat, const uint8_t* blend,
                    const uint8_t* empty_flags);
+/* Grid::Create(w, heightmap) (src/VoxelGrid.cpp:159-213) evaluated on the device: heightmap = w*w signed bytes, row = y;
+ * distance(x,y,z) = clamp((z - 127) - heightmap[y][x], -127, 127) squeezed to the grid's +-4 range, materials 0; BF_Empty of
+ * every block by the codec's rule.  Only the w*w bytes cross PCIe. */
+int vx_grid_create_heightmap(vx_ctx* ctx, uint32_t w, const int8_t* heightmap);
 /* The same, from the Grid file format v1 (what Grid::PackForSave writes and Grid::Load reads, src/VoxelGrid.cpp:215-315):
  * header {1, w, d, h}, 3 stream sizes per block, then per block in id order {flags, distance stream, material stream,
  * blend stream}; a stream is RLE pairs (u8 run length, value) or 4096 raw bytes when its BF_*Uncompressed flag is set

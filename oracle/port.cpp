@@ -882,6 +882,22 @@ vxo_grid* vxo_grid_from_float(uint32_t n, const float* values, const uint8_t* ma
 	return new vxo_grid{ g };
 }
 
+// VoxelGrid(unsigned w, const char* heightmap), src/VoxelGrid.cpp:159-213: distance = clamp(slice - 127 - height(row, column),
+// -127, 127) squeezed to the grid's +-4 range (toGridDistValue), materials and blends zero
+vxo_grid* vxo_grid_from_heightmap(uint32_t n, const char* heightmap)
+{
+	PGrid* g = NewGrid(n);
+	for (u32 z = 0; z < n; ++z)
+	for (u32 y = 0; y < n; ++y)
+	for (u32 x = 0; x < n; ++x) {
+		int h = ((int)z - 127) - (int)heightmap[(size_t)y * n + x];
+		h = h < -127 ? -127 : (h > 127 ? 127 : h);
+		g->dist[(size_t(z) * n + y) * n + x] = ClampGridDistance((int8_t)h);
+	}
+	for (u32 z = 0; z < g->nb; ++z) for (u32 y = 0; y < g->nb; ++y) for (u32 x = 0; x < g->nb; ++x) g->RefreshBlock(x, y, z, true, true);
+	return new vxo_grid{ g };
+}
+
 void vxo_grid_destroy(vxo_grid* g) { if (g) { delete g->g; delete g; } }
 uint32_t vxo_grid_size(const vxo_grid* g) { return g->g->n; }
 

@@ -158,6 +158,13 @@ vxo_grid* vxo_grid_from_float(uint32_t n, const float* values, const uint8_t* ma
 	return new vxo_grid{ g, n };
 }
 
+vxo_grid* vxo_grid_from_heightmap(uint32_t n, const char* heightmap)
+{
+	EnsureInit();
+	Grid* g = Grid::Create(n, heightmap);
+	return g ? new vxo_grid{ g, n } : nullptr;
+}
+
 void vxo_grid_destroy(vxo_grid* g)
 {
 	if (!g) return;

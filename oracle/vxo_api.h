@@ -44,6 +44,8 @@ vxo_grid* vxo_grid_from_dense(uint32_t n, const int8_t* dist, const uint8_t* mat
 /* Grid built through Grid::Create(w,d,h,0,0,0,1,surface): float distances are quantised by the
  * reference rule (VoxelGrid.cpp:37-50). */
 vxo_grid* vxo_grid_from_float(uint32_t n, const float* values, const uint8_t* mat, const uint8_t* blend);
+/* Grid::Create(w, heightmap) (src/VoxelGrid.cpp:159-213): heightmap = w*w signed bytes, row-major (row = y) */
+vxo_grid* vxo_grid_from_heightmap(uint32_t n, const char* heightmap);
 void vxo_grid_destroy(vxo_grid* g);
 uint32_t vxo_grid_size(const vxo_grid* g);
 void vxo_grid_read_dense(const vxo_grid* g, int8_t* dist, uint8_t* mat, uint8_t* blend);

@@ -85,6 +85,14 @@ struct Backend {
 			if (!blob) meta[id * 4 + 3] = flags; else memcpy(blob + where[id], &flags, 4);
 		}
 	}
+	void run_heightmap(const GridView& g, const i8* map, u8* flags)
+	{
+		const u32 n = (u32)g.n, nb = n / 16;
+		i8* dist = const_cast<i8*>(g.dist);
+		for (u32 z = 0; z < n; ++z) for (u32 y = 0; y < n; ++y) for (u32 x = 0; x < n; ++x)
+			dist[((size_t)z * n + y) * n + x] = heightmap_distance((int)z, (int)map[(size_t)y * n + x]);
+		for (u32 id = 0; id < nb * nb * nb; ++id) flags[id] = edit_block_empty(g, id % nb, (id / nb) % nb, id / (nb * nb));
+	}
 	bool d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
 	{

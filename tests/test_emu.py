@@ -423,3 +423,26 @@ def check_pack(p, port, n, seed, noisy):
 @pytest.mark.parametrize("noisy", [False, True])
 def test_emu_grid_pack(emu, port, noisy):
     check_pack(make_poly(emu), port, 64, 41, noisy)
+
+
+def check_heightmap(p, port, n, seed, nrm_tol=0.0):
+    """§8(f) row 3: Grid::Create(w, heightmap) evaluated on the device — file bytes (= voxel data + codec state) and the
+    polygonized surface equal the reference's for the same height map."""
+    rng = np.random.RandomState(seed)
+    base = fields.smooth_noise(n, seed, scale=max(4, n // 4), amp=0.2 * n, octaves=3)[0]
+    hm = np.clip(np.round(base + rng.uniform(-1, 1, (n, n))) + (n // 2 - 127), -128, 127).astype(np.int8)
+    g = port.grid_from_heightmap(n, hm)
+    p.create_heightmap(hm)
+    assert np.array_equal(p.pack(), g.pack()), "the generated grid written as a file"
+    flags = g.block_flags()
+    for bid in (0, 1, (n // 16) ** 3 // 2, (n // 16) ** 3 - 1):
+        assert p.read_block(bid)[3] == flags[bid]
+    p.execute()
+    s = port.execute(g)
+    ok, msg = fields.surface_equal(p.all_levels(), s.all_levels(), nrm_tol=nrm_tol)
+    assert ok, msg
+    assert np.array_equal(p.stats(), s.stats())
+
+
+def test_emu_create_heightmap(emu, port):
+    check_heightmap(make_poly(emu), port, 64, 3)

@@ -434,3 +434,11 @@ def test_hip_grid_pack(poly, port, n, noisy):
     """§8(f) row 1, encode half: k_encode_grid writes the reference's file byte for byte."""
     from test_emu import check_pack
     check_pack(poly, port, n, 43, noisy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 256])
+def test_hip_create_heightmap(poly, port, n):
+    """§8(f) row 3: the reference's height-map constructor evaluated by k_heightmap (+ BF_Empty by k_edit_flags)."""
+    from test_emu import check_heightmap
+    check_heightmap(poly, port, n, 9, nrm_tol=NRM_TOL)

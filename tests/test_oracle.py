@@ -135,3 +135,18 @@ def test_port_vs_reference_edit_and_pack(port, ref):
         assert np.array_equal(a, c)
     assert np.array_equal(gr.pack(), gp.pack())
     assert_same(ref.execute(gr).all_levels(), port.execute(gp).all_levels())
+
+
+def test_port_heightmap_constructor_matches_reference():
+    """Grid::Create(w, heightmap): restatement == reference (dense data, flags, file bytes)."""
+    ref, port = vxo.load_ref(), vxo.load_port()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.RandomState(5)
+    n = 64
+    hm = (rng.randint(-40, 40, (n, n)) + (np.arange(n).reshape(n, 1) - 32)).clip(-128, 127).astype(np.int8)
+    a, b = ref.grid_from_heightmap(n, hm), port.grid_from_heightmap(n, hm)
+    for x, y in zip(a.read_dense(), b.read_dense()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.block_flags(), b.block_flags())
+    assert np.array_equal(a.pack(), b.pack())

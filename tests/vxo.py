@@ -162,6 +162,8 @@ class Oracle:
         lib.vxo_grid_pack.restype = sz
         lib.vxo_grid_pack.argtypes = [vp, vp, sz]
         lib.vxo_grid_load.restype = vp
+        lib.vxo_grid_from_heightmap.restype = vp
+        lib.vxo_grid_from_heightmap.argtypes = [C.c_uint32, vp]
         lib.vxo_grid_load.argtypes = [vp, sz]
         lib.vxo_execute.restype = vp
         lib.vxo_execute.argtypes = [vp, vp, vp, C.c_int]
@@ -196,6 +198,11 @@ class Oracle:
         assert values.shape == (n, n, n) and values.dtype == np.float32 and values.flags.c_contiguous
         h = self.lib.vxo_grid_from_float(n, _ptr(values), _ptr(mat), _ptr(blend))
         return Grid(self.lib, h)
+
+    def grid_from_heightmap(self, n, heightmap):
+        hm = np.ascontiguousarray(heightmap, np.int8)
+        assert hm.shape == (n, n)
+        return Grid(self.lib, self.lib.vxo_grid_from_heightmap(n, _ptr(hm)))
 
     def grid_load(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)

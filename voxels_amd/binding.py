@@ -53,6 +53,7 @@ class HipLibrary:
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
         lib.vx_compact_pools.argtypes = [vp]
         lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
+        lib.vx_grid_create_heightmap.argtypes = [vp, u32, vp]
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
@@ -136,6 +137,13 @@ class Polygonizer:
         blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob.view(np.uint8))
         self._check(self._lib.vx_grid_upload_packed(self._h, _ptr(blob), blob.size), "vx_grid_upload_packed")
         self.n = int(np.frombuffer(blob[4:8].tobytes(), np.uint32)[0])
+
+    def create_heightmap(self, heightmap):
+        """Grid::Create(w, heightmap) evaluated on the device; heightmap int8 [w, w] (row = y)."""
+        hm = np.ascontiguousarray(heightmap, np.int8)
+        assert hm.ndim == 2 and hm.shape[0] == hm.shape[1]
+        self._check(self._lib.vx_grid_create_heightmap(self._h, hm.shape[0], _ptr(hm)), "vx_grid_create_heightmap")
+        self.n = hm.shape[0]
 
     def pack(self):
         """Grid::PackForSave of the resident grid (encoded on the device) -> uint8 array."""

@@ -1190,6 +1190,14 @@ TV_HD u8 edit_block_empty(const GridView& g, u32 bx, u32 by, u32 bz)
 	return empty ? 1 : 0;
 }
 
+// VoxelGrid(unsigned w, const char* heightmap), src/VoxelGrid.cpp:159-213: one distance sample
+TV_HD i8 heightmap_distance(int z, int height)
+{
+	int h = (z - 127) - height;
+	h = h < -127 ? -127 : (h > 127 ? 127 : h);
+	return (i8)(h > 4 ? 4 : (h < -4 ? -4 : h)); // toGridDistValue (:42-50)
+}
+
 // CompressBlock (src/VoxelGrid.cpp:610-672) on one 4096-byte stream given as 256 rows of 16 bytes with stride
 // `rowStride(row)`: returns the coded size (2 bytes per run, runs of at most 255) or 4096 when the code would not fit
 // (then the stream is stored raw); with `out` the bytes are written too.

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WG) void k_edit_flags(GridView g, u8* flags, const 
 	__shared__ i8 lastOfRow[WG];
 	__shared__ int waveMax[WG / 64];
 	__shared__ u32 runs;
-	const u32 nb = (u32)g.n / 16, id = ids[blockIdx.x], t = threadIdx.x;
+	const u32 nb = (u32)g.n / 16, id = ids ? ids[blockIdx.x] : blockIdx.x, t = threadIdx.x; // no list = every block
 	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
 	const i8* base = g.dist + ((size_t)(bz * 16) * g.n + by * 16) * g.n + bx * 16;
 	const uint4 raw = *(const uint4*)(base + ((size_t)(t >> 4) * g.n + (t & 15)) * g.n); // row t = (y = t & 15, z = t >> 4): codec order
@@ -389,6 +389,22 @@ __global__ __launch_bounds__(WG) void k_encode_grid(GridView g, u32* meta, const
 		if (!blob) meta[id * 4 + 3] = flags;
 		else { u8* rec = blob + where[id]; rec[0] = (u8)flags; rec[1] = 0; rec[2] = 0; rec[3] = 0; }
 	}
+}
+
+// k_heightmap: Grid::Create(w, heightmap) — one 16-byte store per lane (16 voxels of a row share y and z)
+__global__ __launch_bounds__(WG) void k_heightmap(GridView g, const i8* map)
+{
+	const u32 n = (u32)g.n, segs = n >> 4;
+	const size_t q = (size_t)blockIdx.x * WG + threadIdx.x; // 16-voxel segment index: x fastest
+	if (q >= (size_t)n * n * segs) return;
+	const u32 sx = (u32)(q % segs), y = (u32)((q / segs) % n), z = (u32)(q / ((size_t)segs * n));
+	i8 h[16], v[16];
+	memcpy(h, map + (size_t)y * n + sx * 16, 16);
+#pragma unroll
+	for (int i = 0; i < 16; ++i) v[i] = heightmap_distance((int)z, (int)h[i]);
+	uint4 out;
+	memcpy(&out, v, 16);
+	*(uint4*)(const_cast<i8*>(g.dist) + ((size_t)z * n + y) * n + sx * 16) = out;
 }
 
 // k_scatter_blocks: edited 16^3 blocks (4096 contiguous bytes each) into the dense fields; lane t owns voxel row t
@@ -1326,6 +1342,14 @@ struct Backend {
 		const u32 nb = (u32)g.n / 16;
 		hipLaunchKernelGGL(k_encode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, g, meta, (const unsigned long long*)where, blob);
 		check(hipGetLastError(), "k_encode_grid launch");
+	}
+	void run_heightmap(const GridView& g, const i8* map, u8* flags)
+	{
+		const u32 n = (u32)g.n, nb = n / 16;
+		const size_t segs = (size_t)n * n * (n / 16);
+		hipLaunchKernelGGL(k_heightmap, dim3((u32)((segs + WG - 1) / WG)), dim3(WG), 0, stream, g, map);
+		hipLaunchKernelGGL(k_edit_flags, dim3(nb * nb * nb), dim3(WG), 0, stream, g, flags, (const u32*)nullptr, nb * nb * nb);
+		check(hipGetLastError(), "k_heightmap launch");
 	}
 	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
 	{

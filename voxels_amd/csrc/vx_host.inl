@@ -443,6 +443,33 @@ int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload: copy failed: " + c->be.error());
 }
 
+int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
+{
+	if (!c || !heightmap || n < 16 || (n & 15)) return fail(c, VX_ERR_INVALID, "vx_grid_create_heightmap: w must be a multiple of 16, heightmap non-null");
+	const u32 nb = n / 16;
+	const size_t blocks = (size_t)nb * nb * nb, tot = (size_t)n * n * n;
+	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n && c->yBegin == 0 && c->yEnd == n)) {
+		release_grid(c);
+		c->dDist = c->be.alloc(tot); c->dMat = c->be.alloc(tot); c->dBlend = c->be.alloc(tot); c->dFlags = c->be.alloc(blocks);
+		c->ownsGrid = true;
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_create_heightmap: device allocation failed: " + c->be.error()); }
+	}
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
+	c->haveSurface = false;
+	void* dMap = c->be.alloc((size_t)n * n);
+	bool ok = dMap && c->be.h2d(dMap, heightmap, (size_t)n * n) && c->be.fill(c->dMat, 0, tot) && c->be.fill(c->dBlend, 0, tot);
+	if (ok) {
+		GridView g;
+		g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
+		g.n = (int)n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)n; g.pitchYMat = (int)n;
+		c->be.run_heightmap(g, (const i8*)dMap, (u8*)c->dFlags);
+		ok = c->be.sync_ok();
+	}
+	c->be.free(dMap);
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_create_heightmap: device pass failed: " + c->be.error());
+}
+
 int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 {
 	if (!c || !blobPtr || size < 16) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: null or truncated blob");
