@@ -442,3 +442,33 @@ def test_hip_create_heightmap(poly, port, n):
     """§8(f) row 3: the reference's height-map constructor evaluated by k_heightmap (+ BF_Empty by k_edit_flags)."""
     from test_emu import check_heightmap
     check_heightmap(poly, port, n, 9, nrm_tol=NRM_TOL)
+
+
+@pytest.mark.gpu
+def test_hip_device_only_pipeline_512(poly, port):
+    """Everything the widened path offers, chained on a grid that never exists on the host in dense form: height-map
+    constructor -> polygonize -> write file -> ball edit -> incremental polygonize -> compact -> write file; against the
+    oracle doing the same with Grid::Create / Execute / PackForSave / InjectSurface."""
+    n = 512
+    base = fields.smooth_noise(n, 77, scale=n // 4, amp=0.2 * n, octaves=3)[0]
+    hm = np.clip(np.round(base) + (n // 2 - 127), -128, 127).astype(np.int8)
+    g = port.grid_from_heightmap(n, hm)
+    poly.create_heightmap(hm)
+    poly.execute()
+    s = port.execute(g)
+    ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+    assert ok, msg
+    assert np.array_equal(poly.pack(), g.pack())
+    zs = int(hm[n // 2, n // 2]) + 127
+    pos, ext, r = (n / 2.0, n / 2.0, float(zs)), (44.0, 44.0, 44.0), 20.0
+    mn, mx = g.inject_ball(pos, ext, r, 2)
+    mn2, mx2 = poly.inject_ball(pos, ext, r, 2)
+    assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2)
+    ref_ids = port.execute_modify(g, s, mn, mx)
+    got = poly.execute_dirty(mn2, mx2)
+    assert np.array_equal(got, ref_ids)
+    poly.compact_pools()
+    ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+    assert ok, msg
+    assert np.array_equal(poly.stats(), s.stats())
+    assert np.array_equal(poly.pack(), g.pack())
