@@ -472,3 +472,16 @@ def test_hip_device_only_pipeline_512(poly, port):
     assert ok, msg
     assert np.array_equal(poly.stats(), s.stats())
     assert np.array_equal(poly.pack(), g.pack())
+
+
+@pytest.mark.gpu
+def test_hip_single_block_grid(poly, port):
+    """16^3: one block, one level, no neighbours anywhere (every tile, slab and class array at its minimum size)."""
+    rng = np.random.RandomState(16)
+    d = np.clip(np.round(fields.smooth_noise(16, 3, scale=6, amp=3.0)), -4, 4).astype(np.int8)
+    m = rng.randint(0, 3, (16, 16, 16)).astype(np.uint8)
+    b = rng.randint(0, 256, (16, 16, 16)).astype(np.uint8)
+    check_against(poly, port, d, m, b, "16^3")
+    g = port.grid_from_dense(d, m, b)
+    poly.upload_packed(g.pack())
+    assert np.array_equal(poly.pack(), g.pack())
