@@ -1091,6 +1091,12 @@ struct EditSection {
 	float start[3];
 	int count[3];
 	float bmin[3];
+	// the brush is sampled by ITS OWN float loops from sstart (one step per sample) while the grid consumes the samples
+	// with a running index over its loops; float rounding can give the two a different trip count along an axis
+	// (e.g. 5 rows in the grid loop, 6 samples in the brush loop), and then the reference pairs voxels with shifted
+	// samples.  scount = trip counts of the brush loops.
+	float sstart[3];
+	int scount[3];
 };
 
 TV_HD float edit_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -1108,6 +1114,11 @@ TV_HD EditSection edit_section(const EditParams& e, u32 bx, u32 by, u32 bz)
 		int cnt = 0;
 		for (float x = b0; x < b1; ++x) ++cnt; // at most 17 steps; the loop itself is the specification
 		s.count[k] = cnt;
+		const float s0 = (s.bmin[k] + b0) - e.pos[k], s1 = (s.bmin[k] + b1) - e.pos[k]; // surfaceCoordStart / End (:412-413)
+		s.sstart[k] = s0;
+		int sc = 0;
+		for (float x = s0; x < s1; x += 1.0f) ++sc;
+		s.scount[k] = sc;
 	}
 	return s;
 }
@@ -1135,11 +1146,15 @@ TV_HD void edit_voxel(const GridView& g, const EditParams& e, const EditSection&
 	const float x = edit_step(s.start[0], ix), y = edit_step(s.start[1], iy), z = edit_step(s.start[2], iz);
 	const size_t i = ((size_t)((u32)s.bmin[2] + (u32)z) * g.n + ((u32)s.bmin[1] + (u32)y)) * g.n + ((u32)s.bmin[0] + (u32)x);
 	if (e.kind == EDIT_BALL) {
-		// the brush is sampled from (block corner + section start - position) in steps of 1, like the GetSurface call (:405-420)
-		const float sx = edit_step((s.bmin[0] + s.start[0]) - e.pos[0], ix);
-		const float sy = edit_step((s.bmin[1] + s.start[1]) - e.pos[1], iy);
-		const float sz = edit_step((s.bmin[2] + s.start[2]) - e.pos[2], iz);
-		const float sv = sqrtf((sx * sx + sy * sy) + sz * sz) - e.radius;
+		// the voxel's sample is the one its running index meets in the brush's output (:405-441), see EditSection
+		const int vi = (iz * s.count[1] + iy) * s.count[0] + ix;
+		const int plane = s.scount[0] * s.scount[1];
+		float sv = 0.f; // past the last sample the brush wrote (the reference reads unwritten floats there)
+		if (plane > 0 && vi < plane * s.scount[2]) {
+			const int jz = vi / plane, rem = vi - jz * plane, jy = rem / s.scount[0], jx = rem - jy * s.scount[0];
+			const float sx = edit_step(s.sstart[0], jx), sy = edit_step(s.sstart[1], jy), sz = edit_step(s.sstart[2], jz);
+			sv = sqrtf((sx * sx + sy * sy) + sz * sz) - e.radius;
+		}
 		i8* dist = const_cast<i8*>(g.dist);
 		const float value = (float)dist[i];
 		float r;
