@@ -334,7 +334,10 @@ def check_device_edits(p, port, n, seed, surface_tol=0.0):
     nb = n // 16
     edits = (("ball", 2, (c - 2.0, c + 1.5, c - 0.75), (20, 20, 20), 7.0), ("ball", 0, (c + 8, c - 12, c - 7), (16, 16, 16), 6.0),
              ("mat", 3, (c - 3.0, c + 2.0, c - 2.0), (14, 14, 14), 1), ("ball", 2, (3.0, n - 4.0, c - 2), (12, 12, 12), 5.0),
-             ("ball", 1, (c + 0.5, c + 0.25, c - 4.5), (9, 9, 9), 3.5), ("mat", 3, (c - 1.0, c + 1.0, c - 1.0), (10, 10, 10), 0))
+             ("ball", 1, (c + 0.5, c + 0.25, c - 4.5), (9, 9, 9), 3.5), ("mat", 3, (c - 1.0, c + 1.0, c - 1.0), (10, 10, 10), 0),
+             # non-cubic extents at a fractional position: the brush's row loop makes 6 trips, the grid's 5 (float rounding),
+             # so the reference pairs voxels with shifted samples (found by tools/fuzz_parity.py)
+             ("ball", 0, (37.4, 7.1, 51.3), (11.7, 5.0, 20.8), 2.4210112751143384))
     for kind, a, pos, ext, r in edits:
         pre = g.read_dense()
         if kind == "ball":
