@@ -166,7 +166,6 @@ int vx_set_stage_timing(vx_ctx* ctx, int enable);
 int vx_stage_times(vx_ctx* ctx, float ms[6]);
 /* Profiling aid: make the per-block kernels stop after phase `limit` (0 = full pipeline; results are then
  * incomplete by design).  Used by tools/phase_profile.py to attribute kernel time to phases. */
-int vx_debug_phase_limit(vx_ctx* ctx, uint32_t limit);
 
 /* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */
 const char* vx_backend(void);

@@ -5,6 +5,7 @@ struct ExecParamsView; // ExecParams is defined by vx_host.inl; stages are templ
 
 struct Backend {
 	std::string lastError;
+	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
 
 	bool init(int, std::string&) { return true; }
 	void shutdown() {}

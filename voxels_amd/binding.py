@@ -68,7 +68,6 @@ class HipLibrary:
         lib.vx_stats.argtypes = [vp, vp]
         lib.vx_set_stage_timing.argtypes = [vp, C.c_int]
         lib.vx_stage_times.argtypes = [vp, vp]
-        lib.vx_debug_phase_limit.argtypes = [vp, u32]
         self.lib = lib
         self.path = path
         self.backend = lib.vx_backend().decode()
@@ -261,8 +260,6 @@ class Polygonizer:
     def set_stage_timing(self, enable):
         self._check(self._lib.vx_set_stage_timing(self._h, int(bool(enable))), "vx_set_stage_timing")
 
-    def debug_phase_limit(self, limit):
-        self._check(self._lib.vx_debug_phase_limit(self._h, int(limit)), "vx_debug_phase_limit")
 
     def stage_times(self):
         """ms of (reset, classify, hierarchy, material, regular, transition) of the last run."""

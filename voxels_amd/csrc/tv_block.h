@@ -78,7 +78,6 @@ struct Globals {
 	u32* stats;
 	u32 levels;             // number of levels being polygonized (0..levels-1)
 	u32 refLevels;          // the reference's levelsCount = log2(N/16)+1 (decides which levels get transitions)
-	u32 debugPhaseLimit;    // profiling aid: stop the per-block pipeline after this phase (0 = run everything)
 	// incremental (Modification) runs: only the listed blocks are re-polygonized, caches keep their old contents
 	u32 dirty;                        // 0 = full run
 	const u32* workItems[MAX_LEVELS]; // dirty: active slots to process per level

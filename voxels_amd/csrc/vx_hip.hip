@@ -937,7 +937,13 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 	return T;
 }
 
-// One capacity class of the regular pass: blocks with lo < non-trivial cells <= CAP
+} // namespace
+
+#include "vx_regular0.inl"
+
+namespace {
+
+// One capacity class of the regular pass of levels >= 1: blocks with lo < non-trivial cells <= CAP
 template <int CAP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
@@ -960,7 +966,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const Tables T = stage_regular_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
-	const u32 lim = p.G.debugPhaseLimit & 0xFFu;
 
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
@@ -981,7 +986,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 		reg_phase_begin(st, L, b.slot, tid, WG);
 		gpu_reg_stage(p.G.grid, b, st.samp);
 		__syncthreads();
-		if (lim == 1) continue;
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
 		__syncthreads();
 		{
@@ -989,21 +993,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			if (tid == 0) st.wordPrefix[128] = (u16)nt;
 		}
 		__syncthreads();
-		if (lim == 2) continue;
 		reg_phase_list(st, L, b, tid, WG);
 		__syncthreads();
 		reg_phase_cells(st, T, p.G, L, b, tid, WG);
 		__syncthreads();
-		if (lim == 3) continue;
 		reg_phase_count(st, T, b, tid, WG);
 		__syncthreads();
-		if (lim == 4) continue;
 		{
 			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt); }
 		}
 		__syncthreads();
-		if (lim == 5) continue;
 		for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
 			if (chunk) __syncthreads();
 			reg_phase_describe(st, chunk, tid, WG);
@@ -1011,16 +1011,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			reg_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
 		}
 		__syncthreads();
-		if (lim == 6) continue;
 		reg_phase_keep(st, T, p.G, b, tid, WG);
 		__syncthreads();
-		if (lim == 7) continue;
 		{
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[CUR_I], it); }
 		}
 		__syncthreads();
-		if (lim == 8) continue;
 		for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
 			if (chunk) __syncthreads();
 			reg_phase_stage_indices(st, T, chunk, tid, WG);
@@ -1225,7 +1222,11 @@ struct Backend {
 	bool stageOn = false, stageValid = false;
 	std::string lastError;
 	int cus = 256;
+	int device = 0;
 	bool ok = true;
+	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, oldReg0 = 0; } tune;
+	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
 	{
@@ -1240,20 +1241,34 @@ struct Backend {
 		int count = 0;
 		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { err = "no HIP device"; return false; }
 		if (!check(hipSetDevice(device), "hipSetDevice")) { err = lastError; return false; }
+		this->device = device;
+		tune.classifyRowGroup = env_u32("VX_CLASSIFY_ROWGROUP", 4);
+		tune.matGrid = env_u32("VX_MAT_GRID", 0);
+		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
+		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
+		tune.oldReg0 = env_u32("VX_OLD_REG0", 0); // TEMP A/B
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
 		stream = ownStream;
-		(void)hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking);
-		(void)hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking);
-		(void)hipEventCreateWithFlags(&evClassified, hipEventDisableTiming);
-		(void)hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming);
-		(void)hipEventCreateWithFlags(&evSideA, hipEventDisableTiming);
-		(void)hipEventCreateWithFlags(&evSideB, hipEventDisableTiming);
-		(void)hipEventCreate(&ev0);
-		(void)hipEventCreate(&ev1);
+		if (!check(hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking), "hipStreamCreate(side A)")
+		    || !check(hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking), "hipStreamCreate(side B)")
+		    || !check(hipEventCreateWithFlags(&evClassified, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evSideA, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evSideB, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreate(&ev0), "hipEventCreate") || !check(hipEventCreate(&ev1), "hipEventCreate")) {
+			err = lastError;
+			return false;
+		}
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
+		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>)), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
+		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")) {
+			err = lastError;
+			return false;
+		}
 		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")) {
@@ -1306,7 +1321,7 @@ struct Backend {
 	{
 		stageOn = on;
 		stageValid = false;
-		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i]) (void)hipEventCreate(&stageEv[i]);
+		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i] && !check(hipEventCreate(&stageEv[i]), "hipEventCreate(stage)")) { stageOn = false; return; }
 	}
 	void stage_mark(int i)
 	{
@@ -1422,8 +1437,7 @@ struct Backend {
 		const u32 rows = rowsY * (L.zb1 - L.zb0);
 		u32 rowGroup = 0; // 0 = no remap
 		if ((rows & 7u) == 0) {
-			const char* rgEnv = getenv("VX_CLASSIFY_ROWGROUP"); // tuning aid
-			rowGroup = rgEnv ? (u32)atoi(rgEnv) : 4u;
+			rowGroup = tune.classifyRowGroup;
 			while (rowGroup > 1 && rows % (8 * rowGroup)) rowGroup >>= 1;
 			if (!rowGroup) rowGroup = 1;
 		}
@@ -1468,24 +1482,31 @@ struct Backend {
 	{
 		const u32 cap = p.levels[level].cap;
 		if (!cap) return;
-		const char* mgEnv = getenv("VX_MAT_GRID"); // tuning aid
-		const u32 grid = std::min<u32>(cap, mgEnv ? (u32)atoi(mgEnv) : (u32)cus * 8);
+		const u32 grid = std::min<u32>(cap, tune.matGrid ? tune.matGrid : (u32)cus * 8);
 		hipLaunchKernelGGL(k_material, dim3(grid), dim3(WG), 0, stream, dev(p), level);
 		check(hipGetLastError(), "k_material launch");
 	}
+	// Regular cells of the levels [levelBegin, levels): level 0 has its own kernel (vx_regular0.inl).  The 4096-cell
+	// capacity class is only launched when blocks that large are expected (largeClass, set by the host from the
+	// previous run's count; a run that meets an unexpected one is repeated with the class enabled).
+	bool largeClass = true;
 	template <typename P>
-	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on, u32 defaultPerCu = 20)
+	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on)
 	{
+		if (levelBegin == 0 && p.levels[0].cap && !tune.oldReg0) {
+			const u32 cap = p.levels[0].cap;
+			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
+			hipLaunchKernelGGL(k_regular0<REG_CAP_SMALL>, dim3(gridS), dim3(WG), R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), on, dev(p), 0u);
+			if (largeClass) hipLaunchKernelGGL(k_regular0<4096>, dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), R0_TAB_LDS + sizeof(Reg0State<4096>), on, dev(p), (u32)REG_CAP_SMALL);
+			levelBegin = 1;
+		}
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
-		if (!cap) return;
-		const char* wgEnv = getenv("VX_REG_WGS_PER_CU"); // tuning aid
-		const u32 perCu = wgEnv ? (u32)atoi(wgEnv) : defaultPerCu;
-		u32 gridS = std::min<u32>(cap, (u32)cus * perCu);
-		const u32 gridL = std::min<u32>(cap, (u32)cus * 1);
-		if (const char* gEnv = getenv("VX_REG_GRID")) gridS = std::min<u32>(cap, (u32)atoi(gEnv) & ~7u); // experiment: one block per workgroup
-		hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
-		hipLaunchKernelGGL(k_regular<4096>, dim3(gridL), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
+		if (cap) {
+			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
+			hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
+			if (largeClass) hipLaunchKernelGGL(k_regular<4096>, dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
+		}
 		check(hipGetLastError(), "k_regular launch");
 	}
 	template <typename P>
@@ -1501,10 +1522,7 @@ struct Backend {
 	{
 		(void)hipEventRecord(evClassified, stream);
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		{
-			const char* l0Env = getenv("VX_REG_WGS_L0"); // tuning aid
-			launch_regular(p, 0, 1, sideA, l0Env ? (u32)atoi(l0Env) : 20u);
-		}
+		launch_regular(p, 0, 1, sideA);
 		(void)hipEventRecord(evSideA, sideA);
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
 		(void)hipEventRecord(evMaterial, stream);
@@ -1528,8 +1546,7 @@ struct Backend {
 		u32 cap = 0;
 		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
 		if (!cap) return;
-		const char* tgEnv = getenv("VX_TR_GRID"); // tuning aid
-		const u32 grid = std::min<u32>(cap, tgEnv ? ((u32)atoi(tgEnv) & ~7u) : (u32)cus * 12);
+		const u32 grid = std::min<u32>(cap, tune.trGrid ? tune.trGrid : (u32)cus * 12);
 		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		check(hipGetLastError(), "k_transition launch");
 	}

@@ -85,7 +85,8 @@ struct vx_ctx {
 	size_t scratchCap = 0;
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
 	size_t hRecCap = 0;
-	u32 debugPhaseLimit = 0;
+	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
+	bool hostTiming = false;    // VX_HOST_TIMING (read once at context creation): print where a vx_polygonize call spends host time
 };
 
 namespace {
@@ -200,7 +201,6 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
-	p.G.debugPhaseLimit = c->debugPhaseLimit;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
 	p.P.verts = (PolyVertex*)c->dVerts;
 	p.P.idx = (u32*)c->dIdx;
@@ -382,6 +382,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	memset(c->stats, 0, sizeof(c->stats));
 	std::string e;
 	if (!c->be.init(device_index, e)) { delete c; return VX_ERR_DEVICE; }
+	c->hostTiming = getenv("VX_HOST_TIMING") != nullptr;
 	std::vector<u8> img;
 	build_table_image(img);
 	c->dTables = c->be.alloc(TAB_BYTES);
@@ -731,7 +732,8 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	}
 	u32 retries = 0;
 	float ms = 0.f;
-	const bool hostTiming = getenv("VX_HOST_TIMING") != nullptr;
+	const bool hostTiming = c->hostTiming;
+	c->be.largeClass = c->largeHint;
 	auto tNow = []() { return std::chrono::steady_clock::now(); };
 	auto tUs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
 	const auto t0 = tNow();
@@ -756,10 +758,12 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
 		t3 = tNow();
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
+		if (c->hdr[HDR_LARGE] && !c->be.largeClass) { c->be.largeClass = true; continue; } // blocks of the large class showed up: once more, with it
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
 	}
+	c->largeHint = c->hdr[HDR_LARGE] != 0;
 	c->levelsRun = levels;
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->hostVerts = 0; c->hostIdx = 0; // the pools were rewritten
@@ -922,6 +926,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		ExecParams p;
 		fill_params(c, p, levels);
 		p.G.dirty = 1;
+		c->be.largeClass = true;
 		for (u32 L = 0; L < levels; ++L) { p.G.workItems[L] = (const u32*)c->dWork + start[L]; p.G.prevActive[L] = prevActive[L]; }
 		c->be.begin_timing();
 		c->be.stage_mark(0);
@@ -1067,13 +1072,6 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 {
 	if (!c) return VX_ERR_INVALID;
 	c->be.stage_enable(enable != 0);
-	return VX_OK;
-}
-
-int vx_debug_phase_limit(vx_ctx* c, uint32_t limit)
-{
-	if (!c) return VX_ERR_INVALID;
-	c->debugPhaseLimit = limit;
 	return VX_OK;
 }
 

@@ -1,0 +1,611 @@
+// vx_regular0.inl — the regular-cell pass of level 0 (PolygonizeBlock, src/TransVoxelImpl.cpp:1529-1750, for the
+// surface-bearing level-0 blocks), written for gfx950.  Included by vx_hip.hip.
+//
+// Same closed form and the same per-cell arithmetic as the portable phases of tv_block.h (which the CPU emulation runs
+// and which levels >= 1 still use on the GPU); what differs is how a workgroup gets through a block:
+//   * the next block's inputs (19^3 distance neighbourhood, 17^3 material + blend samples, non-trivial bitmap) are
+//     requested into registers while the current block emits its index list, so no phase waits for HBM;
+//   * materials and blends of the block live in LDS: no phase after staging touches global memory except the LUT row
+//     of a vertex and the output stores;
+//   * cell classification, reuse resolution (TransVoxelImpl.cpp:1579-1718), degenerate filter (:1300-1321) and the
+//     vertex / index counts are one pass over the compact cell list; cells whose samples are all non-zero — every cell
+//     of an ordinary surface — take a short path: a crossed edge with non-zero end samples is seen identically by the
+//     neighbour that owns it, so "the neighbour's reuse slot is valid" needs no lookup, only the material test does;
+//   * one packed scan gives vertex and index offsets, both pool reservations are in flight together, vertices and
+//     indices are emitted in the same phase.
+// About 7 workgroup barriers per block instead of 23.
+namespace {
+
+constexpr int R0_MROW = 20;                  // bytes per staged material row: samples 0..16 of the row + padding
+constexpr int R0_MPLANE = 17 * R0_MROW;
+constexpr int R0_MBYTES = 17 * R0_MPLANE;
+constexpr int R0_VDESC = 1024;               // vertex descriptors per chunk
+constexpr int R0_IDESC = 2048;               // index descriptors per chunk
+constexpr u32 R0_TAB_LDS = 512 + 64 + 2048 + 256; // regClass + regCell | edge words | regVert rows (8 bytes each) | regOwn
+
+template <int CAP>
+struct Reg0State {
+	i8 samp[SAMP_BYTES + 8];                                  // tv_block.h layout: 19 x 19 rows of 24 bytes
+	__attribute__((aligned(4))) u8 matId[R0_MBYTES + 4];      // material id of voxel (i,j,k), 0..16 from the block origin
+	__attribute__((aligned(4))) u8 blend[R0_MBYTES + 4];
+	u32 ntBits[128];
+	u16 wordPrefix[132];
+	u32 cellA[CAP];        // compact: cell id | case code << 12 | (corner sample == 0) mask << 20
+	u32 cellB[CAP];        // compact: created vertices (12) | of those, placed at corner v0 (12) << 12 | kept triangles (5) << 24 | any INVALID vertex << 31
+	u32 cellC[CAP];        // compact: created vertex count | kept index count << 16; after the scan: vertex base | index base << 16
+	u16 ords[CAP];         // compact: ordinal (4 bits) of the vertex stored in each of the 4 reuse slots
+	u16 invalidMask[CAP];  // compact: table vertices that resolve to INVALID_INDEX
+	u16 vdesc[R0_VDESC];   // new vertices of the chunk: compact cell | table vertex << 12
+	u16 idesc[R0_IDESC];   // indices of the chunk: compact cell | (triangle * 3 + corner) << 12
+	u32 waveTot[4];
+	u32 vOff, iOff, vTotal, iTotal, degenerate;
+};
+
+__device__ __forceinline__ int r0_samp_off(int corner) { return (corner & 1) + ((corner >> 1) & 1) * SROW + (corner >> 2) * SPLANE; }
+__device__ __forceinline__ int r0_mat_off(int corner) { return (corner & 1) + ((corner >> 1) & 1) * R0_MROW + (corner >> 2) * R0_MPLANE; }
+
+// tables in LDS: like stage_regular_tables, the per-case vertex rows widened to 8 bytes (one ds_read_b64 per case)
+struct R0Tables {
+	const u8* cls;        // 256
+	const u8* cell;       // 16 x 16
+	const u16* edge;      // 16 edge words
+	const unsigned long long* vert; // 256 rows: 12 edge nibbles
+	const u8* own;        // 256
+	__device__ __forceinline__ u32 nibble(unsigned long long row, u32 vi) const { return (u32)(row >> (vi * 4u)) & 15u; }
+};
+
+__device__ __forceinline__ R0Tables r0_stage_tables(u8* lds, const u8* image)
+{
+	copy16(lds, image + TAB_REG_CLASS, 512);
+	copy16(lds + 512, image + TAB_REG_EDGE, 64);
+	for (u32 i = threadIdx.x; i < 256; i += WG) {
+		const u8* src = image + TAB_REG_VERT + i * 6;
+		unsigned long long row = 0;
+#pragma unroll
+		for (int b = 0; b < 6; ++b) row |= (unsigned long long)src[b] << (8 * b);
+		*(unsigned long long*)(lds + 576 + i * 8) = row;
+	}
+	copy16(lds + 2624, image + TAB_REG_OWN, 256);
+	R0Tables T;
+	T.cls = lds; T.cell = lds + 256; T.edge = (const u16*)(lds + 512); T.vert = (const unsigned long long*)(lds + 576); T.own = lds + 2624;
+	return T;
+}
+
+// tv_core.h view of the same LDS image, for the rare paths that run the portable per-cell code
+__device__ __forceinline__ Tables r0_portable_tables(const u8* lds, const u8* packedRows)
+{
+	Tables T;
+	T.regClassP = lds; T.regCellP = lds + 256; T.regEdgeP = (const u16*)(lds + 512); T.regVertP = packedRows; T.regOwnP = lds + 2624;
+	T.trClassP = nullptr; T.trCornerP = nullptr; T.trCellP = nullptr; T.trVertP = nullptr; T.trEdgeP = nullptr; T.trOwnP = nullptr;
+	return T;
+}
+
+struct __attribute__((packed, aligned(4))) R0Dwords3 { u32 a, b, c; };
+
+// what a workgroup holds of the NEXT block while it finishes the current one
+struct R0Prefetch {
+	R0Dwords3 d[3];   // distance half rows (12 bytes each)
+	u32 bits;         // one word of the non-trivial bitmap (lanes < 128)
+	uint4 m[3];       // material / blend rows, samples 0..15
+	u32 mf[3];        // ... sample 16 (in byte 0)
+};
+
+struct R0Block {
+	u32 slot, bx, by, bz, ntc;
+};
+
+template <int CAP>
+struct R0 {
+	typedef Reg0State<CAP> ST;
+
+	// ---- requests for block b (nothing is waited for here) --------------------------------------------------------
+	static __device__ __forceinline__ void request(const GridView& g, const LevelDesc& L, const R0Block& b, R0Prefetch& pf)
+	{
+		const int tid = (int)threadIdx.x;
+		const int n = g.n, cnt = (int)L.cnt;
+		pf.bits = 0;
+		if (tid < 128) pf.bits = L.ntBits[(size_t)b.slot * 128 + tid];
+		// distance rows r = kk * 19 + jj: voxels [bx*16 - 4, bx*16 + 20) of row (y,z) = (by*16 - 1 + jj, bz*16 - 1 + kk), clamped
+		{
+			const int gx0 = (int)b.bx * 16 - 4;
+			const int l0 = gx0 < 0 ? 0 : gx0;                       // first voxel of the half-0 load
+			const int l1 = (gx0 + 12 > n - 12) ? n - 12 : gx0 + 12; // first voxel of the half-1 load
+			const int y0 = max((int)b.by * 16 - 1, 0), z0 = max((int)b.bz * 16 - 1, 0);
+			const i8* base = g.dist + dist_offset(g, l0, y0, z0);
+			const int pitch = g.pitchY;
+#pragma unroll
+			for (int q = 0; q < 3; ++q) {
+				const int h = tid + q * WG;
+				pf.d[q].a = 0; pf.d[q].b = 0; pf.d[q].c = 0;
+				if (h < 722) {
+					const int r = h >> 1, half = h & 1;
+					const int kk = r / 19, jj = r - kk * 19;
+					const int y = clampi((int)b.by * 16 - 1 + jj, 0, n - 1), z = clampi((int)b.bz * 16 - 1 + kk, 0, n - 1);
+					const u32 off = (u32)(((z - z0) * pitch + (y - y0)) * n + ((half ? l1 : l0) - l0));
+					pf.d[q] = *(const R0Dwords3*)(base + off);
+				}
+			}
+		}
+		// material / blend rows: samples 0..16 of row (j,k), j,k = 0..16, clamped at the far side of the grid
+		{
+			const size_t origin = mat_offset(g, (int)b.bx * 16, (int)b.by * 16, (int)b.bz * 16);
+			const u8* mbase = g.mat + origin;
+			const u8* bbase = g.blend + origin;
+			const int pitch = g.pitchYMat;
+			const int maxY = n - 1 - (int)b.by * 16, maxZ = n - 1 - (int)b.bz * 16;
+			const bool lastX = (int)b.bx + 1 == cnt;
+#pragma unroll
+			for (int q = 0; q < 3; ++q) {
+				const int t = tid + q * WG;
+				pf.m[q] = make_uint4(0, 0, 0, 0);
+				pf.mf[q] = 0;
+				if (t < 578) {
+					const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
+					const int k = r / 17, j = r - k * 17;
+					const u32 off = (u32)((min(k, maxZ) * pitch + min(j, maxY)) * n);
+					const u8* src = (arr ? bbase : mbase) + off;
+					pf.m[q] = *(const uint4*)src;
+					if (!lastX) pf.mf[q] = *(const u32*)(src + 16);
+				}
+			}
+		}
+	}
+
+	// ---- registers -> LDS ---------------------------------------------------------------------------------------------
+	static __device__ __forceinline__ void deposit(ST& st, const GridView& g, const LevelDesc& L, const R0Block& b, const R0Prefetch& pf)
+	{
+		const int tid = (int)threadIdx.x;
+		const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
+		if (tid < 128) st.ntBits[tid] = pf.bits;
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			const int h = tid + q * WG;
+			if (h < 722) {
+				const int r = h >> 1, half = h & 1;
+				u32 a = pf.d[q].a, bb = pf.d[q].b, c = pf.d[q].c;
+				if (!half && firstX) { c = bb; bb = a; a = a << 24; }                            // loaded 4 voxels further right: sample -1 = sample 0
+				if (half && lastX) { a = bb; bb = c; c = (c >> 24) * 0x01010101u; }             // loaded 4 voxels further left: samples 16, 17 = sample 15
+				u32* dst = (u32*)(st.samp + r * SROW + half * 12);
+				dst[0] = a; dst[1] = bb; dst[2] = c;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			const int t = tid + q * WG;
+			if (t < 578) {
+				const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
+				const int k = r / 17, j = r - k * 17;
+				u32* dst = (u32*)((arr ? st.blend : st.matId) + k * R0_MPLANE + j * R0_MROW);
+				dst[0] = pf.m[q].x; dst[1] = pf.m[q].y; dst[2] = pf.m[q].z; dst[3] = pf.m[q].w;
+				dst[4] = lastX ? (pf.m[q].w >> 24) : pf.mf[q];
+			}
+		}
+	}
+
+	// level-0 central differences at a staged sample (tv_core.h normal_at over the LDS neighbourhood)
+	static __device__ __forceinline__ void normal_lds(const i8* p, float out[3])
+	{
+		out[0] = (float)((int)p[1] - (int)p[-1]) * 0.5f;
+		out[1] = (float)((int)p[SPLANE] - (int)p[-SPLANE]) * 0.5f;
+		out[2] = (float)((int)p[SROW] - (int)p[-SROW]) * 0.5f;
+		normalize_fix_zero(out);
+	}
+
+	// reuse slot of a neighbour cell, recomputed from its samples (only cells with a zero sample ask)
+	struct Neighbour {
+		const ST* st;
+		const Tables* T;
+		int cx, cy, cz;
+		__device__ __forceinline__ void operator()(int dx, int dy, int dz, u32 slot, bool& valid, u32& mat) const
+		{
+			const int x = cx - dx, y = cy - dy, z = cz - dz;
+			const u32 c = (u32)((z << 8) | (y << 4) | x);
+			valid = false; mat = 0;
+			if (!bit_get(st->ntBits, c)) return;
+			i8 V[8];
+			reg_cell_values(st->samp, x, y, z, V);
+			valid = ((reg_slot_valid(*T, reg_zero_mask(V), reg_case_code(V)) >> slot) & 1u) != 0;
+			mat = st->matId[z * R0_MPLANE + y * R0_MROW + x];
+		}
+	};
+
+	struct LdsMaterials {
+		const ST* st;
+		int ox, oy, oz;
+		__device__ __forceinline__ u32 operator()(int, const int P[3]) const
+		{
+			const int o = (P[2] - oz) * R0_MPLANE + (P[1] - oy) * R0_MROW + (P[0] - ox);
+			return (u32)st->matId[o] | ((u32)st->blend[o] << 8);
+		}
+	};
+
+	// ---- one compact cell: case, reuse resolution, degenerate filter, counts ---------------------------------------
+	static __device__ __forceinline__ void cell(ST& st, const R0Tables& RT, const Tables& T, const R0Block& b, u32 k, u32* wgStats)
+	{
+		const u32 c = st.cellA[k] & 0xFFFu;
+		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+		const i8* sp = st.samp + samp_index(cx, cy, cz);
+		i8 V[8];
+		V[0] = sp[0]; V[1] = sp[1]; V[2] = sp[SROW]; V[3] = sp[SROW + 1];
+		V[4] = sp[SPLANE]; V[5] = sp[SPLANE + 1]; V[6] = sp[SPLANE + SROW]; V[7] = sp[SPLANE + SROW + 1];
+		const u32 code = reg_case_code(V), zeroMask = reg_zero_mask(V);
+		const int mo = cz * R0_MPLANE + cy * R0_MROW + cx;
+		const u32 myMat = st.matId[mo];
+		const u32 cls = RT.cls[code];
+		const u32 geom = RT.cell[cls * 16];
+		const u32 nv = geom >> 4, ntri = geom & 15u;
+		atomicAdd(&wgStats[4 + cls], 1u);
+		// reuseValidityMask from the bitmap (reg_mask3 of tv_block.h, with k = rank of this cell)
+		const u32 row = (u32)((cz << 4) | cy);
+		const u32 word = st.ntBits[row >> 1];
+		const u32 rowBits = (word >> ((row & 1u) * 16u)) & 0xFFFFu;
+		const u32 below = rowBits & ((1u << cx) - 1u);
+		const u32 sliceBase = st.wordPrefix[cz * 8];
+		u32 mask3 = below ? 1u : 0u;
+		if (k - (u32)__popc(below) - sliceBase) mask3 |= 2u;
+		if (sliceBase) mask3 |= 4u;
+		const unsigned long long vrow = RT.vert[code];
+		u32 count = 0, ords = 0, newMask = 0, atV0 = 0, invalid = 0;
+		u32 keepMask = (1u << ntri) - 1u, kept = ntri;
+		if (!zeroMask) {
+			// every vertex lies strictly inside its edge: owned edges (direction 8) are created and stored; any other edge is
+			// reused iff the mask allows its direction and the owner cell has this cell's material (its slot is valid
+			// because it sees the same two non-zero samples), else created without being stored.
+			for (u32 vi = 0; vi < nv; ++vi) {
+				const u32 w = RT.edge[RT.nibble(vrow, vi)];
+				const u32 dir = w >> 12, slot = (w >> 8) & 15u;
+				bool create = true;
+				if (dir == 8u) ords = (ords & ~(0xFu << (slot * 4u))) | (count << (slot * 4u));
+				else if ((dir & mask3) == dir) {
+					const u32 nm = st.matId[mo - (int)(dir & 1u) - (int)((dir >> 1) & 1u) * R0_MROW - (int)(dir >> 2) * R0_MPLANE];
+					create = nm != myMat;
+				}
+				if (create) { newMask |= 1u << vi; ++count; }
+			}
+		} else {
+			const Neighbour nb{ &st, &T, cx, cy, cz };
+			for (u32 vi = 0; vi < nv; ++vi) {
+				const u32 w = RT.edge[RT.nibble(vrow, vi)];
+				const Resolution r = reg_resolve(zeroMask, w, mask3, myMat, nb);
+				if (r.kind == RK_NEW_EDGE || r.kind == RK_NEW_CORNER) {
+					if (r.store != NO_SLOT) ords = (ords & ~(0xFu << (r.store * 4))) | (count << (r.store * 4));
+					++count;
+					newMask |= 1u << vi;
+					if (r.kind == RK_NEW_CORNER && r.a == ((w >> 4) & 15)) atV0 |= 1u << vi;
+				} else if (r.kind != RK_REUSE) {
+					invalid |= 1u << vi;
+				}
+			}
+			// a vertex on a corner can make a triangle degenerate (PushBlocksToResult's filter); cells without a zero sample
+			// keep all their triangles: three vertices strictly inside three distinct edges of a unit cell
+			CellGeom geo;
+			geo.mult = 1; geo.level = 0;
+			geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
+			geo.base[0] = (int)(b.bx * 16) + cx; geo.base[1] = (int)(b.by * 16) + cy; geo.base[2] = (int)(b.bz * 16) + cz;
+			const LocalDist d{ st.samp, (int)(b.bx * 16), (int)(b.by * 16), (int)(b.bz * 16) };
+			const u8* cd = T.regCell(cls);
+			keepMask = 0; kept = 0;
+			for (u32 tr = 0; tr < ntri; ++tr) {
+				const u32 a = cd[1 + tr * 3], bb = cd[2 + tr * 3], cc = cd[3 + tr * 3];
+				bool keepIt = true;
+				if (!(((invalid >> a) | (invalid >> bb) | (invalid >> cc)) & 1u)) {
+					float pa[3], pb[3], pc[3];
+					reg_vertex_position(d, geo, V, T.regVert(code, a), ((atV0 >> a) & 1u) != 0, pa);
+					reg_vertex_position(d, geo, V, T.regVert(code, bb), ((atV0 >> bb) & 1u) != 0, pb);
+					reg_vertex_position(d, geo, V, T.regVert(code, cc), ((atV0 >> cc) & 1u) != 0, pc);
+					keepIt = !triangle_degenerate(pa, pb, pc);
+				}
+				if (keepIt) { keepMask |= 1u << tr; ++kept; }
+			}
+			if (kept != ntri) atomicAdd(&st.degenerate, ntri - kept);
+		}
+		st.cellA[k] = c | (code << 12) | (zeroMask << 20);
+		st.cellB[k] = newMask | (atV0 << 12) | (keepMask << 24) | (invalid ? 0x80000000u : 0u);
+		st.cellC[k] = count | ((kept * 3u) << 16);
+		st.ords[k] = (u16)ords;
+		st.invalidMask[k] = (u16)invalid;
+	}
+
+	// descriptors of cell k's new vertices and kept triangle corners that fall into the given chunks
+	static __device__ __forceinline__ void describe(ST& st, u32 k, u32 base, u32 chunkV, u32 chunkI)
+	{
+		const u32 bWord = st.cellB[k];
+		u32 m = bWord & 0xFFFu;
+		u32 j = base & 0xFFFFu;
+		if (j < chunkV + R0_VDESC && j + 12 > chunkV) {
+			while (m) {
+				const u32 vi = (u32)__builtin_ctz(m);
+				m &= m - 1;
+				if (j >= chunkV && j < chunkV + R0_VDESC) st.vdesc[j - chunkV] = (u16)(k | (vi << 12));
+				++j;
+			}
+		}
+		u32 keepMask = (bWord >> 24) & 31u;
+		u32 pos = base >> 16;
+		if (pos < chunkI + R0_IDESC && pos + 15 > chunkI) {
+			while (keepMask) {
+				const u32 tr = (u32)__builtin_ctz(keepMask);
+				keepMask &= keepMask - 1;
+#pragma unroll
+				for (u32 e = 0; e < 3; ++e, ++pos)
+					if (pos >= chunkI && pos < chunkI + R0_IDESC) st.idesc[pos - chunkI] = (u16)(k | ((tr * 3 + e) << 12));
+			}
+		}
+	}
+
+	// ---- one lane = one new vertex of the chunk --------------------------------------------------------------------
+	static __device__ __forceinline__ void emit_vertices(const ST& st, const R0Tables& RT, const Globals& G, const Pools& P, const R0Block& b, u32 chunk)
+	{
+		const u32 end = (st.vTotal - chunk < (u32)R0_VDESC) ? st.vTotal - chunk : (u32)R0_VDESC;
+		PolyVertex* out = P.verts + st.vOff + chunk;
+		const int ox = (int)(b.bx * 16), oy = (int)(b.by * 16), oz = (int)(b.bz * 16);
+		for (u32 j = threadIdx.x; j < end; j += WG) {
+			const u32 desc = st.vdesc[j];
+			const u32 k = desc & 0xFFFu, vi = desc >> 12;
+			const u32 a = st.cellA[k];
+			const u32 c = a & 0xFFFu, code = (a >> 12) & 0xFFu;
+			const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+			const u32 w = RT.edge[RT.nibble(RT.vert[code], vi)];
+			const int v0 = (int)((w >> 4) & 15u), v1 = (int)(w & 15u);
+			const i8* sp = st.samp + samp_index(cx, cy, cz);
+			const int mo = cz * R0_MPLANE + cy * R0_MROW + cx;
+			const u32 cellMat = (u32)st.matId[mo] | ((u32)st.blend[mo] << 8);
+			const unsigned long long lut = lut_row(G.lut, cellMat);
+			const i8* s0 = sp + r0_samp_off(v0);
+			const i8* s1 = sp + r0_samp_off(v1);
+			const int val0 = *s0, val1 = *s1;
+			RawVertex rv;
+			if (val0 != 0 && val1 != 0) {
+				// strictly inside the edge (reg_edge_vertex of tv_core.h at level 0: no LOD chain, no boundary flags)
+				const int t = edge_t(val0, val1), u = 256 - t;
+				const float ft = (float)t, fu = (float)u;
+				const int p0x = ox + cx + (v0 & 1), p0y = oy + cy + ((v0 >> 1) & 1), p0z = oz + cz + (v0 >> 2);
+				const int p1x = ox + cx + (v1 & 1), p1y = oy + cy + ((v1 >> 1) & 1), p1z = oz + cz + (v1 >> 2);
+				rv.p[0] = ft * (float)p0x + fu * (float)p1x;
+				rv.p[1] = ft * (float)p0y + fu * (float)p1y;
+				rv.p[2] = ft * (float)p0z + fu * (float)p1z;
+				float N0[3], N1[3];
+				normal_lds(s0, N0);
+				normal_lds(s1, N1);
+				const int m0 = mo + r0_mat_off(v0), m1 = mo + r0_mat_off(v1);
+				const u32 M0 = (u32)st.matId[m0] | ((u32)st.blend[m0] << 8), M1 = (u32)st.matId[m1] | ((u32)st.blend[m1] << 8);
+				if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (cellMat & 0xFF)) rv.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
+				else rv.mat = cellMat;
+				const float wt = ft / 256.f, wu = fu / 256.f;
+				rv.n[0] = N0[0] * wt + N1[0] * wu; rv.n[1] = N0[1] * wt + N1[1] * wu; rv.n[2] = N0[2] * wt + N1[2] * wu;
+				normalize_fix_zero(rv.n);
+				rv.flags = 0;
+				rv.s[0] = rv.p[0]; rv.s[1] = rv.p[1]; rv.s[2] = rv.p[2];
+			} else {
+				// on a corner (GenerateVertexFromPoint, :1450-1467)
+				const int e = edge_end(val0, val1);
+				const u32 atV0 = (st.cellB[k] >> 12) & 0xFFFu;
+				const int corner = ((atV0 >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0);
+				CellGeom geo;
+				geo.mult = 1; geo.level = 0;
+				geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
+				geo.base[0] = ox + cx; geo.base[1] = oy + cy; geo.base[2] = oz + cz;
+				const LocalDist d{ st.samp, ox, oy, oz };
+				reg_corner_vertex(d, LdsMaterials{ &st, ox, oy, oz }, geo, corner, cellMat, rv);
+			}
+			pack_vertex_row(rv, lut, out + j);
+		}
+	}
+
+	// ---- one lane = one index of the chunk ----------------------------------------------------------------------------
+	static __device__ __forceinline__ void flush_indices(const ST& st, const R0Tables& RT, const Pools& P, u32 chunk)
+	{
+		const u32 end = (st.iTotal - chunk < (u32)R0_IDESC) ? st.iTotal - chunk : (u32)R0_IDESC;
+		u32* out = P.idx + st.iOff + chunk;
+		for (u32 j = threadIdx.x; j < end; j += WG) {
+			const u32 desc = st.idesc[j];
+			const u32 k = desc & 0xFFFu, corner = desc >> 12;
+			const u32 a = st.cellA[k], bWord = st.cellB[k];
+			const u32 c = a & 0xFFFu, code = (a >> 12) & 0xFFu, zeroMask = a >> 20;
+			const u32 vi = RT.cell[RT.cls[code] * 16 + 1 + corner];
+			const u32 newMask = bWord & 0xFFFu;
+			u32 id;
+			if ((newMask >> vi) & 1u) {
+				id = (st.cellC[k] & 0xFFFFu) + (u32)__popc(newMask & ((1u << vi) - 1u));
+			} else if ((bWord >> 31) && ((st.invalidMask[k] >> vi) & 1u)) {
+				id = INVALID_INDEX;
+			} else {
+				u32 dir, slot;
+				reg_reuse_source(zeroMask, RT.edge[RT.nibble(RT.vert[code], vi)], dir, slot);
+				const u32 c2 = c - ((dir & 1u) + (((dir >> 1) & 1u) << 4) + (((dir >> 2) & 1u) << 8));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				id = (st.cellC[k2] & 0xFFFFu) + (((u32)st.ords[k2] >> (slot * 4u)) & 0xFu);
+			}
+			out[j] = id;
+		}
+	}
+};
+
+__device__ __forceinline__ u32 r0_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// what the work list says about item `it` (loads only: requested early, looked at late)
+struct R0Candidate {
+	u32 valid, slot, ntc, skip, coord;
+};
+
+__device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 it)
+{
+	R0Candidate c;
+	c.valid = 0; c.slot = 0; c.ntc = 0; c.skip = 0; c.coord = 0;
+	const u32 item = xcd_item(it);
+	if (it < ((total + 63u) & ~63u) && item < total) {
+		c.valid = 1;
+		c.slot = p.G.dirty ? p.G.workItems[0][item] : item;
+		c.ntc = L.ntCount[c.slot];
+		c.skip = L.skip[c.slot];
+		c.coord = L.slotCoord[c.slot];
+	}
+	return c;
+}
+
+// Does the candidate belong to this workgroup's capacity class and carry geometry?  Blocks without geometry get their
+// empty record here (the first class, lo == 0, owns them).  Uniform over the workgroup.
+template <int CAP>
+__device__ __forceinline__ bool r0_accept(const LevelDesc& L, u32 lo, const R0Candidate& c, R0Block& b)
+{
+	if (!r0_uniform(c.valid)) return false;
+	const u32 slot = r0_uniform(c.slot), ntc = r0_uniform(c.ntc);
+	if ((lo && ntc <= lo) || ntc > (u32)CAP) return false;
+	if (ntc == 0 || r0_uniform(c.skip)) {
+		if (threadIdx.x == 0) reg_write_empty_record(L, slot);
+		return false;
+	}
+	b.slot = slot; b.ntc = ntc;
+	block_coords(r0_uniform(c.coord), L.cnt, b.bx, b.by, b.bz);
+	return true;
+}
+
+// next accepted item at or after `it` (stride gridDim.x), starting with an already requested candidate for `it`
+template <int CAP>
+__device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32& it, R0Candidate c, R0Block& b)
+{
+	const u32 padded = (total + 63u) & ~63u;
+	for (;;) {
+		if (r0_accept<CAP>(L, lo, c, b)) return true;
+		it += gridDim.x;
+		if (it >= padded) return false;
+		c = r0_peek(p, L, total, it);
+	}
+}
+
+template <int CAP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0(ExecParamsDev p, u32 lo)
+{
+	typedef Reg0State<CAP> ST;
+	typedef R0<CAP> K;
+	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
+	u8* tab = smem;
+	ST& st = *(ST*)(smem + R0_TAB_LDS);
+	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
+
+	const LevelDesc& L = p.levels[0];
+	const u32 total = r0_uniform(p.G.dirty ? p.G.workCount[0] : *L.nActive);
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	const int tid = (int)threadIdx.x;
+	if (tid < 20) wgStats[tid] = 0;
+	const R0Tables RT = r0_stage_tables(tab, p.tables);
+	const Tables T = r0_portable_tables(tab, p.tables + TAB_REG_VERT); // the 6-byte rows stay in global memory (rare paths)
+	const GridView& g = p.G.grid;
+
+	u32 it = blockIdx.x;
+	R0Block cur, nxt;
+	R0Prefetch pf;
+	bool have = r0_next_item<CAP>(p, L, total, lo, it, r0_peek(p, L, total, it), cur);
+	if (have) K::request(g, L, cur, pf);
+	while (have) {
+		// the work list entry after this one is requested now and looked at after the vertices are out
+		it += gridDim.x;
+		const R0Candidate cand = r0_peek(p, L, total, it);
+		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
+		K::deposit(st, g, L, cur, pf);
+		if (tid == 0) st.degenerate = 0;
+		__syncthreads();
+
+		// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
+		{
+			const int lane = tid & 63, wave = tid >> 6;
+			const u32 w0 = st.ntBits[lane], w1 = st.ntBits[lane + 64];
+			const u32 c0 = (u32)__popc(w0), c1 = (u32)__popc(w1);
+			const u32 i0 = wave_inclusive_scan(c0);
+			const u32 half = (u32)__shfl((int)i0, 63, 64);
+			const u32 i1 = wave_inclusive_scan(c1) + half;
+			const u32 e0 = i0 - c0, e1 = i1 - c1;
+			if (wave == 0) {
+				st.wordPrefix[lane] = (u16)e0; st.wordPrefix[lane + 64] = (u16)e1;
+				if (lane == 63) st.wordPrefix[128] = (u16)i1;
+			}
+			// row tid = cells [tid * 16, tid * 16 + 16): half of word tid >> 1, held by lane (tid >> 1) & 63 of either set
+			const int src = (tid >> 1) & 63;
+			const u32 wLo = (u32)__shfl((int)w0, src, 64), wHi = (u32)__shfl((int)w1, src, 64);
+			const u32 eLo = (u32)__shfl((int)e0, src, 64), eHi = (u32)__shfl((int)e1, src, 64);
+			const u32 word = (wave >= 2) ? wHi : wLo;
+			u32 kk = (wave >= 2) ? eHi : eLo;
+			u32 bits = word & 0xFFFFu;
+			if (tid & 1) { kk += (u32)__popc(bits); bits = word >> 16; }
+			while (bits) {
+				const u32 x = (u32)__builtin_ctz(bits);
+				bits &= bits - 1;
+				st.cellA[kk++] = (u32)(tid * 16) + x;
+			}
+		}
+		__syncthreads();
+
+		// ---- cells: lane owns `per` consecutive compact cells -----------------------------------------------------
+		const u32 nt = r0_uniform(st.wordPrefix[128]);
+		const u32 per = (nt + WG - 1) / WG;
+		const u32 kBeg = min((u32)tid * per, nt), kEnd = min(kBeg + per, nt);
+		u32 sum = 0;
+		for (u32 k = kBeg; k < kEnd; ++k) {
+			K::cell(st, RT, T, cur, k, wgStats);
+			sum += st.cellC[k];
+		}
+		{
+			const u32 incl = wave_inclusive_scan(sum);
+			if ((tid & 63) == 63) st.waveTot[tid >> 6] = incl;
+			__syncthreads();
+			u32 waveBase = 0, tot = 0;
+#pragma unroll
+			for (int w = 0; w < WG / 64; ++w) {
+				const u32 s = st.waveTot[w];
+				if (w < (tid >> 6)) waveBase += s;
+				tot += s;
+			}
+			const u32 vTotal = tot & 0xFFFFu, iTotal = tot >> 16;
+			// both pool reservations are requested now; their results are first needed after the descriptors are written
+			u32 vOff = 0, iOff = 0;
+			if (tid == 0) {
+				vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
+				iOff = atomicAdd(&p.P.cursors[CUR_I], iTotal);
+			}
+			u32 run = waveBase + incl - sum;
+			for (u32 k = kBeg; k < kEnd; ++k) {
+				const u32 v = st.cellC[k];
+				st.cellC[k] = run;
+				K::describe(st, k, run, 0, 0);
+				run += v;
+			}
+			if (tid == 0) { st.vTotal = vTotal; st.iTotal = iTotal; st.vOff = vOff; st.iOff = iOff; }
+		}
+		__syncthreads();
+
+		const u32 vTotalU = r0_uniform(st.vTotal), iTotalU = r0_uniform(st.iTotal);
+		const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + iTotalU <= p.P.idxCap;
+		if (room) K::emit_vertices(st, RT, p.G, p.P, cur, 0);
+		// the next block's inputs travel while this block's indices (and any further chunks) are written
+		const bool haveNext = r0_next_item<CAP>(p, L, total, lo, it, cand, nxt);
+		if (haveNext) K::request(g, L, nxt, pf);
+		if (room) {
+			K::flush_indices(st, RT, p.P, 0);
+			for (u32 chunk = 1; chunk * R0_VDESC < vTotalU || chunk * R0_IDESC < iTotalU; ++chunk) {
+				__syncthreads();
+				for (u32 k = (u32)tid; k < nt; k += WG) K::describe(st, k, st.cellC[k], chunk * R0_VDESC, chunk * R0_IDESC);
+				__syncthreads();
+				if (chunk * R0_VDESC < vTotalU) K::emit_vertices(st, RT, p.G, p.P, cur, chunk * R0_VDESC);
+				if (chunk * R0_IDESC < iTotalU) K::flush_indices(st, RT, p.P, chunk * R0_IDESC);
+			}
+		}
+		if (tid == 0) {
+			BlockRecord& r = L.records[cur.slot];
+			r.coordId = L.slotCoord[cur.slot];
+			r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.iTotal : 0;
+			if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
+			r.degenerate = st.degenerate;
+			r.ntCells = nt;
+			r.pad = 0;
+			if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
+			wgStats[0] += nt;
+			if (st.vTotal) wgStats[1] += st.degenerate;
+		}
+		cur = nxt;
+		have = haveNext;
+	}
+	__syncthreads();
+	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+}
+
+} // namespace
