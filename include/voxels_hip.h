@@ -161,11 +161,9 @@ int vx_level_ranges(vx_ctx* ctx, uint32_t level, vx_block_ranges* ranges /* one 
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
 
 /* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
- * ms[0..5] = reset, classify, hierarchy, material (all levels), regular, transition of the LAST run. */
+ * ms[0..6] = reset, classify, hierarchy, material (all levels), regular, transition, vertex pass of the LAST run. */
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
-int vx_stage_times(vx_ctx* ctx, float ms[6]);
-/* Profiling aid: make the per-block kernels stop after phase `limit` (0 = full pipeline; results are then
- * incomplete by design).  Used by tools/phase_profile.py to attribute kernel time to phases. */
+int vx_stage_times(vx_ctx* ctx, float ms[7]);
 
 /* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */
 const char* vx_backend(void);

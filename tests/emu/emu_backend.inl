@@ -126,6 +126,7 @@ struct Backend {
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
+	template <typename P> void run_vertices(const P&, u32) {} // the emulated per-block phases write finished vertices
 	bool stage_ms(float*) { return false; }
 
 	// classification of one level-0 block (portable form of k_classify)

@@ -16,17 +16,18 @@ def main():
     levels = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     d, m, b = synth.terrain(n)
-    p = Polygonizer()
+    from voxels_amd.binding import HipLibrary
+    p = Polygonizer(library=HipLibrary(os.environ["VX_LIB"])) if os.environ.get("VX_LIB") else Polygonizer()
     p.upload(d, m, b, synth.block_empty_flags(d))
     p.set_stage_timing(True)
     for _ in range(3):
         p.execute(levels)
-    acc = np.zeros(6)
+    acc = np.zeros(7)
     for _ in range(reps):
         p.execute(levels)
         acc += p.stage_times()
     acc /= reps
-    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular %.4f transition %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
+    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular %.4f transition %.4f vertices %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
 
 
 if __name__ == "__main__":

@@ -262,8 +262,8 @@ class Polygonizer:
 
 
     def stage_times(self):
-        """ms of (reset, classify, hierarchy, material, regular, transition) of the last run."""
-        out = np.zeros(6, np.float32)
+        """ms of (reset, classify, hierarchy, material, regular, transition, vertex pass) of the last run."""
+        out = np.zeros(7, np.float32)
         self._check(self._lib.vx_stage_times(self._h, _ptr(out)), "vx_stage_times")
         return out
 

@@ -20,7 +20,7 @@ def _newer(target, sources):
 def build_hip(force=False, verbose=True):
     """hipcc --offload-arch=gfx950 ... -o voxels_amd/csrc/libvoxels_hip.so (cross-compiles without a GPU)."""
     out = os.path.join(CSRC, "libvoxels_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_tables.inc")]
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_vertices.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_tables.inc")]
     srcs.append(os.path.join(ROOT, "include", "voxels_hip.h"))
     if not force and not _newer(out, srcs):
         return out

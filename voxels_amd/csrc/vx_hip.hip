@@ -939,6 +939,7 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 
 } // namespace
 
+#include "vx_vertices.inl"
 #include "vx_regular0.inl"
 
 namespace {
@@ -1218,7 +1219,7 @@ struct Backend {
 	hipStream_t sideA = nullptr, sideB = nullptr;      // level-0 regular pass / transition pass run beside the material chain
 	hipEvent_t evClassified = nullptr, evMaterial = nullptr, evSideA = nullptr, evSideB = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	hipEvent_t stageEv[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t stageEv[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	bool stageOn = false, stageValid = false;
 	std::string lastError;
 	int cus = 256;
@@ -1264,8 +1265,10 @@ struct Backend {
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
 		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>)), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
-		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")) {
+		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, incremental)")) {
 			err = lastError;
 			return false;
 		}
@@ -1281,7 +1284,7 @@ struct Backend {
 	{
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
-		for (int i = 0; i < 7; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
+		for (int i = 0; i < 8; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
 		if (sideA) (void)hipStreamDestroy(sideA);
 		if (sideB) (void)hipStreamDestroy(sideB);
 		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB }) if (e) (void)hipEventDestroy(e);
@@ -1321,19 +1324,19 @@ struct Backend {
 	{
 		stageOn = on;
 		stageValid = false;
-		if (on) for (int i = 0; i < 7; ++i) if (!stageEv[i] && !check(hipEventCreate(&stageEv[i]), "hipEventCreate(stage)")) { stageOn = false; return; }
+		if (on) for (int i = 0; i < 8; ++i) if (!stageEv[i] && !check(hipEventCreate(&stageEv[i]), "hipEventCreate(stage)")) { stageOn = false; return; }
 	}
 	void stage_mark(int i)
 	{
 		if (!stageOn) return;
 		(void)hipEventRecord(stageEv[i], stream);
-		if (i == 6) stageValid = true;
+		if (i == 7) stageValid = true;
 	}
 	bool stage_ms(float* ms)
 	{
 		if (!stageOn || !stageValid) return false;
-		if (hipEventSynchronize(stageEv[6]) != hipSuccess) return false;
-		for (int i = 0; i < 6; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
+		if (hipEventSynchronize(stageEv[7]) != hipSuccess) return false;
+		for (int i = 0; i < 7; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
 		return true;
 	}
 	void begin_timing() { (void)hipEventRecord(ev0, stream); }
@@ -1496,8 +1499,14 @@ struct Backend {
 		if (levelBegin == 0 && p.levels[0].cap && !tune.oldReg0) {
 			const u32 cap = p.levels[0].cap;
 			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
-			hipLaunchKernelGGL(k_regular0<REG_CAP_SMALL>, dim3(gridS), dim3(WG), R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), on, dev(p), 0u);
-			if (largeClass) hipLaunchKernelGGL(k_regular0<4096>, dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), R0_TAB_LDS + sizeof(Reg0State<4096>), on, dev(p), (u32)REG_CAP_SMALL);
+			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
+			if (p.G.dirty) {
+				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, true>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, true>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+			} else {
+				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, false>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, false>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+			}
 			levelBegin = 1;
 		}
 		u32 cap = 0;
@@ -1539,6 +1548,15 @@ struct Backend {
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}
 	bool stage_timing_on() const { return stageOn; }
+
+	// descriptors -> vertices for the vertices [first, cursor) of the pool; after every per-block kernel of the run
+	template <typename P>
+	void run_vertices(const P& p, u32 first)
+	{
+		if (p.P.vertCap <= first) return;
+		hipLaunchKernelGGL(k_vertices, dim3((p.P.vertCap - first + WG - 1) / WG), dim3(WG), 0, stream, dev(p), first);
+		check(hipGetLastError(), "k_vertices launch");
+	}
 
 	template <typename P>
 	void run_transition(const P& p, u32 levels)

@@ -271,6 +271,7 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	c->be.stage_mark(5);
 	c->be.run_transition(p, levels);
 	c->be.stage_mark(6);
+	c->be.stage_mark(7);
 }
 
 void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
@@ -778,6 +779,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
+#if defined(VX_R0_PROFILE)
+	{
+		static const char* names[10] = { "top barrier", "deposit+barrier", "prefix+list+barrier", "cells", "scan barrier", "reserve+describe", "barrier", "vertices+indices", "record", "next item (drain)" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 10; ++i) sum += c->hdr[HDR_LARGE + 4 + i];
+		for (int i = 0; i < 10; ++i) fprintf(stderr, "[r0 profile] %-22s %10u kcycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 	if (hostTiming) {
 		const auto t5 = tNow();
 		fprintf(stderr, "[vx host] enqueue %.0f us, wait+events %.0f us, header %.0f us, after-header %.0f us, device %.0f us\n",
@@ -950,6 +959,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		c->be.run_transition(p, levels);
 		c->be.run_gather_records(p, levels, start, (BlockRecord*)c->dGather);
 		c->be.stage_mark(6);
+		c->be.stage_mark(7);
 		ms = c->be.end_timing_ms();
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
@@ -1075,7 +1085,7 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 	return VX_OK;
 }
 
-int vx_stage_times(vx_ctx* c, float ms[6])
+int vx_stage_times(vx_ctx* c, float ms[7])
 {
 	if (!c || !ms) return VX_ERR_INVALID;
 	return c->be.stage_ms(ms) ? VX_OK : fail(c, VX_ERR_INVALID, "vx_stage_times: stage timing was not enabled for the last run");

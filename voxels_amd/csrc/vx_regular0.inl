@@ -80,7 +80,10 @@ __device__ __forceinline__ Tables r0_portable_tables(const u8* lds, const u8* pa
 	return T;
 }
 
-struct __attribute__((packed, aligned(4))) R0Dwords3 { u32 a, b, c; };
+// three dwords at dword alignment as ONE register tuple (a struct of three words is split into scalars, and the copies
+// between them and the load's destination make the compiler wait for the load on the spot)
+typedef u32 R0Dwords3 __attribute__((ext_vector_type(3)));
+typedef R0Dwords3 __attribute__((aligned(4))) R0Dwords3Unaligned;
 
 // what a workgroup holds of the NEXT block while it finishes the current one
 struct R0Prefetch {
@@ -91,7 +94,7 @@ struct R0Prefetch {
 };
 
 struct R0Block {
-	u32 slot, bx, by, bz, ntc;
+	u32 slot, coord, bx, by, bz, ntc;
 };
 
 template <int CAP>
@@ -99,12 +102,23 @@ struct R0 {
 	typedef Reg0State<CAP> ST;
 
 	// ---- requests for block b (nothing is waited for here) --------------------------------------------------------
+	// The lane's task decomposition (row numbers etc.) depends on the thread id alone; left alone the compiler computes it
+	// once per kernel and keeps ~20 registers alive across the whole block loop (they end up in scratch, and every reload
+	// drains the memory queue).  An opaque copy of the id makes it recompute the few values where they are used.
+	static __device__ __forceinline__ int opaque_tid()
+	{
+		int t = (int)threadIdx.x;
+		asm volatile("" : "+v"(t));
+		return t;
+	}
+
 	static __device__ __forceinline__ void request(const GridView& g, const LevelDesc& L, const R0Block& b, R0Prefetch& pf)
 	{
-		const int tid = (int)threadIdx.x;
+		const int tid = opaque_tid();
 		const int n = g.n, cnt = (int)L.cnt;
-		pf.bits = 0;
-		if (tid < 128) pf.bits = L.ntBits[(size_t)b.slot * 128 + tid];
+		// every lane loads (indices clamped into range): a conditional load with a default value makes the compiler wait for
+		// the data right behind the load, and these requests must stay in flight
+		pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
 		// distance rows r = kk * 19 + jj: voxels [bx*16 - 4, bx*16 + 20) of row (y,z) = (by*16 - 1 + jj, bz*16 - 1 + kk), clamped
 		{
 			const int gx0 = (int)b.bx * 16 - 4;
@@ -115,15 +129,12 @@ struct R0 {
 			const int pitch = g.pitchY;
 #pragma unroll
 			for (int q = 0; q < 3; ++q) {
-				const int h = tid + q * WG;
-				pf.d[q].a = 0; pf.d[q].b = 0; pf.d[q].c = 0;
-				if (h < 722) {
-					const int r = h >> 1, half = h & 1;
-					const int kk = r / 19, jj = r - kk * 19;
-					const int y = clampi((int)b.by * 16 - 1 + jj, 0, n - 1), z = clampi((int)b.bz * 16 - 1 + kk, 0, n - 1);
-					const u32 off = (u32)(((z - z0) * pitch + (y - y0)) * n + ((half ? l1 : l0) - l0));
-					pf.d[q] = *(const R0Dwords3*)(base + off);
-				}
+				const int h = min(tid + q * WG, 721);
+				const int r = h >> 1, half = h & 1;
+				const int kk = r / 19, jj = r - kk * 19;
+				const int y = clampi((int)b.by * 16 - 1 + jj, 0, n - 1), z = clampi((int)b.bz * 16 - 1 + kk, 0, n - 1);
+				const u32 off = (u32)(((z - z0) * pitch + (y - y0)) * n + ((half ? l1 : l0) - l0));
+				pf.d[q] = *(const R0Dwords3Unaligned*)(base + off);
 			}
 		}
 		// material / blend rows: samples 0..16 of row (j,k), j,k = 0..16, clamped at the far side of the grid
@@ -136,17 +147,13 @@ struct R0 {
 			const bool lastX = (int)b.bx + 1 == cnt;
 #pragma unroll
 			for (int q = 0; q < 3; ++q) {
-				const int t = tid + q * WG;
-				pf.m[q] = make_uint4(0, 0, 0, 0);
-				pf.mf[q] = 0;
-				if (t < 578) {
-					const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
-					const int k = r / 17, j = r - k * 17;
-					const u32 off = (u32)((min(k, maxZ) * pitch + min(j, maxY)) * n);
-					const u8* src = (arr ? bbase : mbase) + off;
-					pf.m[q] = *(const uint4*)src;
-					if (!lastX) pf.mf[q] = *(const u32*)(src + 16);
-				}
+				const int t = min(tid + q * WG, 577);
+				const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
+				const int k = r / 17, j = r - k * 17;
+				const u32 off = (u32)((min(k, maxZ) * pitch + min(j, maxY)) * n);
+				const u8* src = (arr ? bbase : mbase) + off;
+				pf.m[q] = *(const uint4*)src;
+				pf.mf[q] = *(const u32*)(src + (lastX ? 12 : 16)); // sample 16 in byte 0; at the grid's edge the row's last dword (see deposit)
 			}
 		}
 	}
@@ -154,7 +161,7 @@ struct R0 {
 	// ---- registers -> LDS ---------------------------------------------------------------------------------------------
 	static __device__ __forceinline__ void deposit(ST& st, const GridView& g, const LevelDesc& L, const R0Block& b, const R0Prefetch& pf)
 	{
-		const int tid = (int)threadIdx.x;
+		const int tid = opaque_tid();
 		const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
 		if (tid < 128) st.ntBits[tid] = pf.bits;
 #pragma unroll
@@ -162,7 +169,7 @@ struct R0 {
 			const int h = tid + q * WG;
 			if (h < 722) {
 				const int r = h >> 1, half = h & 1;
-				u32 a = pf.d[q].a, bb = pf.d[q].b, c = pf.d[q].c;
+				u32 a = pf.d[q].x, bb = pf.d[q].y, c = pf.d[q].z;
 				if (!half && firstX) { c = bb; bb = a; a = a << 24; }                            // loaded 4 voxels further right: sample -1 = sample 0
 				if (half && lastX) { a = bb; bb = c; c = (c >> 24) * 0x01010101u; }             // loaded 4 voxels further left: samples 16, 17 = sample 15
 				u32* dst = (u32*)(st.samp + r * SROW + half * 12);
@@ -177,7 +184,7 @@ struct R0 {
 				const int k = r / 17, j = r - k * 17;
 				u32* dst = (u32*)((arr ? st.blend : st.matId) + k * R0_MPLANE + j * R0_MROW);
 				dst[0] = pf.m[q].x; dst[1] = pf.m[q].y; dst[2] = pf.m[q].z; dst[3] = pf.m[q].w;
-				dst[4] = lastX ? (pf.m[q].w >> 24) : pf.mf[q];
+				dst[4] = lastX ? (pf.mf[q] >> 24) : pf.mf[q];
 			}
 		}
 	}
@@ -333,13 +340,27 @@ struct R0 {
 		}
 	}
 
-	// ---- one lane = one new vertex of the chunk --------------------------------------------------------------------
-	static __device__ __forceinline__ void emit_vertices(const ST& st, const R0Tables& RT, const Globals& G, const Pools& P, const R0Block& b, u32 chunk)
+	// LUT row of a material id through the scalar cache.  The memory counter of the vector loads retires in order, so a
+	// vector load issued (and consumed) behind the prefetch requests would make its wave wait for all of them; scalar loads
+	// have their own counter.  A block has one or two material ids: the loop over distinct ids runs once or twice.
+	static __device__ __forceinline__ unsigned long long lut_row_waterfall(const u8* lut, u32 id)
 	{
-		const u32 end = (st.vTotal - chunk < (u32)R0_VDESC) ? st.vTotal - chunk : (u32)R0_VDESC;
-		PolyVertex* out = P.verts + st.vOff + chunk;
+		unsigned long long row = 0;
+		bool pending = true;
+		while (pending) {
+			const u32 u = (u32)__builtin_amdgcn_readfirstlane((int)id);
+			unsigned long long r;
+			asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(lut), "s"(u * 8u) : "memory");
+			if (id == u) { row = r; pending = false; }
+		}
+		return row;
+	}
+
+	// ---- one lane = one new vertex of the chunk --------------------------------------------------------------------
+	static __device__ __forceinline__ void emit_vertex(const ST& st, const R0Tables& RT, const Globals& G, const R0Block& b, u32 j, PolyVertex* out)
+	{
 		const int ox = (int)(b.bx * 16), oy = (int)(b.by * 16), oz = (int)(b.bz * 16);
-		for (u32 j = threadIdx.x; j < end; j += WG) {
+		{
 			const u32 desc = st.vdesc[j];
 			const u32 k = desc & 0xFFFu, vi = desc >> 12;
 			const u32 a = st.cellA[k];
@@ -350,7 +371,7 @@ struct R0 {
 			const i8* sp = st.samp + samp_index(cx, cy, cz);
 			const int mo = cz * R0_MPLANE + cy * R0_MROW + cx;
 			const u32 cellMat = (u32)st.matId[mo] | ((u32)st.blend[mo] << 8);
-			const unsigned long long lut = lut_row(G.lut, cellMat);
+			const unsigned long long lut = lut_row_waterfall(G.lut, cellMat & 0xFFu);
 			const i8* s0 = sp + r0_samp_off(v0);
 			const i8* s1 = sp + r0_samp_off(v1);
 			const int val0 = *s0, val1 = *s1;
@@ -393,11 +414,9 @@ struct R0 {
 	}
 
 	// ---- one lane = one index of the chunk ----------------------------------------------------------------------------
-	static __device__ __forceinline__ void flush_indices(const ST& st, const R0Tables& RT, const Pools& P, u32 chunk)
+	static __device__ __forceinline__ void flush_index(const ST& st, const R0Tables& RT, u32 j, u32* out)
 	{
-		const u32 end = (st.iTotal - chunk < (u32)R0_IDESC) ? st.iTotal - chunk : (u32)R0_IDESC;
-		u32* out = P.idx + st.iOff + chunk;
-		for (u32 j = threadIdx.x; j < end; j += WG) {
+		{
 			const u32 desc = st.idesc[j];
 			const u32 k = desc & 0xFFFu, corner = desc >> 12;
 			const u32 a = st.cellA[k], bWord = st.cellB[k];
@@ -428,18 +447,19 @@ struct R0Candidate {
 	u32 valid, slot, ntc, skip, coord;
 };
 
+template <bool DIRTY>
 __device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 it)
 {
+	// loads without conditions (see R0::request): an item beyond the list reads entry 0 and is marked invalid
 	R0Candidate c;
-	c.valid = 0; c.slot = 0; c.ntc = 0; c.skip = 0; c.coord = 0;
-	const u32 item = xcd_item(it);
-	if (it < ((total + 63u) & ~63u) && item < total) {
-		c.valid = 1;
-		c.slot = p.G.dirty ? p.G.workItems[0][item] : item;
-		c.ntc = L.ntCount[c.slot];
-		c.skip = L.skip[c.slot];
-		c.coord = L.slotCoord[c.slot];
-	}
+	u32 item = xcd_item(it);
+	c.valid = (it < ((total + 63u) & ~63u) && item < total) ? 1u : 0u;
+	if (!c.valid) item = 0;
+	c.slot = item;
+	if (DIRTY) c.slot = p.G.workItems[0][item]; // incremental runs list the slots to rebuild (a dependent load: compiled in only there)
+	c.ntc = L.ntCount[c.slot];
+	c.skip = L.skip[c.slot];
+	c.coord = L.slotCoord[c.slot];
 	return c;
 }
 
@@ -448,20 +468,22 @@ __device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const Lev
 template <int CAP>
 __device__ __forceinline__ bool r0_accept(const LevelDesc& L, u32 lo, const R0Candidate& c, R0Block& b)
 {
-	if (!r0_uniform(c.valid)) return false;
-	const u32 slot = r0_uniform(c.slot), ntc = r0_uniform(c.ntc);
+	// every field is taken out of its load register here, on every path: a load that is still formally pending when its
+	// register is reused later costs a full drain of the memory queue at that point
+	const u32 valid = r0_uniform(c.valid), slot = r0_uniform(c.slot), ntc = r0_uniform(c.ntc), skip = r0_uniform(c.skip), coord = r0_uniform(c.coord);
+	if (!valid) return false;
 	if ((lo && ntc <= lo) || ntc > (u32)CAP) return false;
-	if (ntc == 0 || r0_uniform(c.skip)) {
+	if (ntc == 0 || skip) {
 		if (threadIdx.x == 0) reg_write_empty_record(L, slot);
 		return false;
 	}
-	b.slot = slot; b.ntc = ntc;
-	block_coords(r0_uniform(c.coord), L.cnt, b.bx, b.by, b.bz);
+	b.slot = slot; b.ntc = ntc; b.coord = coord;
+	block_coords(b.coord, L.cnt, b.bx, b.by, b.bz);
 	return true;
 }
 
 // next accepted item at or after `it` (stride gridDim.x), starting with an already requested candidate for `it`
-template <int CAP>
+template <int CAP, bool DIRTY>
 __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32& it, R0Candidate c, R0Block& b)
 {
 	const u32 padded = (total + 63u) & ~63u;
@@ -469,13 +491,25 @@ __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const Level
 		if (r0_accept<CAP>(L, lo, c, b)) return true;
 		it += gridDim.x;
 		if (it >= padded) return false;
-		c = r0_peek(p, L, total, it);
+		c = r0_peek<DIRTY>(p, L, total, it);
 	}
 }
 
-template <int CAP>
+// Optional in-kernel phase profile (build with -DVX_R0_PROFILE, tools only): cycles between the marks, summed over the
+// blocks a workgroup handles as seen by its thread 0, land in the header words behind the large-block counter.
+#if defined(VX_R0_PROFILE)
+#define R0_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
+#else
+#define R0_TICK(i) do { } while (0)
+#endif
+
+template <int CAP, bool DIRTY>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0(ExecParamsDev p, u32 lo)
 {
+#if defined(VX_R0_PROFILE)
+	u32 prof[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long tick = __builtin_readcyclecounter();
+#endif
 	typedef Reg0State<CAP> ST;
 	typedef R0<CAP> K;
 	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
@@ -484,7 +518,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
 
 	const LevelDesc& L = p.levels[0];
-	const u32 total = r0_uniform(p.G.dirty ? p.G.workCount[0] : *L.nActive);
+	const u32 total = r0_uniform(DIRTY ? p.G.workCount[0] : *L.nActive);
 	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const int tid = (int)threadIdx.x;
 	if (tid < 20) wgStats[tid] = 0;
@@ -495,16 +529,23 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	u32 it = blockIdx.x;
 	R0Block cur, nxt;
 	R0Prefetch pf;
-	bool have = r0_next_item<CAP>(p, L, total, lo, it, r0_peek(p, L, total, it), cur);
+	// Two blocks are known ahead: `cur` (inputs requested, being processed) and `nxt` (accepted; inputs requested while
+	// `cur` writes its output).  The work list entry behind `nxt` is requested together with nxt's inputs and looked at
+	// when the iteration ends — all requests of an iteration sit in ONE place (see the output loop below).
+	bool have = r0_next_item<CAP, DIRTY>(p, L, total, lo, it, r0_peek<DIRTY>(p, L, total, it), cur);
 	if (have) K::request(g, L, cur, pf);
+	it += gridDim.x;
+	bool haveNext = have && r0_next_item<CAP, DIRTY>(p, L, total, lo, it, r0_peek<DIRTY>(p, L, total, it), nxt);
 	while (have) {
-		// the work list entry after this one is requested now and looked at after the vertices are out
-		it += gridDim.x;
-		const R0Candidate cand = r0_peek(p, L, total, it);
+		const u32 candIt = it + gridDim.x;
+		R0Candidate cand;
+		R0_TICK(9);
 		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
+		R0_TICK(0);
 		K::deposit(st, g, L, cur, pf);
 		if (tid == 0) st.degenerate = 0;
 		__syncthreads();
+		R0_TICK(1);
 
 		// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
 		{
@@ -534,6 +575,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			}
 		}
 		__syncthreads();
+		R0_TICK(2);
 
 		// ---- cells: lane owns `per` consecutive compact cells -----------------------------------------------------
 		const u32 nt = r0_uniform(st.wordPrefix[128]);
@@ -544,10 +586,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			K::cell(st, RT, T, cur, k, wgStats);
 			sum += st.cellC[k];
 		}
+		R0_TICK(3);
 		{
 			const u32 incl = wave_inclusive_scan(sum);
 			if ((tid & 63) == 63) st.waveTot[tid >> 6] = incl;
 			__syncthreads();
+			R0_TICK(4);
 			u32 waveBase = 0, tot = 0;
 #pragma unroll
 			for (int w = 0; w < WG / 64; ++w) {
@@ -557,10 +601,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			}
 			const u32 vTotal = tot & 0xFFFFu, iTotal = tot >> 16;
 			// both pool reservations are requested now; their results are first needed after the descriptors are written
-			u32 vOff = 0, iOff = 0;
-			if (tid == 0) {
-				vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
-				iOff = atomicAdd(&p.P.cursors[CUR_I], iTotal);
+			// the pool reservations are made by the last lane: it owns the tail of the compact list, its wave is the first to
+			// run out of cells and can afford to wait for the two atomics while the others write their descriptors
+			if (tid == WG - 1) {
+				st.vTotal = vTotal; st.iTotal = iTotal;
+				st.vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
+				st.iOff = atomicAdd(&p.P.cursors[CUR_I], iTotal);
 			}
 			u32 run = waveBase + incl - sum;
 			for (u32 k = kBeg; k < kEnd; ++k) {
@@ -569,29 +615,41 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				K::describe(st, k, run, 0, 0);
 				run += v;
 			}
-			if (tid == 0) { st.vTotal = vTotal; st.iTotal = iTotal; st.vOff = vOff; st.iOff = iOff; }
 		}
+		R0_TICK(5);
 		__syncthreads();
+		R0_TICK(6);
 
 		const u32 vTotalU = r0_uniform(st.vTotal), iTotalU = r0_uniform(st.iTotal);
 		const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + iTotalU <= p.P.idxCap;
-		if (room) K::emit_vertices(st, RT, p.G, p.P, cur, 0);
-		// the next block's inputs travel while this block's indices (and any further chunks) are written
-		const bool haveNext = r0_next_item<CAP>(p, L, total, lo, it, cand, nxt);
-		if (haveNext) K::request(g, L, nxt, pf);
+		// Vertices and indices leave in ONE loop (a vertex and an index per lane and trip: two independent dependency
+		// chains for the scheduler), and the next block's inputs are requested inside its first trip: a loop with stores
+		// that is entered while loads are in flight makes the compiler drain the memory queue in front of it.
+		bool requested = false;
 		if (room) {
-			K::flush_indices(st, RT, p.P, 0);
-			for (u32 chunk = 1; chunk * R0_VDESC < vTotalU || chunk * R0_IDESC < iTotalU; ++chunk) {
-				__syncthreads();
-				for (u32 k = (u32)tid; k < nt; k += WG) K::describe(st, k, st.cellC[k], chunk * R0_VDESC, chunk * R0_IDESC);
-				__syncthreads();
-				if (chunk * R0_VDESC < vTotalU) K::emit_vertices(st, RT, p.G, p.P, cur, chunk * R0_VDESC);
-				if (chunk * R0_IDESC < iTotalU) K::flush_indices(st, RT, p.P, chunk * R0_IDESC);
+			for (u32 chunk = 0; chunk == 0 || chunk * R0_VDESC < vTotalU || chunk * R0_IDESC < iTotalU; ++chunk) {
+				if (chunk) {
+					__syncthreads();
+					for (u32 k = (u32)tid; k < nt; k += WG) K::describe(st, k, st.cellC[k], chunk * R0_VDESC, chunk * R0_IDESC);
+					__syncthreads();
+				}
+				const u32 cv = chunk * R0_VDESC, ci = chunk * R0_IDESC;
+				const u32 vEnd = cv < vTotalU ? min(vTotalU - cv, (u32)R0_VDESC) : 0u, iEnd = ci < iTotalU ? min(iTotalU - ci, (u32)R0_IDESC) : 0u;
+				PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
+				u32* iOut = p.P.idx + r0_uniform(st.iOff) + ci;
+				for (u32 base = 0; base < vEnd || base < iEnd; base += WG) {
+					if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<DIRTY>(p, L, total, candIt); requested = true; }
+					const u32 j = base + (u32)tid;
+					if (j < vEnd) K::emit_vertex(st, RT, p.G, cur, j, vOut);
+					if (j < iEnd) K::flush_index(st, RT, j, iOut);
+				}
 			}
 		}
+		if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<DIRTY>(p, L, total, candIt); }
+		R0_TICK(7);
 		if (tid == 0) {
 			BlockRecord& r = L.records[cur.slot];
-			r.coordId = L.slotCoord[cur.slot];
+			r.coordId = cur.coord;
 			r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.iTotal : 0;
 			if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
 			r.degenerate = st.degenerate;
@@ -603,9 +661,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		}
 		cur = nxt;
 		have = haveNext;
+		it = candIt;
+		R0_TICK(8);
+		haveNext = have && r0_next_item<CAP, DIRTY>(p, L, total, lo, it, cand, nxt);
 	}
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+#if defined(VX_R0_PROFILE)
+	if (tid == 0) for (int i = 0; i < 10; ++i) atomicAdd(&p.G.largeBlocks[4 + i], prof[i] >> 10); // units of 1024 cycles
+#endif
 }
 
 } // namespace
