@@ -69,6 +69,20 @@ struct Pools {
 	u32 vertCap, idxCap;
 };
 
+// The distance samples of LOD level L (the lattice of voxels whose coordinates are multiples of 2^L) as a dense array of
+// their own: entry (X,Y,Z) = dist(min(X << L, n-1), min(Y << L, n-1), min(Z << L, n-1)), X,Y,Z in [0, n >> L] — the last
+// index is the reference's clamped far sample.  Written by the level-0 classification pass for every block it reads
+// (blocks it may skip — BC_QUIET — are never written: their samples all share one sign, and readers ask the class
+// first); levels >= 1 then read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.
+enum { PYRAMID_LEVELS = 4 }; // levels 1..3 have a lattice copy; coarser levels (at most 64 blocks) gather from the grid
+struct PyramidLevel {
+	i8* data;           // nullptr: no copy of this level
+	u32 pitchX, pitchY; // entries per row, rows per plane
+	int yOrigin, zOrigin; // lattice coordinates of row 0 / plane 0 (slabs)
+};
+
+TV_HD size_t pyramid_offset(const PyramidLevel& P, int X, int Y, int Z) { return ((size_t)(Z - P.zOrigin) * P.pitchY + (size_t)(Y - P.yOrigin)) * P.pitchX + (size_t)X; }
+
 // stats[0] = non-trivial cells, [1] = degenerate triangles removed, [2] = level-0 blocks processed,
 // stats[4..19] = per-class cell counts
 struct Globals {
@@ -87,6 +101,7 @@ struct Globals {
 	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
 	u8* blockSummary;                 // bit0 = BF_Empty, bit1 = sign of the block's samples (an empty block has one sign)
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
+	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
 };
 
 // BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the

@@ -114,6 +114,17 @@ __device__ __forceinline__ void batched_gather(LoadFn load, StoreFn store)
 	}
 }
 
+// 17 consecutive lattice samples of level `level` starting at lattice point (X0, Y, Z), X0 a multiple of 16
+struct PyramidRow { uint4 lo; u32 far; };
+__device__ __forceinline__ PyramidRow pyramid_row17(const PyramidLevel& P, int X0, int Y, int Z)
+{
+	const i8* src = P.data + pyramid_offset(P, X0, Y, Z);
+	PyramidRow r;
+	r.lo = *(const uint4*)src;
+	r.far = *(const u8*)(src + 16);
+	return r;
+}
+
 // GPU forms of the staging phases of tv_block.h (same results, batched loads)
 __device__ __forceinline__ void gpu_stage_samples17(const GridView& g, u32 bx, u32 by, u32 bz, u32 mult, i8* samp)
 {
@@ -123,9 +134,21 @@ __device__ __forceinline__ void gpu_stage_samples17(const GridView& g, u32 bx, u
 		[&](int s, i8 v) { samp[s] = v; });
 }
 
-__device__ __forceinline__ void gpu_reg_stage(const GridView& g, const RegBlockCtx& b, i8* samp)
+__device__ __forceinline__ void gpu_reg_stage(const Globals& G, const RegBlockCtx& b, i8* samp)
 {
-	if (b.level == 0) {
+	const GridView& g = G.grid;
+	if (b.level >= 1 && b.level < PYRAMID_LEVELS && G.pyr[b.level].data) {
+		// the level's lattice copy: 17 contiguous samples per row.  Entries of blocks nobody read hold no data — and are
+		// never looked at: a non-trivial cell has no corner in such a block.
+		const PyramidLevel& P = G.pyr[b.level];
+		for (int r = (int)threadIdx.x; r < 289; r += WG) {
+			const int k = r / 17, j = r - k * 17;
+			const PyramidRow row = pyramid_row17(P, (int)(b.bx * 16), (int)(b.by * 16) + j, (int)(b.bz * 16) + k);
+			u32* dst = (u32*)(samp + samp_index(0, j, k));
+			dst[0] = row.lo.x; dst[1] = row.lo.y; dst[2] = row.lo.z; dst[3] = row.lo.w;
+			samp[samp_index(16, j, k)] = (i8)row.far;
+		}
+	} else if (b.level == 0) {
 		// one lane per 24-byte row (361 rows): the row address is formed once, the six aligned dwords follow from it
 		const int n = g.n, gx0 = (int)b.bx * 16 - 4;
 		const int xFirst = gx0 < 0 ? 0 : gx0, xLast = (gx0 + 20 > n - 4) ? n - 4 : gx0 + 20; // dword clamps of j = 0 / j = 5
@@ -491,6 +514,52 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 	p.G.blockClass[id] = (u8)c;
 }
 
+// ---- lattice copies of the distance field for the coarser levels (PyramidLevel, tv_block.h) -----------------------------
+// One 16-voxel segment [xs, xs + 16) of the voxel row (y,z) as the classify pass holds it: its samples on the level-L
+// lattice go to the level's copy.  y and z may be the first row beyond the grid (y == n: the loaded data then is the
+// clamped row n - 1, and y >> L is exactly the index of the level's clamped far entry); the voxel n - 1 of a row is also
+// stored as the far entry of its lattice row.
+__device__ __forceinline__ void pyramid_write_segment(const Globals& G, int n, int xs, int y, int z, uint4 d)
+{
+#pragma unroll
+	for (int l = 1; l < PYRAMID_LEVELS; ++l) {
+		const PyramidLevel& P = G.pyr[l];
+		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
+		i8* row = P.data + pyramid_offset(P, 0, y >> l, z >> l);
+		if (l == 1) {
+			uint2 v;
+			v.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200u);
+			v.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200u);
+			*(uint2*)(row + (xs >> 1)) = v;
+		} else if (l == 2) {
+			*(u32*)(row + (xs >> 2)) = __builtin_amdgcn_perm(d.y, d.x, 0x0C0C0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000C0Cu);
+		} else {
+			*(u16*)(row + (xs >> 3)) = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
+		}
+		if (xs + 16 == n) row[n >> l] = (i8)(d.w >> 24);
+	}
+}
+
+// Which of the 17 samples of that row lie in level-0 blocks the classify pass did not read (BC_QUIET)?  Such a sample
+// and everything within a block's width of it has one sign, so a cell of a level <= 3 that touches one is trivial —
+// which is all a reader needs to know about them (their lattice entries hold no data).
+__device__ __forceinline__ u32 pyramid_row_quiet_mask(const Globals& G, const LevelDesc& levels0, int level, int X0, int Y, int Z)
+{
+	const u32 cnt0 = levels0.cnt;
+	// a sample beyond the rank's last block layer (the far samples of that layer, written by its tiles) is as quiet as
+	// the block it was written from
+	const LevelDesc& L0 = levels0;
+	const u32 yb = min((u32)(Y << level) >> 4, L0.yb1 - 1), zb = min((u32)(Z << level) >> 4, L0.zb1 - 1);
+	const u8* cls = G.blockClass + (size_t)block_coord_id(0, yb, zb, cnt0);
+	const u32 xbFirst = (u32)(X0 << level) >> 4, per = 16u >> level; // samples per level-0 block along the row
+	u32 m = 0;
+	for (u32 b = 0; b <= (1u << level); ++b) {
+		const u32 xb = min(xbFirst + b, cnt0 - 1);
+		if (cls[xb] & BC_QUIET) m |= (b == (1u << level)) ? (1u << 16) : (((1u << per) - 1u) << (b * per));
+	}
+	return m;
+}
+
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
 constexpr int TW = TB / 2;        // 32-bit words of sign bits per tile row
 
@@ -557,6 +626,12 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 		},
 		[&](int q, uint4 d) {
 			sgn[q] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
+			// the coarser levels' lattice copies: rows of this block layer, and the first rows beyond it where the rank's
+			// blocks end (nobody else would write those)
+			const int r = q / TB, seg = q - r * TB;
+			const int ry = r % 17, rz = r / 17;
+			if ((ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
+				pyramid_write_segment(p.G, n, x0 + seg * 16, (int)by * 16 + ry, (int)bz * 16 + rz, d);
 		});
 	batched_gather<289, i8, 2>(
 		[&](int r) {
@@ -677,6 +752,7 @@ __global__ __launch_bounds__(WG) void k_hierarchy(ExecParamsDev p, u32 levels)
 // ------------------------------------------------------------------------------------------------------
 struct MatLds {
 	u32 rowMask[292];          // sign bits of the 17 samples of sample row r = k * 17 + j
+	u32 rowQuiet[292];         // ... which of them lie in level-0 blocks nobody read (their cells are trivial)
 	u16 ntRow[256];            // non-trivial cells of cell row (y,z) = the block's ntBits
 	u32 childBits[8][128];     // level 1: consistency bitmaps of the 2x2x2 child blocks
 	int childSlot[8];
@@ -720,6 +796,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 	const int mult = (int)L.mult;
 	constexpr int PER = (SAMPLES + WG - 1) / WG; // 20 samples per lane
 	constexpr int MAT_BATCH = 10;                 // of which this many are in flight together
+#if defined(VX_MAT_PROFILE)
+	u32 prof[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long tick = __builtin_readcyclecounter();
+#define MAT_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
+#else
+#define MAT_TICK(i) do { } while (0)
+#endif
+	MAT_TICK(0);
 	for (u32 it = blockIdx.x; it < nItems; it += gridDim.x) {
 		const u32 slot = p.G.dirty ? p.G.workItems[level][it] : it;
 		u32 bx, by, bz;
@@ -727,6 +811,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
 		u16* cacheOut = L.cache + (size_t)slot * BLOCK_CELLS;
 		__syncthreads(); // the previous block of this workgroup is done with the LDS state
+		MAT_TICK(1);
 
 		// ---- requests: child slots, old cache contents (incremental runs), samples ----------------------
 		int cs = -1;
@@ -739,7 +824,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		const int x0 = (int)(bx * 16) * mult, y0 = (int)(by * 16) * mult, z0 = (int)(bz * 16) * mult;
 		const i8* base = g.dist + dist_offset(g, x0, y0, z0); // uniform; lanes add 32-bit offsets
 		const int pitch = g.pitchY;
-		for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
+		const PyramidLevel& pyr = p.G.pyr[level < PYRAMID_LEVELS ? level : 0];
+		const bool lattice = level < PYRAMID_LEVELS && pyr.data != nullptr;
+		for (int r = tid; r < 292; r += WG) { st.rowMask[r] = 0; st.rowQuiet[r] = 0; }
 		if (tid < 8) st.childSlot[tid] = cs;
 		if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
 		if (defineAll) {
@@ -748,6 +835,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		}
 		((uint4*)st.out)[tid] = old0; ((uint4*)st.out)[tid + WG] = old1;
 		__syncthreads();
+		MAT_TICK(2);
+		if (lattice) {
+			// the level's lattice copy: one 16-byte load + one byte per sample row
+			for (int r = tid; r < 289; r += WG) {
+				const int k = r / 17, j = r - k * 17;
+				const PyramidRow row = pyramid_row17(pyr, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
+				st.rowMask[r] = sign_nibble(row.lo.x) | (sign_nibble(row.lo.y) << 4) | (sign_nibble(row.lo.z) << 8) | (sign_nibble(row.lo.w) << 12) | (((row.far >> 7) & 1u) << 16);
+				st.rowQuiet[r] = pyramid_row_quiet_mask(p.G, p.levels[0], (int)level, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
+			}
+		} else
 #pragma unroll 1
 		for (int q0 = 0; q0 < PER; q0 += MAT_BATCH) {
 			i8 v[MAT_BATCH];
@@ -777,12 +874,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 			}
 		}
 		__syncthreads();
+		MAT_TICK(3);
 		const int y = tid & 15, z = tid >> 4;
 		u32 nt;
 		{
 			const u32 a = st.rowMask[z * 17 + y], b2 = st.rowMask[z * 17 + y + 1], c = st.rowMask[(z + 1) * 17 + y], d = st.rowMask[(z + 1) * 17 + y + 1];
 			const u32 A = a & b2 & c & d, O = a | b2 | c | d;
-			nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+			const u32 Q = st.rowQuiet[z * 17 + y] | st.rowQuiet[z * 17 + y + 1] | st.rowQuiet[(z + 1) * 17 + y] | st.rowQuiet[(z + 1) * 17 + y + 1];
+			nt = ((O | (O >> 1)) & ~(A & (A >> 1)) & ~(Q | (Q >> 1))) & 0xFFFFu;
 			st.ntRow[tid] = (u16)nt;
 			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
 			if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
@@ -792,6 +891,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 			for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
 		}
 		__syncthreads();
+		MAT_TICK(4);
 		// ---- selection: cells that need an entry (non-trivial, or visited by the transition pass) and have
 		//      any child entry to vote on.  All eight children of a cell live in one child block. -----------
 		{
@@ -839,49 +939,89 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 			}
 		}
 		__syncthreads();
-		// ---- vote: the eight child entries of a cell are requested together --------------------------------
+		MAT_TICK(5);
+		// ---- vote.  A lane takes VB cells per trip and requests ALL their child entries before it looks at any: children
+		//      that are neighbours along x come in one load (two u16 entries / two material bytes), and no load is
+		//      conditional (a load with a default value is waited for on the spot) — the children of a cell are always
+		//      inside the grid; entries the consistency bits rule out are masked after the fact. ----------------------------
 		{
 			const int nVote = (int)st.voteCount;
 			const size_t matOrigin = mat_offset(g, (int)(bx * 32), (int)(by * 32), (int)(bz * 32));
 			const u8* matBase = g.mat + matOrigin;
 			const u8* blendBase = g.blend + matOrigin;
 			const int pitchMat = g.pitchYMat;
-			for (int k = tid; k < nVote; k += WG) {
-				const u32 c = st.voteList[k];
-				const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
-				const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
-				u32 e[8];
-				if (level == 1) {
-					u32 m[8], bl[8];
+			if (level == 1) {
+				constexpr int VB = 2;
+				for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
+					u32 mat2[VB][4], bl2[VB][4];
 #pragma unroll
-					for (int i = 0; i < 8; ++i) {
-						const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
-						const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
-						m[i] = EMPTY_MATERIAL; bl[i] = 0;
-						if ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) {
-							const u32 off = (u32)((czz * pitchMat + cyy) * n + cxx);
-							m[i] = matBase[off]; bl[i] = blendBase[off];
+					for (int v = 0; v < VB; ++v) {
+						const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
+						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+#pragma unroll
+						for (int q = 0; q < 4; ++q) {
+							const u32 off = (u32)(((2 * lz + (q >> 1)) * pitchMat + 2 * ly + (q & 1)) * n + 2 * lx);
+							mat2[v][q] = *(const u16*)(matBase + off);
+							bl2[v][q] = *(const u16*)(blendBase + off);
 						}
 					}
 #pragma unroll
-					for (int i = 0; i < 8; ++i) e[i] = m[i] | (bl[i] << 8);
-				} else {
-					const u16* child = C.cache + (size_t)st.childSlot[cb] * BLOCK_CELLS;
+					for (int v = 0; v < VB; ++v) {
+						if (k0 + v * WG >= nVote) continue;
+						const u32 c = st.voteList[k0 + v * WG];
+						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+						const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
+						u32 e[8];
 #pragma unroll
-					for (int i = 0; i < 8; ++i) {
-						const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
-						e[i] = child[((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15)];
+						for (int i = 0; i < 8; ++i) {
+							const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
+							const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
+							const u32 sh = (u32)(i & 1) * 8u;
+							const u32 entry = ((mat2[v][i >> 1] >> sh) & 0xFFu) | (((bl2[v][i >> 1] >> sh) & 0xFFu) << 8);
+							e[i] = ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) ? entry : (u32)EMPTY_MATINFO;
+						}
+						const u32 entry = vote8(e);
+						if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
 					}
 				}
-				const u32 entry = vote8(e);
-				if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
+			} else {
+				constexpr int VB = 4;
+				for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
+					u32 pair[VB][4];
+#pragma unroll
+					for (int v = 0; v < VB; ++v) {
+						const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
+						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+						const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
+						const u16* child = C.cache + (size_t)st.childSlot[cb] * BLOCK_CELLS;
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+							pair[v][q] = *(const u32*)(child + ((((2 * lz + (q >> 1)) & 15) << 8) | (((2 * ly + (q & 1)) & 15) << 4) | ((2 * lx) & 15)));
+					}
+#pragma unroll
+					for (int v = 0; v < VB; ++v) {
+						if (k0 + v * WG >= nVote) continue;
+						const u32 c = st.voteList[k0 + v * WG];
+						u32 e[8];
+#pragma unroll
+						for (int i = 0; i < 8; ++i) e[i] = (pair[v][i >> 1] >> ((u32)(i & 1) * 16u)) & 0xFFFFu;
+						const u32 entry = vote8(e);
+						if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
+					}
+				}
 			}
 		}
 		__syncthreads();
+		MAT_TICK(6);
 		((uint4*)cacheOut)[tid] = ((const uint4*)st.out)[tid];
 		((uint4*)cacheOut)[tid + WG] = ((const uint4*)st.out)[tid + WG];
 	}
+#if defined(VX_MAT_PROFILE)
+	MAT_TICK(9);
+	if (tid == 0 && level == VX_MAT_PROFILE) for (int i = 0; i < 10; ++i) atomicAdd(&p.G.largeBlocks[4 + i], prof[i] >> 4);
+#endif
 }
+
 
 // ------------------------------------------------------------------------------------------------------
 // k_regular / k_transition: workgroups striding over (level, slot) work items
@@ -985,7 +1125,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 		}
 		__syncthreads();
 		reg_phase_begin(st, L, b.slot, tid, WG);
-		gpu_reg_stage(p.G.grid, b, st.samp);
+		gpu_reg_stage(p.G, b, st.samp);
 		__syncthreads();
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
 		__syncthreads();
@@ -1182,6 +1322,19 @@ __global__ __launch_bounds__(WG) void k_classify_blocks(ExecParamsDev p, const u
 		if (tid == 0) ntCells = 0;
 		__syncthreads();
 		mat_phase_classify(st, tid, WG);
+		// the block was read in full: its lattice samples go to the coarser levels' copies (with the far samples where no
+		// further block follows), and whatever a full run knew about it without reading it no longer holds
+		if (tid == 0) p.G.blockClass[coords[k]] = 0;
+		for (int l = 1; l < PYRAMID_LEVELS; ++l) {
+			const PyramidLevel& P = p.G.pyr[l];
+			if (!P.data) continue;
+			const int step = 1 << l, per = 16 >> l;
+			const int cx = per + (bx + 1 == L.cnt ? 1 : 0), cy = per + (by + 1 == L.yb1 ? 1 : 0), cz = per + (bz + 1 == L.zb1 ? 1 : 0);
+			for (int e = tid; e < cx * cy * cz; e += WG) {
+				const int i = (e % cx) * step, j = ((e / cx) % cy) * step, kk = (e / (cx * cy)) * step;
+				P.data[pyramid_offset(P, (int)(bx * 16 + i) >> l, (int)(by * 16 + j) >> l, (int)(bz * 16 + kk) >> l)] = st.samp[(kk * 17 + j) * 17 + i];
+			}
+		}
 		__syncthreads();
 		if (tid < 128) atomicAdd(&ntCells, (u32)__popc(st.ntBits[tid]));
 		__syncthreads();
@@ -1290,6 +1443,7 @@ struct Backend {
 		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB }) if (e) (void)hipEventDestroy(e);
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
+	bool wants_pyramid() const { return true; }
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
 	std::string error() const { return lastError; }
 	void* alloc(size_t bytes)

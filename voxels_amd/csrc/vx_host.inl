@@ -55,6 +55,7 @@ struct vx_ctx {
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
+	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
 	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header (HDR_WORDS u32): slot counts | vertex cursor | index cursor | overflow | stats[20] | workCount[8], one line each
@@ -132,6 +133,7 @@ bool ensure_level_tables(vx_ctx* c)
 		return p;
 	};
 	for (u32 L = 0; L < MAX_LEVELS; ++L) memset(&c->lv[L], 0, sizeof(LevelDesc));
+	memset(c->pyr, 0, sizeof(c->pyr));
 	for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) {
 		LevelDesc& d = c->lv[L];
 		d.mult = 1u << L;
@@ -160,6 +162,17 @@ bool ensure_level_tables(vx_ctx* c)
 			c->dBlockSummary = alloc(total);
 			c->dBlockClass = alloc(total);
 			if (!c->dBlockSummary || !c->dBlockClass) return false;
+		}
+		// lattice copy of the distance samples of this level over the rank's rows / planes (one more than it owns: the far
+		// samples of its last block layer)
+		if (L >= 1 && L < PYRAMID_LEVELS && c->be.wants_pyramid()) {
+			PyramidLevel& P = c->pyr[L];
+			P.pitchX = (c->n >> L) + 16;
+			P.pitchY = ((c->yEnd - c->yBegin) >> L) + 1;
+			P.yOrigin = (int)(c->yBegin >> L); P.zOrigin = (int)(c->zBegin >> L);
+			const size_t planes = ((c->zEnd - c->zBegin) >> L) + 1;
+			P.data = (i8*)alloc((size_t)P.pitchX * P.pitchY * planes + 64);
+			if (!P.data) return false;
 		}
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1; c->tablesYb0 = yb0; c->tablesYb1 = yb1;
@@ -199,6 +212,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
 	p.G.blockSummary = (u8*)c->dBlockSummary;
 	p.G.blockClass = (u8*)c->dBlockClass;
+	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
@@ -381,6 +395,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	*out = nullptr;
 	vx_ctx* c = new vx_ctx;
 	memset(c->stats, 0, sizeof(c->stats));
+	memset(c->pyr, 0, sizeof(c->pyr));
 	std::string e;
 	if (!c->be.init(device_index, e)) { delete c; return VX_ERR_DEVICE; }
 	c->hostTiming = getenv("VX_HOST_TIMING") != nullptr;
@@ -779,6 +794,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
+#if defined(VX_MAT_PROFILE)
+	{
+		static const char* names[10] = { "prologue", "stores + next coords + barrier", "requests + init + barrier", "samples + barrier", "classify + barrier", "select + barrier", "vote + barrier", "-", "-", "tail" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 10; ++i) sum += c->hdr[HDR_LARGE + 4 + i];
+		for (int i = 0; i < 10; ++i) fprintf(stderr, "[material profile, level %d] %-32s %10u x16 cycles  %5.1f %%\n", VX_MAT_PROFILE, names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_R0_PROFILE)
 	{
 		static const char* names[10] = { "top barrier", "deposit+barrier", "prefix+list+barrier", "cells", "scan barrier", "reserve+describe", "barrier", "vertices+indices", "record", "next item (drain)" };
