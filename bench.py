@@ -173,7 +173,7 @@ def main():
     alg = {"k_classify": float(slab_bytes),
            "k_regular": float(2 * 4096 * info.active_blocks[0] + 48 * int(totals[0]) + 4 * int(totals[1])),
            "k_transition": float(48 * int(totals[2]) + 4 * int(totals[3]))}
-    stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular", "k_transition", "k_vertices"]
+    stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular", "k_transition", "k_lists"]
     stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
     dominant = max(alg.keys(), key=lambda k: stage_ms[k])
     achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9

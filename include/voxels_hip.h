@@ -156,12 +156,27 @@ typedef struct vx_block_ranges {
 } vx_block_ranges;
 int vx_device_meshes(vx_ctx* ctx, const vx_vertex** d_verts, const uint32_t** d_indices, uint64_t* n_verts, uint64_t* n_indices);
 int vx_level_ranges(vx_ctx* ctx, uint32_t level, vx_block_ranges* ranges /* one per block, vx_download_level order */);
+/* The same lists as a device-resident table: what PushBlocksToResult (src/TransVoxelImpl.cpp:1266-1293) assembles per
+ * block — ranges of its 1 + 6 meshes in the pools, id (:149-152), Y-up corners (:1283-1293) — for the blocks of one level
+ * in GetBlockForLevel order (:395-401; blocks without a regular vertex are left out, :1274).  A full run writes the
+ * tables on the device as its last step, so a renderer can consume a run without any host round trip beyond the
+ * per-level counts; after an incremental run the (host-maintained) lists are uploaded on the first call.
+ * The table is valid until the next run on this context. */
+typedef struct vx_listed_block {
+	uint32_t coord_id;                     /* (bz * cnt + by) * cnt + bx, internal axes (Z up) */
+	uint32_t v_off, v_count, i_off, i_count;
+	uint32_t tv_off[6], tv_count[6], ti_off[6], ti_count[6];
+	uint32_t degenerate, nt_cells, reserved;
+	uint32_t id;
+	float min_corner[3], max_corner[3];
+} vx_listed_block;
+int vx_device_block_table(vx_ctx* ctx, uint32_t level, const vx_listed_block** d_table, uint32_t* n_blocks);
 /* stats[0..3] = BlocksCalculated, TrivialCells, NonTrivialCells, DegenerateTrianglesRemoved; stats[4..19] =
  * PerCaseCellsCount (include/Polygonizer.h:110-132) */
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
 
 /* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
- * ms[0..6] = reset, classify, hierarchy, material (all levels), regular, transition, vertex pass of the LAST run. */
+ * ms[0..6] = reset, classify, hierarchy, material (all levels), regular, transition, block lists of the LAST run. */
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
 int vx_stage_times(vx_ctx* ctx, float ms[7]);
 

@@ -127,6 +127,19 @@ struct Backend {
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
+	template <typename P>
+	void run_block_lists(const P& p, const ListPlan& plan, u32 levels)
+	{
+		for (u32 l = 0; l < levels; ++l) {
+			const LevelDesc& L = p.levels[l];
+			u32 n = 0;
+			for (u32 id = 0; id < L.cnt * L.cnt * L.cnt; ++id) {
+				const int slot = listed_block_slot(L, id);
+				if (slot >= 0) listed_block_fill(L.listed[n++], L, id, (u32)slot, plan.idBase[l]);
+			}
+			plan.totals[l] = n;
+		}
+	}
 	template <typename P> void run_vertices(const P&, u32) {} // the emulated per-block phases write finished vertices
 	bool stage_ms(float*) { return false; }
 

@@ -398,8 +398,21 @@ def test_hip_device_resident_meshes(poly):
     idx = np.zeros(ni, np.uint32)
     assert hip.hipMemcpy(verts.ctypes.data_as(C.c_void_p), C.c_void_p(dv), nv * 48, 2) == 0
     assert hip.hipMemcpy(idx.ctypes.data_as(C.c_void_p), C.c_void_p(di), ni * 4, 2) == 0
+    from voxels_amd.binding import LISTED_BLOCK_DTYPE
     for l in range(3):
+        # the device-built block table (written by the run itself) read back raw: same blocks, same order, same ranges
+        tab, nb = poly.device_block_table(l)
+        table = np.zeros(nb, LISTED_BLOCK_DTYPE)
+        assert LISTED_BLOCK_DTYPE.itemsize == 156
+        assert nb == 0 or hip.hipMemcpy(table.ctypes.data_as(C.c_void_p), C.c_void_p(tab), nb * 156, 2) == 0
         lv, rg = poly.level(l), poly.level_ranges(l)
+        assert nb == lv.infos.size
+        for name_t, name_i in (("id", "id"), ("v_count", "n_verts"), ("i_count", "n_idx"), ("tv_count", "n_tverts"), ("ti_count", "n_tidx"),
+                               ("min_corner", "min_corner"), ("max_corner", "max_corner")):
+            assert np.array_equal(table[name_t], lv.infos[name_i]), name_t
+        for name in ("v_off", "i_off", "tv_off", "ti_off"):
+            assert np.array_equal(table[name], rg[name]), name
+        assert np.all(np.diff(table["coord_id"].astype(np.int64)) > 0)
         ov = oi = otv = oti = 0
         for k, info in enumerate(lv.infos):
             assert np.array_equal(verts[rg["v_off"][k]:rg["v_off"][k] + info["n_verts"]], lv.verts[ov:ov + info["n_verts"]])

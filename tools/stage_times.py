@@ -27,7 +27,7 @@ def main():
         p.execute(levels)
         acc += p.stage_times()
     acc /= reps
-    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular %.4f transition %.4f vertices %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
+    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular %.4f transition %.4f lists %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
 
 
 if __name__ == "__main__":

@@ -4,6 +4,11 @@ import os
 
 import numpy as np
 
+LISTED_BLOCK_DTYPE = np.dtype([
+    ("coord_id", "<u4"), ("v_off", "<u4"), ("v_count", "<u4"), ("i_off", "<u4"), ("i_count", "<u4"),
+    ("tv_off", "<u4", 6), ("tv_count", "<u4", 6), ("ti_off", "<u4", 6), ("ti_count", "<u4", 6),
+    ("degenerate", "<u4"), ("nt_cells", "<u4"), ("reserved", "<u4"), ("id", "<u4"),
+    ("min_corner", "<f4", 3), ("max_corner", "<f4", 3)])
 VERTEX_DTYPE = np.dtype([("pos", "<f4", 3), ("sec", "<f4", 4), ("nrm", "<f4", 3), ("tex", "u1", 8)])
 BLOCK_INFO_DTYPE = np.dtype([
     ("id", "<u4"), ("n_verts", "<u4"), ("n_idx", "<u4"),
@@ -57,6 +62,7 @@ class HipLibrary:
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
+        lib.vx_device_block_table.argtypes = [vp, u32, vp, vp]
         lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -184,6 +190,12 @@ class Polygonizer:
         self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
         return dv.value, di.value, nv.value, ni.value
 
+    def device_block_table(self, lvl):
+        """(device pointer, count) of the level's block table (vx_listed_block records, GetBlockForLevel order)."""
+        tab, nb = C.c_void_p(), C.c_uint32()
+        self._check(self._lib.vx_device_block_table(self._h, int(lvl), C.byref(tab), C.byref(nb)), "vx_device_block_table")
+        return tab.value, nb.value
+
     def level_ranges(self, lvl):
         """Per block (download order): offsets of its meshes in the device pools."""
         nb = self.level(lvl, with_data=False).infos.size
@@ -262,7 +274,7 @@ class Polygonizer:
 
 
     def stage_times(self):
-        """ms of (reset, classify, hierarchy, material, regular, transition, vertex pass) of the last run."""
+        """ms of (reset, classify, hierarchy, material, regular, transition, block lists) of the last run."""
         out = np.zeros(7, np.float32)
         self._check(self._lib.vx_stage_times(self._h, _ptr(out)), "vx_stage_times")
         return out

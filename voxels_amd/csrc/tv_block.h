@@ -30,6 +30,7 @@ namespace tv {
 
 enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
 enum { CUR_V = 0, CUR_I = 32, CUR_OVF = 64 };
+enum { LIST_WG = 256 }; // block coordinates per workgroup of the list kernels
 enum { LARGE_THRESHOLD = 640 }; // blocks with more non-trivial cells use the 4096-cell LDS class of the regular pass // hot device counters live in separate cache lines (atomics serialise per line)
 
 // One emitted block (regular mesh + 6 transition meshes) inside the shared vertex/index pools
@@ -40,6 +41,16 @@ struct BlockRecord {
 	u32 degenerate;
 	u32 ntCells;
 	u32 pad;
+};
+
+// A block as the result lists it (PushBlocksToResult, src/TransVoxelImpl.cpp:1266-1293): where its meshes are in the
+// pools, its id (:149-152: all blocks of all levels numbered level-major in coordinate order) and its corners (:1283-1293,
+// output axes: Y up).  One table per level, in coordinate order (= PolygonSurface::GetBlockForLevel order), blocks
+// without a regular vertex left out (:1274) — written on the device at the end of a full run.
+struct ListedBlock {
+	BlockRecord rec;
+	u32 id;
+	float minc[3], maxc[3];
 };
 
 // Per-LOD-level device tables
@@ -58,6 +69,7 @@ struct LevelDesc {
 	u8* skip;           // [cap] level 0: block skipped by the emptiness rule
 	u16* ntCount;       // [cap] number of non-trivial cells of the block (picks the LDS capacity class)
 	BlockRecord* records; // [cap]
+	ListedBlock* listed;  // [cap] the level's block list (see ListedBlock)
 	u32 cap;
 	u32 hasTransitions; // 0 < level < levelsCount - 1
 };
@@ -111,6 +123,34 @@ struct Globals {
 enum { BC_SKIPPED = 1, BC_QUIET = 2, BC_NEGATIVE = 4 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
+
+// the work of the list kernels: workgroup w handles the block coordinates [(w - wgStart[l]) * LIST_WG, ...) of its level l
+struct ListPlan {
+	u32 wgStart[MAX_LEVELS + 1];
+	u32 idBase[MAX_LEVELS];   // id of block coordinate 0 of the level
+	u32* counts;              // [wgStart[levels]] listed blocks per workgroup (scratch)
+	u32* totals;              // [MAX_LEVELS] out: listed blocks per level
+};
+
+TV_HD void listed_block_fill(ListedBlock& out, const LevelDesc& L, u32 coordId, u32 slot, u32 idBase)
+{
+	out.rec = L.records[slot];
+	out.id = idBase + coordId;
+	u32 bx, by, bz;
+	bx = coordId % L.cnt; by = (coordId / L.cnt) % L.cnt; bz = coordId / (L.cnt * L.cnt);
+	const float ext = (float)(L.mult * 16);
+	out.minc[0] = (float)bx * ext; out.minc[1] = (float)bz * ext; out.minc[2] = (float)by * ext; // output is Y-up
+	out.maxc[0] = out.minc[0] + ext; out.maxc[1] = out.minc[1] + ext; out.maxc[2] = out.minc[2] + ext;
+}
+
+// does block coordinate `id` of level L appear in the level's list?  (-1: no, else its slot)
+TV_HD int listed_block_slot(const LevelDesc& L, u32 id)
+{
+	if (id >= L.cnt * L.cnt * L.cnt) return -1;
+	const int slot = L.slotOf[id];
+	if (slot < 0) return -1;
+	return L.records[slot].vCount ? slot : -1;
+}
 
 TV_HD void block_coords(u32 id, u32 cnt, u32& bx, u32& by, u32& bz) { bx = id % cnt; by = (id / cnt) % cnt; bz = id / (cnt * cnt); }
 

@@ -1342,6 +1342,58 @@ __global__ __launch_bounds__(WG) void k_classify_blocks(ExecParamsDev p, const u
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_list_count / k_list_write: the result's block lists (ListedBlock, tv_block.h) built where the records are.
+// Coordinate order = index order of the block -> slot maps, so the lists are an ordered compaction of them: counts per
+// workgroup, then every workgroup adds up the counts before it (at most ~1200 of them) and writes its blocks.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 list_level_of(const ListPlan& plan, u32 levels, u32 w)
+{
+	u32 l = 0;
+	for (u32 q = 1; q < levels; ++q) if (w >= plan.wgStart[q]) l = q;
+	return l;
+}
+
+__global__ __launch_bounds__(LIST_WG) void k_list_count(ExecParamsDev p, ListPlan plan, u32 levels)
+{
+	const u32 w = blockIdx.x, l = list_level_of(plan, levels, w);
+	const u32 id = (w - plan.wgStart[l]) * LIST_WG + threadIdx.x;
+	const int n = __syncthreads_count(listed_block_slot(p.levels[l], id) >= 0 ? 1 : 0);
+	if (threadIdx.x == 0) plan.counts[w] = (u32)n;
+}
+
+__global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPlan plan, u32 levels)
+{
+	__shared__ u32 waveSum[LIST_WG / 64];
+	__shared__ u32 baseShared;
+	const u32 w = blockIdx.x, l = list_level_of(plan, levels, w), tid = threadIdx.x;
+	const LevelDesc& L = p.levels[l];
+	const u32 id = (w - plan.wgStart[l]) * LIST_WG + tid;
+	const int slot = listed_block_slot(L, id);
+	// listed blocks of this level in the workgroups before this one
+	u32 before = 0;
+	for (u32 q = plan.wgStart[l] + tid; q < w; q += LIST_WG) before += plan.counts[q];
+	for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+	if ((tid & 63) == 0) waveSum[tid >> 6] = before;
+	__syncthreads();
+	if (tid == 0) { u32 b = 0; for (u32 q = 0; q < LIST_WG / 64; ++q) b += waveSum[q]; baseShared = b; }
+	__syncthreads();
+	const u32 base = baseShared;
+	// rank of this block among the workgroup's listed ones
+	const unsigned long long mask = __ballot(slot >= 0);
+	__syncthreads();
+	if ((tid & 63) == 0) waveSum[tid >> 6] = (u32)__popcll(mask);
+	__syncthreads();
+	u32 rank = (u32)__popcll(mask & ((1ull << (tid & 63)) - 1ull));
+	for (u32 q = 0; q < (tid >> 6); ++q) rank += waveSum[q];
+	if (slot >= 0) listed_block_fill(L.listed[base + rank], L, id, (u32)slot, plan.idBase[l]);
+	if (w + 1 == plan.wgStart[l + 1] && tid == 0) {
+		u32 total = base;
+		for (u32 q = 0; q < LIST_WG / 64; ++q) total += waveSum[q];
+		plan.totals[l] = total;
+	}
+}
+
 struct DirtyRanges { u32 start[MAX_LEVELS + 1]; };
 
 __global__ __launch_bounds__(WG) void k_build_worklist(ExecParamsDev p, const u32* coords, DirtyRanges r, u32 levels, u32* work)
@@ -1702,6 +1754,17 @@ struct Backend {
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}
 	bool stage_timing_on() const { return stageOn; }
+
+	// the result's block lists, written on the device behind the last kernel of a full run
+	template <typename P>
+	void run_block_lists(const P& p, const ListPlan& plan, u32 levels)
+	{
+		const u32 wgs = plan.wgStart[levels];
+		if (!wgs) return;
+		hipLaunchKernelGGL(k_list_count, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
+		hipLaunchKernelGGL(k_list_write, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
+		check(hipGetLastError(), "k_list launch");
+	}
 
 	// descriptors -> vertices for the vertices [first, cursor) of the pool; after every per-block kernel of the run
 	template <typename P>

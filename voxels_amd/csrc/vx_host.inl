@@ -33,14 +33,11 @@ struct ExecParams {
 	const u8* tables; // TAB_BYTES image in device memory
 };
 
-struct EmittedBlock {
-	BlockRecord rec;
-	u32 id;
-	float minc[3], maxc[3];
-	// the meshes live in the output pools (offsets in rec): full runs rewrite the pools, incremental runs append to them
-};
+// the meshes of a listed block live in the output pools (offsets in rec): full runs rewrite the pools, incremental runs
+// append to them
+typedef ListedBlock EmittedBlock;
 
-enum { HDR_WORDS = 192, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 192, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -56,6 +53,8 @@ struct vx_ctx {
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
+	void* dListCounts = nullptr;                         // per-workgroup counts of the list kernels
+	bool deviceLists = false;                            // the device block tables describe the current surface (full run; not after incremental runs)
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
 	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header (HDR_WORDS u32): slot counts | vertex cursor | index cursor | overflow | stats[20] | workCount[8], one line each
@@ -156,8 +155,9 @@ bool ensure_level_tables(vx_ctx* c)
 		d.skip = L ? nullptr : (u8*)alloc(cap);
 		d.ntCount = (u16*)alloc(cap * 2);
 		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
+		d.listed = (ListedBlock*)alloc(cap * sizeof(ListedBlock));
 		d.nActive = (u32*)c->dHeader + L;
-		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
+		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.listed || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 		if (!L) {
 			c->dBlockSummary = alloc(total);
 			c->dBlockClass = alloc(total);
@@ -174,6 +174,12 @@ bool ensure_level_tables(vx_ctx* c)
 			P.data = (i8*)alloc((size_t)P.pitchX * P.pitchY * planes + 64);
 			if (!P.data) return false;
 		}
+	}
+	{
+		size_t wgs = 0;
+		for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) wgs += ((size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt + LIST_WG - 1) / LIST_WG;
+		c->dListCounts = alloc(wgs * 4 + 16);
+		if (!c->dListCounts) return false;
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1; c->tablesYb0 = yb0; c->tablesYb1 = yb1;
 	return true;
@@ -285,7 +291,6 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	c->be.stage_mark(5);
 	c->be.run_transition(p, levels);
 	c->be.stage_mark(6);
-	c->be.stage_mark(7);
 }
 
 void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
@@ -333,52 +338,20 @@ bool grow_pools_keeping(vx_ctx* c, u32 needVerts, u32 needIdx)
 	return true;
 }
 
-// Block lists of a full run: every surface-bearing block with at least one regular vertex, in coordinate order; ids
-// number ALL blocks of all levels in level-major order (TransVoxelImpl.cpp:395-401).  Part of the result download
-// (not of the device run): done on first access.
+// Host copy of the block lists of a full run (every block with at least one regular vertex, in coordinate order; ids
+// number ALL blocks of all levels in level-major order, TransVoxelImpl.cpp:395-401).  The lists themselves are part of
+// the device run; this is only their download, done on first access.
 int ensure_lists(vx_ctx* c)
 {
 	if (c->listsReady) return VX_OK;
-	const u32 levels = c->levelsRun;
-	size_t recTotal = 0;
-	for (u32 L = 0; L < levels; ++L) recTotal += c->hdr[L];
-	if (recTotal > c->hRecCap) {
-		c->be.free_pinned(c->hRecs);
-		c->hRecCap = recTotal + recTotal / 4 + 256;
-		c->hRecs = (BlockRecord*)c->be.alloc_pinned(c->hRecCap * sizeof(BlockRecord));
-		if (!c->hRecs) { c->hRecCap = 0; return fail(c, VX_ERR_DEVICE, "block lists: pinned allocation failed"); }
-	}
-	{
-		size_t off = 0;
-		bool ok = true;
-		for (u32 L = 0; L < levels; ++L) {
-			if (c->hdr[L]) ok = ok && c->be.d2h_async(c->hRecs + off, c->lv[L].records, (size_t)c->hdr[L] * sizeof(BlockRecord));
-			off += c->hdr[L];
-		}
-		if (!ok || !c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "block lists: record download failed: " + c->be.error());
-	}
-	size_t recOff = 0;
-	u32 idBase = 0;
-	std::vector<std::pair<u32, u32> > order;
-	for (u32 L = 0; L < levels; ++L) {
-		const LevelDesc& d = c->lv[L];
-		const u32 nAct = c->hdr[L];
-		const BlockRecord* recs = c->hRecs + recOff;
-		recOff += nAct;
-		order.clear();
-		for (u32 k = 0; k < nAct; ++k) if (recs[k].vCount) order.push_back(std::make_pair(recs[k].coordId, k));
-		std::sort(order.begin(), order.end());
+	// the tables were written by the run itself (k_list_count / k_list_write): one copy per level, nothing to sort
+	for (u32 L = 0; L < c->levelsRun; ++L) {
+		const u32 count = c->hdr[HDR_LISTS + L];
 		std::vector<EmittedBlock>& out = c->blocks[L];
-		out.clear();
-		out.resize(order.size());
-		for (size_t k = 0; k < order.size(); ++k) {
-			EmittedBlock& e = out[k];
-			e.rec = recs[order[k].second];
-			e.id = idBase + e.rec.coordId;
-			block_corners(d, e.rec.coordId, e.minc, e.maxc);
-		}
-		idBase += d.cnt * d.cnt * d.cnt;
+		out.resize(count);
+		if (count && !c->be.d2h_async(out.data(), c->lv[L].listed, (size_t)count * sizeof(EmittedBlock))) return fail(c, VX_ERR_DEVICE, "block lists: download failed: " + c->be.error());
 	}
+	if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "block lists: download failed: " + c->be.error());
 	c->listsReady = true;
 	return VX_OK;
 }
@@ -761,6 +734,24 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		c->be.stage_mark(0);
 		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS); // header = 0, slot maps = -1
 		run_pipeline(c, p, levels);
+		{
+			ListPlan plan;
+			memset(&plan, 0, sizeof(plan));
+			u32 wg = 0, idBase = 0;
+			for (u32 L = 0; L <= MAX_LEVELS; ++L) {
+				plan.wgStart[L] = wg;
+				if (L < levels) {
+					const u32 ids = c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt;
+					plan.idBase[L] = idBase;
+					idBase += ids;
+					wg += (ids + LIST_WG - 1) / LIST_WG;
+				}
+			}
+			plan.counts = (u32*)c->dListCounts;
+			plan.totals = (u32*)c->dHeader + HDR_LISTS;
+			c->be.run_block_lists(p, plan, levels);
+			c->be.stage_mark(7);
+		}
 		c->be.end_timing_record();
 		// the header travels right behind the kernels: one host wait per run
 		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned(HDR_WORDS * 4);
@@ -784,7 +775,8 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->hostVerts = 0; c->hostIdx = 0; // the pools were rewritten
 	c->haveSurface = true;
-	c->listsReady = false; // block lists (record read-back + ordering) are materialised on first access
+	c->listsReady = false; // the host copy of the block lists is fetched on first access
+	c->deviceLists = true;
 	u32 idBase = 0;
 	u32 blocksCalculated = 0, trivial = 0;
 	for (u32 L = 0; L < levels; ++L) {
@@ -886,6 +878,7 @@ int vx_compact_pools(vx_ctx* c)
 	if (!ok) { c->be.free(newV); c->be.free(newI); return fail(c, VX_ERR_DEVICE, "vx_compact_pools: device copy failed: " + c->be.error()); }
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
 	c->dVerts = newV; c->dIdx = newI; c->vertCap = capV; c->idxCap = capI;
+	c->deviceLists = false;
 	c->poolVerts = nv; c->poolIdx = ni;
 	c->hostVerts = 0; c->hostIdx = 0; // the host mirror describes the old layout
 	for (u32 L = 0; L < c->levelsRun; ++L) c->blocks[L].swap(moved[L]);
@@ -990,6 +983,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 		if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
+	c->deviceLists = false;
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	std::vector<BlockRecord> recs(total);
@@ -1101,6 +1095,25 @@ int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
 	return VX_OK;
 }
 
+int vx_device_block_table(vx_ctx* c, uint32_t level, const vx_listed_block** dTable, uint32_t* nBlocks)
+{
+	static_assert(sizeof(vx_listed_block) == sizeof(ListedBlock), "vx_listed_block layout");
+	if (!c || !c->haveSurface || level >= c->levelsRun || !dTable || !nBlocks) return fail(c, VX_ERR_INVALID, "vx_device_block_table: no such level");
+	if (!c->deviceLists) {
+		// incremental runs and pool compaction edit the lists on the host: bring the device tables up to date
+		if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
+		for (u32 L = 0; L < c->levelsRun; ++L) {
+			const std::vector<EmittedBlock>& b = c->blocks[L];
+			if (b.size() > c->lv[L].cap) return fail(c, VX_ERR_DEVICE, "vx_device_block_table: list larger than the level's table");
+			if (!b.empty() && !c->be.h2d(c->lv[L].listed, b.data(), b.size() * sizeof(EmittedBlock))) return fail(c, VX_ERR_DEVICE, "vx_device_block_table: upload failed: " + c->be.error());
+		}
+		c->deviceLists = true;
+	}
+	*dTable = (const vx_listed_block*)c->lv[level].listed;
+	*nBlocks = c->listsReady ? (u32)c->blocks[level].size() : c->hdr[HDR_LISTS + level];
+	return VX_OK;
+}
+
 int vx_set_stage_timing(vx_ctx* c, int enable)
 {
 	if (!c) return VX_ERR_INVALID;
@@ -1108,7 +1121,7 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 	return VX_OK;
 }
 
-int vx_stage_times(vx_ctx* c, float ms[7])
+int vx_stage_times(vx_ctx* c, float ms[7]) /* reset, classify, hierarchy, material, regular, transition, block lists */
 {
 	if (!c || !ms) return VX_ERR_INVALID;
 	return c->be.stage_ms(ms) ? VX_OK : fail(c, VX_ERR_INVALID, "vx_stage_times: stage timing was not enabled for the last run");
