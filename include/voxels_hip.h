@@ -57,6 +57,9 @@ typedef struct vx_exec_info {
 	uint64_t total_indices;
 	uint32_t active_blocks[8];  /* surface-bearing blocks per level */
 	uint64_t algorithmic_bytes; /* n^3 + 2*4096*surface blocks + 48*V + 4*I */
+	uint32_t blocks_read;       /* level-0 blocks whose distance samples the run had to read (the others are proven
+	                               surface-free by the BF_Empty flags of their 27-neighbourhood); 0 for incremental runs */
+	uint32_t reserved;
 } vx_exec_info;
 
 /* ---- context ------------------------------------------------------------------------------------------- */
@@ -176,9 +179,10 @@ int vx_device_block_table(vx_ctx* ctx, uint32_t level, const vx_listed_block** d
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
 
 /* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
- * ms[0..6] = reset, classify, hierarchy, material (all levels), regular, transition, block lists of the LAST run. */
+ * ms[0..7] = reset, classify, hierarchy, material (all levels), regular cells of level 0, of the levels >= 1,
+ * transition cells, block lists of the LAST run. */
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
-int vx_stage_times(vx_ctx* ctx, float ms[7]);
+int vx_stage_times(vx_ctx* ctx, float ms[8]);
 
 /* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */
 const char* vx_backend(void);

@@ -132,10 +132,7 @@ class Grid:
         return buf
 
 
-def default_lut():
-    """MaterialMap used by the fixtures: material m -> Ids0 = (6m, 6m+1, 6m+2), Ids1 = (6m+3..6m+5) mod 256."""
-    lut = (np.arange(256 * 6, dtype=np.uint32) % 251).astype(np.uint8).reshape(256, 6)
-    return lut
+from voxels_amd.synth import default_lut  # noqa: E402,F401  (the MaterialMap of the fixtures lives with the synthetic inputs)
 
 
 class Oracle:

@@ -22,12 +22,12 @@ def main():
     p.set_stage_timing(True)
     for _ in range(3):
         p.execute(levels)
-    acc = np.zeros(7)
+    acc = np.zeros(8)
     for _ in range(reps):
         p.execute(levels)
         acc += p.stage_times()
     acc /= reps
-    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular %.4f transition %.4f lists %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
+    print("n=%d levels=%d  reset %.4f classify %.4f hierarchy %.4f material %.4f regular0 %.4f regularN %.4f transition %.4f lists %.4f  sum %.4f ms" % ((n, levels) + tuple(acc) + (acc.sum(),)))
 
 
 if __name__ == "__main__":

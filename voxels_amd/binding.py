@@ -24,7 +24,8 @@ class VoxelsHipError(RuntimeError):
 class ExecInfo(C.Structure):
     _fields_ = [("levels", C.c_uint32), ("retries", C.c_uint32), ("device_ms", C.c_float),
                 ("total_verts", C.c_uint64), ("total_indices", C.c_uint64),
-                ("active_blocks", C.c_uint32 * 8), ("algorithmic_bytes", C.c_uint64)]
+                ("active_blocks", C.c_uint32 * 8), ("algorithmic_bytes", C.c_uint64),
+                ("blocks_read", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def hip_library_path():
@@ -274,8 +275,8 @@ class Polygonizer:
 
 
     def stage_times(self):
-        """ms of (reset, classify, hierarchy, material, regular, transition, block lists) of the last run."""
-        out = np.zeros(7, np.float32)
+        """ms of (reset, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists) of the last run."""
+        out = np.zeros(8, np.float32)
         self._check(self._lib.vx_stage_times(self._h, _ptr(out)), "vx_stage_times")
         return out
 

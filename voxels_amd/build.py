@@ -73,6 +73,16 @@ def build_dropin_tests(force=False):
     return out, ref_out
 
 
+def build_dropin_bench(force=False):
+    """tools/dropin_bench.cpp: end-to-end Polygonizer::Execute through libVoxels.so (used by bench.py's e2e figure)."""
+    src = os.path.join(ROOT, "tools", "dropin_bench.cpp")
+    out = os.path.join(ROOT, "tools", "dropin_bench")
+    if force or _newer(out, [src, os.path.join(CSRC, "libVoxels.so")]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-o", out, src, "-I" + os.path.join(ROOT, "include"),
+                               "-L" + CSRC, "-lVoxels", "-Wl,-rpath," + CSRC])
+    return out
+
+
 def build_emu(force=False):
     """CPU emulation of the device phases — tests only (tests/emu)."""
     d = os.path.join(ROOT, "tests", "emu")

@@ -512,6 +512,9 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 		if (((all ^ any) & 2u) == 0) c |= BC_QUIET | ((all & 2u) ? BC_NEGATIVE : 0u);
 	}
 	p.G.blockClass[id] = (u8)c;
+	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py)
+	const unsigned long long readers = __ballot(!(c & BC_QUIET));
+	if ((threadIdx.x & 63u) == (u32)__ffsll((long long)__ballot(1)) - 1u && readers) atomicAdd(&p.G.largeBlocks[1], (u32)__popcll(readers));
 }
 
 // ---- lattice copies of the distance field for the coarser levels (PyramidLevel, tv_block.h) -----------------------------
@@ -1424,7 +1427,7 @@ struct Backend {
 	hipStream_t sideA = nullptr, sideB = nullptr;      // level-0 regular pass / transition pass run beside the material chain
 	hipEvent_t evClassified = nullptr, evMaterial = nullptr, evSideA = nullptr, evSideB = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	hipEvent_t stageEv[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t stageEv[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; // [8]: between the level-0 and the level >= 1 regular pass
 	bool stageOn = false, stageValid = false;
 	std::string lastError;
 	int cus = 256;
@@ -1489,7 +1492,7 @@ struct Backend {
 	{
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
-		for (int i = 0; i < 8; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
+		for (int i = 0; i < 9; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
 		if (sideA) (void)hipStreamDestroy(sideA);
 		if (sideB) (void)hipStreamDestroy(sideB);
 		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB }) if (e) (void)hipEventDestroy(e);
@@ -1530,7 +1533,7 @@ struct Backend {
 	{
 		stageOn = on;
 		stageValid = false;
-		if (on) for (int i = 0; i < 8; ++i) if (!stageEv[i] && !check(hipEventCreate(&stageEv[i]), "hipEventCreate(stage)")) { stageOn = false; return; }
+		if (on) for (int i = 0; i < 9; ++i) if (!stageEv[i] && !check(hipEventCreate(&stageEv[i]), "hipEventCreate(stage)")) { stageOn = false; return; }
 	}
 	void stage_mark(int i)
 	{
@@ -1542,7 +1545,9 @@ struct Backend {
 	{
 		if (!stageOn || !stageValid) return false;
 		if (hipEventSynchronize(stageEv[7]) != hipSuccess) return false;
-		for (int i = 0; i < 7; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[i], stageEv[i + 1]); }
+		// reset, classify, hierarchy, material | regular level 0, regular levels >= 1 | transition, block lists
+		static const int from[8] = { 0, 1, 2, 3, 4, 8, 5, 6 }, to[8] = { 1, 2, 3, 4, 8, 5, 6, 7 };
+		for (int i = 0; i < 8; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[from[i]], stageEv[to[i]]); }
 		return true;
 	}
 	void begin_timing() { (void)hipEventRecord(ev0, stream); }
@@ -1714,6 +1719,7 @@ struct Backend {
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, false>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
 			}
 			levelBegin = 1;
+			if (stageOn && on == stream) (void)hipEventRecord(stageEv[8], on);
 		}
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;

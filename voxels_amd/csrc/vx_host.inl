@@ -822,6 +822,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		info->total_indices = c->poolIdx;
 		for (u32 L = 0; L < levels && L < 8; ++L) info->active_blocks[L] = c->hdr[L];
 		info->algorithmic_bytes = (uint64_t)c->n * slabRows * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
+		info->blocks_read = c->hdr[HDR_LARGE + 1];
 	}
 	return VX_OK;
 }
@@ -1121,7 +1122,7 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 	return VX_OK;
 }
 
-int vx_stage_times(vx_ctx* c, float ms[7]) /* reset, classify, hierarchy, material, regular, transition, block lists */
+int vx_stage_times(vx_ctx* c, float ms[8]) /* reset, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists */
 {
 	if (!c || !ms) return VX_ERR_INVALID;
 	return c->be.stage_ms(ms) ? VX_OK : fail(c, VX_ERR_INVALID, "vx_stage_times: stage timing was not enabled for the last run");

@@ -44,3 +44,9 @@ def block_empty_flags(dist):
     fl = np.zeros((n // 16) ** 2 * (planes // 16), np.uint8)
     _load().vxs_block_empty_flags(n, planes, dist.ctypes.data, fl.ctypes.data)
     return fl
+
+
+def default_lut():
+    """MaterialMap of the synthetic workloads and fixtures: material m -> Ids0 = (6m, 6m+1, 6m+2), Ids1 = (6m+3..6m+5)
+    (mod 251), the six texture ids of Voxels::MaterialMap::Material (include/MaterialMap.h)."""
+    return (np.arange(256 * 6, dtype=np.uint32) % 251).astype(np.uint8).reshape(256, 6)
