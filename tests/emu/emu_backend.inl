@@ -8,7 +8,8 @@ struct Backend {
 	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
 
 	bool init(int, std::string&) { return true; }
-	bool wants_pyramid() const { return false; } // the emulated phases sample the grid directly
+	bool wants_pyramid() const { return false; }
+	void make_current() {} // the emulated phases sample the grid directly
 	void shutdown() {}
 	void set_stream(void*) {}
 	std::string error() const { return lastError; }

@@ -37,3 +37,14 @@ def test_same_application_same_bytes(tmp_path, n):
     if da != db:
         first = next(i for i in range(len(da)) if da[i] != db[i])
         raise AssertionError("dumps differ at byte %d of %d" % (first, len(da)))
+
+
+@pytest.mark.gpu
+def test_device_mirror_tracks_grids_and_edits():
+    """a Polygonizer reused on a new grid at a recycled address must upload it; two Polygonizers on one grid
+    must both see an edit (tests/cpp/mirror_test.cpp)."""
+    from voxels_amd import build
+    build.build_cpp_api()
+    build.build_dropin_tests()
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "mirror_ours")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr

@@ -449,3 +449,23 @@ def check_heightmap(p, port, n, seed, nrm_tol=0.0):
 
 def test_emu_create_heightmap(emu, port):
     check_heightmap(make_poly(emu), port, 64, 3)
+
+
+def test_emu_rejects_misaligned_slabs_and_oversized_grids(emu):
+    """a slab whose ORIGIN is not a multiple of the coarsest block would make the coarser levels read planes
+    outside slab + halo; grids beyond 2048 would overrun the level tables."""
+    from voxels_amd.binding import VoxelsHipError
+    n = 64
+    d = np.zeros((n, n, n), np.int8)
+    m = np.zeros((n, n, n), np.uint8)
+    flags = np.zeros((n // 16) ** 3, np.uint8)
+    p = make_poly(emu)
+    p.attach(n, 16, 48, d.ctypes.data, 0, m.ctypes.data, m.ctypes.data, 0, flags.ctypes.data)  # 32 thick, origin 16
+    with pytest.raises(VoxelsHipError):
+        p.execute(2)                                                                          # coarsest block = 32
+    p.execute(1)                                                                              # level 0 alone is fine
+    q = make_poly(emu)
+    q.attach(n, 32, 64, d.ctypes.data, 0, m.ctypes.data, m.ctypes.data, 0, flags.ctypes.data)
+    q.execute(2)
+    with pytest.raises(VoxelsHipError):
+        make_poly(emu).attach(4096, 0, 4096, d.ctypes.data, 0, m.ctypes.data, m.ctypes.data, 0, flags.ctypes.data)

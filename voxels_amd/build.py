@@ -64,6 +64,11 @@ def build_dropin_tests(force=False):
     if force or _newer(out, [src, os.path.join(CSRC, "libVoxels.so")]):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-o", out, src, "-I" + os.path.join(ROOT, "include"),
                                "-L" + CSRC, "-lVoxels", "-Wl,-rpath," + CSRC])
+    msrc = os.path.join(ROOT, "tests", "cpp", "mirror_test.cpp")
+    mout = os.path.join(ROOT, "tests", "cpp", "mirror_ours")
+    if force or _newer(mout, [msrc, os.path.join(CSRC, "libVoxels.so")]):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-o", mout, msrc, "-I" + os.path.join(ROOT, "include"),
+                               "-L" + CSRC, "-lVoxels", "-Wl,-rpath," + CSRC])
     ref_out = os.path.join(ROOT, "oracle", "_ref", "dropin_ref")
     ref_lib = os.path.join(ROOT, "oracle", "_ref", "libvoxels_ref.so")
     if os.path.isdir("/root/reference/include") and os.path.exists(ref_lib) and (force or _newer(ref_out, [src, ref_lib])):

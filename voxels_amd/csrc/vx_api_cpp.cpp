@@ -282,7 +282,7 @@ class TransVoxelImpl
 {
 public:
 	vx_ctx* Ctx = nullptr;
-	const VoxelGrid* ResidentGrid = nullptr;
+	uint64_t ResidentGridUid = 0; // VoxelGrid::Uid of the grid mirrored in HBM (0 = none; never compare addresses: they get reused)
 	uint64_t ResidentGeneration = 0;
 
 	~TransVoxelImpl() { if (Ctx) vx_ctx_destroy(Ctx); }
@@ -303,7 +303,7 @@ public:
 	{
 		std::vector<uint8_t> flags;
 		g.EmptyFlags(flags);
-		if (ResidentGrid != &g) {
+		if (ResidentGridUid != g.Uid()) {
 			// a grid that came from Grid::Load and was not edited since travels as its (much smaller) file and is
 			// expanded on the device; anything else as dense fields
 			const std::vector<char>* file = g.PristineFile();
@@ -311,11 +311,10 @@ public:
 			                    : vx_grid_upload(Ctx, g.Size(), g.Distances(), g.Materials(), g.Blends(), flags.data());
 			if (rc != VX_OK) return false;
 			g.DropFile();
-			ResidentGrid = &g;
+			ResidentGridUid = g.Uid();
 		} else if (ResidentGeneration != g.Generation()) {
-			std::vector<uint32_t> ids = g.DirtyBlocks();
-			std::sort(ids.begin(), ids.end());
-			ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+			std::vector<uint32_t> ids;
+			g.DirtySince(ResidentGeneration, ids); // per-consumer: another Polygonizer mirroring the same grid is not affected
 			std::vector<int8_t> d(ids.size() * 4096);
 			std::vector<uint8_t> m(ids.size() * 4096), b(ids.size() * 4096);
 			const uint32_t nb = g.BlocksPerAxis();
@@ -323,7 +322,6 @@ public:
 				g.GetBlock(ids[i] % nb, (ids[i] / nb) % nb, ids[i] / (nb * nb), d.data() + i * 4096, m.data() + i * 4096, b.data() + i * 4096);
 			if (vx_grid_update_blocks(Ctx, (uint32_t)ids.size(), ids.data(), d.data(), m.data(), b.data(), flags.data()) != VX_OK) return false;
 		}
-		g.ClearDirty();
 		ResidentGeneration = g.Generation();
 		return true;
 	}
@@ -378,7 +376,10 @@ public:
 		}
 		const float mn[3] = { modification->MinCornerModified.x, modification->MinCornerModified.y, modification->MinCornerModified.z };
 		const float mx[3] = { modification->MaxCornerModified.x, modification->MaxCornerModified.y, modification->MaxCornerModified.z };
-		std::vector<uint32_t> ids(1u << 16);
+		// room for every block of every level: the run cannot report more, so it never has to be repeated for space
+		size_t allBlocks = 0;
+		for (uint32_t cnt = g->Size() / 16; cnt; cnt >>= 1) allBlocks += (size_t)cnt * cnt * cnt;
+		std::vector<uint32_t> ids(allBlocks + 1);
 		uint32_t count = 0;
 		int rc = vx_polygonize_dirty(Ctx, mn, mx, &info, ids.data(), (uint32_t)ids.size(), &count);
 		if (rc == VX_OK && count > ids.size()) {

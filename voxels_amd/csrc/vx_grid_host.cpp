@@ -4,6 +4,7 @@
 #include "vx_grid_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -73,13 +74,16 @@ inline float Clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi 
 
 } // namespace
 
-VoxelGrid::VoxelGrid(uint32_t n) : m_N(n), m_Nb(n / BLOCK), m_Generation(1)
+namespace { std::atomic<uint64_t> g_NextGridUid(1); }
+
+VoxelGrid::VoxelGrid(uint32_t n) : m_N(n), m_Nb(n / BLOCK), m_Uid(g_NextGridUid.fetch_add(1)), m_Generation(1)
 {
 	const size_t tot = size_t(n) * n * n;
 	m_Dist.assign(tot, 0);
 	m_Mat.assign(tot, 0);
 	m_Blend.assign(tot, 0);
 	m_Meta.assign(size_t(m_Nb) * m_Nb * m_Nb, BlockMeta{ 0, 0, 0, 0 });
+	m_BlockGeneration.assign(size_t(m_Nb) * m_Nb * m_Nb, 0);
 }
 
 void VoxelGrid::Gather(const uint8_t* src, uint32_t bx, uint32_t by, uint32_t bz, uint8_t* out) const
@@ -98,8 +102,13 @@ void VoxelGrid::Scatter(uint8_t* dst, uint32_t bx, uint32_t by, uint32_t bz, con
 
 void VoxelGrid::Touch(uint32_t blockId)
 {
-	++m_Generation;
-	m_Dirty.push_back(blockId);
+	m_BlockGeneration[blockId] = ++m_Generation;
+}
+
+void VoxelGrid::DirtySince(uint64_t generation, std::vector<uint32_t>& out) const
+{
+	out.clear();
+	for (size_t id = 0; id < m_BlockGeneration.size(); ++id) if (m_BlockGeneration[id] > generation) out.push_back((uint32_t)id);
 }
 
 // what PushBlock / Modify*Data derive from the codec (:52-77, :696-741)

@@ -46,10 +46,12 @@ public:
 	void InjectSurface(const float pos[3], const float ext[3], VoxelSurface* surface, int type, float outMin[3], float outMax[3]);
 	void InjectMaterial(const float pos[3], const float ext[3], uint8_t material, bool add, float outMin[3], float outMax[3]);
 
-	// change tracking for the device mirror
+	// Change tracking for device mirrors.  Every grid has a process-unique id (a new grid may reuse the address of a
+	// destroyed one) and a generation that grows with every edited block; every block remembers the generation of its
+	// last edit, so any number of mirrors can ask "what changed since the generation I hold" without sharing state.
+	uint64_t Uid() const { return m_Uid; }
 	uint64_t Generation() const { return m_Generation; }
-	const std::vector<uint32_t>& DirtyBlocks() const { return m_Dirty; }
-	void ClearDirty() { m_Dirty.clear(); }
+	void DirtySince(uint64_t generation, std::vector<uint32_t>& out) const;
 	// the file a grid was loaded from, kept until the first upload so that the device can expand it itself
 	// (valid only while nothing was edited since the load)
 	const std::vector<char>* PristineFile() const { return (m_FileGeneration == m_Generation && !m_File.empty()) ? &m_File : nullptr; }
@@ -67,8 +69,9 @@ private:
 	std::vector<int8_t> m_Dist;
 	std::vector<uint8_t> m_Mat, m_Blend;
 	std::vector<BlockMeta> m_Meta;
+	uint64_t m_Uid;
 	uint64_t m_Generation;
-	std::vector<uint32_t> m_Dirty;
+	std::vector<uint64_t> m_BlockGeneration; // per block: generation of its last edit (0 = as created)
 	std::vector<char> m_File;
 	uint64_t m_FileGeneration = 0;
 };

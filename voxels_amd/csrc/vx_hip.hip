@@ -1499,6 +1499,7 @@ struct Backend {
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
 	bool wants_pyramid() const { return true; }
+	void make_current() { (void)hipSetDevice(device); }
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
 	std::string error() const { return lastError; }
 	void* alloc(size_t bytes)

@@ -37,6 +37,8 @@ struct ExecParams {
 // append to them
 typedef ListedBlock EmittedBlock;
 
+// largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
+enum { VX_MAX_GRID = 2048 };
 enum { HDR_WORDS = 192, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
 
 } // namespace
@@ -88,6 +90,9 @@ struct vx_ctx {
 	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
 	bool hostTiming = false;    // VX_HOST_TIMING (read once at context creation): print where a vx_polygonize call spends host time
 };
+
+// every entry point makes the context's device the calling thread's current device (the HIP current device is per thread)
+#define VX_ENTER(c) do { if (c) (c)->be.make_current(); } while (0)
 
 namespace {
 
@@ -391,6 +396,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 
 void vx_ctx_destroy(vx_ctx* c)
 {
+	VX_ENTER(c);
 	if (!c) return;
 	c->be.sync();
 	release_grid(c);
@@ -409,6 +415,7 @@ const char* vx_last_error(const vx_ctx* c) { return c ? c->err.c_str() : "null c
 
 int vx_set_stream(vx_ctx* c, void* stream)
 {
+	VX_ENTER(c);
 	if (!c) return VX_ERR_INVALID;
 	c->be.set_stream(stream);
 	return VX_OK;
@@ -416,7 +423,8 @@ int vx_set_stream(vx_ctx* c, void* stream)
 
 int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat, const uint8_t* blend, const uint8_t* flags)
 {
-	if (!c || !dist || !flags || n < 16 || (n & 15)) return fail(c, VX_ERR_INVALID, "vx_grid_upload: n must be a multiple of 16, dist and empty_flags non-null");
+	VX_ENTER(c);
+	if (!c || !dist || !flags || n < 16 || (n & 15) || n > VX_MAX_GRID) return fail(c, VX_ERR_INVALID, "vx_grid_upload: n must be a multiple of 16 up to 2048, dist and empty_flags non-null");
 	const size_t tot = (size_t)n * n * n, nb = (size_t)(n / 16) * (n / 16) * (n / 16);
 	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n)) {
 		release_grid(c);
@@ -435,7 +443,8 @@ int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat
 
 int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 {
-	if (!c || !heightmap || n < 16 || (n & 15)) return fail(c, VX_ERR_INVALID, "vx_grid_create_heightmap: w must be a multiple of 16, heightmap non-null");
+	VX_ENTER(c);
+	if (!c || !heightmap || n < 16 || (n & 15) || n > VX_MAX_GRID) return fail(c, VX_ERR_INVALID, "vx_grid_create_heightmap: w must be a multiple of 16 up to 2048, heightmap non-null");
 	const u32 nb = n / 16;
 	const size_t blocks = (size_t)nb * nb * nb, tot = (size_t)n * n * n;
 	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n && c->yBegin == 0 && c->yEnd == n)) {
@@ -462,12 +471,13 @@ int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 
 int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 {
+	VX_ENTER(c);
 	if (!c || !blobPtr || size < 16) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: null or truncated blob");
 	const u8* blob = (const u8*)blobPtr;
 	auto rd32 = [&](uint64_t off) { u32 v; memcpy(&v, blob + off, 4); return v; };
 	if (rd32(0) != 1) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: not a version-1 grid file");
 	const u32 n = rd32(4);
-	if (n < 16 || (n & 15) || rd32(8) != n || rd32(12) != n) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: the grid must be a cube with an edge that is a multiple of 16");
+	if (n < 16 || (n & 15) || n > VX_MAX_GRID || rd32(8) != n || rd32(12) != n) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: the grid must be a cube with an edge that is a multiple of 16 up to 2048");
 	const u32 nb = n / 16;
 	const size_t blocks = (size_t)nb * nb * nb, tot = (size_t)n * n * n;
 	const uint64_t tableEnd = 16 + (uint64_t)blocks * 12;
@@ -505,6 +515,7 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 
 int vx_grid_pack(vx_ctx* c, void* out, uint64_t capacity, uint64_t* size)
 {
+	VX_ENTER(c);
 	if (!c || !size) return fail(c, VX_ERR_INVALID, "vx_grid_pack: null argument");
 	if (!c->n || !c->dDist || (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n)) return fail(c, VX_ERR_INVALID, "vx_grid_pack: needs a whole grid resident");
 	const u32 n = c->n, nb = n / 16;
@@ -547,6 +558,7 @@ int vx_grid_pack(vx_ctx* c, void* out, uint64_t capacity, uint64_t* size)
 
 int vx_grid_read_block(vx_ctx* c, uint32_t id, int8_t* dist, uint8_t* mat, uint8_t* blend, uint8_t* emptyFlag)
 {
+	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: no grid resident");
 	const u32 n = c->n, nb = n / 16;
 	if (id >= nb * nb * nb) return fail(c, VX_ERR_INVALID, "vx_grid_read_block: block id out of range");
@@ -570,7 +582,8 @@ int vx_grid_read_block(vx_ctx* c, uint32_t id, int8_t* dist, uint8_t* mat, uint8
 int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, const void* d_dist, int32_t dist_z0,
                    const void* d_mat, const void* d_blend, int32_t mat_z0, const void* d_flags)
 {
-	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || z_begin >= z_end || z_end > n || (z_begin & 15) || (z_end & 15))
+	VX_ENTER(c);
+	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || n > VX_MAX_GRID || z_begin >= z_end || z_end > n || (z_begin & 15) || (z_end & 15))
 		return fail(c, VX_ERR_INVALID, "vx_grid_attach: bad arguments (slab bounds must be multiples of 16)");
 	release_grid(c);
 	c->n = n; c->zBegin = z_begin; c->zEnd = z_end;
@@ -584,7 +597,8 @@ int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, cons
 int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
                      const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_flags)
 {
-	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || y_begin >= y_end || y_end > n || (y_begin & 15) || (y_end & 15) || !dist_rows || !mat_rows)
+	VX_ENTER(c);
+	if (!c || !d_dist || !d_mat || !d_blend || !d_flags || n < 16 || (n & 15) || n > VX_MAX_GRID || y_begin >= y_end || y_end > n || (y_begin & 15) || (y_end & 15) || !dist_rows || !mat_rows)
 		return fail(c, VX_ERR_INVALID, "vx_grid_attach_y: bad arguments (slab bounds must be multiples of 16)");
 	release_grid(c);
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
@@ -598,6 +612,7 @@ int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, co
 int vx_grid_update_blocks(vx_ctx* c, uint32_t count, const uint32_t* ids, const int8_t* dist, const uint8_t* mat,
                           const uint8_t* blend, const uint8_t* flags)
 {
+	VX_ENTER(c);
 	if (!c || !c->ownsGrid || !c->n) return fail(c, VX_ERR_INVALID, "vx_grid_update_blocks: needs a grid uploaded with vx_grid_upload");
 	const u32 n = c->n, nb = n / 16;
 	bool ok = true;
@@ -678,6 +693,7 @@ int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3]
 
 int vx_grid_inject_ball(vx_ctx* c, const float pos[3], const float ext[3], float radius, int type, float outMin[3], float outMax[3])
 {
+	VX_ENTER(c);
 	if (type < 0 || type > 2) return fail(c, VX_ERR_INVALID, "vx_grid_inject_ball: unknown injection type");
 	EditParams e;
 	memset(&e, 0, sizeof(e));
@@ -688,6 +704,7 @@ int vx_grid_inject_ball(vx_ctx* c, const float pos[3], const float ext[3], float
 
 int vx_grid_inject_material(vx_ctx* c, const float pos[3], const float ext[3], uint8_t material, int add, float outMin[3], float outMax[3])
 {
+	VX_ENTER(c);
 	EditParams e;
 	memset(&e, 0, sizeof(e));
 	if (pos && ext) for (int k = 0; k < 3; ++k) { e.pos[k] = pos[k]; e.ext[k] = ext[k]; }
@@ -697,6 +714,7 @@ int vx_grid_inject_material(vx_ctx* c, const float pos[3], const float ext[3], u
 
 int vx_material_lut(vx_ctx* c, const uint8_t* lut, const uint8_t* valid)
 {
+	VX_ENTER(c);
 	if (!c || !lut) return fail(c, VX_ERR_INVALID, "vx_material_lut: null argument");
 	std::vector<u8> img(256 * 8, 0);
 	for (int i = 0; i < 256; ++i) {
@@ -708,12 +726,18 @@ int vx_material_lut(vx_ctx* c, const uint8_t* lut, const uint8_t* valid)
 
 int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 {
+	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
 	if (!ensure_level_tables(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: level table allocation failed: " + c->be.error());
 	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
 	const u32 slabPlanes = c->zEnd - c->zBegin, slabRows = c->yEnd - c->yBegin;
-	if (levels > 1 && (((slabPlanes % (16u << (levels - 1))) && (c->zBegin != 0 || c->zEnd != c->n)) || ((slabRows % (16u << (levels - 1))) && (c->yBegin != 0 || c->yEnd != c->n))))
-		return fail(c, VX_ERR_INVALID, "vx_polygonize: slab thickness must be a multiple of the coarsest block size");
+	{
+		// a slab must hold whole blocks of the coarsest level: thickness AND origin multiples of its block size
+		const u32 coarse = 16u << (levels - 1);
+		const bool zSlab = c->zBegin != 0 || c->zEnd != c->n, ySlab = c->yBegin != 0 || c->yEnd != c->n;
+		if (levels > 1 && ((zSlab && ((slabPlanes % coarse) || (c->zBegin % coarse))) || (ySlab && ((slabRows % coarse) || (c->yBegin % coarse)))))
+			return fail(c, VX_ERR_INVALID, "vx_polygonize: slab bounds must be multiples of the coarsest block size");
+	}
 	if (!c->vertCap) {
 		// first guess: ~3 vertices and ~12 indices per surface voxel column; grown on demand (exact need is known after a run)
 		const u32 area = c->n * c->n;
@@ -845,6 +869,7 @@ void live_totals(const vx_ctx* c, uint64_t& verts, uint64_t& idx)
 
 int vx_compact_pools(vx_ctx* c)
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_compact_pools: no surface");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	uint64_t liveV, liveI;
@@ -889,6 +914,7 @@ int vx_compact_pools(vx_ctx* c)
 int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
                         uint32_t* modified_ids, uint32_t cap, uint32_t* count)
 {
+	VX_ENTER(c);
 	if (!c || !min_corner || !max_corner) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: null argument");
 	if (!c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: run vx_polygonize first");
 	if (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on slabs");
@@ -905,7 +931,11 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		}
 	}
 	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
+	// Nothing of the context's surface state (block lists, id counter) is touched before the device run has succeeded:
+	// the lists without the dropped blocks are built aside and swapped in at the end.
 	std::vector<u32> coords, ids;
+	std::vector<EmittedBlock> kept[MAX_LEVELS];
+	u32 nextId = c->nextId;
 	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
 	const float ext = (float)c->n;
 	for (u32 L = 0; L < levels; ++L) {
@@ -918,16 +948,15 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			lo[k] = std::min(std::max(lo[k], 0.f), ext);
 			hi[k] = std::min(std::max(hi[k], 0.f), ext);
 		}
-		std::vector<EmittedBlock>& old = c->blocks[L];
-		old.erase(std::remove_if(old.begin(), old.end(), [&](const EmittedBlock& e) {
-			return e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2];
-		}), old.end());
+		kept[L].reserve(c->blocks[L].size());
+		for (const EmittedBlock& e : c->blocks[L])
+			if (!(e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2])) kept[L].push_back(e);
 		start[L] = (u32)coords.size();
 		for (u32 z = (u32)(lo[1] / bm); z < (u32)(hi[1] / bm); ++z)      // internal z = output y
 		for (u32 y = (u32)(lo[2] / bm); y < (u32)(hi[2] / bm); ++y)
 		for (u32 x = (u32)(lo[0] / bm); x < (u32)(hi[0] / bm); ++x) {
 			coords.push_back(block_coord_id(x, y, z, d.cnt));
-			ids.push_back(c->nextId++);
+			ids.push_back(nextId++);
 		}
 		cnt[L] = (u32)coords.size() - start[L];
 	}
@@ -984,11 +1013,11 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 		if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
-	c->deviceLists = false;
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
-	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	std::vector<BlockRecord> recs(total);
 	if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
+	c->deviceLists = false;
 	u32 trivialBlocks = c->hdr[HDR_STATS + 2];
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
@@ -1008,10 +1037,12 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			e.rec = r;
 			e.id = ids[start[L] + k];
 			block_corners(d, coord, e.minc, e.maxc);
-			c->blocks[L].push_back(std::move(e));
+			kept[L].push_back(std::move(e));
 		}
 		if (L) trivialBlocks += cnt[L];
 	}
+	for (u32 L = 0; L < levels; ++L) c->blocks[L].swap(kept[L]);
+	c->nextId = nextId;
 	c->stats[0] = total;
 	c->stats[2] = c->hdr[HDR_STATS + 0];
 	c->stats[1] = BLOCK_CELLS * trivialBlocks - c->stats[2];
@@ -1032,6 +1063,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 
 int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t totals[4])
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_level_counts: no such level");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	uint64_t t[4] = { 0, 0, 0, 0 };
@@ -1046,6 +1078,7 @@ int vx_level_counts(vx_ctx* c, uint32_t level, uint32_t* n_blocks, uint64_t tota
 
 int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex* verts, uint32_t* idx, vx_vertex* tverts, uint32_t* tidx)
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	if ((verts || idx || tverts || tidx) && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
@@ -1075,6 +1108,7 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 
 int vx_device_meshes(vx_ctx* c, const vx_vertex** dVerts, const uint32_t** dIdx, uint64_t* nVerts, uint64_t* nIdx)
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_device_meshes: no surface");
 	if (dVerts) *dVerts = (const vx_vertex*)c->dVerts;
 	if (dIdx) *dIdx = (const uint32_t*)c->dIdx;
@@ -1085,6 +1119,7 @@ int vx_device_meshes(vx_ctx* c, const vx_vertex** dVerts, const uint32_t** dIdx,
 
 int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface || level >= c->levelsRun || !ranges) return fail(c, VX_ERR_INVALID, "vx_level_ranges: no such level");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	size_t k = 0;
@@ -1098,6 +1133,7 @@ int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
 
 int vx_device_block_table(vx_ctx* c, uint32_t level, const vx_listed_block** dTable, uint32_t* nBlocks)
 {
+	VX_ENTER(c);
 	static_assert(sizeof(vx_listed_block) == sizeof(ListedBlock), "vx_listed_block layout");
 	if (!c || !c->haveSurface || level >= c->levelsRun || !dTable || !nBlocks) return fail(c, VX_ERR_INVALID, "vx_device_block_table: no such level");
 	if (!c->deviceLists) {
@@ -1117,6 +1153,7 @@ int vx_device_block_table(vx_ctx* c, uint32_t level, const vx_listed_block** dTa
 
 int vx_set_stage_timing(vx_ctx* c, int enable)
 {
+	VX_ENTER(c);
 	if (!c) return VX_ERR_INVALID;
 	c->be.stage_enable(enable != 0);
 	return VX_OK;
@@ -1124,12 +1161,14 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 
 int vx_stage_times(vx_ctx* c, float ms[8]) /* reset, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists */
 {
+	VX_ENTER(c);
 	if (!c || !ms) return VX_ERR_INVALID;
 	return c->be.stage_ms(ms) ? VX_OK : fail(c, VX_ERR_INVALID, "vx_stage_times: stage timing was not enabled for the last run");
 }
 
 int vx_stats(vx_ctx* c, uint32_t stats[20])
 {
+	VX_ENTER(c);
 	if (!c || !c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_stats: nothing polygonized yet");
 	memcpy(stats, c->stats, 80);
 	return VX_OK;
