@@ -107,6 +107,26 @@ int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
 int vx_grid_attach_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end,
                      const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
                      const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_empty_flags);
+/* ---- multi-GPU: halo exchange of attached slabs -------------------------------------------
+ * The reference has one address space and an OpenMP block loop (src/TransVoxelImpl.cpp:500-503); here the grid is cut
+ * into slabs (vx_grid_attach / vx_grid_attach_y), one per GPU, rank r owning the r-th slab along the cut axis.  What a
+ * rank reads beyond its own layers (a layer = a z-plane, or the y-row of every plane) comes from its neighbours:
+ *   from the slab above: 2 distance layers, 1 material layer, 1 blend layer, the BF_Empty flags of its first block layer
+ *   from the slab below: 1 distance layer, the BF_Empty flags of its last block layer
+ * The attached buffers must have exactly that halo (dist_z0 = z_begin - 1 with 3 layers more than the slab, mat_z0 =
+ * z_begin with 1 more; likewise along y), as voxels_amd/slab.py lays them out.
+ *
+ * vx_halo_exchange: one process per GPU.  vx_comm_init joins an RCCL communicator (the id comes from
+ * vx_comm_unique_id on rank 0 and travels by whatever means the launcher has); the exchange is one grouped
+ * ncclSend/ncclRecv batch per call on the context's stream with pack / unpack kernels around it — no host wait.
+ * vx_halo_exchange_group: one process driving several contexts (one per GPU, or several slabs on one GPU): the same
+ * packing with peer copies as transport; contexts in slab order. */
+#define VX_COMM_ID_BYTES 128
+int vx_comm_unique_id(void* id /* VX_COMM_ID_BYTES bytes out */);
+int vx_comm_init(vx_ctx* ctx, int nranks, int rank, const void* id /* VX_COMM_ID_BYTES bytes */);
+int vx_comm_destroy(vx_ctx* ctx);
+int vx_halo_exchange(vx_ctx* ctx);
+int vx_halo_exchange_group(vx_ctx* const* ctxs, int count);
 /* Re-upload `count` edited 16^3 blocks (block ids, x-fastest 4096-byte blocks) + the full flag array. */
 int vx_grid_update_blocks(vx_ctx* ctx, uint32_t count, const uint32_t* block_ids, const int8_t* dist,
                           const uint8_t* mat, const uint8_t* blend, const uint8_t* empty_flags);

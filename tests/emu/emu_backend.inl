@@ -128,6 +128,24 @@ struct Backend {
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
+	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange
+	// through torch.distributed in voxels_amd/slab.py)
+	void run_halo_move(const HaloMove& mv)
+	{
+		for (u32 i = 0; i < mv.count; ++i) {
+			const HaloPiece& p = mv.piece[i];
+			for (int l = 0; l < p.layers; ++l) for (u32 a = 0; a < p.rows; ++a) {
+				u8* f = p.field + halo_field_offset(p, p.firstLayer + l, a);
+				u8* s = mv.staging + p.stagingOffset + ((size_t)l * p.rows + a) * p.rowBytes;
+				if (mv.unpack) memcpy(f, s, p.rowBytes); else memcpy(s, f, p.rowBytes);
+			}
+		}
+	}
+	static bool comm_unique_id(void*) { return false; }
+	bool comm_init(int, int, const void*) { lastError = "the emulation has no communicator"; return false; }
+	void comm_destroy() {}
+	bool comm_exchange(int, const void*, size_t, void*, size_t, int, const void*, size_t, void*, size_t) { lastError = "the emulation has no communicator"; return false; }
+	bool copy_from_peer(void* dst, Backend&, const void* src, size_t bytes) { memcpy(dst, src, bytes); return true; }
 	template <typename P>
 	void run_block_lists(const P& p, const ListPlan& plan, u32 levels)
 	{

@@ -109,3 +109,38 @@ def edited_blocks(pre, post):
     return ids, out
 
 
+
+
+def check_halo_exchange_group(make_poly, torch, device, n, levels, world, axis, reference_levels, seed=7, nrm_tol=0.0):
+    """`world` contexts of one process, each with ONLY its own slab filled (halo layers and the neighbours' flag layers
+    zero): vx_halo_exchange_group must bring in exactly what the path reads beyond the slab, i.e. the union of the
+    ranks' results equals the surface of the whole grid.  Shared by the CPU emulation and the GPU test."""
+    from voxels_amd import synth
+    from voxels_amd.binding import Polygonizer
+    from voxels_amd.slab import SlabBuffers, merge_rank_levels
+    d, m, b = synth.terrain(n, 0, n, seed)
+    flags = synth.block_empty_flags(d)
+    polys, slabs = [], []
+    per = flags.size // world
+    for r in range(world):
+        slab = SlabBuffers(torch, n, r, world, device, axis=axis)
+        sl = slice(slab.z0, slab.z1)
+        if axis == "z":
+            slab.fill_own(np.ascontiguousarray(d[sl]), np.ascontiguousarray(m[sl]), np.ascontiguousarray(b[sl]), flags[r * per:(r + 1) * per])
+        else:
+            own = np.zeros_like(flags).reshape(n // 16, n // 16, n // 16)  # [bz][by][bx]: only this rank's block rows
+            own[:, slab.z0 // 16:slab.z1 // 16] = flags.reshape(own.shape)[:, slab.z0 // 16:slab.z1 // 16]
+            slab.fill_own(np.ascontiguousarray(d[:, sl]), np.ascontiguousarray(m[:, sl]), np.ascontiguousarray(b[:, sl]), own.reshape(-1))
+        p = make_poly()
+        slab.attach(p)
+        polys.append(p)
+        slabs.append(slab)
+    if hasattr(torch, "cuda") and device.type == "cuda":
+        torch.cuda.synchronize()
+    Polygonizer.halo_exchange_group(polys)
+    parts = []
+    for p in polys:
+        p.execute(levels)
+        parts.append(p.all_levels())
+    ok, msg = surface_equal(merge_rank_levels(parts), reference_levels[:levels], nrm_tol=nrm_tol)
+    assert ok, msg

@@ -469,3 +469,23 @@ def test_emu_rejects_misaligned_slabs_and_oversized_grids(emu):
     q.execute(2)
     with pytest.raises(VoxelsHipError):
         make_poly(emu).attach(4096, 0, 4096, d.ctypes.data, 0, m.ctypes.data, m.ctypes.data, 0, flags.ctypes.data)
+
+
+@pytest.mark.parametrize("world,axis", [(2, "z"), (2, "y"), (4, "y")])
+def test_emu_halo_exchange_group(emu, world, axis):
+    """vx_halo_exchange_group (the C-ABI halo exchange with in-process transport): region logic + piece descriptors on the CPU."""
+    import torch
+    from voxels_amd import synth
+    n, levels = 128, 3 if world == 2 else 2
+    d, m, b = synth.terrain(n, 0, n, 7)
+    whole = make_poly(emu)
+    whole.upload(d, m, b, synth.block_empty_flags(d))
+    whole.execute(levels)
+
+    def mk():
+        p = make_poly(emu)
+        p.set_materials(vxo.default_lut())
+        return p
+    whole.set_materials(vxo.default_lut())
+    whole.execute(levels)
+    fields.check_halo_exchange_group(mk, torch, torch.device("cpu"), n, levels, world, axis, whole.all_levels())

@@ -353,6 +353,50 @@ def test_hip_slab_attach_matches_full_run(poly, port, world, axis):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,axis", [(2, "z"), (4, "z"), (2, "y"), (4, "y")])
+def test_hip_halo_exchange_group(port, world, axis):
+    """Row b8 on one GPU: `world` contexts hold one slab each with NOTHING but their own layers; vx_halo_exchange_group
+    (k_halo_move pack -> peer copy -> unpack, the flags' boundary layers included) must make the union of their runs the
+    reference's surface.  The RCCL variant (vx_halo_exchange) shares everything but the transport."""
+    import torch
+    from voxels_amd import Polygonizer, synth
+    n, levels, seed = 256, 3, 7
+    d, m, b = synth.terrain(n, 0, n, seed)
+    ref = port.execute(port.grid_from_dense(d, m, b))
+
+    def mk():
+        p = Polygonizer(device=0)
+        p.set_materials(vxo.default_lut())
+        return p
+    fields.check_halo_exchange_group(mk, torch, torch.device("cuda", 0), n, levels, world, axis, ref.all_levels(), seed=seed, nrm_tol=NRM_TOL)
+
+
+@pytest.mark.gpu
+def test_hip_rccl_communicator_single_rank(port):
+    """vx_comm_unique_id / vx_comm_init / vx_halo_exchange with one rank: the RCCL library is found, the communicator
+    comes up on this GPU, and an exchange without neighbours is an empty group that leaves the slab intact."""
+    import torch
+    from voxels_amd import Polygonizer, synth
+    from voxels_amd.slab import SlabBuffers
+    n, levels = 64, 2
+    d, m, b = synth.terrain(n, 0, n, 3)
+    flags = synth.block_empty_flags(d)
+    dev = torch.device("cuda", 0)
+    slab = SlabBuffers(torch, n, 0, 1, dev, axis="y")
+    slab.fill_own(d, m, b, flags)
+    torch.cuda.synchronize()
+    p = Polygonizer(device=0)
+    p.set_materials(vxo.default_lut())
+    slab.attach(p)
+    p.comm_init(1, 0, p.comm_unique_id())
+    p.halo_exchange()
+    p.execute(levels)
+    ref = port.execute(port.grid_from_dense(d, m, b))
+    ok, msg = fields.surface_equal(p.all_levels(), ref.all_levels()[:levels], nrm_tol=NRM_TOL)
+    assert ok, msg
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,noisy", [(128, False), (64, True)])
 def test_hip_upload_packed_grid(poly, port, n, noisy):
     """§8(f) row 1: the reference's grid file (PackForSave) expanded on the device — blocks byte for byte, flags, and

@@ -64,6 +64,11 @@ class HipLibrary:
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
         lib.vx_device_block_table.argtypes = [vp, u32, vp, vp]
+        lib.vx_comm_unique_id.argtypes = [vp]
+        lib.vx_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.vx_comm_destroy.argtypes = [vp]
+        lib.vx_halo_exchange.argtypes = [vp]
+        lib.vx_halo_exchange_group.argtypes = [vp, C.c_int]
         lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -190,6 +195,32 @@ class Polygonizer:
         nv, ni = C.c_uint64(), C.c_uint64()
         self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
         return dv.value, di.value, nv.value, ni.value
+
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 creates it, every rank passes it to comm_init)."""
+        buf = np.zeros(128, np.uint8)
+        rc = self._lib.vx_comm_unique_id(_ptr(buf))
+        if rc != 0:
+            raise VoxelsHipError("vx_comm_unique_id failed (%d): RCCL not available?" % rc)
+        return buf
+
+    def comm_init(self, nranks, rank, unique_id):
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        assert uid.size == 128
+        self._check(self._lib.vx_comm_init(self._h, int(nranks), int(rank), _ptr(uid)), "vx_comm_init")
+
+    def halo_exchange(self):
+        """Halo of the attached slab over RCCL (queued on the context's stream, no host wait)."""
+        self._check(self._lib.vx_halo_exchange(self._h), "vx_halo_exchange")
+
+    @staticmethod
+    def halo_exchange_group(polys):
+        """The same between several contexts of this process (slab order)."""
+        arr = (C.c_void_p * len(polys))(*[p._h for p in polys])
+        rc = polys[0]._lib.vx_halo_exchange_group(arr, len(polys))
+        if rc != 0:
+            bad = next((p for p in polys if p._lib.vx_last_error(p._h)), polys[0])
+            raise VoxelsHipError("vx_halo_exchange_group failed (%d): %s" % (rc, bad._lib.vx_last_error(bad._h).decode()))
 
     def device_block_table(self, lvl):
         """(device pointer, count) of the level's block table (vx_listed_block records, GetBlockForLevel order)."""

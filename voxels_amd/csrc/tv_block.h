@@ -124,6 +124,31 @@ enum { BC_SKIPPED = 1, BC_QUIET = 2, BC_NEGATIVE = 4 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }
 
+// One piece of a halo message: `layers` consecutive layers of a voxel field (n x n bytes each) or one block layer of
+// the flag array (cnt x cnt bytes), between the field and a contiguous staging buffer.  Element (layer l, a, x) of a
+// field lives at ((l - origin) * strideLayer + a * strideA) * rowBytes + x: for slabs of z-planes strideLayer = rows per
+// plane and strideA = 1; for slabs of y-rows strideLayer = 1 and strideA = rows per plane.
+struct HaloPiece {
+	u8* field;
+	u32 stagingOffset;   // bytes
+	int firstLayer, layers, origin;
+	u32 strideLayer, strideA;
+	u32 rowBytes;        // n for voxel fields, cnt for flags
+	u32 rows;            // a runs over [0, rows): n or cnt
+};
+enum { HALO_MAX_PIECES = 4 };
+struct HaloMove {
+	HaloPiece piece[HALO_MAX_PIECES];
+	u32 count;
+	u8* staging;
+	u32 unpack;          // 0: field -> staging, 1: staging -> field
+};
+
+TV_HD size_t halo_piece_bytes(const HaloPiece& p) { return (size_t)p.layers * p.rows * p.rowBytes; }
+
+// byte offset inside the field of (layer l, row a), x = 0
+TV_HD size_t halo_field_offset(const HaloPiece& p, int l, u32 a) { return ((size_t)(l - p.origin) * p.strideLayer + (size_t)a * p.strideA) * p.rowBytes; }
+
 // the work of the list kernels: workgroup w handles the block coordinates [(w - wgStart[l]) * LIST_WG, ...) of its level l
 struct ListPlan {
 	u32 wgStart[MAX_LEVELS + 1];

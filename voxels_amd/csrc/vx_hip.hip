@@ -20,6 +20,8 @@
 // No MFMA: this is table-driven integer/byte work bound by HBM bandwidth and latency.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1397,6 +1399,64 @@ __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPla
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_halo_move: the pieces of one halo message between their fields and a contiguous staging buffer (HaloMove,
+// tv_block.h).  One workgroup per row (n bytes of a voxel field, cnt bytes of the flag array).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_halo_move(HaloMove mv)
+{
+	u32 row = blockIdx.x;
+	u32 pi = 0;
+	while (pi + 1 < mv.count && row >= (u32)mv.piece[pi].layers * mv.piece[pi].rows) { row -= (u32)mv.piece[pi].layers * mv.piece[pi].rows; ++pi; }
+	const HaloPiece& p = mv.piece[pi];
+	if (row >= (u32)p.layers * p.rows) return;
+	const int l = (int)(row / p.rows);
+	const u32 a = row - (u32)l * p.rows;
+	u8* f = p.field + halo_field_offset(p, p.firstLayer + l, a);
+	u8* s = mv.staging + p.stagingOffset + (size_t)row * p.rowBytes;
+	u8* dst = mv.unpack ? f : s;
+	const u8* src = mv.unpack ? s : f;
+	if ((p.rowBytes & 15u) == 0 && (((size_t)dst | (size_t)src) & 15u) == 0) {
+		for (u32 i = threadIdx.x; i < p.rowBytes / 16; i += WG) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+	} else {
+		for (u32 i = threadIdx.x; i < p.rowBytes; i += WG) dst[i] = src[i];
+	}
+}
+
+// RCCL through its C API, bound at run time: a process that never shards a grid does not load the library
+struct Rccl {
+	typedef struct { char internal[128]; } UniqueId;
+	void* lib = nullptr;
+	int (*GetUniqueId)(UniqueId*) = nullptr;
+	int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+	int (*CommDestroy)(void*) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	bool load(std::string& err)
+	{
+		if (lib) return true;
+		lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+		if (!lib) { err = std::string("librccl.so not found: ") + dlerror(); return false; }
+		bool ok = true;
+		auto sym = [&](const char* name) { void* p = dlsym(lib, name); if (!p) { ok = false; err = std::string("missing RCCL symbol ") + name; } return p; };
+		GetUniqueId = (int (*)(UniqueId*))sym("ncclGetUniqueId");
+		CommInitRank = (int (*)(void**, int, UniqueId, int))sym("ncclCommInitRank");
+		CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+		GroupStart = (int (*)())sym("ncclGroupStart");
+		GroupEnd = (int (*)())sym("ncclGroupEnd");
+		Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+		Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+		GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+		if (!ok) { dlclose(lib); lib = nullptr; }
+		return ok;
+	}
+};
+Rccl& rccl() { static Rccl r; return r; }
+
 struct DirtyRanges { u32 start[MAX_LEVELS + 1]; };
 
 __global__ __launch_bounds__(WG) void k_build_worklist(ExecParamsDev p, const u32* coords, DirtyRanges r, u32 levels, u32* work)
@@ -1761,6 +1821,59 @@ struct Backend {
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}
 	bool stage_timing_on() const { return stageOn; }
+
+	// ---- halo messages of attached slabs (vx_halo_exchange*, vx_host.inl) -----------------------------------------------
+	void run_halo_move(const HaloMove& mv)
+	{
+		u32 rows = 0;
+		for (u32 i = 0; i < mv.count; ++i) rows += (u32)mv.piece[i].layers * mv.piece[i].rows;
+		if (!rows) return;
+		hipLaunchKernelGGL(k_halo_move, dim3(rows), dim3(WG), 0, stream, mv);
+		check(hipGetLastError(), "k_halo_move launch");
+	}
+	void* comm = nullptr;
+	static bool comm_unique_id(void* id)
+	{
+		std::string err;
+		return rccl().load(err) && rccl().GetUniqueId((Rccl::UniqueId*)id) == 0;
+	}
+	bool rccl_ok(int rc, const char* what)
+	{
+		if (rc == 0) return true;
+		lastError = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+		return false;
+	}
+	bool comm_init(int nranks, int rank, const void* id)
+	{
+		if (!rccl().load(lastError)) return false;
+		comm_destroy();
+		Rccl::UniqueId uid;
+		memcpy(&uid, id, sizeof(uid));
+		return rccl_ok(rccl().CommInitRank(&comm, nranks, uid, rank), "ncclCommInitRank");
+	}
+	void comm_destroy()
+	{
+		if (comm) { (void)hipStreamSynchronize(stream); (void)rccl().CommDestroy(comm); comm = nullptr; }
+	}
+	// one grouped batch: everything a rank sends and receives in an exchange progresses together (xGMI links are
+	// point to point: the two neighbours are two different links)
+	bool comm_exchange(int peerLo, const void* sendLo, size_t sendLoBytes, void* recvLo, size_t recvLoBytes,
+	                   int peerHi, const void* sendHi, size_t sendHiBytes, void* recvHi, size_t recvHiBytes)
+	{
+		if (!comm) { lastError = "no communicator"; return false; }
+		enum { NCCL_UINT8 = 1 };
+		bool ok = rccl_ok(rccl().GroupStart(), "ncclGroupStart");
+		if (ok && peerLo >= 0) ok = rccl_ok(rccl().Send(sendLo, sendLoBytes, NCCL_UINT8, peerLo, comm, stream), "ncclSend") && rccl_ok(rccl().Recv(recvLo, recvLoBytes, NCCL_UINT8, peerLo, comm, stream), "ncclRecv");
+		if (ok && peerHi >= 0) ok = rccl_ok(rccl().Send(sendHi, sendHiBytes, NCCL_UINT8, peerHi, comm, stream), "ncclSend") && rccl_ok(rccl().Recv(recvHi, recvHiBytes, NCCL_UINT8, peerHi, comm, stream), "ncclRecv");
+		const bool ended = rccl_ok(rccl().GroupEnd(), "ncclGroupEnd");
+		return ok && ended;
+	}
+	// in-process transport (several contexts driven by one process): a copy between two contexts' staging buffers
+	bool copy_from_peer(void* dst, Backend& from, const void* src, size_t bytes)
+	{
+		if (from.device == device) return check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(D2D)");
+		return check(hipMemcpyPeerAsync(dst, device, src, from.device, bytes, stream), "hipMemcpyPeerAsync");
+	}
 
 	// the result's block lists, written on the device behind the last kernel of a full run
 	template <typename P>

@@ -56,6 +56,10 @@ struct vx_ctx {
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	void* dListCounts = nullptr;                         // per-workgroup counts of the list kernels
+	void* haloBuf[4] = { nullptr, nullptr, nullptr, nullptr }; // staging of the halo messages: send below, send above, receive from below, receive from above
+	size_t haloCap[4] = { 0, 0, 0, 0 };
+	int slabAxis = 0;                                    // how the grid was attached: 0 = not attached, 1 = slab of z-planes, 2 = slab of y-rows
+	int commRanks = 0, commRank = 0;                     // RCCL communicator joined by vx_comm_init (0 = none)
 	bool deviceLists = false;                            // the device block tables describe the current surface (full run; not after incremental runs)
 	int distZ0 = 0, matZ0 = 0;
 	// constant device data
@@ -123,6 +127,7 @@ void release_grid(vx_ctx* c)
 	}
 	c->dDist = c->dMat = c->dBlend = c->dFlags = nullptr;
 	c->ownsGrid = false;
+	c->slabAxis = 0;
 }
 
 bool ensure_level_tables(vx_ctx* c)
@@ -405,6 +410,8 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
+	for (void* hb : c->haloBuf) c->be.free(hb);
+	c->be.comm_destroy();
 	c->be.free_pinned(c->hdrPinned);
 	c->be.free(c->dScratch);
 	c->be.shutdown();
@@ -591,6 +598,7 @@ int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, cons
 	c->distZ0 = dist_z0; c->matZ0 = mat_z0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
+	c->slabAxis = 1;
 	return VX_OK;
 }
 
@@ -606,6 +614,158 @@ int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, co
 	c->dDist = (void*)d_dist; c->dMat = (void*)d_mat; c->dBlend = (void*)d_blend; c->dFlags = (void*)d_flags;
 	c->distY0 = dist_y0; c->matY0 = mat_y0; c->distRows = dist_rows; c->matRows = mat_rows;
 	c->haveSurface = false;
+	c->slabAxis = 2;
+	return VX_OK;
+}
+
+namespace {
+
+// The four halo messages of an attached slab (see include/voxels_hip.h): which layers of which field go where.
+// Layer = z-plane (slabs of planes) or y-row of every plane (slabs of rows).
+struct HaloPlan {
+	HaloMove sendLo, sendHi, recvLo, recvHi; // below = towards smaller coordinates
+	bool hasLo, hasHi;
+};
+
+bool halo_plan(vx_ctx* c, HaloPlan& pl, std::string& why)
+{
+	if (!c->n || !c->dDist || c->ownsGrid || !c->slabAxis) { why = "needs a slab attached with vx_grid_attach / vx_grid_attach_y"; return false; }
+	const bool alongY = c->slabAxis == 2;
+	const int b = (int)(alongY ? c->yBegin : c->zBegin), e = (int)(alongY ? c->yEnd : c->zEnd);
+	const int n = (int)c->n, cnt = n / 16;
+	const int dOrigin = alongY ? c->distY0 : c->distZ0, mOrigin = alongY ? c->matY0 : c->matZ0;
+	if (dOrigin != b - 1 || mOrigin != b) { why = "the attached buffers must start one distance layer below the slab and at the slab's first material layer"; return false; }
+	if (alongY && (c->distRows != (u32)(e - b) + 3 || c->matRows != (u32)(e - b) + 1)) { why = "y-slab buffers must hold the slab's rows plus 3 (distances) / plus 1 (materials)"; return false; }
+	memset(&pl, 0, sizeof(pl));
+	pl.hasLo = b > 0; pl.hasHi = e < n;
+	auto field = [&](void* base, int first, int layers, int origin, u32 rowsPerPlane) {
+		HaloPiece p;
+		p.field = (u8*)base; p.stagingOffset = 0; p.firstLayer = first; p.layers = layers; p.origin = origin;
+		p.strideLayer = alongY ? 1u : rowsPerPlane; p.strideA = alongY ? rowsPerPlane : 1u;
+		p.rowBytes = (u32)n; p.rows = (u32)n;
+		return p;
+	};
+	auto flags = [&](int blockLayer) {
+		HaloPiece p;
+		p.field = (u8*)c->dFlags; p.stagingOffset = 0; p.firstLayer = blockLayer; p.layers = 1; p.origin = 0;
+		p.strideLayer = alongY ? 1u : (u32)cnt; p.strideA = alongY ? (u32)cnt : 1u;
+		p.rowBytes = (u32)cnt; p.rows = (u32)cnt;
+		return p;
+	};
+	auto pack = [&](HaloMove& mv, std::initializer_list<HaloPiece> pieces, u32 unpack, void* staging) {
+		u32 off = 0;
+		mv.count = 0;
+		for (HaloPiece p : pieces) { p.stagingOffset = off; off += (u32)halo_piece_bytes(p); mv.piece[mv.count++] = p; }
+		mv.unpack = unpack; mv.staging = (u8*)staging;
+		return (size_t)off;
+	};
+	const u32 dRows = alongY ? c->distRows : (u32)n, mRows = alongY ? c->matRows : (u32)n;
+	const size_t loBytes = 4 * (size_t)n * n + (size_t)cnt * cnt, hiBytes = (size_t)n * n + (size_t)cnt * cnt;
+	const size_t need[4] = { pl.hasLo ? loBytes : 0, pl.hasHi ? hiBytes : 0, pl.hasLo ? hiBytes : 0, pl.hasHi ? loBytes : 0 };
+	for (int i = 0; i < 4; ++i) if (need[i] > c->haloCap[i]) {
+		c->be.free(c->haloBuf[i]);
+		c->haloBuf[i] = c->be.alloc(need[i]);
+		c->haloCap[i] = c->haloBuf[i] ? need[i] : 0;
+		if (!c->haloBuf[i]) { why = "staging allocation failed"; return false; }
+	}
+	if (pl.hasLo) {
+		pack(pl.sendLo, { field(c->dDist, b, 2, dOrigin, dRows), field(c->dMat, b, 1, mOrigin, mRows), field(c->dBlend, b, 1, mOrigin, mRows), flags(b / 16) }, 0, c->haloBuf[0]);
+		pack(pl.recvLo, { field(c->dDist, b - 1, 1, dOrigin, dRows), flags(b / 16 - 1) }, 1, c->haloBuf[2]);
+	}
+	if (pl.hasHi) {
+		pack(pl.sendHi, { field(c->dDist, e - 1, 1, dOrigin, dRows), flags(e / 16 - 1) }, 0, c->haloBuf[1]);
+		pack(pl.recvHi, { field(c->dDist, e, 2, dOrigin, dRows), field(c->dMat, e, 1, mOrigin, mRows), field(c->dBlend, e, 1, mOrigin, mRows), flags(e / 16) }, 1, c->haloBuf[3]);
+	}
+	return true;
+}
+
+size_t halo_move_bytes(const HaloMove& mv)
+{
+	size_t s = 0;
+	for (u32 i = 0; i < mv.count; ++i) s += halo_piece_bytes(mv.piece[i]);
+	return s;
+}
+
+} // namespace
+
+int vx_comm_unique_id(void* id)
+{
+	if (!id) return VX_ERR_INVALID;
+	return Backend::comm_unique_id(id) ? VX_OK : VX_ERR_DEVICE;
+}
+
+int vx_comm_init(vx_ctx* c, int nranks, int rank, const void* id)
+{
+	VX_ENTER(c);
+	if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, VX_ERR_INVALID, "vx_comm_init: bad arguments");
+	if (!c->be.comm_init(nranks, rank, id)) return fail(c, VX_ERR_DEVICE, "vx_comm_init: " + c->be.error());
+	c->commRanks = nranks; c->commRank = rank;
+	return VX_OK;
+}
+
+int vx_comm_destroy(vx_ctx* c)
+{
+	VX_ENTER(c);
+	if (!c) return VX_ERR_INVALID;
+	c->be.comm_destroy();
+	c->commRanks = 0;
+	return VX_OK;
+}
+
+int vx_halo_exchange(vx_ctx* c)
+{
+	VX_ENTER(c);
+	if (!c) return VX_ERR_INVALID;
+	if (!c->commRanks) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: call vx_comm_init first");
+	HaloPlan pl;
+	std::string why;
+	if (!halo_plan(c, pl, why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: " + why);
+	if ((pl.hasLo && c->commRank == 0) || (pl.hasHi && c->commRank + 1 == c->commRanks)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: rank r must own the r-th slab");
+	// pack -> one grouped send/recv batch -> unpack, all queued on the context's stream: nothing waits on the host
+	if (pl.hasLo) c->be.run_halo_move(pl.sendLo);
+	if (pl.hasHi) c->be.run_halo_move(pl.sendHi);
+	const bool ok = c->be.comm_exchange(pl.hasLo ? c->commRank - 1 : -1, pl.hasLo ? c->haloBuf[0] : nullptr, pl.hasLo ? halo_move_bytes(pl.sendLo) : 0,
+	                                    pl.hasLo ? c->haloBuf[2] : nullptr, pl.hasLo ? halo_move_bytes(pl.recvLo) : 0,
+	                                    pl.hasHi ? c->commRank + 1 : -1, pl.hasHi ? c->haloBuf[1] : nullptr, pl.hasHi ? halo_move_bytes(pl.sendHi) : 0,
+	                                    pl.hasHi ? c->haloBuf[3] : nullptr, pl.hasHi ? halo_move_bytes(pl.recvHi) : 0);
+	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange: " + c->be.error());
+	if (pl.hasLo) c->be.run_halo_move(pl.recvLo);
+	if (pl.hasHi) c->be.run_halo_move(pl.recvHi);
+	c->haveSurface = false;
+	return VX_OK;
+}
+
+int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
+{
+	if (!ctxs || count < 1) return VX_ERR_INVALID;
+	std::vector<HaloPlan> plans((size_t)count);
+	std::string why;
+	for (int i = 0; i < count; ++i) {
+		vx_ctx* c = ctxs[i];
+		VX_ENTER(c);
+		if (!c) return VX_ERR_INVALID;
+		if (!halo_plan(c, plans[(size_t)i], why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: " + why);
+		if (plans[(size_t)i].hasLo != (i > 0) || plans[(size_t)i].hasHi != (i + 1 < count)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: contexts must be the slabs of one grid in order");
+		if (plans[(size_t)i].hasLo) c->be.run_halo_move(plans[(size_t)i].sendLo);
+		if (plans[(size_t)i].hasHi) c->be.run_halo_move(plans[(size_t)i].sendHi);
+	}
+	for (int i = 0; i < count; ++i) { VX_ENTER(ctxs[i]); if (!ctxs[i]->be.sync_ok()) return fail(ctxs[i], VX_ERR_DEVICE, "vx_halo_exchange_group: pack failed: " + ctxs[i]->be.error()); }
+	for (int i = 0; i + 1 < count; ++i) {
+		vx_ctx *lo = ctxs[i], *hi = ctxs[i + 1];
+		// upward: lo's last layer -> hi's layer below; downward: hi's first layers -> lo's layers above
+		VX_ENTER(hi);
+		if (!hi->be.copy_from_peer(hi->haloBuf[2], lo->be, lo->haloBuf[1], halo_move_bytes(plans[(size_t)i].sendHi))) return fail(hi, VX_ERR_DEVICE, "vx_halo_exchange_group: peer copy failed: " + hi->be.error());
+		VX_ENTER(lo);
+		if (!lo->be.copy_from_peer(lo->haloBuf[3], hi->be, hi->haloBuf[0], halo_move_bytes(plans[(size_t)i + 1].sendLo))) return fail(lo, VX_ERR_DEVICE, "vx_halo_exchange_group: peer copy failed: " + lo->be.error());
+	}
+	for (int i = 0; i < count; ++i) {
+		vx_ctx* c = ctxs[i];
+		VX_ENTER(c);
+		if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange_group: copy failed: " + c->be.error());
+		if (plans[(size_t)i].hasLo) c->be.run_halo_move(plans[(size_t)i].recvLo);
+		if (plans[(size_t)i].hasHi) c->be.run_halo_move(plans[(size_t)i].recvHi);
+		c->haveSurface = false;
+	}
 	return VX_OK;
 }
 
