@@ -9,9 +9,10 @@ terrain, LOD levels 0..3 with transition cells and materials, on N MI355X GPUs o
 A step = one vx_polygonize over the resident grid (classify -> hierarchy -> material -> regular -> transition
 kernels, the device-built block lists, and the small header read-back that tells the host the counts).  With N > 1 the grid is sharded in slabs
 (along y by default: a terrain's surface lives in a few z-layers; strong scaling: the 1024^3 grid is fixed), and every
-step also re-exchanges the slab halo (1 distance layer down, 2 distance + 1 material + 1 blend layer up) over RCCL,
-as the path does after an edit.  Inputs are generated
-on the host (voxels_synth) and are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+step also re-exchanges the slab halo (1 distance layer down, 2 distance + 1 material + 1 blend layer up) over RCCL
+through the C ABI (vx_halo_exchange), as the path does after an edit.  Inputs are generated on the device
+(vx_grid_create_terrain / vx_grid_fill_terrain: the bytes of the host generator voxels_synth) and are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -131,39 +132,38 @@ def main():
     planes = n // world
     z0, z1 = rank * planes, (rank + 1) * planes
 
-    # ---- host generation of this rank's slab + residency ----------------------------------------------
-    axis = args.slab_axis if world > 1 else "z"  # one rank: the whole grid in its natural layout
-    t_gen = time.perf_counter()
-    from voxels_amd.slab import SlabBuffers
-    slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
-    if axis == "z":
-        d, m, b = synth.terrain(n, z0, z1, seed)
-        flags_own = synth.block_empty_flags(d)
-        t_gen = time.perf_counter() - t_gen
-        slab.fill_own(d, m, b, flags_own)
-    else:
-        # rows [z0, z1) of every plane; the generator works plane-wise, so the whole field is produced and sliced (host
-        # work outside the timed region), and the flags of all blocks are derived locally
-        d, m, b = synth.terrain(n, 0, n, seed)
-        flags_all = synth.block_empty_flags(d)
-        t_gen = time.perf_counter() - t_gen
-        sl = slice(z0, z1)
-        slab.fill_own(np.ascontiguousarray(d[:, sl]), np.ascontiguousarray(m[:, sl]), np.ascontiguousarray(b[:, sl]), flags_all)
-    del d, m, b
-    slab.gather_flags(dist_pkg)
-
-    def halo_exchange():
-        """1 distance plane from the slab below; 2 distance planes + 1 material + 1 blend plane from the slab above."""
-        slab.halo_exchange(dist_pkg)
-
-    halo_exchange()
-    torch.cuda.synchronize()
-
+    # ---- the grid is generated where it lives (vx_grid_create_terrain / vx_grid_fill_terrain: the host generator's bytes,
+    #      checked in tests/) — nothing crosses PCIe.  One rank owns the whole grid; N ranks attach one slab each (torch
+    #      tensors with the halo layers the path reads) and exchange halos through the C ABI over RCCL. -------------------
+    axis = args.slab_axis if world > 1 else "z"
     poly = Polygonizer(device=local_rank)
     assert poly.backend == "hip:gfx950"
     poly.set_stream(torch.cuda.current_stream().cuda_stream)
     poly.set_materials(synth.default_lut())
-    slab.attach(poly)
+    t_gen = time.perf_counter()
+    slab = None
+    if world == 1:
+        poly.create_terrain(n, seed)
+    else:
+        from voxels_amd.slab import SlabBuffers
+        slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
+        slab.attach(poly)
+        poly.fill_terrain(seed)
+        uid = torch.from_numpy(poly.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+        dist_pkg.broadcast(uid, 0)
+        poly.comm_init(world, rank, uid.cpu().numpy())
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+
+    def halo_exchange():
+        """1 distance layer from the slab below; 2 distance layers + 1 material + 1 blend layer and the flags of the
+        boundary block layers from the slab above — vx_halo_exchange: pack kernel, one grouped ncclSend/ncclRecv batch on the
+        library's stream, unpack kernel; no host wait."""
+        if world > 1:
+            poly.halo_exchange()
+
+    halo_exchange()
+    torch.cuda.synchronize()
 
     if args.serialize:
         poly.set_stage_timing(True)
@@ -302,7 +302,7 @@ def main():
                        "surface_only": {"surface_blocks_per_s": round(surface_blocks / step_s, 1),
                                         "Mvoxels_per_s_over_surface_blocks": round(surface_blocks * 4096 / step_s / 1e6, 2),
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
-                       "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "host_gen_s": round(t_gen, 2),
+                       "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
                        "halo_exchange_in_step": world > 1},
             "roofline": roofline,
         }

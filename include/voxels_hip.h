@@ -107,6 +107,18 @@ int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
 int vx_grid_attach_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end,
                      const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
                      const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_empty_flags);
+/* ---- generation on the device ------------------------------------------------------------------------------------------
+ * Grid::Create(w, h, d, ..., VoxelSurface*) samples an application callback on the host (src/VoxelGrid.cpp:79-132) and
+ * quantises the samples (:37-50).  For the benchmark's synthetic surface (include/voxels_synth.h, vxs_terrain) the same
+ * step runs where the grid lives: the fields are byte for byte what vxs_terrain + vxs_block_empty_flags produce on the
+ * host, without 3 n^3 bytes crossing PCIe.
+ * vx_grid_create_terrain: a whole n^3 grid owned by the context (like vx_grid_upload).
+ * vx_grid_fill_terrain: the slab attached with vx_grid_attach / vx_grid_attach_y — every resident layer that lies
+ * inside the grid (the halo included) and the BF_Empty flags of the rank's own blocks (the neighbours' flag layers come
+ * with vx_halo_exchange). */
+int vx_grid_create_terrain(vx_ctx* ctx, uint32_t n, uint32_t seed);
+int vx_grid_fill_terrain(vx_ctx* ctx, uint32_t seed);
+
 /* ---- multi-GPU: halo exchange of attached slabs -------------------------------------------
  * The reference has one address space and an OpenMP block loop (src/TransVoxelImpl.cpp:500-503); here the grid is cut
  * into slabs (vx_grid_attach / vx_grid_attach_y), one per GPU, rank r owning the r-th slab along the cut axis.  What a

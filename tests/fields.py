@@ -144,3 +144,32 @@ def check_halo_exchange_group(make_poly, torch, device, n, levels, world, axis, 
         parts.append(p.all_levels())
     ok, msg = surface_equal(merge_rank_levels(parts), reference_levels[:levels], nrm_tol=nrm_tol)
     assert ok, msg
+
+
+def check_device_terrain(make_poly, torch, device, n, seed=1337, world=2):
+    """§8(f) row 3: the synthetic terrain generated on the device equals the host generator byte for byte — the whole
+    grid (compared through the grid file: every voxel of all three fields + the codec's flags) and slabs with halo."""
+    from voxels_amd import synth
+    from voxels_amd.slab import SlabBuffers
+    d, m, b = synth.terrain(n, 0, n, seed)
+    flags = synth.block_empty_flags(d)
+    host = make_poly()
+    host.upload(d, m, b, flags)
+    dev = make_poly()
+    dev.create_terrain(n, seed)
+    assert np.array_equal(host.pack(), dev.pack())
+    for axis in ("z", "y"):
+        for r in range(world):
+            want = SlabBuffers(torch, n, r, world, device, axis=axis)
+            want.fill_from_full(d, m, b, flags)
+            got = SlabBuffers(torch, n, r, world, device, axis=axis)
+            p = make_poly()
+            got.attach(p)
+            p.fill_terrain(seed)
+            assert torch.equal(got.dist, want.dist) and torch.equal(got.mat, want.mat) and torch.equal(got.blend, want.blend), (axis, r)
+            fl_got, fl_want = got.flags.cpu().numpy().reshape(n // 16, n // 16, n // 16), flags.reshape(n // 16, n // 16, n // 16)
+            own = slice(got.z0 // 16, got.z1 // 16)
+            if axis == "z":
+                assert np.array_equal(fl_got[own], fl_want[own]), (axis, r)
+            else:
+                assert np.array_equal(fl_got[:, own], fl_want[:, own]), (axis, r)

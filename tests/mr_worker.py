@@ -1,5 +1,6 @@
-"""Worker of tests/test_multirank_gloo.py: one rank of a world_size-N run of the slab path on CPU (gloo + the
-emulation backend), mirroring what bench.py does with RCCL on GPUs."""
+"""Worker of tests/test_multirank_gloo.py and tests/test_multirank_rccl.py: one rank of a world_size-N run of the slab path —
+on CPU (gloo + the emulation backend, halo exchange by voxels_amd/slab.py) or, with a fifth argument "rccl", on GPU
+`LOCAL_RANK` through the C ABI exactly like bench.py: vx_grid_fill_terrain, vx_comm_init, vx_halo_exchange."""
 import os
 import sys
 
@@ -17,6 +18,8 @@ def main():
     axis = sys.argv[4] if len(sys.argv) > 4 else "z"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 5 and sys.argv[5] == "rccl":
+        return main_rccl(out_dir, n, levels, axis, rank, world)
     from emu_lib import emu_library
     from voxels_amd import synth
     from voxels_amd.binding import Polygonizer
@@ -45,6 +48,44 @@ def main():
         out["L%d_tverts" % li] = lv.tverts
         out["L%d_tidx" % li] = lv.tidx
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def save(out_dir, rank, p):
+    out = {"stats": p.stats()}
+    for li, lv in enumerate(p.all_levels()):
+        out["L%d_infos" % li] = lv.infos
+        out["L%d_verts" % li] = lv.verts
+        out["L%d_idx" % li] = lv.idx
+        out["L%d_tverts" % li] = lv.tverts
+        out["L%d_tidx" % li] = lv.tidx
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+
+
+def main_rccl(out_dir, n, levels, axis, rank, world):
+    from voxels_amd import Polygonizer, synth
+    from voxels_amd.slab import SlabBuffers
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
+    p = Polygonizer(device=local)
+    p.set_materials(synth.default_lut())
+    slab.attach(p)
+    p.fill_terrain(5)                      # own layers + halo + own flags; the neighbours' flag layers are still missing
+    uid = torch.from_numpy(p.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8))
+    dist.broadcast(uid, 0)                 # over gloo: the id only has to reach every rank somehow
+    p.comm_init(world, rank, uid.numpy())
+    # wipe the halo so that the exchange has to deliver it
+    if axis == "z":
+        slab.dist[0].zero_(); slab.dist[-2:].zero_(); slab.mat[-1].zero_(); slab.blend[-1].zero_()
+    else:
+        slab.dist[:, 0].zero_(); slab.dist[:, -2:].zero_(); slab.mat[:, -1].zero_(); slab.blend[:, -1].zero_()
+    torch.cuda.synchronize()
+    p.halo_exchange()
+    p.execute(levels)
+    save(out_dir, rank, p)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -489,3 +489,8 @@ def test_emu_halo_exchange_group(emu, world, axis):
     whole.set_materials(vxo.default_lut())
     whole.execute(levels)
     fields.check_halo_exchange_group(mk, torch, torch.device("cpu"), n, levels, world, axis, whole.all_levels())
+
+
+def test_emu_device_terrain(emu):
+    import torch
+    fields.check_device_terrain(lambda: make_poly(emu), torch, torch.device("cpu"), 64, seed=11)

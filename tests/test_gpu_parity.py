@@ -372,6 +372,16 @@ def test_hip_halo_exchange_group(port, world, axis):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [256])
+def test_hip_device_terrain(n):
+    """§8(f) row 3: k_terrain_height / k_terrain_fill + k_edit_flags reproduce vxs_terrain + vxs_block_empty_flags byte for
+    byte (whole grid through the grid file; 2 slabs per axis with their halo layers)."""
+    import torch
+    from voxels_amd import Polygonizer
+    fields.check_device_terrain(lambda: Polygonizer(device=0), torch, torch.device("cuda", 0), n)
+
+
+@pytest.mark.gpu
 def test_hip_rccl_communicator_single_rank(port):
     """vx_comm_unique_id / vx_comm_init / vx_halo_exchange with one rank: the RCCL library is found, the communicator
     comes up on this GPU, and an exchange without neighbours is an empty group that leaves the slab intact."""

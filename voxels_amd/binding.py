@@ -60,6 +60,8 @@ class HipLibrary:
         lib.vx_compact_pools.argtypes = [vp]
         lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
         lib.vx_grid_create_heightmap.argtypes = [vp, u32, vp]
+        lib.vx_grid_create_terrain.argtypes = [vp, u32, u32]
+        lib.vx_grid_fill_terrain.argtypes = [vp, u32]
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
         lib.vx_level_ranges.argtypes = [vp, u32, vp]
@@ -195,6 +197,15 @@ class Polygonizer:
         nv, ni = C.c_uint64(), C.c_uint64()
         self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
         return dv.value, di.value, nv.value, ni.value
+
+    def create_terrain(self, n, seed=1337):
+        """The synthetic noise terrain (voxels_amd.synth.terrain) generated on the device into a grid the context owns."""
+        self._check(self._lib.vx_grid_create_terrain(self._h, int(n), int(seed)), "vx_grid_create_terrain")
+        self.n = n
+
+    def fill_terrain(self, seed=1337):
+        """The same into the attached slab (own layers + halo) with the BF_Empty flags of the rank's own blocks."""
+        self._check(self._lib.vx_grid_fill_terrain(self._h, int(seed)), "vx_grid_fill_terrain")
 
     def comm_unique_id(self):
         """128-byte RCCL id (rank 0 creates it, every rank passes it to comm_init)."""

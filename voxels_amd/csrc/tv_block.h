@@ -1265,14 +1265,14 @@ TV_HD void edit_voxel(const GridView& g, const EditParams& e, const EditSection&
 // strictly the sign of the first sample (walk in codec order: x, then y, then z)
 TV_HD u8 edit_block_empty(const GridView& g, u32 bx, u32 by, u32 bz)
 {
-	const i8* base = g.dist + ((size_t)(bz * 16) * g.n + by * 16) * g.n + bx * 16;
+	const i8* base = g.dist + dist_offset(g, (int)(bx * 16), (int)(by * 16), (int)(bz * 16)); // whole grids and slabs alike
 	const i8 first = base[0];
 	i8 last = first;
 	u32 counter = 0, size = 1;
 	bool empty = true;
 	for (u32 z = 0; z < 16; ++z)
 	for (u32 y = 0; y < 16; ++y) {
-		const i8* row = base + ((size_t)z * g.n + y) * g.n;
+		const i8* row = base + ((size_t)z * g.pitchY + y) * g.n;
 		for (u32 x = 0; x < 16; ++x) {
 			const i8 cur = row[x];
 			if (last == cur && counter < 0xFF) { ++counter; continue; }

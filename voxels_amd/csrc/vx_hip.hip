@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "tv_block.h"
+#include "vx_terrain_math.h"
 
 #define VX_BACKEND_NAME "hip:gfx950"
 
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(WG) void k_edit_flags(GridView g, u8* flags, const 
 	__shared__ u32 runs;
 	const u32 nb = (u32)g.n / 16, id = ids ? ids[blockIdx.x] : blockIdx.x, t = threadIdx.x; // no list = every block
 	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
-	const i8* base = g.dist + ((size_t)(bz * 16) * g.n + by * 16) * g.n + bx * 16;
-	const uint4 raw = *(const uint4*)(base + ((size_t)(t >> 4) * g.n + (t & 15)) * g.n); // row t = (y = t & 15, z = t >> 4): codec order
+	const i8* base = g.dist + dist_offset(g, (int)(bx * 16), (int)(by * 16), (int)(bz * 16)); // whole grids and slabs alike
+	const uint4 raw = *(const uint4*)(base + ((size_t)(t >> 4) * g.pitchY + (t & 15)) * g.n); // row t = (y = t & 15, z = t >> 4): codec order
 	i8 v[16];
 	memcpy(v, &raw, 16);
 	lastOfRow[t] = v[15];
@@ -430,6 +431,37 @@ __global__ __launch_bounds__(WG) void k_heightmap(GridView g, const i8* map)
 	uint4 out;
 	memcpy(&out, v, 16);
 	*(uint4*)(const_cast<i8*>(g.dist) + ((size_t)z * n + y) * n + sx * 16) = out;
+}
+
+// k_terrain_height / k_terrain_fill: the benchmark's synthetic terrain (include/voxels_synth.h, vx_terrain_math.h)
+// evaluated where the grid lives — the VoxelSurface -> Grid step (src/VoxelGrid.cpp:79-132, :37-50) for this one surface.
+// Heights once per voxel column; then one lane per 16-voxel row segment, 16-byte stores.
+struct TerrainRange { int z0, z1, y0, y1; }; // resident layers of a field inside the grid: planes [z0, z1), rows [y0, y1)
+
+__global__ __launch_bounds__(WG) void k_terrain_height(u32 n, u32 seed, float* height)
+{
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (i < n * n) height[i] = vxt::height(n, i % n, i / n, seed);
+}
+
+__global__ __launch_bounds__(WG) void k_terrain_fill(GridView g, u32 seed, const float* height, TerrainRange dr, TerrainRange mr)
+{
+	const u32 n = (u32)g.n, segs = n >> 4;
+	const u32 rows = (u32)(dr.y1 - dr.y0);
+	const size_t q = (size_t)blockIdx.x * WG + threadIdx.x;
+	if (q >= (size_t)segs * rows * (u32)(dr.z1 - dr.z0)) return;
+	const u32 sx = (u32)(q % segs), y = (u32)dr.y0 + (u32)((q / segs) % rows), z = (u32)dr.z0 + (u32)(q / ((size_t)segs * rows));
+	i8 d[16]; u8 m[16], b[16];
+#pragma unroll 4
+	for (u32 i = 0; i < 16; ++i) vxt::voxel(sx * 16 + i, y, z, height[(size_t)y * n + sx * 16 + i], seed, d[i], m[i], b[i]);
+	uint4 v;
+	memcpy(&v, d, 16);
+	*(uint4*)(const_cast<i8*>(g.dist) + dist_offset(g, (int)(sx * 16), (int)y, (int)z)) = v;
+	if ((int)z >= mr.z0 && (int)z < mr.z1 && (int)y >= mr.y0 && (int)y < mr.y1) {
+		const size_t o = mat_offset(g, (int)(sx * 16), (int)y, (int)z);
+		memcpy(&v, m, 16); *(uint4*)(const_cast<u8*>(g.mat) + o) = v;
+		memcpy(&v, b, 16); *(uint4*)(const_cast<u8*>(g.blend) + o) = v;
+	}
 }
 
 // k_scatter_blocks: edited 16^3 blocks (4096 contiguous bytes each) into the dense fields; lane t owns voxel row t
@@ -1640,6 +1672,17 @@ struct Backend {
 		hipLaunchKernelGGL(k_heightmap, dim3((u32)((segs + WG - 1) / WG)), dim3(WG), 0, stream, g, map);
 		hipLaunchKernelGGL(k_edit_flags, dim3(nb * nb * nb), dim3(WG), 0, stream, g, flags, (const u32*)nullptr, nb * nb * nb);
 		check(hipGetLastError(), "k_heightmap launch");
+	}
+	// the synthetic terrain into the resident fields (dist over dr, material + blend over mr), BF_Empty of the listed blocks
+	void run_terrain(const GridView& g, u32 seed, float* height, const int dr[4], const int mr[4], u8* flags, const u32* ids, u32 count)
+	{
+		const u32 n = (u32)g.n;
+		TerrainRange d = { dr[0], dr[1], dr[2], dr[3] }, m = { mr[0], mr[1], mr[2], mr[3] };
+		hipLaunchKernelGGL(k_terrain_height, dim3((n * n + WG - 1) / WG), dim3(WG), 0, stream, n, seed, height);
+		const size_t segs = (size_t)(n / 16) * (size_t)(d.y1 - d.y0) * (size_t)(d.z1 - d.z0);
+		if (segs) hipLaunchKernelGGL(k_terrain_fill, dim3((u32)((segs + WG - 1) / WG)), dim3(WG), 0, stream, g, seed, (const float*)height, d, m);
+		if (count) hipLaunchKernelGGL(k_edit_flags, dim3(count), dim3(WG), 0, stream, g, flags, ids, count);
+		check(hipGetLastError(), "k_terrain launch");
 	}
 	void run_copy_segments(const u32* seg, u32 count, const void* src, void* dst, u32 elemBytes)
 	{

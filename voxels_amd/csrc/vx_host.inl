@@ -476,6 +476,69 @@ int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_create_heightmap: device pass failed: " + c->be.error());
 }
 
+namespace {
+
+GridView resident_view(const vx_ctx* c)
+{
+	GridView g;
+	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
+	g.n = (int)c->n; g.zOrigin = c->distZ0; g.zOriginMat = c->matZ0; g.yOrigin = c->distY0; g.yOriginMat = c->matY0;
+	g.pitchY = (int)c->distRows; g.pitchYMat = (int)c->matRows;
+	return g;
+}
+
+// the synthetic terrain over everything resident (own layers + halo, clamped to the grid) + flags of the own blocks
+int generate_terrain(vx_ctx* c, u32 seed, const char* what)
+{
+	const u32 n = c->n, nb = n / 16;
+	const int N = (int)n;
+	const bool alongY = c->slabAxis == 2;
+	const int zb = (int)c->zBegin, ze = (int)c->zEnd, yb = (int)c->yBegin, ye = (int)c->yEnd;
+	const bool slab = c->slabAxis != 0;
+	// resident layers: a slab carries 1 distance layer below and 2 above, 1 material layer above (include/voxels_hip.h)
+	const int dr[4] = { (slab && !alongY) ? std::max(zb - 1, 0) : 0, (slab && !alongY) ? std::min(ze + 2, N) : N,
+	                    (slab && alongY) ? std::max(yb - 1, 0) : 0, (slab && alongY) ? std::min(ye + 2, N) : N };
+	const int mr[4] = { (slab && !alongY) ? zb : 0, (slab && !alongY) ? std::min(ze + 1, N) : N,
+	                    (slab && alongY) ? yb : 0, (slab && alongY) ? std::min(ye + 1, N) : N };
+	std::vector<u32> ids;
+	for (u32 z = (u32)zb / 16; z < (u32)ze / 16; ++z) for (u32 y = (u32)yb / 16; y < (u32)ye / 16; ++y) for (u32 x = 0; x < nb; ++x) ids.push_back((z * nb + y) * nb + x);
+	void* dHeight = c->be.alloc((size_t)n * n * 4);
+	void* dIds = c->be.alloc(ids.size() * 4 + 16);
+	bool ok = dHeight && dIds && c->be.h2d(dIds, ids.data(), ids.size() * 4);
+	if (ok) {
+		c->be.run_terrain(resident_view(c), seed, (float*)dHeight, dr, mr, (u8*)c->dFlags, (const u32*)dIds, (u32)ids.size());
+		ok = c->be.sync_ok();
+	}
+	c->be.free(dHeight); c->be.free(dIds);
+	c->haveSurface = false;
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device pass failed: " + c->be.error());
+}
+
+} // namespace
+
+int vx_grid_create_terrain(vx_ctx* c, uint32_t n, uint32_t seed)
+{
+	VX_ENTER(c);
+	if (!c || n < 16 || (n & 15) || n > VX_MAX_GRID) return fail(c, VX_ERR_INVALID, "vx_grid_create_terrain: n must be a multiple of 16 up to 2048");
+	const size_t tot = (size_t)n * n * n, blocks = (size_t)(n / 16) * (n / 16) * (n / 16);
+	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n && c->yBegin == 0 && c->yEnd == n)) {
+		release_grid(c);
+		c->dDist = c->be.alloc(tot); c->dMat = c->be.alloc(tot); c->dBlend = c->be.alloc(tot); c->dFlags = c->be.alloc(blocks);
+		c->ownsGrid = true;
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_create_terrain: device allocation failed: " + c->be.error()); }
+	}
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
+	return generate_terrain(c, seed, "vx_grid_create_terrain");
+}
+
+int vx_grid_fill_terrain(vx_ctx* c, uint32_t seed)
+{
+	VX_ENTER(c);
+	if (!c || !c->n || !c->dDist || !c->slabAxis) return fail(c, VX_ERR_INVALID, "vx_grid_fill_terrain: needs a slab attached with vx_grid_attach / vx_grid_attach_y");
+	return generate_terrain(c, seed, "vx_grid_fill_terrain");
+}
+
 int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 {
 	VX_ENTER(c);
