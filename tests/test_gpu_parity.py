@@ -223,19 +223,76 @@ def test_hip_256_properties(poly, port):
             assert np.all((np.abs(ln - 1) < 1e-4) | (ln == 0))
 
 
+_BENCH_ORACLE = {}
+
+
+def bench_oracle(port, n):
+    """The oracle's surface of the bench terrain (levels 0..3), computed once per size for the tests that compare with it."""
+    if n not in _BENCH_ORACLE:
+        from voxels_amd import synth
+        d, m, b = synth.terrain(n)
+        g = port.grid_from_dense(d, m, b)
+        _BENCH_ORACLE[n] = (port.execute(g).all_levels()[:4], np.ascontiguousarray(g.block_flags(), np.uint8))
+    return _BENCH_ORACLE[n]
+
+
 @pytest.mark.parametrize("n", [512, 1024])
 def test_hip_bench_terrain_full_parity(poly, port, n):
     """The bench workload itself (synthetic terrain, LOD levels 0..3) against the oracle port, every byte, twice
-    (pool offsets differ between runs, block contents must not)."""
-    from voxels_amd import synth
-    d, m, b = synth.terrain(n)
-    g = port.grid_from_dense(d, m, b)
-    ref = port.execute(g).all_levels()[:4]
-    poly.upload(d, m, b, g.block_flags())
+    (pool offsets differ between runs, block contents must not).  The grid is generated on the device, as bench.py does."""
+    ref, flags = bench_oracle(port, n)
+    poly.create_terrain(n)
     for _ in range(2):
         poly.execute(4)
         ok, msg = fields.surface_equal(poly.all_levels(), ref, nrm_tol=NRM_TOL)
         assert ok, msg
+
+
+@pytest.mark.parametrize("axis", ["y", "z"])
+def test_hip_config4_1024_eight_slabs(port, axis):
+    """BASELINE config 4 on one GPU: the 1024^3 terrain, LOD levels 0..3, cut into 8 slabs (128 voxels = one level-3 block
+    layer each) along y and along z.  Eight contexts hold one slab each — generated on the device, own layers only — the
+    halo comes from vx_halo_exchange_group, every context polygonizes its slab, and the merged result must be the
+    oracle's surface of the whole grid, every byte."""
+    import torch
+    from voxels_amd import Polygonizer
+    from voxels_amd.slab import SlabBuffers, merge_rank_levels
+    n, levels, world = 1024, 4, 8
+    ref, _ = bench_oracle(port, n)
+    dev = torch.device("cuda", 0)
+    polys, slabs = [], []
+    for r in range(world):
+        slab = SlabBuffers(torch, n, r, world, dev, axis=axis)
+        p = Polygonizer(device=0)
+        p.set_materials(vxo.default_lut())
+        slab.attach(p)
+        p.fill_terrain(1337)
+        # drop everything the rank does not own: halo layers and the other ranks' flags must come from the exchange
+        if axis == "z":
+            slab.dist[0].zero_(); slab.dist[-2:].zero_(); slab.mat[-1].zero_(); slab.blend[-1].zero_()
+        else:
+            slab.dist[:, 0].zero_(); slab.dist[:, -2:].zero_(); slab.mat[:, -1].zero_(); slab.blend[:, -1].zero_()
+        polys.append(p); slabs.append(slab)
+    torch.cuda.synchronize()
+    Polygonizer.halo_exchange_group(polys)
+    parts = []
+    for p in polys:
+        p.execute(levels)
+        parts.append(p.all_levels())
+        p.close()
+    del slabs
+    ok, msg = fields.surface_equal(merge_rank_levels(parts), ref, nrm_tol=NRM_TOL)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("seed", [300, 304, 317])
+def test_hip_slab_fuzz_seeds(seed):
+    """Three fixed configurations of tools/fuzz_slabs.py (random field kind, size, level limit, world size, axis): the
+    ranks' slabs polygonized one after the other merge into the whole-grid result of the same library."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_slabs
+    assert fuzz_slabs.check_seed(seed) is not None
 
 
 def test_hip_carve_modify_matches_reference_fixture(poly, port):

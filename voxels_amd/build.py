@@ -32,6 +32,17 @@ def build_hip(force=False, verbose=True):
     return out
 
 
+def build_hip_casedump(force=False):
+    """Test build of the HIP library that also records the case codes it looks up (tests/test_case_codes.py)."""
+    out = os.path.join(CSRC, "libvoxels_hip_casedump.so")
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_vertices.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_tables.inc")]
+    if not force and not _newer(out, srcs):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc] + HIP_FLAGS + ["-DVX_CASE_DUMP", "-o", out, os.path.join(CSRC, "vx_hip.hip")], cwd=CSRC)
+    return out
+
+
 def build_synth(force=False):
     """Host-side synthetic input generator (include/voxels_synth.h)."""
     out = os.path.join(CSRC, "libvoxels_synth.so")

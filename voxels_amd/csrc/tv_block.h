@@ -70,6 +70,12 @@ struct LevelDesc {
 	u16* ntCount;       // [cap] number of non-trivial cells of the block (picks the LDS capacity class)
 	BlockRecord* records; // [cap]
 	ListedBlock* listed;  // [cap] the level's block list (see ListedBlock)
+#if defined(VX_CASE_DUMP)
+	// test builds only (libvoxels_hip_casedump.so): the case code of every cell the passes looked up in Lengyel's tables,
+	// for tests/test_case_codes.py (case codes are not part of the public result)
+	u8* caseDump;         // [cap][4096] regular cells: CalcCaseCode of the non-trivial cells, 0 elsewhere
+	u16* trCaseDump;      // [cap][6 * 256] transition cells: the 9-bit code of the non-trivial ones, 0 elsewhere
+#endif
 	u32 cap;
 	u32 hasTransitions; // 0 < level < levelsCount - 1
 };
@@ -495,6 +501,9 @@ TV_HD void reg_phase_cells(ST& st, const Tables& T, const Globals& G, const Leve
 		const u32 code = reg_case_code(V);
 		const u32 zeroMask = reg_zero_mask(V);
 		st.cellBits[k] = (u16)(code | (zeroMask << 8));
+#if defined(VX_CASE_DUMP)
+		L.caseDump[(size_t)b.slot * BLOCK_CELLS + (u32)c] = (u8)code;
+#endif
 		st.info[k] = reg_slot_valid(T, zeroMask, code) << 16;
 		u32 m;
 		if (b.level == 0) m = mat_at(G.grid, (int)(b.bx * 16 + cx), (int)(b.by * 16 + cy), (int)(b.bz * 16 + cz));
@@ -965,6 +974,9 @@ TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const
 		tr_expand_values(v9, v);
 		st.cellOf[k] = (u16)c;
 		const u32 code = tr_case_code(v9);
+#if defined(VX_CASE_DUMP)
+		L.trCaseDump[(size_t)b.slot * TR_CELLS + (u32)c] = (u16)code;
+#endif
 		st.cellBits[k] = code | (tr_zero_mask(v) << 9);
 		st.valid[k] = (u16)tr_slot_valid(T, v, code);
 		int local[3];

@@ -166,6 +166,11 @@ bool ensure_level_tables(vx_ctx* c)
 		d.ntCount = (u16*)alloc(cap * 2);
 		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
 		d.listed = (ListedBlock*)alloc(cap * sizeof(ListedBlock));
+#if defined(VX_CASE_DUMP)
+		d.caseDump = (u8*)alloc(cap * BLOCK_CELLS);
+		d.trCaseDump = (u16*)alloc(cap * TR_CELLS * 2);
+		if (!d.caseDump || !d.trCaseDump) return false;
+#endif
 		d.nActive = (u32*)c->dHeader + L;
 		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.listed || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 		if (!L) {
@@ -980,6 +985,9 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		c->be.begin_timing();
 		c->be.stage_mark(0);
 		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS); // header = 0, slot maps = -1
+#if defined(VX_CASE_DUMP)
+		for (u32 L = 0; L < levels; ++L) { c->be.fill(c->lv[L].caseDump, 0, (size_t)c->lv[L].cap * BLOCK_CELLS); c->be.fill(c->lv[L].trCaseDump, 0, (size_t)c->lv[L].cap * TR_CELLS * 2); }
+#endif
 		run_pipeline(c, p, levels);
 		{
 			ListPlan plan;
@@ -1373,6 +1381,24 @@ int vx_device_block_table(vx_ctx* c, uint32_t level, const vx_listed_block** dTa
 	*nBlocks = c->listsReady ? (u32)c->blocks[level].size() : c->hdr[HDR_LISTS + level];
 	return VX_OK;
 }
+
+#if defined(VX_CASE_DUMP)
+// test builds only: the case codes the last full run looked up, per active block of a level (slot order)
+int vx_debug_case_dump(vx_ctx* c, uint32_t level, uint32_t cap, uint32_t* coords, uint8_t* cases, uint16_t* trCases, uint32_t* count)
+{
+	VX_ENTER(c);
+	if (!c || !c->haveSurface || level >= c->levelsRun || !count) return VX_ERR_INVALID;
+	*count = c->hdr[level];
+	if (*count > cap) return VX_OK;
+	const LevelDesc& d = c->lv[level];
+	bool ok = true;
+	if (*count) {
+		ok = c->be.d2h(coords, d.slotCoord, (size_t)*count * 4) && c->be.d2h(cases, d.caseDump, (size_t)*count * BLOCK_CELLS)
+		  && c->be.d2h(trCases, d.trCaseDump, (size_t)*count * TR_CELLS * 2);
+	}
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_debug_case_dump: download failed");
+}
+#endif
 
 int vx_set_stage_timing(vx_ctx* c, int enable)
 {

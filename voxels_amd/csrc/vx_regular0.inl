@@ -227,7 +227,7 @@ struct R0 {
 	};
 
 	// ---- one compact cell: case, reuse resolution, degenerate filter, counts ---------------------------------------
-	static __device__ __forceinline__ void cell(ST& st, const R0Tables& RT, const Tables& T, const R0Block& b, u32 k, u32* wgStats)
+	static __device__ __forceinline__ void cell(ST& st, const R0Tables& RT, const Tables& T, const LevelDesc& L, const R0Block& b, u32 k, u32* wgStats)
 	{
 		const u32 c = st.cellA[k] & 0xFFFu;
 		const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
@@ -236,6 +236,9 @@ struct R0 {
 		V[0] = sp[0]; V[1] = sp[1]; V[2] = sp[SROW]; V[3] = sp[SROW + 1];
 		V[4] = sp[SPLANE]; V[5] = sp[SPLANE + 1]; V[6] = sp[SPLANE + SROW]; V[7] = sp[SPLANE + SROW + 1];
 		const u32 code = reg_case_code(V), zeroMask = reg_zero_mask(V);
+#if defined(VX_CASE_DUMP)
+		L.caseDump[(size_t)b.slot * BLOCK_CELLS + c] = (u8)code;
+#endif
 		const int mo = cz * R0_MPLANE + cy * R0_MROW + cx;
 		const u32 myMat = st.matId[mo];
 		const u32 cls = RT.cls[code];
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		const u32 kBeg = min((u32)tid * per, nt), kEnd = min(kBeg + per, nt);
 		u32 sum = 0;
 		for (u32 k = kBeg; k < kEnd; ++k) {
-			K::cell(st, RT, T, cur, k, wgStats);
+			K::cell(st, RT, T, L, cur, k, wgStats);
 			sum += st.cellC[k];
 		}
 		R0_TICK(3);
