@@ -597,6 +597,15 @@ __device__ __forceinline__ u32 pyramid_row_quiet_mask(const Globals& G, const Le
 	return m;
 }
 
+// Load order of the 17 x 17 voxel rows of a classify tile: the 81 rows with even y and even z first (the only ones that
+// hold samples of the coarser levels' lattices), then the rest.  rr in [0, 289) -> (ry, rz).
+__device__ __forceinline__ void classify_row(int rr, int& ry, int& rz)
+{
+	if (rr < 81) { rz = 2 * (rr / 9); ry = 2 * (rr - (rr / 9) * 9); }
+	else if (rr < 153) { const int e = rr - 81; rz = 2 * (e >> 3); ry = 2 * (e & 7) + 1; }
+	else { const int e = rr - 153; rz = 2 * (e / 17) + 1; ry = e - (e / 17) * 17; }
+}
+
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
 constexpr int TW = TB / 2;        // 32-bit words of sign bits per tile row
 
@@ -648,8 +657,9 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	//      before the first sign mask is formed -------------------------------------------------------------
 	batched_gather<289 * TB, uint4, 6>(
 		[&](int q) {
-			const int r = q / TB, seg = q - r * TB;
-			const int ry = r % 17, rz = r / 17;
+			const int rr = q / TB, seg = q - rr * TB;
+			int ry, rz;
+			classify_row(rr, ry, rz);
 			uint4 d = make_uint4(0, 0, 0, 0);
 			const u32 cls = blockCls[seg];
 			if (cls & BC_QUIET) {
@@ -662,12 +672,14 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 			return d;
 		},
 		[&](int q, uint4 d) {
-			sgn[q] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
-			// the coarser levels' lattice copies: rows of this block layer, and the first rows beyond it where the rank's
+			const int rr = q / TB, seg = q - rr * TB;
+			int ry, rz;
+			classify_row(rr, ry, rz);
+			sgn[(rz * 17 + ry) * TB + seg] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
+			// the coarser levels' lattice copies (only rows with even y and z carry lattice samples: the first 81 rows of the
+			// load order, so whole waves skip this): rows of this block layer, and the first rows beyond it where the rank's
 			// blocks end (nobody else would write those)
-			const int r = q / TB, seg = q - r * TB;
-			const int ry = r % 17, rz = r / 17;
-			if ((ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
+			if (rr < 81 && (ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
 				pyramid_write_segment(p.G, n, x0 + seg * 16, (int)by * 16 + ry, (int)bz * 16 + rz, d);
 		});
 	batched_gather<289, i8, 2>(
@@ -1214,32 +1226,31 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 template <int F>
 __device__ __forceinline__ void tr_face_request(const GridView& g, const RegBlockCtx& b, u32 on, int tid, i8 (&v)[5])
 {
-#pragma unroll
-	for (int q = 0; q < 5; ++q) v[q] = 0;
-	if (!((on >> F) & 1u)) return;
+	// a face without a neighbour block is requested all the same (its plane clamped into the grid) and zeroed by
+	// tr_face_store: a branch around the loads would end with a wait for them, one round trip per face
 	const FaceGeom fg = face_geom(F);
 	const int n = g.n, mult = (int)b.mult, half = mult >> 1;
 	int o[3] = { (int)(b.bx * 16) * mult, (int)(b.by * 16) * mult, (int)(b.bz * 16) * mult };
 	const int maxU = n - 1 - o[fg.ua], maxV = n - 1 - o[fg.va];
-	if (fg.positive) o[fg.axis] += 16 * mult;
+	if (fg.positive) o[fg.axis] = min(o[fg.axis] + 16 * mult, n - 1);
 	const i8* base = g.dist + dist_offset(g, o[0], o[1], o[2]);
 	const u32 stride[3] = { 1u, (u32)n, (u32)g.pitchY * (u32)n };
 	const u32 su = stride[fg.ua], sv = stride[fg.va];
+	// no load is conditional (a load with a default value is waited for on the spot: 15 round trips instead of one);
+	// lanes beyond the plane re-read its last sample and tr_face_store drops it
 #pragma unroll
 	for (int q = 0; q < 5; ++q) {
-		const int r = tid + q * WG;
-		if (r < PLANE) {
-			const int vv = r / 33, uu = r - vv * 33;
-			const u32 off = (u32)min(uu * half, maxU) * su + (u32)min(vv * half, maxV) * sv;
-			v[q] = base[off];
-		}
+		const int r = min(tid + q * WG, PLANE - 1);
+		const int vv = r / 33, uu = r - vv * 33;
+		const u32 off = (u32)min(uu * half, maxU) * su + (u32)min(vv * half, maxV) * sv;
+		v[q] = base[off];
 	}
 }
 
-__device__ __forceinline__ void tr_face_store(i8* plane, int tid, const i8 (&v)[5])
+__device__ __forceinline__ void tr_face_store(i8* plane, int tid, const i8 (&v)[5], bool faceOn)
 {
 #pragma unroll
-	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) plane[r] = v[q]; }
+	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) plane[r] = faceOn ? v[q] : (i8)0; }
 }
 
 __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
@@ -1263,6 +1274,13 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 	const Tables T = stage_transition_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
 
+#if defined(VX_TR_PROFILE)
+	u32 prof[24] = { 0 };
+	unsigned long long tick = __builtin_readcyclecounter();
+#define TR_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
+#else
+#define TR_TICK(i) do { } while (0)
+#endif
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
@@ -1282,35 +1300,35 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 				const FaceGeom fg = face_geom(f);
 				if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
 			}
-			__syncthreads();
+			__syncthreads(); TR_TICK(2);
 			if (tid == 0) st.faceOn = on;
 			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
 			// 33 x 33 samples per face; three faces (15 loads per lane) are in flight together
 			i8 v[3][5];
 			tr_face_request<0>(p.G.grid, b, on, tid, v[0]); tr_face_request<1>(p.G.grid, b, on, tid, v[1]); tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
-			tr_face_store(st.plane[0], tid, v[0]); tr_face_store(st.plane[1], tid, v[1]); tr_face_store(st.plane[2], tid, v[2]);
+			tr_face_store(st.plane[0], tid, v[0], (on & 1u) != 0); tr_face_store(st.plane[1], tid, v[1], (on & 2u) != 0); tr_face_store(st.plane[2], tid, v[2], (on & 4u) != 0);
 			tr_face_request<3>(p.G.grid, b, on, tid, v[0]); tr_face_request<4>(p.G.grid, b, on, tid, v[1]); tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
-			tr_face_store(st.plane[3], tid, v[0]); tr_face_store(st.plane[4], tid, v[1]); tr_face_store(st.plane[5], tid, v[2]);
+			tr_face_store(st.plane[3], tid, v[0], (on & 8u) != 0); tr_face_store(st.plane[4], tid, v[1], (on & 16u) != 0); tr_face_store(st.plane[5], tid, v[2], (on & 32u) != 0);
 		}
-		__syncthreads();
+		__syncthreads(); TR_TICK(3);
 		tr_phase_classify(st, tid, WG);
-		__syncthreads();
+		__syncthreads(); TR_TICK(4);
 		for (int f0 = 0; f0 < 6;) {
 			const int f1 = tr_batch_end(st, f0); // uniform
-			__syncthreads();
+			__syncthreads(); TR_TICK(5);
 			tr_phase_batch_bits(st, f0, f1, tid, WG);
 			if (tid == 0) { st.vTotal = st.iTotal = st.vOff = st.iOff = 0; }
-			__syncthreads();
+			__syncthreads(); TR_TICK(6);
 			{
 				const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
 				if (tid == 0) st.wordPrefix[48] = (u16)nt;
 			}
-			__syncthreads();
+			__syncthreads(); TR_TICK(7);
 			if (st.wordPrefix[48] != 0) {
 				tr_phase_list(st, T, L, b, tid, WG);
-				__syncthreads();
+				__syncthreads(); TR_TICK(8);
 				tr_phase_count(st, T, tid, WG);
-				__syncthreads();
+				__syncthreads(); TR_TICK(9);
 				{
 					const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
 					const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
@@ -1320,26 +1338,30 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 						st.iOff = atomicAdd(&p.P.cursors[CUR_I], it2);
 					}
 				}
-				__syncthreads();
+				__syncthreads(); TR_TICK(10);
 				for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
-					if (chunk) __syncthreads();
+					if (chunk) __syncthreads(); TR_TICK(11);
 					tr_phase_describe(st, chunk, tid, WG);
-					__syncthreads();
+					__syncthreads(); TR_TICK(12);
 					tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
 				}
 				for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
-					__syncthreads();
+					__syncthreads(); TR_TICK(13);
 					tr_phase_stage_indices(st, T, chunk, tid, WG);
-					__syncthreads();
+					__syncthreads(); TR_TICK(14);
 					tr_phase_flush_indices(st, T, p.P, chunk, tid, WG);
 				}
 			}
 			tr_phase_record(st, L, b, p.P, f0, f1, tid);
 			f0 = f1;
 		}
-		__syncthreads();
+		__syncthreads(); TR_TICK(15);
 	}
+#if defined(VX_TR_PROFILE)
+	if (tid == 0) for (int i = 0; i < 24; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[16 + i], prof[i] >> 6); // header words 192..215
+#endif
 }
+
 
 // ------------------------------------------------------------------------------------------------------
 // incremental (Modification) runs: classify only the dirty level-0 blocks, list the slots to rebuild

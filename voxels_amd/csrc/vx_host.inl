@@ -39,7 +39,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 192, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -1041,6 +1041,13 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
+#if defined(VX_TR_PROFILE)
+	{
+		unsigned long long sum = 0;
+		for (int i = 0; i < 24; ++i) sum += c->hdr[HDR_LARGE + 16 + i];
+		for (int i = 0; i < 24; ++i) if (c->hdr[HDR_LARGE + 16 + i]) fprintf(stderr, "[transition profile] tick %2d %10u x64 cycles  %5.1f %%\n", i, c->hdr[HDR_LARGE + 16 + i], 100.0 * c->hdr[HDR_LARGE + 16 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_MAT_PROFILE)
 	{
 		static const char* names[10] = { "prologue", "stores + next coords + barrier", "requests + init + barrier", "samples + barrier", "classify + barrier", "select + barrier", "vote + barrier", "-", "-", "tail" };
