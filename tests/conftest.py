@@ -9,3 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """torch's bundled HIP runtime has to initialise before libvoxels_hip.so brings in the system one, whatever the
+    order the test modules load them in (the slab tests hand torch device tensors to the library)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield

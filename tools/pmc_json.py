@@ -5,8 +5,8 @@ import json
 import re
 import sys
 
-CLASSES = {"k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular": "k_regular",
-           "k_block_summary": "k_classify", "k_block_class": "k_classify"}
+CLASSES = {"k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular0": "k_regular0",
+           "k_regular": "k_regular", "k_block_summary": "k_classify", "k_block_class": "k_classify", "k_list": "k_lists"}
 
 
 def parse(path):
@@ -18,6 +18,8 @@ def parse(path):
             name, counter, samples, total = parts[0], parts[1], int(parts[2]), float(parts[3])
             for key, cls in CLASSES.items():
                 if key in name:
+                    if key == "k_regular" and "k_regular0" in name:
+                        continue
                     sums.setdefault(cls, {}).setdefault(counter, 0.0)
                     sums[cls][counter] += total
                     if key == "k_classify":
@@ -33,14 +35,17 @@ def main():
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) of "
                      "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; summaries committed as profiles/%s_pmc_*.txt" % label,
            "units": "FETCH_SIZE/WRITE_SIZE are KiB, summed over the dispatches of a kernel and divided by the number of polygonizations",
-           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced (16 B/lane) "
-                         "reads. k_classify's density stream is 16 B/lane, so its FETCH_SIZE is doubled; the other kernels read with 1-8 byte "
-                         "gathers (uncalibrated, taken as reported). WRITE_SIZE is uncalibrated."}
+           "correction": "calibrated on known access patterns (tools/pmc_calib.hip, profiles/%s_pmc_calibration.txt): on gfx950 FETCH_SIZE "
+                         "reports exactly half of the bytes of the 128-byte lines a kernel pulls in, for every access width tried (16 / 8 / 4 / 1 bytes "
+                         "per lane, contiguous or strided up to one byte per line) - every kernel's FETCH_SIZE is doubled; WRITE_SIZE equals the bytes "
+                         "written (16-byte, 4-byte and 48-byte-record stores) and is taken as reported." % label}
     fk = {k: v.get("FETCH_SIZE", 0.0) / max(ex1, 1) for k, v in fetch.items()}
     wk = {k: v.get("WRITE_SIZE", 0.0) / max(ex2, 1) for k, v in write.items()}
     out["fetch_kib_per_execute"] = {k: round(v, 1) for k, v in fk.items()}
     out["write_kib_per_execute"] = {k: round(v, 1) for k, v in wk.items()}
-    out["hbm_bytes_per_launch"] = {k: int((fk.get(k, 0.0) * (2.0 if k == "k_classify" else 1.0) + wk.get(k, 0.0)) * 1024) for k in fk}
+    out["read_bytes_per_launch"] = {k: int(fk[k] * 2.0 * 1024) for k in fk}
+    out["write_bytes_per_launch"] = {k: int(wk.get(k, 0.0) * 1024) for k in fk}
+    out["hbm_bytes_per_launch"] = {k: int((fk.get(k, 0.0) * 2.0 + wk.get(k, 0.0)) * 1024) for k in fk}
     try:
         tcc, _ = parse(d + "/pass3.txt")
         out["l2_hit_rate"] = {k: round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 3) for k, v in tcc.items()}

@@ -1,6 +1,7 @@
 """ctypes binding of include/voxels_hip.h (libvoxels_hip.so)."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -45,6 +46,11 @@ class HipLibrary:
             raise VoxelsHipError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        # torch wheels bundle their own HIP runtime; when torch is in the process it has to initialise before the
+        # system runtime this library links (the other order leaves torch without a visible GPU)
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.init()
         lib = C.CDLL(path)
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
         lib.vx_backend.restype = C.c_char_p
