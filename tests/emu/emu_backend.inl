@@ -9,6 +9,8 @@ struct Backend {
 
 	bool init(int, std::string&) { return true; }
 	bool wants_pyramid() const { return false; }
+	bool wants_bricks() const { return false; } // the emulation reads the dense fields
+	void run_rebrick(const GridView&, const int*, const int*, const int*, const u32*, u32) {}
 	void make_current() {} // the emulated phases sample the grid directly
 	void shutdown() {}
 	void set_stream(void*) {}

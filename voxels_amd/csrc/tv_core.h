@@ -112,6 +112,13 @@ TV_HD Tables tables_from_image(const u8* base)
 // grid plus halo: the z-planes [zOrigin, ...) and, within every plane, the rows [yOrigin, yOrigin + pitchY) (a whole
 // grid has zOrigin = yOrigin = 0 and pitchY = n; slabs are cut along z OR along y).  Coordinates are always global
 // and are clamped to the GLOBAL extent [0, n-1] exactly like the reference clamps every fetch.
+//
+// Brick mirrors (GPU backend): the same three fields a second time, block-major — the 4096 bytes of a 16^3 block are
+// contiguous, inside it 128-byte tiles of 16 x 4 x 2 voxels (brick_local).  The dense fields are the interchange layout
+// (uploads, attached slabs, the grid file codec, edits, halo messages, the streaming classify pass); everything that
+// gathers around the surface — block neighbourhoods, boundary planes, the samples around a vertex — reads the bricks:
+// a dense row puts 16 useful bytes into every 128-byte line it touches and a plane x = const one, a tile 128 / 8.  The
+// mirrors are brought up to date where the grid changes (vx_host.inl: rebrick), never by a polygonization.
 struct GridView {
 	const i8* dist;
 	const u8* mat;
@@ -121,6 +128,11 @@ struct GridView {
 	int zOriginMat; // global z of plane 0 of mat[] / blend[]
 	int yOrigin, yOriginMat; // global y of row 0 of every plane
 	int pitchY, pitchYMat;   // rows per plane
+	const i8* bDist;         // brick mirrors (nullptr: none — the CPU emulation reads the dense fields)
+	const u8* bMat;
+	const u8* bBlend;
+	int bYb0, bZb0;          // first resident block row / block plane of the mirrors (halo layers included)
+	int bRowsY;              // resident block rows per block plane
 };
 
 TV_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -129,18 +141,34 @@ TV_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v)
 TV_HD size_t dist_offset(const GridView& g, int x, int y, int z) { return ((size_t)(z - g.zOrigin) * g.pitchY + (y - g.yOrigin)) * g.n + x; }
 TV_HD size_t mat_offset(const GridView& g, int x, int y, int z) { return ((size_t)(z - g.zOriginMat) * g.pitchYMat + (y - g.yOriginMat)) * g.n + x; }
 
+// brick mirrors: byte offset of voxel (x,y,z) of a block (0..15 each) inside its brick: tile (y >> 2, z >> 1) of 16 x 4 x 2
+// voxels = one 128-byte line, tiles ordered y fastest; a voxel row (16 bytes) stays contiguous
+enum { BRICK_BYTES = 4096 };
+TV_HD u32 brick_local(u32 x, u32 y, u32 z) { return ((z >> 1) << 9) | ((y >> 2) << 7) | ((z & 1u) << 6) | ((y & 3u) << 4) | x; }
+TV_HD size_t brick_base(const GridView& g, int bx, int by, int bz) { return (((size_t)(bz - g.bZb0) * (size_t)g.bRowsY + (size_t)(by - g.bYb0)) * (size_t)(g.n >> 4) + (size_t)bx) * BRICK_BYTES; }
+TV_HD size_t brick_offset(const GridView& g, int x, int y, int z) { return brick_base(g, x >> 4, y >> 4, z >> 4) + brick_local((u32)x & 15u, (u32)y & 15u, (u32)z & 15u); }
+
 TV_HD int dist_at(const GridView& g, int x, int y, int z)
 {
 	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+	return g.bDist[brick_offset(g, x, y, z)];
+#else
 	return g.dist[dist_offset(g, x, y, z)];
+#endif
 }
 
 // material info packed as id | blend << 8
 TV_HD u32 mat_at(const GridView& g, int x, int y, int z)
 {
 	x = clampi(x, 0, g.n - 1); y = clampi(y, 0, g.n - 1); z = clampi(z, 0, g.n - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+	const size_t i = brick_offset(g, x, y, z);
+	return (u32)g.bMat[i] | ((u32)g.bBlend[i] << 8);
+#else
 	const size_t i = mat_offset(g, x, y, z);
 	return (u32)g.mat[i] | ((u32)g.blend[i] << 8);
+#endif
 }
 
 TV_HD void normalize_fix_zero(float v[3])

@@ -476,6 +476,44 @@ __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, co
 	if (sb) *(uint4*)(blend + rowOff) = *(const uint4*)(sb + srcOff);
 }
 
+// k_rebrick: dense fields -> brick mirrors (tv_core.h GridView).  Box mode (ids == nullptr): a workgroup copies the 8
+// x-neighbour blocks that share the 128-byte lines of their voxel rows, 8 consecutive lanes per line; list mode: one
+// block per workgroup, one voxel row per lane.  Only rows that are resident in the dense fields are copied (a slab's halo
+// block layers hold a few planes / rows each).
+struct RebrickRanges { int dz0, dz1, dy0, dy1, mz0, mz1, my0, my1; };
+
+__device__ __forceinline__ void rebrick_row(const GridView& g, const RebrickRanges& r, int bx, int gy, int gz)
+{
+	const size_t dst = brick_base(g, bx, gy >> 4, gz >> 4) + brick_local(0u, (u32)gy & 15u, (u32)gz & 15u);
+	if (gz >= r.dz0 && gz < r.dz1 && gy >= r.dy0 && gy < r.dy1)
+		*(uint4*)(const_cast<i8*>(g.bDist) + dst) = *(const uint4*)(g.dist + dist_offset(g, bx * 16, gy, gz));
+	if (gz >= r.mz0 && gz < r.mz1 && gy >= r.my0 && gy < r.my1) {
+		const size_t src = mat_offset(g, bx * 16, gy, gz);
+		*(uint4*)(const_cast<u8*>(g.bMat) + dst) = *(const uint4*)(g.mat + src);
+		*(uint4*)(const_cast<u8*>(g.bBlend) + dst) = *(const uint4*)(g.blend + src);
+	}
+}
+
+__global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, int yb0, int ybCount, int zb0, const u32* ids)
+{
+	const int nb = g.n >> 4, tid = (int)threadIdx.x;
+	if (ids) {
+		const u32 id = ids[blockIdx.x];
+		const int bx = (int)(id % (u32)nb), by = (int)((id / (u32)nb) % (u32)nb), bz = (int)(id / (u32)(nb * nb));
+		rebrick_row(g, r, bx, by * 16 + (tid & 15), bz * 16 + (tid >> 4));
+		return;
+	}
+	const int groups = (nb + 7) >> 3;
+	const int gx = (int)blockIdx.x % groups, by = yb0 + ((int)blockIdx.x / groups) % ybCount, bz = zb0 + (int)blockIdx.x / (groups * ybCount);
+	const int bx = gx * 8 + (tid & 7);
+	if (bx >= nb) return;
+#pragma unroll
+	for (int it = 0; it < 8; ++it) {
+		const int row = it * 32 + (tid >> 3);
+		rebrick_row(g, r, bx, by * 16 + (row & 15), bz * 16 + (row >> 4));
+	}
+}
+
 // ---- start of a full run: header = 0, block -> slot maps = -1 (one launch instead of a memset per array) -------------
 struct ResetRanges {
 	u32* header;
@@ -995,10 +1033,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		//      inside the grid; entries the consistency bits rule out are masked after the fact. ----------------------------
 		{
 			const int nVote = (int)st.voteCount;
-			const size_t matOrigin = mat_offset(g, (int)(bx * 32), (int)(by * 32), (int)(bz * 32));
-			const u8* matBase = g.mat + matOrigin;
-			const u8* blendBase = g.blend + matOrigin;
-			const int pitchMat = g.pitchYMat;
+			// the children's materials come from the brick mirrors: the 2 x 2 x 2 child blocks are 8 consecutive-in-x pairs of
+			// 4 KB bricks, a cell's 8 children sit in 2 lines per field (4 in the dense fields)
+			const size_t childOrigin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
+			const u8* matBase = g.bMat + childOrigin;
+			const u8* blendBase = g.bBlend + childOrigin;
+			const u32 brickRow = (u32)(g.n >> 4) * BRICK_BYTES, brickPlane = (u32)g.bRowsY * brickRow; // next child block along y / z
 			if (level == 1) {
 				constexpr int VB = 2;
 				for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
@@ -1009,7 +1049,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
 #pragma unroll
 						for (int q = 0; q < 4; ++q) {
-							const u32 off = (u32)(((2 * lz + (q >> 1)) * pitchMat + 2 * ly + (q & 1)) * n + 2 * lx);
+							const u32 cx = 2u * (u32)lx, cy = 2u * (u32)ly + (u32)(q & 1), cz = 2u * (u32)lz + (u32)(q >> 1);
+							const u32 off = (cz >> 4) * brickPlane + (cy >> 4) * brickRow + (cx >> 4) * BRICK_BYTES + brick_local(cx & 15u, cy & 15u, cz & 15u);
 							mat2[v][q] = *(const u16*)(matBase + off);
 							bl2[v][q] = *(const u16*)(blendBase + off);
 						}
@@ -1233,17 +1274,18 @@ __device__ __forceinline__ void tr_face_request(const GridView& g, const RegBloc
 	int o[3] = { (int)(b.bx * 16) * mult, (int)(b.by * 16) * mult, (int)(b.bz * 16) * mult };
 	const int maxU = n - 1 - o[fg.ua], maxV = n - 1 - o[fg.va];
 	if (fg.positive) o[fg.axis] = min(o[fg.axis] + 16 * mult, n - 1);
-	const i8* base = g.dist + dist_offset(g, o[0], o[1], o[2]);
-	const u32 stride[3] = { 1u, (u32)n, (u32)g.pitchY * (u32)n };
-	const u32 su = stride[fg.ua], sv = stride[fg.va];
 	// no load is conditional (a load with a default value is waited for on the spot: 15 round trips instead of one);
-	// lanes beyond the plane re-read its last sample and tr_face_store drops it
+	// lanes beyond the plane re-read its last sample and tr_face_store drops it.  The samples come from the brick mirror:
+	// a plane x = const puts 8 of its samples into every 128-byte line it touches (one in the dense field).
 #pragma unroll
 	for (int q = 0; q < 5; ++q) {
 		const int r = min(tid + q * WG, PLANE - 1);
 		const int vv = r / 33, uu = r - vv * 33;
-		const u32 off = (u32)min(uu * half, maxU) * su + (u32)min(vv * half, maxV) * sv;
-		v[q] = base[off];
+		int c[3];
+		c[fg.axis] = o[fg.axis];
+		c[fg.ua] = o[fg.ua] + min(uu * half, maxU);
+		c[fg.va] = o[fg.va] + min(vv * half, maxV);
+		v[q] = g.bDist[brick_offset(g, c[0], c[1], c[2])];
 	}
 }
 
@@ -1613,6 +1655,21 @@ struct Backend {
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
 	bool wants_pyramid() const { return true; }
+	bool wants_bricks() const { return true; }
+	// dense fields -> brick mirrors: the blocks of the box { yb0, yb1, zb0, zb1 } (all x), or the listed blocks
+	void run_rebrick(const GridView& g, const int dr[4], const int mr[4], const int box[4], const u32* ids, u32 count)
+	{
+		const RebrickRanges r = { dr[0], dr[1], dr[2], dr[3], mr[0], mr[1], mr[2], mr[3] };
+		if (ids) {
+			hipLaunchKernelGGL(k_rebrick, dim3(count), dim3(WG), 0, stream, g, r, 0, 1, 0, ids);
+		} else {
+			const int nb = g.n >> 4, groups = (nb + 7) >> 3;
+			const int yc = box[1] - box[0], zc = box[3] - box[2];
+			if (yc <= 0 || zc <= 0) return;
+			hipLaunchKernelGGL(k_rebrick, dim3((u32)(groups * yc * zc)), dim3(WG), 0, stream, g, r, box[0], yc, box[2], (const u32*)nullptr);
+		}
+		check(hipGetLastError(), "k_rebrick launch");
+	}
 	void make_current() { (void)hipSetDevice(device); }
 	void set_stream(void* s) { stream = s ? (hipStream_t)s : ownStream; }
 	std::string error() const { return lastError; }

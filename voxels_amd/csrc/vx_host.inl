@@ -55,6 +55,11 @@ struct vx_ctx {
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
+	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
+	// planes [brickZb0, +brickPlanesZ); stale = everything has to be copied again before the next polygonization
+	void* dBrick[3] = { nullptr, nullptr, nullptr };
+	u32 brickN = 0, brickYb0 = 0, brickZb0 = 0, brickRowsY = 0, brickPlanesZ = 0;
+	bool bricksStale = true;
 	void* dListCounts = nullptr;                         // per-workgroup counts of the list kernels
 	void* haloBuf[4] = { nullptr, nullptr, nullptr, nullptr }; // staging of the halo messages: send below, send above, receive from below, receive from above
 	size_t haloCap[4] = { 0, 0, 0, 0 };
@@ -128,6 +133,83 @@ void release_grid(vx_ctx* c)
 	c->dDist = c->dMat = c->dBlend = c->dFlags = nullptr;
 	c->ownsGrid = false;
 	c->slabAxis = 0;
+	c->bricksStale = true;
+}
+
+void free_bricks(vx_ctx* c)
+{
+	for (void*& b : c->dBrick) { c->be.free(b); b = nullptr; }
+	c->brickN = 0;
+	c->bricksStale = true;
+}
+
+// layers of the dense fields that are resident, in global coordinates: { z0, z1, y0, y1 } for the distance field (dr) and
+// for material / blend (mr).  A slab carries 1 distance layer below and 2 above, 1 material layer above
+// (include/voxels_hip.h), clamped to the grid.
+void resident_ranges(const vx_ctx* c, int dr[4], int mr[4])
+{
+	const int N = (int)c->n;
+	const bool alongY = c->slabAxis == 2, slab = c->slabAxis != 0;
+	const int zb = (int)c->zBegin, ze = (int)c->zEnd, yb = (int)c->yBegin, ye = (int)c->yEnd;
+	dr[0] = (slab && !alongY) ? std::max(zb - 1, 0) : 0; dr[1] = (slab && !alongY) ? std::min(ze + 2, N) : N;
+	dr[2] = (slab && alongY) ? std::max(yb - 1, 0) : 0;  dr[3] = (slab && alongY) ? std::min(ye + 2, N) : N;
+	mr[0] = (slab && !alongY) ? zb : 0; mr[1] = (slab && !alongY) ? std::min(ze + 1, N) : N;
+	mr[2] = (slab && alongY) ? yb : 0;  mr[3] = (slab && alongY) ? std::min(ye + 1, N) : N;
+}
+
+GridView resident_view(const vx_ctx* c)
+{
+	GridView g;
+	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
+	g.n = (int)c->n; g.zOrigin = c->distZ0; g.zOriginMat = c->matZ0; g.yOrigin = c->distY0; g.yOriginMat = c->matY0;
+	g.pitchY = (int)c->distRows; g.pitchYMat = (int)c->matRows;
+	g.bDist = (const i8*)c->dBrick[0]; g.bMat = (const u8*)c->dBrick[1]; g.bBlend = (const u8*)c->dBrick[2];
+	g.bYb0 = (int)c->brickYb0; g.bZb0 = (int)c->brickZb0; g.bRowsY = (int)c->brickRowsY;
+	return g;
+}
+
+// Brick mirrors allocated for the resident block layers (halo layers included) and brought up to date.  Called at the
+// start of every polygonization; between runs the mutation entry points re-copy what they touched (rebrick_*), so a run on
+// an unchanged grid finds nothing to do here.
+bool ensure_bricks(vx_ctx* c)
+{
+	if (!c->be.wants_bricks()) return true;
+	const u32 nb = c->n / 16;
+	int dr[4], mr[4];
+	resident_ranges(c, dr, mr);
+	const u32 zb0 = (u32)dr[0] / 16, zb1 = ((u32)dr[1] + 15) / 16, yb0 = (u32)dr[2] / 16, yb1 = ((u32)dr[3] + 15) / 16;
+	if (!c->dBrick[0] || c->brickN != c->n || c->brickYb0 != yb0 || c->brickZb0 != zb0 || c->brickRowsY != yb1 - yb0 || c->brickPlanesZ != zb1 - zb0) {
+		free_bricks(c);
+		const size_t bytes = (size_t)nb * (yb1 - yb0) * (zb1 - zb0) * BRICK_BYTES;
+		for (void*& b : c->dBrick) b = c->be.alloc(bytes);
+		if (!c->dBrick[0] || !c->dBrick[1] || !c->dBrick[2]) { free_bricks(c); return false; }
+		c->brickN = c->n; c->brickYb0 = yb0; c->brickZb0 = zb0; c->brickRowsY = yb1 - yb0; c->brickPlanesZ = zb1 - zb0;
+	}
+	if (c->bricksStale) {
+		const int box[4] = { (int)yb0, (int)yb1, (int)zb0, (int)zb1 };
+		c->be.run_rebrick(resident_view(c), dr, mr, box, nullptr, 0);
+		c->bricksStale = false;
+	}
+	return true;
+}
+
+// the mirrors of the listed blocks (device id list) / of a box of blocks follow a change of the dense fields; nothing to
+// do while the mirrors wait for a full copy anyway
+void rebrick_blocks(vx_ctx* c, const u32* dIds, u32 count)
+{
+	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0] || !count) return;
+	int dr[4], mr[4];
+	resident_ranges(c, dr, mr);
+	c->be.run_rebrick(resident_view(c), dr, mr, nullptr, dIds, count);
+}
+
+void rebrick_box(vx_ctx* c, int yb0, int yb1, int zb0, int zb1)
+{
+	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0]) return;
+	int dr[4], mr[4];
+	resident_ranges(c, dr, mr);
+	const int box[4] = { yb0, yb1, zb0, zb1 };
+	c->be.run_rebrick(resident_view(c), dr, mr, box, nullptr, 0);
 }
 
 bool ensure_level_tables(vx_ctx* c)
@@ -218,14 +300,7 @@ bool ensure_pools(vx_ctx* c, u32 needVerts, u32 needIdx)
 void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 {
 	memset(&p, 0, sizeof(p));
-	p.G.grid.dist = (const i8*)c->dDist;
-	p.G.grid.mat = (const u8*)c->dMat;
-	p.G.grid.blend = (const u8*)c->dBlend;
-	p.G.grid.n = (int)c->n;
-	p.G.grid.zOrigin = c->distZ0;
-	p.G.grid.zOriginMat = c->matZ0;
-	p.G.grid.yOrigin = c->distY0; p.G.grid.yOriginMat = c->matY0;
-	p.G.grid.pitchY = (int)c->distRows; p.G.grid.pitchYMat = (int)c->matRows;
+	p.G.grid = resident_view(c);
 	p.G.emptyFlags = (const u8*)c->dFlags;
 	p.G.lut = (const u8*)c->dLut;
 	p.G.stats = (u32*)c->dHeader + HDR_STATS;
@@ -410,6 +485,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	if (!c) return;
 	c->be.sync();
 	release_grid(c);
+	free_bricks(c);
 	free_level_tables(c);
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
@@ -450,6 +526,7 @@ int vx_grid_upload(vx_ctx* c, uint32_t n, const int8_t* dist, const uint8_t* mat
 	ok = ok && (mat ? c->be.h2d(c->dMat, mat, tot) : c->be.fill(c->dMat, 0, tot));
 	ok = ok && (blend ? c->be.h2d(c->dBlend, blend, tot) : c->be.fill(c->dBlend, 0, tot));
 	c->haveSurface = false;
+	c->bricksStale = true;
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload: copy failed: " + c->be.error());
 }
 
@@ -468,13 +545,11 @@ int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
+	c->bricksStale = true;
 	void* dMap = c->be.alloc((size_t)n * n);
 	bool ok = dMap && c->be.h2d(dMap, heightmap, (size_t)n * n) && c->be.fill(c->dMat, 0, tot) && c->be.fill(c->dBlend, 0, tot);
 	if (ok) {
-		GridView g;
-		g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-		g.n = (int)n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)n; g.pitchYMat = (int)n;
-		c->be.run_heightmap(g, (const i8*)dMap, (u8*)c->dFlags);
+		c->be.run_heightmap(resident_view(c), (const i8*)dMap, (u8*)c->dFlags);
 		ok = c->be.sync_ok();
 	}
 	c->be.free(dMap);
@@ -483,28 +558,13 @@ int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 
 namespace {
 
-GridView resident_view(const vx_ctx* c)
-{
-	GridView g;
-	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-	g.n = (int)c->n; g.zOrigin = c->distZ0; g.zOriginMat = c->matZ0; g.yOrigin = c->distY0; g.yOriginMat = c->matY0;
-	g.pitchY = (int)c->distRows; g.pitchYMat = (int)c->matRows;
-	return g;
-}
-
 // the synthetic terrain over everything resident (own layers + halo, clamped to the grid) + flags of the own blocks
 int generate_terrain(vx_ctx* c, u32 seed, const char* what)
 {
 	const u32 n = c->n, nb = n / 16;
-	const int N = (int)n;
-	const bool alongY = c->slabAxis == 2;
 	const int zb = (int)c->zBegin, ze = (int)c->zEnd, yb = (int)c->yBegin, ye = (int)c->yEnd;
-	const bool slab = c->slabAxis != 0;
-	// resident layers: a slab carries 1 distance layer below and 2 above, 1 material layer above (include/voxels_hip.h)
-	const int dr[4] = { (slab && !alongY) ? std::max(zb - 1, 0) : 0, (slab && !alongY) ? std::min(ze + 2, N) : N,
-	                    (slab && alongY) ? std::max(yb - 1, 0) : 0, (slab && alongY) ? std::min(ye + 2, N) : N };
-	const int mr[4] = { (slab && !alongY) ? zb : 0, (slab && !alongY) ? std::min(ze + 1, N) : N,
-	                    (slab && alongY) ? yb : 0, (slab && alongY) ? std::min(ye + 1, N) : N };
+	int dr[4], mr[4];
+	resident_ranges(c, dr, mr);
 	std::vector<u32> ids;
 	for (u32 z = (u32)zb / 16; z < (u32)ze / 16; ++z) for (u32 y = (u32)yb / 16; y < (u32)ye / 16; ++y) for (u32 x = 0; x < nb; ++x) ids.push_back((z * nb + y) * nb + x);
 	void* dHeight = c->be.alloc((size_t)n * n * 4);
@@ -516,6 +576,7 @@ int generate_terrain(vx_ctx* c, u32 seed, const char* what)
 	}
 	c->be.free(dHeight); c->be.free(dIds);
 	c->haveSurface = false;
+	c->bricksStale = true;
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device pass failed: " + c->be.error());
 }
 
@@ -577,6 +638,7 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
+	c->bricksStale = true;
 	void* dBlob = c->be.alloc(off + 16);
 	void* dWhere = c->be.alloc(where.size() * 8);
 	bool ok = dBlob && dWhere && c->be.h2d(dBlob, blob, off) && c->be.h2d(dWhere, where.data(), where.size() * 8);
@@ -595,9 +657,7 @@ int vx_grid_pack(vx_ctx* c, void* out, uint64_t capacity, uint64_t* size)
 	if (!c->n || !c->dDist || (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n)) return fail(c, VX_ERR_INVALID, "vx_grid_pack: needs a whole grid resident");
 	const u32 n = c->n, nb = n / 16;
 	const size_t blocks = (size_t)nb * nb * nb;
-	GridView g;
-	g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-	g.n = (int)n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)n; g.pitchYMat = (int)n;
+	const GridView g = resident_view(c);
 	// pass 1: stream sizes + flags of every block
 	void* dMeta = c->be.alloc(blocks * 16);
 	std::vector<u32> meta(blocks * 4);
@@ -666,6 +726,7 @@ int vx_grid_attach(vx_ctx* c, uint32_t n, uint32_t z_begin, uint32_t z_end, cons
 	c->distZ0 = dist_z0; c->matZ0 = mat_z0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
+	c->bricksStale = true;
 	c->slabAxis = 1;
 	return VX_OK;
 }
@@ -682,6 +743,7 @@ int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, co
 	c->dDist = (void*)d_dist; c->dMat = (void*)d_mat; c->dBlend = (void*)d_blend; c->dFlags = (void*)d_flags;
 	c->distY0 = dist_y0; c->matY0 = mat_y0; c->distRows = dist_rows; c->matRows = mat_rows;
 	c->haveSurface = false;
+	c->bricksStale = true;
 	c->slabAxis = 2;
 	return VX_OK;
 }
@@ -747,6 +809,19 @@ bool halo_plan(vx_ctx* c, HaloPlan& pl, std::string& why)
 	return true;
 }
 
+// the received layers land in the dense fields; their block layers of the brick mirrors follow
+void rebrick_halo(vx_ctx* c, const HaloPlan& pl)
+{
+	const bool alongY = c->slabAxis == 2;
+	const int b = (int)(alongY ? c->yBegin : c->zBegin) / 16, e = (int)(alongY ? c->yEnd : c->zEnd) / 16, cnt = (int)c->n / 16;
+	for (int side = 0; side < 2; ++side) {
+		if (!(side ? pl.hasHi : pl.hasLo)) continue;
+		const int layer = side ? e : b - 1;
+		if (alongY) rebrick_box(c, layer, layer + 1, 0, cnt);
+		else rebrick_box(c, 0, cnt, layer, layer + 1);
+	}
+}
+
 size_t halo_move_bytes(const HaloMove& mv)
 {
 	size_t s = 0;
@@ -799,6 +874,7 @@ int vx_halo_exchange(vx_ctx* c)
 	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange: " + c->be.error());
 	if (pl.hasLo) c->be.run_halo_move(pl.recvLo);
 	if (pl.hasHi) c->be.run_halo_move(pl.recvHi);
+	rebrick_halo(c, pl);
 	c->haveSurface = false;
 	return VX_OK;
 }
@@ -832,6 +908,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange_group: copy failed: " + c->be.error());
 		if (plans[(size_t)i].hasLo) c->be.run_halo_move(plans[(size_t)i].recvLo);
 		if (plans[(size_t)i].hasHi) c->be.run_halo_move(plans[(size_t)i].recvHi);
+		rebrick_halo(c, plans[(size_t)i]);
 		c->haveSurface = false;
 	}
 	return VX_OK;
@@ -855,6 +932,7 @@ int vx_grid_update_blocks(vx_ctx* c, uint32_t count, const uint32_t* ids, const 
 		for (int k = 0; k < 3 && ok; ++k) if (src[k]) ok = stage[k] && c->be.h2d(stage[k], src[k], bytes);
 		if (ok) {
 			c->be.run_scatter_blocks((const u32*)dIds, count, n, (const u8*)stage[0], (const u8*)stage[1], (const u8*)stage[2], (u8*)c->dDist, (u8*)c->dMat, (u8*)c->dBlend);
+			rebrick_blocks(c, (const u32*)dIds, count);
 			ok = c->be.sync_ok();
 		}
 		c->be.free(dIds);
@@ -908,10 +986,8 @@ int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3]
 	void* dIds = c->dScratch;
 	bool ok = c->be.h2d(dIds, touched.data(), touched.size() * 4);
 	if (ok) {
-		GridView g;
-		g.dist = (const i8*)c->dDist; g.mat = (const u8*)c->dMat; g.blend = (const u8*)c->dBlend;
-		g.n = (int)c->n; g.zOrigin = 0; g.zOriginMat = 0; g.yOrigin = 0; g.yOriginMat = 0; g.pitchY = (int)c->n; g.pitchYMat = (int)c->n;
-		c->be.run_edit(g, (u8*)c->dFlags, (const u32*)dIds, (u32)touched.size(), e);
+		c->be.run_edit(resident_view(c), (u8*)c->dFlags, (const u32*)dIds, (u32)touched.size(), e);
+		rebrick_blocks(c, (const u32*)dIds, (u32)touched.size());
 		ok = c->be.sync_ok();
 	}
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device edit failed: " + c->be.error());
@@ -957,6 +1033,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
 	if (!ensure_level_tables(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: level table allocation failed: " + c->be.error());
+	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: brick mirror allocation failed: " + c->be.error());
 	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
 	const u32 slabPlanes = c->zEnd - c->zBegin, slabRows = c->yEnd - c->yBegin;
 	{
@@ -1158,6 +1235,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on slabs");
 	const u32 levels = c->levelsRun;
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
+	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: brick mirror allocation failed: " + c->be.error());
 	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;
 	// once more than half of the pools is dead they are packed first
 	{

@@ -80,14 +80,10 @@ __device__ __forceinline__ Tables r0_portable_tables(const u8* lds, const u8* pa
 	return T;
 }
 
-// three dwords at dword alignment as ONE register tuple (a struct of three words is split into scalars, and the copies
-// between them and the load's destination make the compiler wait for the load on the spot)
-typedef u32 R0Dwords3 __attribute__((ext_vector_type(3)));
-typedef R0Dwords3 __attribute__((aligned(4))) R0Dwords3Unaligned;
-
 // what a workgroup holds of the NEXT block while it finishes the current one
 struct R0Prefetch {
-	R0Dwords3 d[3];   // distance half rows (12 bytes each)
+	uint2 dOwn[3];    // distance half rows: the 8 bytes that lie in the row's own brick ...
+	u32 dNb[3];       // ... and the 4 bytes from the x-neighbour brick (left of half 0, right of half 1)
 	u32 bits;         // one word of the non-trivial bitmap (lanes < 128)
 	uint4 m[3];       // material / blend rows, samples 0..15
 	u32 mf[3];        // ... sample 16 (in byte 0)
@@ -119,41 +115,41 @@ struct R0 {
 		// every lane loads (indices clamped into range): a conditional load with a default value makes the compiler wait for
 		// the data right behind the load, and these requests must stay in flight
 		pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
-		// distance rows r = kk * 19 + jj: voxels [bx*16 - 4, bx*16 + 20) of row (y,z) = (by*16 - 1 + jj, bz*16 - 1 + kk), clamped
+		// Everything comes from the brick mirrors (tv_core.h): a voxel row of a block is 16 contiguous bytes, 8 rows share a
+		// 128-byte line.  Distance rows r = kk * 19 + jj: voxels [bx*16 - 4, bx*16 + 20) of row (y,z) = (by*16 - 1 + jj,
+		// bz*16 - 1 + kk), clamped, as two halves of 12 bytes: 8 bytes of the row's own brick + 4 of the x-neighbour brick
+		// (bricks of x-neighbour blocks follow each other).  At the grid's first / last block the missing neighbour is
+		// replaced by the row itself and patched in deposit().
+		const int brickRow = (n >> 4) * BRICK_BYTES, brickPlane = g.bRowsY * brickRow; // next block along y / z
+		const size_t own = brick_base(g, (int)b.bx, (int)b.by, (int)b.bz);
+		const bool firstX = b.bx == 0, lastX = (int)b.bx + 1 == cnt;
 		{
-			const int gx0 = (int)b.bx * 16 - 4;
-			const int l0 = gx0 < 0 ? 0 : gx0;                       // first voxel of the half-0 load
-			const int l1 = (gx0 + 12 > n - 12) ? n - 12 : gx0 + 12; // first voxel of the half-1 load
-			const int y0 = max((int)b.by * 16 - 1, 0), z0 = max((int)b.bz * 16 - 1, 0);
-			const i8* base = g.dist + dist_offset(g, l0, y0, z0);
-			const int pitch = g.pitchY;
+			const i8* base = g.bDist + own;
 #pragma unroll
 			for (int q = 0; q < 3; ++q) {
 				const int h = min(tid + q * WG, 721);
 				const int r = h >> 1, half = h & 1;
 				const int kk = r / 19, jj = r - kk * 19;
 				const int y = clampi((int)b.by * 16 - 1 + jj, 0, n - 1), z = clampi((int)b.bz * 16 - 1 + kk, 0, n - 1);
-				const u32 off = (u32)(((z - z0) * pitch + (y - y0)) * n + ((half ? l1 : l0) - l0));
-				pf.d[q] = *(const R0Dwords3Unaligned*)(base + off);
+				const int row = ((z >> 4) - (int)b.bz) * brickPlane + ((y >> 4) - (int)b.by) * brickRow + (int)brick_local(0u, (u32)y & 15u, (u32)z & 15u);
+				pf.dOwn[q] = *(const uint2*)(base + row + half * 8);
+				pf.dNb[q] = *(const u32*)(base + row + (half ? (lastX ? 12 : BRICK_BYTES) : (firstX ? 0 : 12 - BRICK_BYTES)));
 			}
 		}
 		// material / blend rows: samples 0..16 of row (j,k), j,k = 0..16, clamped at the far side of the grid
 		{
-			const size_t origin = mat_offset(g, (int)b.bx * 16, (int)b.by * 16, (int)b.bz * 16);
-			const u8* mbase = g.mat + origin;
-			const u8* bbase = g.blend + origin;
-			const int pitch = g.pitchYMat;
-			const int maxY = n - 1 - (int)b.by * 16, maxZ = n - 1 - (int)b.bz * 16;
-			const bool lastX = (int)b.bx + 1 == cnt;
+			const u8* mbase = g.bMat + own;
+			const u8* bbase = g.bBlend + own;
 #pragma unroll
 			for (int q = 0; q < 3; ++q) {
 				const int t = min(tid + q * WG, 577);
 				const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
 				const int k = r / 17, j = r - k * 17;
-				const u32 off = (u32)((min(k, maxZ) * pitch + min(j, maxY)) * n);
-				const u8* src = (arr ? bbase : mbase) + off;
+				const int y = min((int)b.by * 16 + j, n - 1), z = min((int)b.bz * 16 + k, n - 1);
+				const int row = ((z >> 4) - (int)b.bz) * brickPlane + ((y >> 4) - (int)b.by) * brickRow + (int)brick_local(0u, (u32)y & 15u, (u32)z & 15u);
+				const u8* src = (arr ? bbase : mbase) + row;
 				pf.m[q] = *(const uint4*)src;
-				pf.mf[q] = *(const u32*)(src + (lastX ? 12 : 16)); // sample 16 in byte 0; at the grid's edge the row's last dword (see deposit)
+				pf.mf[q] = *(const u32*)(src + (lastX ? 12 : BRICK_BYTES)); // sample 16 in byte 0; at the grid's edge the row's last dword (see deposit)
 			}
 		}
 	}
@@ -169,9 +165,9 @@ struct R0 {
 			const int h = tid + q * WG;
 			if (h < 722) {
 				const int r = h >> 1, half = h & 1;
-				u32 a = pf.d[q].x, bb = pf.d[q].y, c = pf.d[q].z;
-				if (!half && firstX) { c = bb; bb = a; a = a << 24; }                            // loaded 4 voxels further right: sample -1 = sample 0
-				if (half && lastX) { a = bb; bb = c; c = (c >> 24) * 0x01010101u; }             // loaded 4 voxels further left: samples 16, 17 = sample 15
+				u32 a = half ? pf.dOwn[q].x : pf.dNb[q], bb = half ? pf.dOwn[q].y : pf.dOwn[q].x, c = half ? pf.dNb[q] : pf.dOwn[q].y;
+				if (!half && firstX) a = bb << 24;                          // no left neighbour: sample -1 = sample 0
+				if (half && lastX) c = (bb >> 24) * 0x01010101u;            // no right neighbour: samples 16, 17 = sample 15
 				u32* dst = (u32*)(st.samp + r * SROW + half * 12);
 				dst[0] = a; dst[1] = bb; dst[2] = c;
 			}
