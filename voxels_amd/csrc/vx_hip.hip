@@ -566,8 +566,9 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
 	const u32 rowsY = L.yb1 - L.yb0;
-	if (i >= L.cnt * rowsY * (L.zb1 - L.zb0)) return;
-	const u32 bx = i % L.cnt, by = L.yb0 + (i / L.cnt) % rowsY, bz = L.zb0 + i / (L.cnt * rowsY);
+	const bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
+	const u32 ii = inRange ? i : 0u;
+	const u32 bx = ii % L.cnt, by = L.yb0 + (ii / L.cnt) % rowsY, bz = L.zb0 + ii / (L.cnt * rowsY);
 	const u32 id = block_coord_id(bx, by, bz, L.cnt);
 	u32 all = 3u, any = 0u; // AND / OR over the 27 summaries (neighbour coordinates clamped like the reference's)
 #pragma unroll
@@ -583,10 +584,11 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 		c = BC_SKIPPED;
 		if (((all ^ any) & 2u) == 0) c |= BC_QUIET | ((all & 2u) ? BC_NEGATIVE : 0u);
 	}
-	p.G.blockClass[id] = (u8)c;
-	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py)
-	const unsigned long long readers = __ballot(!(c & BC_QUIET));
-	if ((threadIdx.x & 63u) == (u32)__ffsll((long long)__ballot(1)) - 1u && readers) atomicAdd(&p.G.largeBlocks[1], (u32)__popcll(readers));
+	if (inRange) p.G.blockClass[id] = (u8)c;
+	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py);
+	// one atomic per workgroup (one per wave on a single address serialised the whole launch)
+	const int readers = __syncthreads_count(inRange && !(c & BC_QUIET));
+	if (threadIdx.x == 0 && readers) atomicAdd(&p.G.largeBlocks[1], (u32)readers);
 }
 
 // ---- lattice copies of the distance field for the coarser levels (PyramidLevel, tv_block.h) -----------------------------
@@ -633,15 +635,6 @@ __device__ __forceinline__ u32 pyramid_row_quiet_mask(const Globals& G, const Le
 		if (cls[xb] & BC_QUIET) m |= (b == (1u << level)) ? (1u << 16) : (((1u << per) - 1u) << (b * per));
 	}
 	return m;
-}
-
-// Load order of the 17 x 17 voxel rows of a classify tile: the 81 rows with even y and even z first (the only ones that
-// hold samples of the coarser levels' lattices), then the rest.  rr in [0, 289) -> (ry, rz).
-__device__ __forceinline__ void classify_row(int rr, int& ry, int& rz)
-{
-	if (rr < 81) { rz = 2 * (rr / 9); ry = 2 * (rr - (rr / 9) * 9); }
-	else if (rr < 153) { const int e = rr - 81; rz = 2 * (e >> 3); ry = 2 * (e & 7) + 1; }
-	else { const int e = rr - 153; rz = 2 * (e / 17) + 1; ry = e - (e / 17) * 17; }
 }
 
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
@@ -691,34 +684,55 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	}
 	if (__syncthreads_and((myClass & BC_QUIET) != 0)) return;
 
-	// ---- load: 289 rows x TB segments of 16 bytes, fully coalesced; several loads of a thread are in flight
-	//      before the first sign mask is formed -------------------------------------------------------------
-	batched_gather<289 * TB, uint4, 6>(
+	// ---- load from the brick mirror: the TB blocks of a tile are 64 KB of consecutive addresses, lane t takes the 16-byte
+	//      voxel row t (memory order) of every block, so a wave reads 1 KB at a stretch (the dense field would hand out the
+	//      same bytes as 289 pieces of 256 bytes, 1 KB apart: one DRAM page per piece).  Then the rows y = 16 and z = 16
+	//      from the neighbour bricks and the voxel right of the tile.  Several loads of a thread are in flight before the
+	//      first sign mask is formed. --------------------------------------------------------------------------------------
+	const auto keep = [&](int seg, int ry, int rz, uint4 d) {
+		sgn[(rz * 17 + ry) * TB + seg] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
+		// the coarser levels' lattice copies (only rows with even y and z carry lattice samples): rows of this block layer,
+		// and the first rows beyond it where the rank's blocks end (nobody else would write those)
+		if (!((ry | rz) & 1) && (ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
+			pyramid_write_segment(p.G, n, x0 + seg * 16, (int)by * 16 + ry, (int)bz * 16 + rz, d);
+	};
+	const auto quiet_fill = [&](u32 cls) {
+		return (cls & BC_NEGATIVE) ? make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u) : make_uint4(0, 0, 0, 0);
+	};
+	{
+		const i8* tileBase = g.bDist + brick_base(g, (int)(tx * TB), (int)by, (int)bz);
+		const int ry = ((tid >> 3) & 3) * 4 + (tid & 3), rz = (tid >> 5) * 2 + ((tid >> 2) & 1); // brick_local, inverted
+		batched_gather<256 * TB, uint4, 8>(
+			[&](int q) {
+				const int seg = q >> 8;
+				const u32 cls = blockCls[seg];
+				uint4 d = make_uint4(0, 0, 0, 0);
+				if (cls & BC_QUIET) d = quiet_fill(cls);
+				else if (seg * 16 < validCells) d = *(const uint4*)(tileBase + (size_t)seg * BRICK_BYTES + (size_t)tid * 16);
+				return d;
+			},
+			[&](int q, uint4 d) { keep(q >> 8, ry, rz, d); });
+	}
+	batched_gather<16 * TB + 17 * TB, uint4, 3>(
 		[&](int q) {
-			const int rr = q / TB, seg = q - rr * TB;
-			int ry, rz;
-			classify_row(rr, ry, rz);
-			uint4 d = make_uint4(0, 0, 0, 0);
+			int seg, ry, rz;
+			if (q < 16 * TB) { seg = q >> 4; ry = 16; rz = q & 15; }
+			else { const int e = q - 16 * TB; seg = e / 17; ry = e - seg * 17; rz = 16; }
 			const u32 cls = blockCls[seg];
-			if (cls & BC_QUIET) {
-				if (cls & BC_NEGATIVE) d = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-			} else if (seg * 16 < validCells) {
+			uint4 d = make_uint4(0, 0, 0, 0);
+			if (cls & BC_QUIET) d = quiet_fill(cls);
+			else if (seg * 16 < validCells) {
 				const int y = clampi((int)by * 16 + ry, 0, n - 1);
 				const int z = clampi((int)bz * 16 + rz, 0, n - 1);
-				d = *(const uint4*)(g.dist + dist_offset(g, x0 + seg * 16, y, z));
+				d = *(const uint4*)(g.bDist + brick_offset(g, x0 + seg * 16, y, z));
 			}
 			return d;
 		},
 		[&](int q, uint4 d) {
-			const int rr = q / TB, seg = q - rr * TB;
-			int ry, rz;
-			classify_row(rr, ry, rz);
-			sgn[(rz * 17 + ry) * TB + seg] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
-			// the coarser levels' lattice copies (only rows with even y and z carry lattice samples: the first 81 rows of the
-			// load order, so whole waves skip this): rows of this block layer, and the first rows beyond it where the rank's
-			// blocks end (nobody else would write those)
-			if (rr < 81 && (ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
-				pyramid_write_segment(p.G, n, x0 + seg * 16, (int)by * 16 + ry, (int)bz * 16 + rz, d);
+			int seg, ry, rz;
+			if (q < 16 * TB) { seg = q >> 4; ry = 16; rz = q & 15; }
+			else { const int e = q - 16 * TB; seg = e / 17; ry = e - seg * 17; rz = 16; }
+			keep(seg, ry, rz, d);
 		});
 	batched_gather<289, i8, 2>(
 		[&](int r) {
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 			const int y = clampi((int)by * 16 + ry, 0, n - 1);
 			const int z = clampi((int)bz * 16 + rz, 0, n - 1);
 			const int x = clampi(x0 + validCells, 0, n - 1);
-			return g.dist[dist_offset(g, x, y, z)];
+			return g.bDist[brick_offset(g, x, y, z)];
 		},
 		[&](int r, i8 v) { halo[r] = (u8)((u32)(v >> 7) & 1u); });
 	__syncthreads();
@@ -1590,7 +1604,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, oldReg0 = 0; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, oldReg0 = 0, r0LdsPad = 0; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -1612,6 +1626,7 @@ struct Backend {
 		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
 		tune.oldReg0 = env_u32("VX_OLD_REG0", 0); // TEMP A/B
+		tune.r0LdsPad = env_u32("VX_R0_LDS_PAD", 0); // experiment: extra LDS per workgroup of the level-0 regular pass (fewer resident workgroups)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -1628,7 +1643,7 @@ struct Backend {
 		}
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
-		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>)), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
+		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>) + tune.r0LdsPad), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
 		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
@@ -1893,7 +1908,7 @@ struct Backend {
 		if (levelBegin == 0 && p.levels[0].cap && !tune.oldReg0) {
 			const u32 cap = p.levels[0].cap;
 			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
-			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
+			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>) + tune.r0LdsPad, ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
 			if (p.G.dirty) {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, true>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, true>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
