@@ -87,19 +87,25 @@ struct Pools {
 	u32 vertCap, idxCap;
 };
 
-// The distance samples of LOD level L (the lattice of voxels whose coordinates are multiples of 2^L) as a dense array of
+// The distance samples of LOD level L (the lattice of voxels whose coordinates are multiples of 2^L) as an array of
 // their own: entry (X,Y,Z) = dist(min(X << L, n-1), min(Y << L, n-1), min(Z << L, n-1)), X,Y,Z in [0, n >> L] — the last
 // index is the reference's clamped far sample.  Written by the level-0 classification pass for every block it reads
 // (blocks it may skip — BC_QUIET — are never written: their samples all share one sign, and readers ask the class
-// first); levels >= 1 then read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.
+// first); levels >= 1 then read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.  Same brick
+// layout as the grid's mirrors (tv_core.h brick_local): the 16^3 lattice samples of a level-L block are 4 KB of
+// consecutive addresses; the far samples live in one more brick along every axis.
 enum { PYRAMID_LEVELS = 4 }; // levels 1..3 have a lattice copy; coarser levels (at most 64 blocks) gather from the grid
 struct PyramidLevel {
-	i8* data;           // nullptr: no copy of this level
-	u32 pitchX, pitchY; // entries per row, rows per plane
+	i8* data;             // nullptr: no copy of this level
+	u32 bricksX, bricksY; // bricks per row of bricks, rows of bricks per plane of bricks
 	int yOrigin, zOrigin; // lattice coordinates of row 0 / plane 0 (slabs)
 };
 
-TV_HD size_t pyramid_offset(const PyramidLevel& P, int X, int Y, int Z) { return ((size_t)(Z - P.zOrigin) * P.pitchY + (size_t)(Y - P.yOrigin)) * P.pitchX + (size_t)X; }
+TV_HD size_t pyramid_offset(const PyramidLevel& P, int X, int Y, int Z)
+{
+	const u32 y = (u32)(Y - P.yOrigin), z = (u32)(Z - P.zOrigin);
+	return (((size_t)(z >> 4) * P.bricksY + (size_t)(y >> 4)) * P.bricksX + (size_t)((u32)X >> 4)) * BRICK_BYTES + brick_local((u32)X & 15u, y & 15u, z & 15u);
+}
 
 // stats[0] = non-trivial cells, [1] = degenerate triangles removed, [2] = level-0 blocks processed,
 // stats[4..19] = per-class cell counts

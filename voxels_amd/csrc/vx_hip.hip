@@ -124,7 +124,7 @@ __device__ __forceinline__ PyramidRow pyramid_row17(const PyramidLevel& P, int X
 	const i8* src = P.data + pyramid_offset(P, X0, Y, Z);
 	PyramidRow r;
 	r.lo = *(const uint4*)src;
-	r.far = *(const u8*)(src + 16);
+	r.far = *(const u8*)(src + BRICK_BYTES); // sample X0 + 16: the same row of the next brick
 	return r;
 }
 
@@ -602,18 +602,18 @@ __device__ __forceinline__ void pyramid_write_segment(const Globals& G, int n, i
 	for (int l = 1; l < PYRAMID_LEVELS; ++l) {
 		const PyramidLevel& P = G.pyr[l];
 		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
-		i8* row = P.data + pyramid_offset(P, 0, y >> l, z >> l);
+		i8* at = P.data + pyramid_offset(P, xs >> l, y >> l, z >> l); // 8 / 4 / 2 lattice samples: inside one brick row
 		if (l == 1) {
 			uint2 v;
 			v.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200u);
 			v.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200u);
-			*(uint2*)(row + (xs >> 1)) = v;
+			*(uint2*)at = v;
 		} else if (l == 2) {
-			*(u32*)(row + (xs >> 2)) = __builtin_amdgcn_perm(d.y, d.x, 0x0C0C0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000C0Cu);
+			*(u32*)at = __builtin_amdgcn_perm(d.y, d.x, 0x0C0C0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000C0Cu);
 		} else {
-			*(u16*)(row + (xs >> 3)) = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
+			*(u16*)at = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
 		}
-		if (xs + 16 == n) row[n >> l] = (i8)(d.w >> 24);
+		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
 	}
 }
 

@@ -264,11 +264,12 @@ bool ensure_level_tables(vx_ctx* c)
 		// samples of its last block layer)
 		if (L >= 1 && L < PYRAMID_LEVELS && c->be.wants_pyramid()) {
 			PyramidLevel& P = c->pyr[L];
-			P.pitchX = (c->n >> L) + 16;
-			P.pitchY = ((c->yEnd - c->yBegin) >> L) + 1;
+			// entries [0, extent >> L] along every axis, in bricks of 16^3 entries
+			P.bricksX = ((c->n >> L) >> 4) + 1;
+			P.bricksY = (((c->yEnd - c->yBegin) >> L) >> 4) + 1;
 			P.yOrigin = (int)(c->yBegin >> L); P.zOrigin = (int)(c->zBegin >> L);
-			const size_t planes = ((c->zEnd - c->zBegin) >> L) + 1;
-			P.data = (i8*)alloc((size_t)P.pitchX * P.pitchY * planes + 64);
+			const size_t bricksZ = (((c->zEnd - c->zBegin) >> L) >> 4) + 1;
+			P.data = (i8*)alloc((size_t)P.bricksX * P.bricksY * bricksZ * BRICK_BYTES + 64);
 			if (!P.data) return false;
 		}
 	}
