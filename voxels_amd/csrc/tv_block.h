@@ -636,6 +636,10 @@ struct FetchedMaterials {
 };
 
 enum { EMIT_BATCH = 4 };     // vertices per lane whose fetches are in flight together
+#if !defined(VX_LOD_BATCH)
+#define VX_LOD_BATCH 4
+#endif
+enum { LOD_BATCH = VX_LOD_BATCH }; // ... whose LOD chains advance in lockstep (levels >= 1)
 
 // mat_at() for the corners of a level-0 block's cells: one base address per block, 32-bit offsets per corner.
 // The only clamp that can bite is the far corner layer of the last block of an axis.
@@ -726,6 +730,91 @@ TV_HD void reg_vertices_emit_with(ST& st, const D& d, const Tables& T, const Glo
 	}
 }
 
+// Levels >= 1: the LOD chain (FindBestVertexInLODChain, TransVoxelImpl.cpp:1484-1509) is a sequence of dependent
+// fetches — one per level — before a vertex knows its level-0 edge.  A lane walks the chains of all its vertices of the
+// chunk in lockstep (one memory round trip per chain step for the whole batch, not per vertex), then finishes them one
+// after the other with everything a vertex reads around its end points requested together (reg_edge_finish).
+template <typename ST, typename D>
+TV_HD void reg_vertices_emit_lod(ST& st, const D& d, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
+{
+	const bool room = st.vOff + st.vTotal <= P.vertCap;
+	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
+	const int ox = (int)(b.bx * 16 * b.mult), oy = (int)(b.by * 16 * b.mult), oz = (int)(b.bz * 16 * b.mult);
+	enum { NO_VERTEX = 0x200, EDGE_VERTEX = 0x100 }; // state word: sample p0 (byte 0) | sample p1 (byte 1) | corner id or one of these << 16
+	for (u32 j0 = (u32)tid; j0 < end; j0 += (u32)nth * LOD_BATCH) {
+		// per vertex of the batch: descriptor + table word, the two end points, the state word — nothing else lives across
+		// the chain (registers: the batch is what a lane keeps in flight)
+		u32 key[LOD_BATCH];            // compact cell | table vertex << 12 | table word << 16
+		int P0[LOD_BATCH][3], P1[LOD_BATCH][3];
+		u32 state[LOD_BATCH];
+#pragma unroll
+		for (int r = 0; r < LOD_BATCH; ++r) {
+			const u32 j = j0 + (u32)r * (u32)nth;
+			key[r] = 0; state[r] = (u32)NO_VERTEX << 16;
+			P0[r][0] = P1[r][0] = ox; P0[r][1] = P1[r][1] = oy; P0[r][2] = P1[r][2] = oz; // a vertex-less slot reads the block's origin
+			if (j >= end) continue;
+			const u32 desc = st.vdesc[j];
+			const u32 k = desc & 0xFFFu, vi = desc >> 12;
+			const u32 w = T.regVert(st.cellBits[k] & 0xFFu, vi);
+			key[r] = desc | (w << 16);
+			const u32 c = st.cellOf[k];
+			const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+			const int v0 = (w >> 4) & 15, v1 = w & 15;
+			const int s0 = st.samp[samp_index(cx + (v0 & 1), cy + ((v0 >> 1) & 1), cz + (v0 >> 2))];
+			const int s1 = st.samp[samp_index(cx + (v1 & 1), cy + ((v1 >> 1) & 1), cz + (v1 >> 2))];
+			const int e = edge_end(s0, s1);
+			const int corner = (e != 1) ? (((st.atV0Mask[k] >> vi) & 1u) ? v0 : ((e == 0) ? v1 : v0)) : (int)EDGE_VERTEX;
+			state[r] = ((u32)s0 & 0xFFu) | (((u32)s1 & 0xFFu) << 8) | ((u32)corner << 16);
+			const int a = (e != 1) ? corner : v0, bb = (e != 1) ? corner : v1;
+			const int mult = (int)b.mult;
+			P0[r][0] = ox + (cx + (a & 1)) * mult; P0[r][1] = oy + (cy + ((a >> 1) & 1)) * mult; P0[r][2] = oz + (cz + (a >> 2)) * mult;
+			P1[r][0] = ox + (cx + (bb & 1)) * mult; P1[r][1] = oy + (cy + ((bb >> 1) & 1)) * mult; P1[r][2] = oz + (cz + (bb >> 2)) * mult;
+		}
+		// the chains, one step of every vertex at a time (a slot without an edge vertex has P0 == P1: it reads that point and
+		// changes nothing)
+		for (int lev = (int)b.level; lev > 0; --lev) {
+			int mv[LOD_BATCH];
+#pragma unroll
+			for (int r = 0; r < LOD_BATCH; ++r)
+				mv[r] = d(P0[r][0] + (P1[r][0] - P0[r][0]) / 2, P0[r][1] + (P1[r][1] - P0[r][1]) / 2, P0[r][2] + (P1[r][2] - P0[r][2]) / 2);
+#pragma unroll
+			for (int r = 0; r < LOD_BATCH; ++r) {
+				if ((state[r] >> 16) != (u32)EDGE_VERTEX) continue;
+				const int mx = P0[r][0] + (P1[r][0] - P0[r][0]) / 2, my = P0[r][1] + (P1[r][1] - P0[r][1]) / 2, mz = P0[r][2] + (P1[r][2] - P0[r][2]) / 2;
+				const int v0s = (int)(i8)(state[r] & 0xFFu);
+				if (v0s * mv[r] <= 0) { P1[r][0] = mx; P1[r][1] = my; P1[r][2] = mz; state[r] = (state[r] & 0xFFFF00FFu) | (((u32)mv[r] & 0xFFu) << 8); }
+				else { P0[r][0] = mx; P0[r][1] = my; P0[r][2] = mz; state[r] = (state[r] & 0xFFFFFF00u) | ((u32)mv[r] & 0xFFu); }
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < LOD_BATCH; ++r) {
+			const u32 kind = state[r] >> 16;
+			if (kind == (u32)NO_VERTEX) continue;
+			const u32 j = j0 + (u32)r * (u32)nth;
+			const u32 k = key[r] & 0xFFFu, w = key[r] >> 16;
+			const u32 c = st.cellOf[k];
+			const int cx = (int)(c & 15), cy = (int)((c >> 4) & 15), cz = (int)(c >> 8);
+			CellGeom geo;
+			geo.mult = (int)b.mult; geo.level = (int)b.level;
+			geo.local[0] = cx; geo.local[1] = cy; geo.local[2] = cz;
+			geo.base[0] = ox + cx * (int)b.mult; geo.base[1] = oy + cy * (int)b.mult; geo.base[2] = oz + cz * (int)b.mult;
+			const u32 cellMat = st.cellMat[k];
+			const unsigned long long lut = lut_row(G.lut, cellMat); // requested with the end-point samples below
+			RawVertex rv;
+			bool interior = false;
+			if (kind != (u32)EDGE_VERTEX) {
+				reg_corner_vertex(d, GridMaterials{ &G.grid }, geo, (int)kind, cellMat, rv);
+			} else {
+				const int p0 = (int)(i8)(state[r] & 0xFFu), p1 = (int)(i8)((state[r] >> 8) & 0xFFu);
+				const int t = (p0 != p1) ? edge_t(p0, p1) : 0;
+				interior = reg_edge_finish(d, GridMaterials{ &G.grid }, geo, (int)((w >> 4) & 15), (int)(w & 15), P0[r], P1[r], p0, p1, t, cellMat, rv);
+			}
+			if (!interior) reg_mark_suspect(st, cx, cy, cz);
+			if (room) pack_vertex_row(rv, lut, P.verts + st.vOff + chunkBase + j);
+		}
+	}
+}
+
 template <typename ST>
 TV_HD void reg_phase_emit_vertices(ST& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
 {
@@ -734,7 +823,7 @@ TV_HD void reg_phase_emit_vertices(ST& st, const Tables& T, const Globals& G, co
 		reg_vertices_emit_with<ST, LocalDist, true>(st, d, T, G, P, b, chunkBase, tid, nth);
 	} else {
 		const GlobalDist d{ &G.grid };
-		reg_vertices_emit_with<ST, GlobalDist, false>(st, d, T, G, P, b, chunkBase, tid, nth);
+		reg_vertices_emit_lod<ST, GlobalDist>(st, d, T, G, P, b, chunkBase, tid, nth);
 	}
 }
 

@@ -238,6 +238,36 @@ TV_HD void lod_chain(const D& d, int level, int P0[3], int P1[3], int& val0, int
 	}
 }
 
+// Everything a vertex reads around its two end points — the stencils of both central differences and both materials —
+// requested together, before anything is computed with them: as separate reads followed by their arithmetic (normal_at
+// twice, then the materials) the device code waits for every pair of samples in turn, nine memory round trips per
+// vertex instead of one.
+struct EndpointSamples {
+	int a[6], b[6]; // x+1, x-1, z+1, z-1, y+1, y-1 around P0 / P1 (normal_at's order)
+	u32 M0, M1;
+};
+
+template <typename D, typename MF>
+TV_HD void gather_endpoints(const D& d, const MF& mats, const int P0[3], const int P1[3], EndpointSamples& e)
+{
+	e.a[0] = d(P0[0] + 1, P0[1], P0[2]); e.a[1] = d(P0[0] - 1, P0[1], P0[2]);
+	e.a[2] = d(P0[0], P0[1], P0[2] + 1); e.a[3] = d(P0[0], P0[1], P0[2] - 1);
+	e.a[4] = d(P0[0], P0[1] + 1, P0[2]); e.a[5] = d(P0[0], P0[1] - 1, P0[2]);
+	e.b[0] = d(P1[0] + 1, P1[1], P1[2]); e.b[1] = d(P1[0] - 1, P1[1], P1[2]);
+	e.b[2] = d(P1[0], P1[1], P1[2] + 1); e.b[3] = d(P1[0], P1[1], P1[2] - 1);
+	e.b[4] = d(P1[0], P1[1] + 1, P1[2]); e.b[5] = d(P1[0], P1[1] - 1, P1[2]);
+	e.M0 = mats(0, P0); e.M1 = mats(1, P1);
+}
+
+// normal_at() from samples already fetched
+TV_HD void normal_from(const int s[6], float out[3])
+{
+	out[0] = (float)(s[0] - s[1]) * 0.5f;
+	out[1] = (float)(s[2] - s[3]) * 0.5f;
+	out[2] = (float)(s[4] - s[5]) * 0.5f;
+	normalize_fix_zero(out);
+}
+
 // (v1 << 8) / (v1 - v0) with C truncation.  Evaluated as a correctly rounded fp32 division: for |v| <= 128 the
 // quotient is either an integer or at least 1/255 away from one while fp32 resolves 1/1024 there, so truncating
 // the rounded quotient is exact (checked exhaustively over all 65280 int8 pairs in tests/test_core_math.py).
@@ -504,25 +534,46 @@ struct GridMaterials {
 	TV_HD u32 operator()(int, const int P[3]) const { return mat_at(*g, P[0], P[1], P[2]); }
 };
 
-// `mats(which, P)` = id | blend << 8 at end point `which` (0/1) located at P: the grid, or values fetched ahead
+// An edge vertex once its level-0 edge P0-P1 with samples p0 / p1 is known (the cell's own edge at level 0, the end of
+// the LOD chain above): position, normals, material, adjacency.  `mats(which, P)` = id | blend << 8 at end point `which`
+// (0/1) located at P: the grid, or values fetched ahead.
 template <typename D, typename MF>
-TV_HD bool reg_edge_vertex(const D& d, const MF& mats, const CellGeom& c, int v0, int v1, int t0, int val0, int val1, u32 cellMat, RawVertex& o)
+TV_HD bool reg_edge_finish(const D& d, const MF& mats, const CellGeom& c, int v0, int v1, const int P0[3], const int P1[3], int p0, int p1, int t, u32 cellMat, RawVertex& o)
 {
-	int P0[3], P1[3], t;
-	const bool interior = reg_edge_position(d, c, v0, v1, t0, val0, val1, P0, P1, t, o.p);
+	EndpointSamples e;
+	gather_endpoints(d, mats, P0, P1, e);
+	const bool interior = p0 * p1 < 0; // samples of strictly opposite sign: 0 < t < 256, vertex strictly inside its edge
 	const int u = 256 - t;
+	const float ft = (float)t, fu = (float)u;
+	o.p[0] = ft * (float)P0[0] + fu * (float)P1[0];
+	o.p[1] = ft * (float)P0[1] + fu * (float)P1[1];
+	o.p[2] = ft * (float)P0[2] + fu * (float)P1[2];
 	float N0[3], N1[3];
-	normal_at(d, P0[0], P0[1], P0[2], N0);
-	normal_at(d, P1[0], P1[1], P1[2], N1);
-	const u32 M0 = mats(0, P0), M1 = mats(1, P1);
+	normal_from(e.a, N0);
+	normal_from(e.b, N1);
+	const u32 M0 = e.M0, M1 = e.M1;
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, v0, v1);
 	if ((M0 & 0xFF) == (M1 & 0xFF) && (M0 & 0xFF) == (cellMat & 0xFF)) o.mat = (M0 & 0xFF) | (lerp_blend(t, u, M0 >> 8, M1 >> 8) << 8);
 	else o.mat = cellMat;
-	const float wt = (float)t / 256.f, wu = (float)u / 256.f;
+	const float wt = ft / 256.f, wu = fu / 256.f;
 	o.n[0] = N0[0] * wt + N1[0] * wu; o.n[1] = N0[1] * wt + N1[1] * wu; o.n[2] = N0[2] * wt + N1[2] * wu;
 	normalize_fix_zero(o.n);
 	finish_secondary(o, c.mult);
 	return interior;
+}
+
+template <typename D, typename MF>
+TV_HD bool reg_edge_vertex(const D& d, const MF& mats, const CellGeom& c, int v0, int v1, int t0, int val0, int val1, u32 cellMat, RawVertex& o)
+{
+	int P0[3], P1[3];
+	corner_pos(c, v0, P0);
+	corner_pos(c, v1, P1);
+	int t = t0, p0 = val0, p1 = val1;
+	if (c.level > 0) {
+		lod_chain(d, c.level, P0, P1, p0, p1);
+		t = (p0 != p1) ? edge_t(p0, p1) : 0;
+	}
+	return reg_edge_finish(d, mats, c, v0, v1, P0, P1, p0, p1, t, cellMat, o);
 }
 
 template <typename D>
@@ -553,8 +604,12 @@ TV_HD void reg_corner_vertex(const D& d, const MF& mats, const CellGeom& c, int 
 	int P[3];
 	corner_pos(c, corner, P);
 	o.p[0] = (float)P[0] * 256.f; o.p[1] = (float)P[1] * 256.f; o.p[2] = (float)P[2] * 256.f;
-	normal_at(d, P[0], P[1], P[2], o.n);
+	int s[6];
+	s[0] = d(P[0] + 1, P[1], P[2]); s[1] = d(P[0] - 1, P[1], P[2]);
+	s[2] = d(P[0], P[1], P[2] + 1); s[3] = d(P[0], P[1], P[2] - 1);
+	s[4] = d(P[0], P[1] + 1, P[2]); s[5] = d(P[0], P[1] - 1, P[2]);
 	const u32 mine = mats(0, P);
+	normal_from(s, o.n);
 	o.mat = ((cellMat & 0xFF) != (mine & 0xFF)) ? cellMat : mine;
 	o.flags = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, corner, corner);
 	finish_secondary(o, c.mult);
@@ -743,27 +798,33 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
 	float N0[3] = { 0.f, 0.f, 0.f }, N1[3] = { 0.f, 0.f, 0.f };
 	int t = r.t, u = 0;
 	u32 adjacency = 0;
+	int p0 = v[v0], p1 = v[v1];
+	if (!r.endpoint) {
+		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
+		if (lodOfEdge > 0) lod_chain(d, lodOfEdge, I0, I1, p0, p1);
+	}
+	// both stencils and both materials in one round trip (an end-point vertex uses one of the two normals; the other
+	// stencil is read all the same: no second dependent trip, no branch around loads)
+	EndpointSamples es;
+	gather_endpoints(d, GridMaterials{ &g }, I0, I1, es);
 	if (r.endpoint) {
 		if (t == 0) {
 			u = 256;
-			normal_at(d, I1[0], I1[1], I1[2], N1);
+			normal_from(es.b, N1);
 			if (v1 >= 9) { const int cid = low_corner_id(fg, v1 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		} else {
 			u = 0; t = 256;
-			normal_at(d, I0[0], I0[1], I0[2], N0);
+			normal_from(es.a, N0);
 			if (v0 >= 9) { const int cid = low_corner_id(fg, v0 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		}
 	} else {
-		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
-		int p0 = v[v0], p1 = v[v1];
-		if (lodOfEdge > 0) lod_chain(d, lodOfEdge, I0, I1, p0, p1);
 		t = (p0 != p1) ? edge_t(p0, p1) : 0;
 		u = 256 - t;
-		normal_at(d, I0[0], I0[1], I0[2], N0);
-		normal_at(d, I1[0], I1[1], I1[2], N1);
+		normal_from(es.a, N0);
+		normal_from(es.b, N1);
 		if (v0 >= 9 && v1 >= 9) adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, low_corner_id(fg, v0 - 9), low_corner_id(fg, v1 - 9));
 	}
-	const u32 M0 = mat_at(g, I0[0], I0[1], I0[2]), M1 = mat_at(g, I1[0], I1[1], I1[2]);
+	const u32 M0 = es.M0, M1 = es.M1;
 	float P0[3] = { (float)I0[0], (float)I0[1], (float)I0[2] }, P1[3] = { (float)I1[0], (float)I1[1], (float)I1[2] };
 	float S0[3] = { P0[0], P0[1], P0[2] }, S1[3] = { P1[0], P1[1], P1[2] };
 	if (v0 >= 9 || v1 >= 9) {

@@ -1189,8 +1189,13 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 namespace {
 
 // One capacity class of the regular pass of levels >= 1: blocks with lo < non-trivial cells <= CAP
+// 4 waves per SIMD: the lockstep LOD chains of the vertex emission keep a batch of vertices in registers; at 5 waves (96
+// registers) the pass spilled them to scratch — and produced wrong vertices now and then (drop-in byte-dump test)
+#if !defined(VX_REG_WAVES)
+#define VX_REG_WAVES 4
+#endif
 template <int CAP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
 	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
@@ -1211,6 +1216,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const Tables T = stage_regular_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
+#if defined(VX_REG_PROFILE)
+	u32 prof[16] = { 0 };
+	unsigned long long tick = __builtin_readcyclecounter();
+#define RG_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
+#else
+#define RG_TICK(i) do { } while (0)
+#endif
 
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
@@ -1227,10 +1239,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			if (tid == 0) reg_write_empty_record(L, b.slot);
 			continue;
 		}
+		RG_TICK(0);
 		__syncthreads();
+		RG_TICK(1);
 		reg_phase_begin(st, L, b.slot, tid, WG);
 		gpu_reg_stage(p.G, b, st.samp);
 		__syncthreads();
+		RG_TICK(2);
 		for (int w = tid; w < 128; w += WG) st.wordPrefix[w] = (u16)__popc(st.ntBits[w]);
 		__syncthreads();
 		{
@@ -1238,39 +1253,55 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			if (tid == 0) st.wordPrefix[128] = (u16)nt;
 		}
 		__syncthreads();
+		RG_TICK(3);
 		reg_phase_list(st, L, b, tid, WG);
 		__syncthreads();
+		RG_TICK(4);
 		reg_phase_cells(st, T, p.G, L, b, tid, WG);
 		__syncthreads();
+		RG_TICK(5);
 		reg_phase_count(st, T, b, tid, WG);
 		__syncthreads();
+		RG_TICK(6);
 		{
 			const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.vTotal = vt; st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt); }
 		}
 		__syncthreads();
+		RG_TICK(7);
 		for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
 			if (chunk) __syncthreads();
 			reg_phase_describe(st, chunk, tid, WG);
 			__syncthreads();
+			RG_TICK(8);
 			reg_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+			RG_TICK(9);
 		}
 		__syncthreads();
+		RG_TICK(10);
 		reg_phase_keep(st, T, p.G, b, tid, WG);
 		__syncthreads();
+		RG_TICK(11);
 		{
 			const u32 it = block_exclusive_scan_u16(st.ibase, st.wordPrefix[128], scanScratch);
 			if (tid == 0) { st.iTotal = it; st.iOff = atomicAdd(&p.P.cursors[CUR_I], it); }
 		}
 		__syncthreads();
+		RG_TICK(12);
 		for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
 			if (chunk) __syncthreads();
 			reg_phase_stage_indices(st, T, chunk, tid, WG);
 			__syncthreads();
+			RG_TICK(13);
 			reg_phase_flush_indices(st, T, p.P, chunk, tid, WG);
+			RG_TICK(14);
 		}
 		reg_phase_record(st, wgStats, L, b, p.P, tid);
+		RG_TICK(15);
 	}
+#if defined(VX_REG_PROFILE)
+	if (tid == 0 && !lo) for (int i = 0; i < 16; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[16 + i], prof[i] >> 10); // header words 192..207, units of 1024 cycles
+#endif
 	__syncthreads();
 	if (threadIdx.x < 20 && wgStats[threadIdx.x]) atomicAdd(&p.G.stats[threadIdx.x], wgStats[threadIdx.x]);
 }

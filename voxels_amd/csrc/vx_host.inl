@@ -1134,6 +1134,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		for (int i = 0; i < 10; ++i) fprintf(stderr, "[material profile, level %d] %-32s %10u x16 cycles  %5.1f %%\n", VX_MAT_PROFILE, names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
 	}
 #endif
+#if defined(VX_REG_PROFILE)
+	{
+		static const char* names[16] = { "next item", "top barrier", "begin+stage+barrier", "prefix scan", "list+barrier", "cells+barrier", "count+barrier", "vertex scan+reserve", "describe+barrier", "emit vertices", "barrier", "keep+barrier", "index scan+reserve", "stage indices+barrier", "flush indices", "record" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 16; ++i) sum += c->hdr[HDR_LARGE + 16 + i];
+		for (int i = 0; i < 16; ++i) fprintf(stderr, "[regular profile, levels >= 1] %-24s %10u kcycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 16 + i], 100.0 * c->hdr[HDR_LARGE + 16 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_R0_PROFILE)
 	{
 		static const char* names[10] = { "top barrier", "deposit+barrier", "prefix+list+barrier", "cells", "scan barrier", "reserve+describe", "barrier", "vertices+indices", "record", "next item (drain)" };
