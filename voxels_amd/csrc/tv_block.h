@@ -1055,7 +1055,7 @@ TV_HD void tr_phase_classify(TrState& st, int tid, int nth)
 // local (x,y,z) of the low-res cell behind transition cell (f,row,col)
 TV_HD void tr_low_local(const FaceGeom& fg, int row, int col, int local[3])
 {
-	local[fg.ua] = col; local[fg.va] = row; local[fg.axis] = fg.positive ? 15 : 0;
+	face_scatter(fg, col, row, fg.positive ? 15 : 0, local);
 }
 
 TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)

@@ -674,6 +674,15 @@ TV_HD FaceGeom face_geom(int f)
 	return g;
 }
 
+// (u, v, a) = coordinates along the face's in-plane axes and its normal axis -> (x, y, z).  Written with comparisons,
+// not as P[fg.ua] = u ...: an array indexed by a run-time value lives in scratch memory on the device.
+TV_HD void face_scatter(const FaceGeom& fg, int u, int v, int a, int P[3])
+{
+	P[0] = fg.axis == 0 ? a : u;
+	P[1] = fg.axis == 2 ? v : (fg.axis == 1 ? a : u);
+	P[2] = fg.axis == 2 ? a : v;
+}
+
 // corner ids (0..7) of the low-res cell for samples 9..12
 TV_HD int low_corner_id(const FaceGeom& fg, int k)
 {
@@ -782,9 +791,9 @@ TV_HD void tr_sample_pos(const FaceGeom& fg, const TrCellGeom& c, int k, int P[3
 	if (k < 9) { i = k % 3; j = k / 3; }
 	else { i = ((k - 9) & 1) * 2; j = ((k - 9) >> 1) * 2; }
 	const int half = c.mult >> 1;
-	P[fg.ua] = c.lowBase[fg.ua] + i * half;
-	P[fg.va] = c.lowBase[fg.va] + j * half;
-	P[fg.axis] = c.lowBase[fg.axis] + (fg.positive ? c.mult : 0);
+	int off[3];
+	face_scatter(fg, i * half, j * half, fg.positive ? c.mult : 0, off);
+	P[0] = c.lowBase[0] + off[0]; P[1] = c.lowBase[1] + off[1]; P[2] = c.lowBase[2] + off[2];
 }
 
 TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom& c, const i8 v[13], u32 w,
@@ -798,7 +807,18 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
 	float N0[3] = { 0.f, 0.f, 0.f }, N1[3] = { 0.f, 0.f, 0.f };
 	int t = r.t, u = 0;
 	u32 adjacency = 0;
-	int p0 = v[v0], p1 = v[v1];
+	// v[v0], v[v1] without indexing the array by a run-time value (an array indexed that way lives in scratch memory on
+	// the device): the 13 samples packed into four words with compile-time indices, the word picked by comparisons
+	int p0, p1;
+	{
+		u32 pk[4] = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int i = 0; i < 13; ++i) pk[i >> 2] |= ((u32)v[i] & 0xFFu) << ((i & 3) * 8);
+		const u32 w0 = v0 < 4 ? pk[0] : (v0 < 8 ? pk[1] : (v0 < 12 ? pk[2] : pk[3]));
+		const u32 w1 = v1 < 4 ? pk[0] : (v1 < 8 ? pk[1] : (v1 < 12 ? pk[2] : pk[3]));
+		p0 = (int)(i8)((w0 >> ((v0 & 3) * 8)) & 0xFFu);
+		p1 = (int)(i8)((w1 >> ((v1 & 3) * 8)) & 0xFFu);
+	}
 	if (!r.endpoint) {
 		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
 		if (lodOfEdge > 0) lod_chain(d, lodOfEdge, I0, I1, p0, p1);
