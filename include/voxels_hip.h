@@ -97,6 +97,9 @@ int vx_grid_read_block(vx_ctx* ctx, uint32_t block_id, int8_t* dist, uint8_t* ma
  * [z_begin, z_end) of the global n^3 grid.  d_dist holds the z-planes [dist_z0, ...) and must cover
  * [z_begin-1, z_end+1] clamped to the grid; d_mat/d_blend hold planes [mat_z0, ...) covering [z_begin, z_end]
  * clamped.  d_empty_flags is the FULL (n/16)^3 flag array (neighbour layers of other ranks included). */
+/* The library keeps brick-ordered mirrors of the fields for its gathers and refreshes them where IT changes
+ * the grid (vx_grid_fill_terrain, vx_halo_exchange*).  A caller that rewrites attached memory itself after a
+ * polygonization has run must attach it again before the next one (attaching is cheap; the mirrors are then rebuilt). */
 int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
                    const void* d_dist, int32_t dist_z0, const void* d_mat, const void* d_blend, int32_t mat_z0,
                    const void* d_empty_flags);

@@ -83,7 +83,9 @@ class SlabBuffers:
     def halo_exchange(self, dist_pkg):
         """1 distance layer from the slab below; 2 distance layers + 1 material + 1 blend layer from the slab above (a layer
         = a z-plane or a y-row of every plane).  One grouped send/recv batch; strided row slices travel through
-        contiguous staging tensors."""
+        contiguous staging tensors.  (torch.distributed transport, used by the CPU tests; the product path is
+        Polygonizer.halo_exchange = vx_halo_exchange.  It rewrites the attached tensors behind the library's back: call
+        attach() again before the next polygonization.)"""
         if self.world == 1:
             return
         r, w, p = self.rank, self.world, self.planes
