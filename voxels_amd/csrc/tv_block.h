@@ -125,6 +125,7 @@ struct Globals {
 	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
 	u8* blockSummary;                 // bit0 = BF_Empty, bit1 = sign of the block's samples (an empty block has one sign)
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
+	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
 	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
 };
 

@@ -559,6 +559,8 @@ __global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo,
 		s = 1u | (((u32)(v >> 7) & 1u) << 1);
 	}
 	p.G.blockSummary[id] = (u8)s;
+	if ((bx & 15u) == 0 && by >= L.yb0 && by < L.yb1 && bz >= L.zb0 && bz < L.zb1)
+		p.G.tileWork[((bz - L.zb0) * (L.yb1 - L.yb0) + (by - L.yb0)) * ((L.cnt + 15u) / 16u) + bx / 16u] = 0;
 }
 
 __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
@@ -584,7 +586,11 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 		c = BC_SKIPPED;
 		if (((all ^ any) & 2u) == 0) c |= BC_QUIET | ((all & 2u) ? BC_NEGATIVE : 0u);
 	}
-	if (inRange) p.G.blockClass[id] = (u8)c;
+	if (inRange) {
+		p.G.blockClass[id] = (u8)c;
+		// classify tiles (TB blocks along x) that hold a block to read; zeroed by k_block_summary of the same run
+		if (!(c & BC_QUIET)) p.G.tileWork[((bz - L.zb0) * rowsY + (by - L.yb0)) * ((L.cnt + 15u) / 16u) + bx / 16u] = 1;
+	}
 	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py);
 	// one atomic per workgroup (one per wave on a single address serialised the whole launch)
 	const int readers = __syncthreads_count(inRange && !(c & BC_QUIET));
@@ -675,14 +681,16 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	const int validCells = (n - x0) < 16 * TB ? (n - x0) : 16 * TB; // multiple of 16
 	const int tid = threadIdx.x;
 
-	// what the flags say: quiet blocks are not read at all, a tile of quiet blocks is done
+	// what the flags say: quiet blocks are not read at all, a tile of quiet blocks is done (most tiles of a terrain: the
+	// test is one uniform byte per workgroup, written by k_block_class)
+	if (!p.G.tileWork[tile]) return;
 	u32 myClass = BC_SKIPPED | BC_QUIET;
 	if (tid < TB) {
 		const u32 bx = tx * TB + (u32)tid;
 		if (bx < L.cnt) myClass = p.G.blockClass[block_coord_id(bx, by, bz, L.cnt)];
 		blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockCls[tid] = myClass;
 	}
-	if (__syncthreads_and((myClass & BC_QUIET) != 0)) return;
+	__syncthreads();
 
 	// ---- load from the brick mirror: the TB blocks of a tile are 64 KB of consecutive addresses, lane t takes the 16-byte
 	//      voxel row t (memory order) of every block, so a wave reads 1 KB at a stretch (the dense field would hand out the
@@ -701,14 +709,19 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	};
 	{
 		const i8* tileBase = g.bDist + brick_base(g, (int)(tx * TB), (int)by, (int)bz);
-		const int ry = ((tid >> 3) & 3) * 4 + (tid & 3), rz = (tid >> 5) * 2 + ((tid >> 2) & 1); // brick_local, inverted
+		// Row of the lane (memory order): the 64 rows with even y and even z — the only ones that hold samples of the coarser
+		// levels' lattices — go to wave 0, so the other three waves skip the lattice writes as a whole; a wave still reads
+		// two rows of every 128-byte line, the four waves of the workgroup together read each line once.
+		const int wv = tid >> 6, li = tid & 63;
+		const int row = ((li >> 1) << 3) | ((wv >> 1) << 2) | ((li & 1) << 1) | (wv & 1);
+		const int ry = ((row >> 3) & 3) * 4 + (row & 3), rz = (row >> 5) * 2 + ((row >> 2) & 1); // brick_local, inverted
 		batched_gather<256 * TB, uint4, 8>(
 			[&](int q) {
 				const int seg = q >> 8;
 				const u32 cls = blockCls[seg];
 				uint4 d = make_uint4(0, 0, 0, 0);
 				if (cls & BC_QUIET) d = quiet_fill(cls);
-				else if (seg * 16 < validCells) d = *(const uint4*)(tileBase + (size_t)seg * BRICK_BYTES + (size_t)tid * 16);
+				else if (seg * 16 < validCells) d = *(const uint4*)(tileBase + (size_t)seg * BRICK_BYTES + (size_t)row * 16);
 				return d;
 			},
 			[&](int q, uint4 d) { keep(q >> 8, ry, rz, d); });
@@ -1968,12 +1981,16 @@ struct Backend {
 	//   side stream B : transition cells (after the material chain)
 	// The small, latency-bound material launches no longer leave the chip idle.
 	template <typename P>
-	void run_overlapped_tail(const P& p, u32 levels)
+	void run_overlapped_level0(const P& p)
 	{
 		(void)hipEventRecord(evClassified, stream);
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
 		launch_regular(p, 0, 1, sideA);
 		(void)hipEventRecord(evSideA, sideA);
+	}
+	template <typename P>
+	void run_overlapped_tail(const P& p, u32 levels)
+	{
 		for (u32 L = 1; L < levels; ++L) run_material(p, L);
 		(void)hipEventRecord(evMaterial, stream);
 		(void)hipStreamWaitEvent(sideB, evMaterial, 0);

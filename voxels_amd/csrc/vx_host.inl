@@ -54,6 +54,7 @@ struct vx_ctx {
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
+	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
 	// planes [brickZb0, +brickPlanesZ); stale = everything has to be copied again before the next polygonization
@@ -258,7 +259,8 @@ bool ensure_level_tables(vx_ctx* c)
 		if (!L) {
 			c->dBlockSummary = alloc(total);
 			c->dBlockClass = alloc(total);
-			if (!c->dBlockSummary || !c->dBlockClass) return false;
+			c->dTileWork = alloc((size_t)((d.cnt + 15) / 16) * (d.yb1 - d.yb0) * (d.zb1 - d.zb0) + 16);
+			if (!c->dBlockSummary || !c->dBlockClass || !c->dTileWork) return false;
 		}
 		// lattice copy of the distance samples of this level over the rank's rows / planes (one more than it owns: the far
 		// samples of its last block layer)
@@ -309,6 +311,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
 	p.G.blockSummary = (u8*)c->dBlockSummary;
 	p.G.blockClass = (u8*)c->dBlockClass;
+	p.G.tileWork = (u8*)c->dTileWork;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
@@ -369,12 +372,15 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	c->be.stage_mark(1);
 	c->be.run_classify(p);
 	c->be.stage_mark(2);
-	c->be.run_hierarchy(p, levels);
 	if (!c->be.stage_timing_on()) {
-		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless)
+		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless); the level-0
+		// regular pass needs nothing of the hierarchy pass and is released right behind the classify pass
+		c->be.run_overlapped_level0(p);
+		c->be.run_hierarchy(p, levels);
 		c->be.run_overlapped_tail(p, levels);
 		return;
 	}
+	c->be.run_hierarchy(p, levels);
 	c->be.stage_mark(3);
 	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
 	c->be.stage_mark(4);
