@@ -174,7 +174,6 @@ struct Backend {
 			plan.totals[l] = n;
 		}
 	}
-	template <typename P> void run_vertices(const P&, u32) {} // the emulated per-block phases write finished vertices
 	bool stage_ms(float*) { return false; }
 
 	// classification of one level-0 block (portable form of k_classify)

@@ -609,3 +609,56 @@ def test_hip_single_block_grid(poly, port):
     g = port.grid_from_dense(d, m, b)
     poly.upload_packed(g.pack())
     assert np.array_equal(poly.pack(), g.pack())
+
+
+@pytest.mark.gpu
+def test_hip_brick_mirrors_follow_the_grid(port):
+    """The gathers of a run read brick-ordered mirrors of the fields; the mirrors have to follow every way a
+    grid changes between two runs of ONE context: a second upload, host-edited blocks (vx_grid_update_blocks) followed by a
+    FULL run, and attached memory that the caller rewrote and attached again."""
+    import torch
+    from voxels_amd import Polygonizer, synth
+    from voxels_amd.slab import SlabBuffers
+    n, levels = 128, 3
+    p = Polygonizer(device=0)
+    p.set_materials(vxo.default_lut())
+
+    def expect(d, m, b):
+        return port.execute(port.grid_from_dense(d, m, b)).all_levels()[:levels]
+
+    def check(tag, want):
+        p.execute(levels)
+        ok, msg = fields.surface_equal(p.all_levels(), want, nrm_tol=NRM_TOL)
+        assert ok, tag + ": " + msg
+
+    a = synth.terrain(n, 0, n, 3)
+    b2 = synth.terrain(n, 0, n, 4)
+    p.upload(*a, synth.block_empty_flags(a[0]))
+    check("first upload", expect(*a))
+    p.upload(*b2, synth.block_empty_flags(b2[0]))
+    check("second upload into the same context", expect(*b2))
+    # host-edited blocks: a cube of blocks takes the other terrain's voxels
+    d, m, bl = (x.copy() for x in b2)
+    nb = n // 16
+    ids = [(z * nb + y) * nb + x for z in range(2, 5) for y in range(1, 4) for x in range(3, 6)]
+    blocks = [np.zeros((len(ids), 16, 16, 16), t) for t in (np.int8, np.uint8, np.uint8)]
+    for i, bid in enumerate(ids):
+        bx, by, bz = bid % nb, (bid // nb) % nb, bid // (nb * nb)
+        sl = (slice(bz * 16, bz * 16 + 16), slice(by * 16, by * 16 + 16), slice(bx * 16, bx * 16 + 16))
+        for dst, src, blk in zip((d, m, bl), a, blocks):
+            dst[sl] = src[sl]
+            blk[i] = src[sl]
+    p.update_blocks(np.array(ids, np.uint32), blocks[0], blocks[1], blocks[2], synth.block_empty_flags(d))
+    check("vx_grid_update_blocks + full run", expect(d, m, bl))
+    # attached memory rewritten by the caller, attached again
+    dev = torch.device("cuda", 0)
+    slab = SlabBuffers(torch, n, 0, 1, dev, axis="z")
+    slab.fill_from_full(*a, synth.block_empty_flags(a[0]))
+    torch.cuda.synchronize()
+    slab.attach(p)
+    check("attached", expect(*a))
+    slab.fill_from_full(*b2, synth.block_empty_flags(b2[0]))
+    torch.cuda.synchronize()
+    slab.attach(p)
+    check("rewritten and attached again", expect(*b2))
+    p.close()

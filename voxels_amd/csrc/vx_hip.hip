@@ -151,25 +151,6 @@ __device__ __forceinline__ void gpu_reg_stage(const Globals& G, const RegBlockCt
 			dst[0] = row.lo.x; dst[1] = row.lo.y; dst[2] = row.lo.z; dst[3] = row.lo.w;
 			samp[samp_index(16, j, k)] = (i8)row.far;
 		}
-	} else if (b.level == 0) {
-		// one lane per 24-byte row (361 rows): the row address is formed once, the six aligned dwords follow from it
-		const int n = g.n, gx0 = (int)b.bx * 16 - 4;
-		const int xFirst = gx0 < 0 ? 0 : gx0, xLast = (gx0 + 20 > n - 4) ? n - 4 : gx0 + 20; // dword clamps of j = 0 / j = 5
-#pragma unroll 1
-		for (int r = (int)threadIdx.x; r < 361; r += WG) {
-			const int jj = r % 19, kk = r / 19;
-			const int y = clampi((int)b.by * 16 + jj - 1, 0, n - 1);
-			const int z = clampi((int)b.bz * 16 + kk - 1, 0, n - 1);
-			const i8* row = g.dist + dist_offset(g, 0, y, z);
-			u32 v[6];
-			v[0] = *(const u32*)(row + xFirst);
-#pragma unroll
-			for (int j = 1; j < 5; ++j) v[j] = *(const u32*)(row + gx0 + 4 * j);
-			v[5] = *(const u32*)(row + xLast);
-			u32* dst = (u32*)(samp + kk * SPLANE + jj * SROW);
-#pragma unroll
-			for (int j = 0; j < 6; ++j) dst[j] = v[j];
-		}
 	} else {
 		batched_gather<SAMPLES, i8, 5>(
 			[&](int s) { const int i = s % 17, j = (s / 17) % 17, k = s / 289;
@@ -1196,7 +1177,6 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 
 } // namespace
 
-#include "vx_vertices.inl"
 #include "vx_regular0.inl"
 
 namespace {
@@ -1648,7 +1628,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, oldReg0 = 0, r0LdsPad = 0; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -1669,8 +1649,6 @@ struct Backend {
 		tune.matGrid = env_u32("VX_MAT_GRID", 0);
 		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
-		tune.oldReg0 = env_u32("VX_OLD_REG0", 0); // TEMP A/B
-		tune.r0LdsPad = env_u32("VX_R0_LDS_PAD", 0); // experiment: extra LDS per workgroup of the level-0 regular pass (fewer resident workgroups)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -1687,7 +1665,7 @@ struct Backend {
 		}
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
-		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>) + tune.r0LdsPad), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
+		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>)), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
 		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
@@ -1949,10 +1927,10 @@ struct Backend {
 	template <typename P>
 	void launch_regular(const P& p, u32 levelBegin, u32 levels, hipStream_t on)
 	{
-		if (levelBegin == 0 && p.levels[0].cap && !tune.oldReg0) {
+		if (levelBegin == 0 && p.levels[0].cap) {
 			const u32 cap = p.levels[0].cap;
 			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
-			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>) + tune.r0LdsPad, ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
+			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
 			if (p.G.dirty) {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, true>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, true>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
@@ -2069,15 +2047,6 @@ struct Backend {
 		hipLaunchKernelGGL(k_list_count, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
 		hipLaunchKernelGGL(k_list_write, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
 		check(hipGetLastError(), "k_list launch");
-	}
-
-	// descriptors -> vertices for the vertices [first, cursor) of the pool; after every per-block kernel of the run
-	template <typename P>
-	void run_vertices(const P& p, u32 first)
-	{
-		if (p.P.vertCap <= first) return;
-		hipLaunchKernelGGL(k_vertices, dim3((p.P.vertCap - first + WG - 1) / WG), dim3(WG), 0, stream, dev(p), first);
-		check(hipGetLastError(), "k_vertices launch");
 	}
 
 	template <typename P>
