@@ -145,14 +145,18 @@ struct Backend {
 	void stage_mark(int) {}
 	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange
 	// through torch.distributed in voxels_amd/slab.py)
-	void run_halo_move(const HaloMove& mv)
+	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView&, bool)
 	{
-		for (u32 i = 0; i < mv.count; ++i) {
-			const HaloPiece& p = mv.piece[i];
-			for (int l = 0; l < p.layers; ++l) for (u32 a = 0; a < p.rows; ++a) {
-				u8* f = p.field + halo_field_offset(p, p.firstLayer + l, a);
-				u8* s = mv.staging + p.stagingOffset + ((size_t)l * p.rows + a) * p.rowBytes;
-				if (mv.unpack) memcpy(f, s, p.rowBytes); else memcpy(s, f, p.rowBytes);
+		for (const HaloMove* m : { lo, hi }) {
+			if (!m) continue;
+			const HaloMove& mv = *m;
+			for (u32 i = 0; i < mv.count; ++i) {
+				const HaloPiece& p = mv.piece[i];
+				for (int l = 0; l < p.layers; ++l) for (u32 a = 0; a < p.rows; ++a) {
+					u8* f = p.field + halo_field_offset(p, p.firstLayer + l, a);
+					u8* s = mv.staging + p.stagingOffset + ((size_t)l * p.rows + a) * p.rowBytes;
+					if (mv.unpack) memcpy(f, s, p.rowBytes); else memcpy(s, f, p.rowBytes);
+				}
 			}
 		}
 	}

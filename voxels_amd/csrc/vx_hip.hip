@@ -1534,13 +1534,19 @@ __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPla
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_halo_move: the pieces of one halo message between their fields and a contiguous staging buffer (HaloMove,
-// tv_block.h).  One workgroup per row (n bytes of a voxel field, cnt bytes of the flag array).
+// k_halo_move: the pieces of the halo messages of one side pair (below / above) between their fields and contiguous
+// staging buffers (HaloMove, tv_block.h): blockIdx.y picks the message, one workgroup per row (n bytes of a voxel field,
+// cnt bytes of the flag array).  Unpacking also writes the rows into the brick mirrors (tv_core.h GridView) when the view
+// carries them, so an exchange is two launches around the RCCL batch: pack, unpack.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_halo_move(HaloMove mv)
+struct HaloPair { HaloMove m[2]; };
+
+__global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, int alongY)
 {
+	const HaloMove& mv = pair.m[blockIdx.y];
 	u32 row = blockIdx.x;
 	u32 pi = 0;
+	if (!mv.count) return;
 	while (pi + 1 < mv.count && row >= (u32)mv.piece[pi].layers * mv.piece[pi].rows) { row -= (u32)mv.piece[pi].layers * mv.piece[pi].rows; ++pi; }
 	const HaloPiece& p = mv.piece[pi];
 	if (row >= (u32)p.layers * p.rows) return;
@@ -1550,10 +1556,26 @@ __global__ __launch_bounds__(WG) void k_halo_move(HaloMove mv)
 	u8* s = mv.staging + p.stagingOffset + (size_t)row * p.rowBytes;
 	u8* dst = mv.unpack ? f : s;
 	const u8* src = mv.unpack ? s : f;
+	// the mirror of this piece's field, if it is a voxel field of the view (the flag array has none)
+	u8* brick = nullptr;
+	if (mv.unpack && g.bDist && p.rowBytes == (u32)g.n) {
+		if (p.field == (const u8*)g.dist) brick = (u8*)const_cast<i8*>(g.bDist);
+		else if (p.field == g.mat) brick = const_cast<u8*>(g.bMat);
+		else if (p.field == g.blend) brick = const_cast<u8*>(g.bBlend);
+	}
+	const int layer = p.firstLayer + l;
+	const int y = alongY ? layer : (int)a, z = alongY ? (int)a : layer;
 	if ((p.rowBytes & 15u) == 0 && (((size_t)dst | (size_t)src) & 15u) == 0) {
-		for (u32 i = threadIdx.x; i < p.rowBytes / 16; i += WG) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+		for (u32 i = threadIdx.x; i < p.rowBytes / 16; i += WG) {
+			const uint4 v = ((const uint4*)src)[i];
+			((uint4*)dst)[i] = v;
+			if (brick) *(uint4*)(brick + brick_offset(g, (int)(i * 16), y, z)) = v;
+		}
 	} else {
-		for (u32 i = threadIdx.x; i < p.rowBytes; i += WG) dst[i] = src[i];
+		for (u32 i = threadIdx.x; i < p.rowBytes; i += WG) {
+			dst[i] = src[i];
+			if (brick) brick[brick_offset(g, (int)i, y, z)] = src[i];
+		}
 	}
 }
 
@@ -1986,12 +2008,21 @@ struct Backend {
 	bool stage_timing_on() const { return stageOn; }
 
 	// ---- halo messages of attached slabs (vx_halo_exchange*, vx_host.inl) -----------------------------------------------
-	void run_halo_move(const HaloMove& mv)
+	// both messages of a direction (pack: what goes below / above; unpack: what came from below / above) in one launch;
+	// either may be absent.  `g` carries the brick mirrors an unpack keeps current (null pointers: none).
+	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView& g, bool alongY)
 	{
-		u32 rows = 0;
-		for (u32 i = 0; i < mv.count; ++i) rows += (u32)mv.piece[i].layers * mv.piece[i].rows;
-		if (!rows) return;
-		hipLaunchKernelGGL(k_halo_move, dim3(rows), dim3(WG), 0, stream, mv);
+		HaloPair pair;
+		memset(&pair, 0, sizeof(pair));
+		if (lo) pair.m[0] = *lo;
+		if (hi) pair.m[1] = *hi;
+		const HaloMove &a = pair.m[0], &b = pair.m[1];
+		u32 rows[2] = { 0, 0 };
+		for (u32 i = 0; i < a.count; ++i) rows[0] += (u32)a.piece[i].layers * a.piece[i].rows;
+		for (u32 i = 0; i < b.count; ++i) rows[1] += (u32)b.piece[i].layers * b.piece[i].rows;
+		const u32 most = std::max(rows[0], rows[1]);
+		if (!most) return;
+		hipLaunchKernelGGL(k_halo_move, dim3(most, 2), dim3(WG), 0, stream, pair, g, alongY ? 1 : 0);
 		check(hipGetLastError(), "k_halo_move launch");
 	}
 	void* comm = nullptr;

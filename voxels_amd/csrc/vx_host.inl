@@ -194,8 +194,8 @@ bool ensure_bricks(vx_ctx* c)
 	return true;
 }
 
-// the mirrors of the listed blocks (device id list) / of a box of blocks follow a change of the dense fields; nothing to
-// do while the mirrors wait for a full copy anyway
+// the mirrors of the listed blocks (device id list) follow a change of the dense fields; nothing to do while the mirrors
+// wait for a full copy anyway (the rows of a halo exchange are written into the mirrors by its unpack kernel)
 void rebrick_blocks(vx_ctx* c, const u32* dIds, u32 count)
 {
 	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0] || !count) return;
@@ -204,14 +204,6 @@ void rebrick_blocks(vx_ctx* c, const u32* dIds, u32 count)
 	c->be.run_rebrick(resident_view(c), dr, mr, nullptr, dIds, count);
 }
 
-void rebrick_box(vx_ctx* c, int yb0, int yb1, int zb0, int zb1)
-{
-	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0]) return;
-	int dr[4], mr[4];
-	resident_ranges(c, dr, mr);
-	const int box[4] = { yb0, yb1, zb0, zb1 };
-	c->be.run_rebrick(resident_view(c), dr, mr, box, nullptr, 0);
-}
 
 bool ensure_level_tables(vx_ctx* c)
 {
@@ -816,17 +808,13 @@ bool halo_plan(vx_ctx* c, HaloPlan& pl, std::string& why)
 	return true;
 }
 
-// the received layers land in the dense fields; their block layers of the brick mirrors follow
-void rebrick_halo(vx_ctx* c, const HaloPlan& pl)
+// the view an unpack writes through: with the brick mirrors while they are current (they then follow the received rows),
+// without them while they wait for a full copy anyway
+GridView halo_view(const vx_ctx* c)
 {
-	const bool alongY = c->slabAxis == 2;
-	const int b = (int)(alongY ? c->yBegin : c->zBegin) / 16, e = (int)(alongY ? c->yEnd : c->zEnd) / 16, cnt = (int)c->n / 16;
-	for (int side = 0; side < 2; ++side) {
-		if (!(side ? pl.hasHi : pl.hasLo)) continue;
-		const int layer = side ? e : b - 1;
-		if (alongY) rebrick_box(c, layer, layer + 1, 0, cnt);
-		else rebrick_box(c, 0, cnt, layer, layer + 1);
-	}
+	GridView g = resident_view(c);
+	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0]) { g.bDist = nullptr; g.bMat = nullptr; g.bBlend = nullptr; }
+	return g;
 }
 
 size_t halo_move_bytes(const HaloMove& mv)
@@ -872,16 +860,14 @@ int vx_halo_exchange(vx_ctx* c)
 	if (!halo_plan(c, pl, why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: " + why);
 	if ((pl.hasLo && c->commRank == 0) || (pl.hasHi && c->commRank + 1 == c->commRanks)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: rank r must own the r-th slab");
 	// pack -> one grouped send/recv batch -> unpack, all queued on the context's stream: nothing waits on the host
-	if (pl.hasLo) c->be.run_halo_move(pl.sendLo);
-	if (pl.hasHi) c->be.run_halo_move(pl.sendHi);
+	const bool alongY = c->slabAxis == 2;
+	c->be.run_halo_moves(pl.hasLo ? &pl.sendLo : nullptr, pl.hasHi ? &pl.sendHi : nullptr, halo_view(c), alongY);
 	const bool ok = c->be.comm_exchange(pl.hasLo ? c->commRank - 1 : -1, pl.hasLo ? c->haloBuf[0] : nullptr, pl.hasLo ? halo_move_bytes(pl.sendLo) : 0,
 	                                    pl.hasLo ? c->haloBuf[2] : nullptr, pl.hasLo ? halo_move_bytes(pl.recvLo) : 0,
 	                                    pl.hasHi ? c->commRank + 1 : -1, pl.hasHi ? c->haloBuf[1] : nullptr, pl.hasHi ? halo_move_bytes(pl.sendHi) : 0,
 	                                    pl.hasHi ? c->haloBuf[3] : nullptr, pl.hasHi ? halo_move_bytes(pl.recvHi) : 0);
 	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange: " + c->be.error());
-	if (pl.hasLo) c->be.run_halo_move(pl.recvLo);
-	if (pl.hasHi) c->be.run_halo_move(pl.recvHi);
-	rebrick_halo(c, pl);
+	c->be.run_halo_moves(pl.hasLo ? &pl.recvLo : nullptr, pl.hasHi ? &pl.recvHi : nullptr, halo_view(c), alongY);
 	c->haveSurface = false;
 	return VX_OK;
 }
@@ -897,8 +883,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		if (!c) return VX_ERR_INVALID;
 		if (!halo_plan(c, plans[(size_t)i], why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: " + why);
 		if (plans[(size_t)i].hasLo != (i > 0) || plans[(size_t)i].hasHi != (i + 1 < count)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: contexts must be the slabs of one grid in order");
-		if (plans[(size_t)i].hasLo) c->be.run_halo_move(plans[(size_t)i].sendLo);
-		if (plans[(size_t)i].hasHi) c->be.run_halo_move(plans[(size_t)i].sendHi);
+		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].sendLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].sendHi : nullptr, halo_view(c), c->slabAxis == 2);
 	}
 	for (int i = 0; i < count; ++i) { VX_ENTER(ctxs[i]); if (!ctxs[i]->be.sync_ok()) return fail(ctxs[i], VX_ERR_DEVICE, "vx_halo_exchange_group: pack failed: " + ctxs[i]->be.error()); }
 	for (int i = 0; i + 1 < count; ++i) {
@@ -913,9 +898,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		vx_ctx* c = ctxs[i];
 		VX_ENTER(c);
 		if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange_group: copy failed: " + c->be.error());
-		if (plans[(size_t)i].hasLo) c->be.run_halo_move(plans[(size_t)i].recvLo);
-		if (plans[(size_t)i].hasHi) c->be.run_halo_move(plans[(size_t)i].recvHi);
-		rebrick_halo(c, plans[(size_t)i]);
+		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].recvLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].recvHi : nullptr, halo_view(c), c->slabAxis == 2);
 		c->haveSurface = false;
 	}
 	return VX_OK;
