@@ -229,12 +229,14 @@ def main():
     achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
     # HBM bytes per launch from rocprofv3 PMC passes of this same command, when a summary was committed
     traffic = None
+    traffic_all = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
             if pm.get("n") == n and pm.get("levels") == levels and pm.get("gpus") == world:
                 traffic = pm.get("hbm_bytes_per_launch", {}).get(dominant)
+                traffic_all = pm.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
@@ -251,6 +253,8 @@ def main():
              "frac_of_8TBps_nominal": round(bytes_nominal / (run_dev_ms * 1e-3) / 8e12, 5),
              "achieved_GBps": round(bytes_needed / (run_dev_ms * 1e-3) / 1e9, 2),
              "frac_of_8TBps": round(bytes_needed / (run_dev_ms * 1e-3) / 8e12, 5),
+             "line_traffic_bytes_per_kernel": traffic_all,
+             "line_traffic_bytes": int(sum(traffic_all.values())) if traffic_all else None,
              "note": "frac_of_8TBps counts the bytes a run has to touch (distance samples of the blocks that are not proven "
                      "surface-free by their flags, material+blend of surface blocks, outputs); the *_nominal figures use "
                      "SURVEY.md §8(d)'s n^3 term although most of it is never read"}

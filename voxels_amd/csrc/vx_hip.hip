@@ -1188,7 +1188,7 @@ namespace {
 #define VX_REG_WAVES 4
 #endif
 template <int CAP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CAP_SMALL ? 1 : VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
 	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
