@@ -10,7 +10,7 @@ struct Backend {
 	bool init(int, std::string&) { return true; }
 	bool wants_pyramid() const { return false; }
 	bool wants_bricks() const { return false; } // the emulation reads the dense fields
-	void run_rebrick(const GridView&, const int*, const int*, const int*, const u32*, u32) {}
+	void run_rebrick(const GridView&, const int*, const int*, const MirrorState&, const int*, const u32*, u32) {}
 	void make_current() {} // the emulated phases sample the grid directly
 	void shutdown() {}
 	void set_stream(void*) {}
@@ -145,7 +145,7 @@ struct Backend {
 	void stage_mark(int) {}
 	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange
 	// through torch.distributed in voxels_amd/slab.py)
-	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView&, bool)
+	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView&, const MirrorState&, bool)
 	{
 		for (const HaloMove* m : { lo, hi }) {
 			if (!m) continue;

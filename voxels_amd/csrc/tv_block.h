@@ -89,9 +89,9 @@ struct Pools {
 
 // The distance samples of LOD level L (the lattice of voxels whose coordinates are multiples of 2^L) as an array of
 // their own: entry (X,Y,Z) = dist(min(X << L, n-1), min(Y << L, n-1), min(Z << L, n-1)), X,Y,Z in [0, n >> L] — the last
-// index is the reference's clamped far sample.  Written by the level-0 classification pass for every block it reads
-// (blocks it may skip — BC_QUIET — are never written: their samples all share one sign, and readers ask the class
-// first); levels >= 1 then read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.  Same brick
+// index is the reference's clamped far sample.  A mirror of the grid like the bricks: written where the grid changes
+// (k_rebrick, the unpack of a halo exchange), complete over the rank's range, never touched by a polygonization;
+// levels >= 1 read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.  Same brick
 // layout as the grid's mirrors (tv_core.h brick_local): the 16^3 lattice samples of a level-L block are 4 KB of
 // consecutive addresses; the far samples live in one more brick along every axis.
 enum { PYRAMID_LEVELS = 4 }; // levels 1..3 have a lattice copy; coarser levels (at most 64 blocks) gather from the grid
@@ -126,13 +126,22 @@ struct Globals {
 	u8* blockSummary;                 // bit0 = BF_Empty, bit1 = sign of the block's samples (an empty block has one sign)
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
 	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
+	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)
 	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
 };
 
 // BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the
-// first one.  A block whose 27-neighbourhood is BF_Empty is skipped by the reference (TransVoxelImpl.cpp:520); if all
-// 27 also share one sign, no cell of the block — including the cells that reach into the +x/+y/+z neighbours — can
-// be non-trivial, so the classify pass does not have to read it ("quiet").
+// first one.  A block whose 27-neighbourhood is BF_Empty is skipped by the reference (TransVoxelImpl.cpp:520).  Apart
+// from that: if a block and the parts of the seven blocks its cells reach into (the first plane / line / voxel of the +x,
+// +y, +z neighbours) are of one and the same sign (blockSign), no cell of the block can be non-trivial, so the classify
+// pass does not have to read it ("quiet").
+
+// What the mirrors of a grid carry beside the bricks (handed to the kernels that keep them current)
+struct MirrorState {
+	PyramidLevel pyr[PYRAMID_LEVELS];
+	u16* blockSign;                 // per level-0 block: field f = dx | dy << 1 | dz << 2 (2 bits each) summarises the voxels with x = 0 (dx), y = 0 (dy), z = 0 (dz): 1 = all >= 0, 2 = all < 0, 0 = mixed or not all resident
+	int yBegin, yEnd, zBegin, zEnd; // the rank's own rows / planes
+};
 enum { BC_SKIPPED = 1, BC_QUIET = 2, BC_NEGATIVE = 4 };
 
 TV_HD u32 block_coord_id(u32 bx, u32 by, u32 bz, u32 cnt) { return (bz * cnt + by) * cnt + bx; }

@@ -141,8 +141,7 @@ __device__ __forceinline__ void gpu_reg_stage(const Globals& G, const RegBlockCt
 {
 	const GridView& g = G.grid;
 	if (b.level >= 1 && b.level < PYRAMID_LEVELS && G.pyr[b.level].data) {
-		// the level's lattice copy: 17 contiguous samples per row.  Entries of blocks nobody read hold no data — and are
-		// never looked at: a non-trivial cell has no corner in such a block.
+		// the level's lattice copy: 17 contiguous samples per row
 		const PyramidLevel& P = G.pyr[b.level];
 		for (int r = (int)threadIdx.x; r < 289; r += WG) {
 			const int k = r / 17, j = r - k * 17;
@@ -457,42 +456,122 @@ __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, co
 	if (sb) *(uint4*)(blend + rowOff) = *(const uint4*)(sb + srcOff);
 }
 
-// k_rebrick: dense fields -> brick mirrors (tv_core.h GridView).  Box mode (ids == nullptr): a workgroup copies the 8
+// ---- lattice copies of the distance field for the coarser levels (PyramidLevel, tv_block.h) -----------------------------
+// One 16-voxel segment [xs, xs + 16) of the voxel row (y,z): its samples on the level-L lattice go to the level's copy.  y and z may be the first row beyond the grid (y == n: the loaded data then is the
+// clamped row n - 1, and y >> L is exactly the index of the level's clamped far entry); the voxel n - 1 of a row is also
+// stored as the far entry of its lattice row.
+__device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, int n, int xs, int y, int z, uint4 d)
+{
+#pragma unroll
+	for (int l = 1; l < PYRAMID_LEVELS; ++l) {
+		const PyramidLevel& P = pyr[l];
+		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
+		i8* at = P.data + pyramid_offset(P, xs >> l, y >> l, z >> l); // 8 / 4 / 2 lattice samples: inside one brick row
+		if (l == 1) {
+			uint2 v;
+			v.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200u);
+			v.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200u);
+			*(uint2*)at = v;
+		} else if (l == 2) {
+			*(u32*)at = __builtin_amdgcn_perm(d.y, d.x, 0x0C0C0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000C0Cu);
+		} else {
+			*(u16*)at = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
+		}
+		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
+	}
+}
+
+// What the mirrors keep beside the bricks (all of it a function of the grid alone, brought up to date with them):
+//   * the lattice copies of levels 1..3 (PyramidLevel): every distance row with even y and z of the rank's range
+//     [yBegin, yEnd] x [zBegin, zEnd] carries lattice samples; the grid's last row / plane (n - 1) also is the clamped far
+//     sample n of every level;
+//   * blockSign[id]: 1 = every distance sample of the block is >= 0, 2 = every sample is < 0, 0 = mixed or not all resident.
+
+__device__ __forceinline__ void lattice_rows_of(const MirrorState& X, int n, int xs, int y, int z, uint4 d)
+{
+	if (!X.pyr[1].data && !X.pyr[2].data && !X.pyr[3].data) return;
+	if (y < X.yBegin || y > X.yEnd || z < X.zBegin || z > X.zEnd) return;
+	const bool yFar = y == n - 1, zFar = z == n - 1;
+	if (!((y | z) & 1)) pyramid_write_segment(X.pyr, n, xs, y, z, d);
+	if (yFar && !(z & 1)) pyramid_write_segment(X.pyr, n, xs, n, z, d);
+	if (zFar && !(y & 1)) pyramid_write_segment(X.pyr, n, xs, y, n, d);
+	if (yFar && zFar) pyramid_write_segment(X.pyr, n, xs, n, n, d);
+}
+
+// k_rebrick: dense fields -> mirrors (tv_core.h GridView).  Box mode (ids == nullptr): a workgroup copies the 8
 // x-neighbour blocks that share the 128-byte lines of their voxel rows, 8 consecutive lanes per line; list mode: one
 // block per workgroup, one voxel row per lane.  Only rows that are resident in the dense fields are copied (a slab's halo
 // block layers hold a few planes / rows each).
 struct RebrickRanges { int dz0, dz1, dy0, dy1, mz0, mz1, my0, my1; };
 
-__device__ __forceinline__ void rebrick_row(const GridView& g, const RebrickRanges& r, int bx, int gy, int gz)
+// blockSign fields (2 bits each, field f = dx | dy << 1 | dz << 2): the signs found in the part of the block that the
+// cells of its -x / -y / -z neighbours reach into — all voxels (f = 0), the plane x = 0 (f = 1), y = 0 (f = 2), the line
+// x = y = 0 (f = 3), the plane z = 0 (f = 4), ... the voxel (0,0,0) (f = 7).  While collecting: bit 0 = a sample >= 0 was
+// seen, bit 1 = a sample < 0; a row that is not resident sets every bit (unknown).
+__device__ __forceinline__ u32 rebrick_row(const GridView& g, const RebrickRanges& r, const MirrorState& X, int bx, int gy, int gz)
 {
 	const size_t dst = brick_base(g, bx, gy >> 4, gz >> 4) + brick_local(0u, (u32)gy & 15u, (u32)gz & 15u);
-	if (gz >= r.dz0 && gz < r.dz1 && gy >= r.dy0 && gy < r.dy1)
-		*(uint4*)(const_cast<i8*>(g.bDist) + dst) = *(const uint4*)(g.dist + dist_offset(g, bx * 16, gy, gz));
+	u32 fields = 0xFFFFu;
+	if (gz >= r.dz0 && gz < r.dz1 && gy >= r.dy0 && gy < r.dy1) {
+		const uint4 d = *(const uint4*)(g.dist + dist_offset(g, bx * 16, gy, gz));
+		*(uint4*)(const_cast<i8*>(g.bDist) + dst) = d;
+		lattice_rows_of(X, g.n, bx * 16, gy, gz, d);
+		const u32 any = (d.x | d.y | d.z | d.w) & 0x80808080u, all = (d.x & d.y & d.z & d.w) & 0x80808080u;
+		const u32 rowAll = (any ? 2u : 0u) | (all != 0x80808080u ? 1u : 0u);
+		const u32 rowX0 = (d.x & 0x80u) ? 2u : 1u;
+		const u32 pair = rowAll | (rowX0 << 2);                   // fields 0 and 1 of this row
+		const bool y0 = (gy & 15) == 0, z0 = (gz & 15) == 0;
+		fields = pair | (y0 ? pair << 4 : 0u) | (z0 ? pair << 8 : 0u) | (y0 && z0 ? pair << 12 : 0u);
+	}
 	if (gz >= r.mz0 && gz < r.mz1 && gy >= r.my0 && gy < r.my1) {
 		const size_t src = mat_offset(g, bx * 16, gy, gz);
 		*(uint4*)(const_cast<u8*>(g.bMat) + dst) = *(const uint4*)(g.mat + src);
 		*(uint4*)(const_cast<u8*>(g.bBlend) + dst) = *(const uint4*)(g.blend + src);
 	}
+	return fields;
 }
 
-__global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, int yb0, int ybCount, int zb0, const u32* ids)
+// collected field bits -> blockSign: per field 1 = all >= 0, 2 = all < 0, 0 = mixed or unknown
+__device__ __forceinline__ u16 block_sign_word(u32 collected)
 {
+	u32 w = 0;
+#pragma unroll
+	for (int f = 0; f < 8; ++f) {
+		const u32 b = (collected >> (2 * f)) & 3u;
+		w |= ((b == 1u || b == 2u) ? b : 0u) << (2 * f);
+	}
+	return (u16)w;
+}
+
+__global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
+{
+	__shared__ u32 blockSigns[8];
 	const int nb = g.n >> 4, tid = (int)threadIdx.x;
+	if (tid < 8) blockSigns[tid] = 0;
+	__syncthreads();
 	if (ids) {
 		const u32 id = ids[blockIdx.x];
 		const int bx = (int)(id % (u32)nb), by = (int)((id / (u32)nb) % (u32)nb), bz = (int)(id / (u32)(nb * nb));
-		rebrick_row(g, r, bx, by * 16 + (tid & 15), bz * 16 + (tid >> 4));
+		atomicOr(&blockSigns[0], rebrick_row(g, r, X, bx, by * 16 + (tid & 15), bz * 16 + (tid >> 4)));
+		__syncthreads();
+		if (tid == 0 && X.blockSign) X.blockSign[id] = block_sign_word(blockSigns[0]);
 		return;
 	}
 	const int groups = (nb + 7) >> 3;
 	const int gx = (int)blockIdx.x % groups, by = yb0 + ((int)blockIdx.x / groups) % ybCount, bz = zb0 + (int)blockIdx.x / (groups * ybCount);
 	const int bx = gx * 8 + (tid & 7);
-	if (bx >= nb) return;
+	u32 signs = 0;
+	if (bx < nb) {
 #pragma unroll
-	for (int it = 0; it < 8; ++it) {
-		const int row = it * 32 + (tid >> 3);
-		rebrick_row(g, r, bx, by * 16 + (row & 15), bz * 16 + (row >> 4));
+		for (int it = 0; it < 8; ++it) {
+			const int row = it * 32 + (tid >> 3);
+			signs |= rebrick_row(g, r, X, bx, by * 16 + (row & 15), bz * 16 + (row >> 4));
+		}
+		atomicOr(&blockSigns[tid & 7], signs);
 	}
+	__syncthreads();
+	if (tid < 8 && gx * 8 + tid < nb && X.blockSign)
+		X.blockSign[block_coord_id((u32)(gx * 8 + tid), (u32)by, (u32)bz, (u32)nb)] = block_sign_word(blockSigns[tid]);
 }
 
 // ---- start of a full run: header = 0, block -> slot maps = -1 (one launch instead of a memset per array) -------------
@@ -562,11 +641,22 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 		const u32 s = p.G.blockSummary[block_coord_id(cx, cy, cz, L.cnt)];
 		all &= s; any |= s;
 	}
-	u32 c = 0;
-	if (all & 1u) {
-		c = BC_SKIPPED;
-		if (((all ^ any) & 2u) == 0) c |= BC_QUIET | ((all & 2u) ? BC_NEGATIVE : 0u);
+	u32 c = (all & 1u) ? (u32)BC_SKIPPED : 0u;
+	// quiet: the block itself and the parts of its +x / +y / +z neighbours that its cells reach into (their first plane,
+	// line or voxel: the fields of blockSign) are of one sign, so none of its cells can be non-trivial.  At the grid's far
+	// side the samples are clamped, i.e. the block's own.
+	u32 signAll = 3u, signAny = 0u;
+#pragma unroll
+	for (u32 k = 0; k < 8; ++k) {
+		u32 f = k;
+		u32 cx = bx + (k & 1u), cy = by + ((k >> 1) & 1u), cz = bz + (k >> 2);
+		if (cx >= L.cnt) { cx = bx; f &= ~1u; }
+		if (cy >= L.cnt) { cy = by; f &= ~2u; }
+		if (cz >= L.cnt) { cz = bz; f &= ~4u; }
+		const u32 sg = ((u32)p.G.blockSign[block_coord_id(cx, cy, cz, L.cnt)] >> (2u * f)) & 3u;
+		signAll &= sg; signAny |= sg;
 	}
+	if (signAll == signAny && signAll != 0u) c |= BC_QUIET | (signAll == 2u ? (u32)BC_NEGATIVE : 0u);
 	if (inRange) {
 		p.G.blockClass[id] = (u8)c;
 		// classify tiles (TB blocks along x) that hold a block to read; zeroed by k_block_summary of the same run
@@ -576,52 +666,10 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 	// one atomic per workgroup (one per wave on a single address serialised the whole launch)
 	const int readers = __syncthreads_count(inRange && !(c & BC_QUIET));
 	if (threadIdx.x == 0 && readers) atomicAdd(&p.G.largeBlocks[1], (u32)readers);
-}
-
-// ---- lattice copies of the distance field for the coarser levels (PyramidLevel, tv_block.h) -----------------------------
-// One 16-voxel segment [xs, xs + 16) of the voxel row (y,z) as the classify pass holds it: its samples on the level-L
-// lattice go to the level's copy.  y and z may be the first row beyond the grid (y == n: the loaded data then is the
-// clamped row n - 1, and y >> L is exactly the index of the level's clamped far entry); the voxel n - 1 of a row is also
-// stored as the far entry of its lattice row.
-__device__ __forceinline__ void pyramid_write_segment(const Globals& G, int n, int xs, int y, int z, uint4 d)
-{
-#pragma unroll
-	for (int l = 1; l < PYRAMID_LEVELS; ++l) {
-		const PyramidLevel& P = G.pyr[l];
-		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
-		i8* at = P.data + pyramid_offset(P, xs >> l, y >> l, z >> l); // 8 / 4 / 2 lattice samples: inside one brick row
-		if (l == 1) {
-			uint2 v;
-			v.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200u);
-			v.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200u);
-			*(uint2*)at = v;
-		} else if (l == 2) {
-			*(u32*)at = __builtin_amdgcn_perm(d.y, d.x, 0x0C0C0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000C0Cu);
-		} else {
-			*(u16*)at = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
-		}
-		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
-	}
-}
-
-// Which of the 17 samples of that row lie in level-0 blocks the classify pass did not read (BC_QUIET)?  Such a sample
-// and everything within a block's width of it has one sign, so a cell of a level <= 3 that touches one is trivial —
-// which is all a reader needs to know about them (their lattice entries hold no data).
-__device__ __forceinline__ u32 pyramid_row_quiet_mask(const Globals& G, const LevelDesc& levels0, int level, int X0, int Y, int Z)
-{
-	const u32 cnt0 = levels0.cnt;
-	// a sample beyond the rank's last block layer (the far samples of that layer, written by its tiles) is as quiet as
-	// the block it was written from
-	const LevelDesc& L0 = levels0;
-	const u32 yb = min((u32)(Y << level) >> 4, L0.yb1 - 1), zb = min((u32)(Z << level) >> 4, L0.zb1 - 1);
-	const u8* cls = G.blockClass + (size_t)block_coord_id(0, yb, zb, cnt0);
-	const u32 xbFirst = (u32)(X0 << level) >> 4, per = 16u >> level; // samples per level-0 block along the row
-	u32 m = 0;
-	for (u32 b = 0; b <= (1u << level); ++b) {
-		const u32 xb = min(xbFirst + b, cnt0 - 1);
-		if (cls[xb] & BC_QUIET) m |= (b == (1u << level)) ? (1u << 16) : (((1u << per) - 1u) << (b * per));
-	}
-	return m;
+	// the reference's "blocks calculated" on level 0: every block its emptiness rule does not skip (:1511-1527), whether
+	// the classify pass has to read it or not
+	const int calculated = __syncthreads_count(inRange && !(c & BC_SKIPPED));
+	if (threadIdx.x == 0 && calculated) atomicAdd(&p.G.stats[2], (u32)calculated);
 }
 
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
@@ -680,21 +728,13 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 	//      first sign mask is formed. --------------------------------------------------------------------------------------
 	const auto keep = [&](int seg, int ry, int rz, uint4 d) {
 		sgn[(rz * 17 + ry) * TB + seg] = (u16)(sign_nibble(d.x) | (sign_nibble(d.y) << 4) | (sign_nibble(d.z) << 8) | (sign_nibble(d.w) << 12));
-		// the coarser levels' lattice copies (only rows with even y and z carry lattice samples): rows of this block layer,
-		// and the first rows beyond it where the rank's blocks end (nobody else would write those)
-		if (!((ry | rz) & 1) && (ry < 16 || by + 1 == L.yb1) && (rz < 16 || bz + 1 == L.zb1) && seg * 16 < validCells && !(blockCls[seg] & BC_QUIET))
-			pyramid_write_segment(p.G, n, x0 + seg * 16, (int)by * 16 + ry, (int)bz * 16 + rz, d);
 	};
 	const auto quiet_fill = [&](u32 cls) {
 		return (cls & BC_NEGATIVE) ? make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u) : make_uint4(0, 0, 0, 0);
 	};
 	{
 		const i8* tileBase = g.bDist + brick_base(g, (int)(tx * TB), (int)by, (int)bz);
-		// Row of the lane (memory order): the 64 rows with even y and even z — the only ones that hold samples of the coarser
-		// levels' lattices — go to wave 0, so the other three waves skip the lattice writes as a whole; a wave still reads
-		// two rows of every 128-byte line, the four waves of the workgroup together read each line once.
-		const int wv = tid >> 6, li = tid & 63;
-		const int row = ((li >> 1) << 3) | ((wv >> 1) << 2) | ((li & 1) << 1) | (wv & 1);
+		const int row = tid; // the lane's voxel row of every block, in memory order
 		const int ry = ((row >> 3) & 3) * 4 + (row & 3), rz = (row >> 5) * 2 + ((row >> 2) & 1); // brick_local, inverted
 		batched_gather<256 * TB, uint4, 8>(
 			[&](int q) {
@@ -784,10 +824,9 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 		const u32 bx = tx * TB + (u32)tid;
 		const bool skipped = mine && (blockCls[tid] & BC_SKIPPED) != 0;
 		const bool active = mine && blockAny[tid] != 0;
-		const unsigned long long calcMask = __ballot(mine && !skipped), actMask = __ballot(active);
+		const unsigned long long actMask = __ballot(active);
 		u32 base = 0;
 		if (tid == 0) {
-			if (calcMask) atomicAdd(&p.G.stats[2], (u32)__popcll(calcMask));
 			if (actMask) base = atomicAdd(L.nActive, (u32)__popcll(actMask));
 		}
 		base = __shfl(base, 0);
@@ -847,7 +886,6 @@ __global__ __launch_bounds__(WG) void k_hierarchy(ExecParamsDev p, u32 levels)
 // ------------------------------------------------------------------------------------------------------
 struct MatLds {
 	u32 rowMask[292];          // sign bits of the 17 samples of sample row r = k * 17 + j
-	u32 rowQuiet[292];         // ... which of them lie in level-0 blocks nobody read (their cells are trivial)
 	u16 ntRow[256];            // non-trivial cells of cell row (y,z) = the block's ntBits
 	u32 childBits[8][128];     // level 1: consistency bitmaps of the 2x2x2 child blocks
 	int childSlot[8];
@@ -921,7 +959,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		const int pitch = g.pitchY;
 		const PyramidLevel& pyr = p.G.pyr[level < PYRAMID_LEVELS ? level : 0];
 		const bool lattice = level < PYRAMID_LEVELS && pyr.data != nullptr;
-		for (int r = tid; r < 292; r += WG) { st.rowMask[r] = 0; st.rowQuiet[r] = 0; }
+		for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
 		if (tid < 8) st.childSlot[tid] = cs;
 		if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
 		if (defineAll) {
@@ -932,12 +970,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		__syncthreads();
 		MAT_TICK(2);
 		if (lattice) {
-			// the level's lattice copy: one 16-byte load + one byte per sample row
+			// the level's lattice copy (complete: it is kept with the grid's mirrors): one 16-byte load + one byte per sample row
 			for (int r = tid; r < 289; r += WG) {
 				const int k = r / 17, j = r - k * 17;
 				const PyramidRow row = pyramid_row17(pyr, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
 				st.rowMask[r] = sign_nibble(row.lo.x) | (sign_nibble(row.lo.y) << 4) | (sign_nibble(row.lo.z) << 8) | (sign_nibble(row.lo.w) << 12) | (((row.far >> 7) & 1u) << 16);
-				st.rowQuiet[r] = pyramid_row_quiet_mask(p.G, p.levels[0], (int)level, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
 			}
 		} else
 #pragma unroll 1
@@ -975,8 +1012,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 		{
 			const u32 a = st.rowMask[z * 17 + y], b2 = st.rowMask[z * 17 + y + 1], c = st.rowMask[(z + 1) * 17 + y], d = st.rowMask[(z + 1) * 17 + y + 1];
 			const u32 A = a & b2 & c & d, O = a | b2 | c | d;
-			const u32 Q = st.rowQuiet[z * 17 + y] | st.rowQuiet[z * 17 + y + 1] | st.rowQuiet[(z + 1) * 17 + y] | st.rowQuiet[(z + 1) * 17 + y + 1];
-			nt = ((O | (O >> 1)) & ~(A & (A >> 1)) & ~(Q | (Q >> 1))) & 0xFFFFu;
+			nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
 			st.ntRow[tid] = (u16)nt;
 			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
 			if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
@@ -1461,19 +1497,8 @@ __global__ __launch_bounds__(WG) void k_classify_blocks(ExecParamsDev p, const u
 		if (tid == 0) ntCells = 0;
 		__syncthreads();
 		mat_phase_classify(st, tid, WG);
-		// the block was read in full: its lattice samples go to the coarser levels' copies (with the far samples where no
-		// further block follows), and whatever a full run knew about it without reading it no longer holds
+		// whatever a full run knew about the block without reading it no longer holds
 		if (tid == 0) p.G.blockClass[coords[k]] = 0;
-		for (int l = 1; l < PYRAMID_LEVELS; ++l) {
-			const PyramidLevel& P = p.G.pyr[l];
-			if (!P.data) continue;
-			const int step = 1 << l, per = 16 >> l;
-			const int cx = per + (bx + 1 == L.cnt ? 1 : 0), cy = per + (by + 1 == L.yb1 ? 1 : 0), cz = per + (bz + 1 == L.zb1 ? 1 : 0);
-			for (int e = tid; e < cx * cy * cz; e += WG) {
-				const int i = (e % cx) * step, j = ((e / cx) % cy) * step, kk = (e / (cx * cy)) * step;
-				P.data[pyramid_offset(P, (int)(bx * 16 + i) >> l, (int)(by * 16 + j) >> l, (int)(bz * 16 + kk) >> l)] = st.samp[(kk * 17 + j) * 17 + i];
-			}
-		}
 		__syncthreads();
 		if (tid < 128) atomicAdd(&ntCells, (u32)__popc(st.ntBits[tid]));
 		__syncthreads();
@@ -1536,12 +1561,13 @@ __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPla
 // ------------------------------------------------------------------------------------------------------
 // k_halo_move: the pieces of the halo messages of one side pair (below / above) between their fields and contiguous
 // staging buffers (HaloMove, tv_block.h): blockIdx.y picks the message, one workgroup per row (n bytes of a voxel field,
-// cnt bytes of the flag array).  Unpacking also writes the rows into the brick mirrors (tv_core.h GridView) when the view
-// carries them, so an exchange is two launches around the RCCL batch: pack, unpack.
+// cnt bytes of the flag array).  Unpacking also writes the rows into the brick mirrors (tv_core.h GridView) and the lattice
+// copies when the view carries them, so an exchange is two launches around the RCCL batch: pack, unpack.  (The sign
+// summaries of the halo block layers stay "unknown": those blocks are never resident as a whole.)
 // ------------------------------------------------------------------------------------------------------
 struct HaloPair { HaloMove m[2]; };
 
-__global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, int alongY)
+__global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, MirrorState X, int alongY)
 {
 	const HaloMove& mv = pair.m[blockIdx.y];
 	u32 row = blockIdx.x;
@@ -1569,7 +1595,10 @@ __global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, int
 		for (u32 i = threadIdx.x; i < p.rowBytes / 16; i += WG) {
 			const uint4 v = ((const uint4*)src)[i];
 			((uint4*)dst)[i] = v;
-			if (brick) *(uint4*)(brick + brick_offset(g, (int)(i * 16), y, z)) = v;
+			if (brick) {
+				*(uint4*)(brick + brick_offset(g, (int)(i * 16), y, z)) = v;
+				if (brick == (u8*)g.bDist) lattice_rows_of(X, g.n, (int)(i * 16), y, z, v); // the lattice copies follow as well
+			}
 		}
 	} else {
 		for (u32 i = threadIdx.x; i < p.rowBytes; i += WG) {
@@ -1715,17 +1744,17 @@ struct Backend {
 	}
 	bool wants_pyramid() const { return true; }
 	bool wants_bricks() const { return true; }
-	// dense fields -> brick mirrors: the blocks of the box { yb0, yb1, zb0, zb1 } (all x), or the listed blocks
-	void run_rebrick(const GridView& g, const int dr[4], const int mr[4], const int box[4], const u32* ids, u32 count)
+	// dense fields -> mirrors: the blocks of the box { yb0, yb1, zb0, zb1 } (all x), or the listed blocks
+	void run_rebrick(const GridView& g, const int dr[4], const int mr[4], const MirrorState& ms, const int box[4], const u32* ids, u32 count)
 	{
 		const RebrickRanges r = { dr[0], dr[1], dr[2], dr[3], mr[0], mr[1], mr[2], mr[3] };
 		if (ids) {
-			hipLaunchKernelGGL(k_rebrick, dim3(count), dim3(WG), 0, stream, g, r, 0, 1, 0, ids);
+			hipLaunchKernelGGL(k_rebrick, dim3(count), dim3(WG), 0, stream, g, r, ms, 0, 1, 0, ids);
 		} else {
 			const int nb = g.n >> 4, groups = (nb + 7) >> 3;
 			const int yc = box[1] - box[0], zc = box[3] - box[2];
 			if (yc <= 0 || zc <= 0) return;
-			hipLaunchKernelGGL(k_rebrick, dim3((u32)(groups * yc * zc)), dim3(WG), 0, stream, g, r, box[0], yc, box[2], (const u32*)nullptr);
+			hipLaunchKernelGGL(k_rebrick, dim3((u32)(groups * yc * zc)), dim3(WG), 0, stream, g, r, ms, box[0], yc, box[2], (const u32*)nullptr);
 		}
 		check(hipGetLastError(), "k_rebrick launch");
 	}
@@ -2010,7 +2039,7 @@ struct Backend {
 	// ---- halo messages of attached slabs (vx_halo_exchange*, vx_host.inl) -----------------------------------------------
 	// both messages of a direction (pack: what goes below / above; unpack: what came from below / above) in one launch;
 	// either may be absent.  `g` carries the brick mirrors an unpack keeps current (null pointers: none).
-	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView& g, bool alongY)
+	void run_halo_moves(const HaloMove* lo, const HaloMove* hi, const GridView& g, const MirrorState& ms, bool alongY)
 	{
 		HaloPair pair;
 		memset(&pair, 0, sizeof(pair));
@@ -2022,7 +2051,7 @@ struct Backend {
 		for (u32 i = 0; i < b.count; ++i) rows[1] += (u32)b.piece[i].layers * b.piece[i].rows;
 		const u32 most = std::max(rows[0], rows[1]);
 		if (!most) return;
-		hipLaunchKernelGGL(k_halo_move, dim3(most, 2), dim3(WG), 0, stream, pair, g, alongY ? 1 : 0);
+		hipLaunchKernelGGL(k_halo_move, dim3(most, 2), dim3(WG), 0, stream, pair, g, ms, alongY ? 1 : 0);
 		check(hipGetLastError(), "k_halo_move launch");
 	}
 	void* comm = nullptr;

@@ -59,6 +59,7 @@ struct vx_ctx {
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
 	// planes [brickZb0, +brickPlanesZ); stale = everything has to be copied again before the next polygonization
 	void* dBrick[3] = { nullptr, nullptr, nullptr };
+	void* dBlockSign = nullptr;          // per level-0 block: sign summary of its samples (MirrorState)
 	u32 brickN = 0, brickYb0 = 0, brickZb0 = 0, brickRowsY = 0, brickPlanesZ = 0;
 	bool bricksStale = true;
 	void* dListCounts = nullptr;                         // per-workgroup counts of the list kernels
@@ -140,6 +141,7 @@ void release_grid(vx_ctx* c)
 void free_bricks(vx_ctx* c)
 {
 	for (void*& b : c->dBrick) { c->be.free(b); b = nullptr; }
+	c->be.free(c->dBlockSign); c->dBlockSign = nullptr;
 	c->brickN = 0;
 	c->bricksStale = true;
 }
@@ -169,6 +171,16 @@ GridView resident_view(const vx_ctx* c)
 	return g;
 }
 
+// what the kernels that keep the mirrors current need beside the view
+MirrorState mirror_state(const vx_ctx* c)
+{
+	MirrorState ms;
+	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) ms.pyr[L] = c->pyr[L];
+	ms.blockSign = (u16*)c->dBlockSign;
+	ms.yBegin = (int)c->yBegin; ms.yEnd = (int)c->yEnd; ms.zBegin = (int)c->zBegin; ms.zEnd = (int)c->zEnd;
+	return ms;
+}
+
 // Brick mirrors allocated for the resident block layers (halo layers included) and brought up to date.  Called at the
 // start of every polygonization; between runs the mutation entry points re-copy what they touched (rebrick_*), so a run on
 // an unchanged grid finds nothing to do here.
@@ -183,12 +195,14 @@ bool ensure_bricks(vx_ctx* c)
 		free_bricks(c);
 		const size_t bytes = (size_t)nb * (yb1 - yb0) * (zb1 - zb0) * BRICK_BYTES;
 		for (void*& b : c->dBrick) b = c->be.alloc(bytes);
-		if (!c->dBrick[0] || !c->dBrick[1] || !c->dBrick[2]) { free_bricks(c); return false; }
+		c->dBlockSign = c->be.alloc((size_t)nb * nb * nb * 2);
+		if (!c->dBrick[0] || !c->dBrick[1] || !c->dBrick[2] || !c->dBlockSign) { free_bricks(c); return false; }
+		if (!c->be.fill(c->dBlockSign, 0, (size_t)nb * nb * nb * 2)) { free_bricks(c); return false; } // blocks outside the resident range: unknown
 		c->brickN = c->n; c->brickYb0 = yb0; c->brickZb0 = zb0; c->brickRowsY = yb1 - yb0; c->brickPlanesZ = zb1 - zb0;
 	}
 	if (c->bricksStale) {
 		const int box[4] = { (int)yb0, (int)yb1, (int)zb0, (int)zb1 };
-		c->be.run_rebrick(resident_view(c), dr, mr, box, nullptr, 0);
+		c->be.run_rebrick(resident_view(c), dr, mr, mirror_state(c), box, nullptr, 0);
 		c->bricksStale = false;
 	}
 	return true;
@@ -201,7 +215,7 @@ void rebrick_blocks(vx_ctx* c, const u32* dIds, u32 count)
 	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0] || !count) return;
 	int dr[4], mr[4];
 	resident_ranges(c, dr, mr);
-	c->be.run_rebrick(resident_view(c), dr, mr, nullptr, dIds, count);
+	c->be.run_rebrick(resident_view(c), dr, mr, mirror_state(c), nullptr, dIds, count);
 }
 
 
@@ -304,6 +318,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.blockSummary = (u8*)c->dBlockSummary;
 	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.tileWork = (u8*)c->dTileWork;
+	p.G.blockSign = (const u16*)c->dBlockSign;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
@@ -861,13 +876,13 @@ int vx_halo_exchange(vx_ctx* c)
 	if ((pl.hasLo && c->commRank == 0) || (pl.hasHi && c->commRank + 1 == c->commRanks)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: rank r must own the r-th slab");
 	// pack -> one grouped send/recv batch -> unpack, all queued on the context's stream: nothing waits on the host
 	const bool alongY = c->slabAxis == 2;
-	c->be.run_halo_moves(pl.hasLo ? &pl.sendLo : nullptr, pl.hasHi ? &pl.sendHi : nullptr, halo_view(c), alongY);
+	c->be.run_halo_moves(pl.hasLo ? &pl.sendLo : nullptr, pl.hasHi ? &pl.sendHi : nullptr, halo_view(c), mirror_state(c), alongY);
 	const bool ok = c->be.comm_exchange(pl.hasLo ? c->commRank - 1 : -1, pl.hasLo ? c->haloBuf[0] : nullptr, pl.hasLo ? halo_move_bytes(pl.sendLo) : 0,
 	                                    pl.hasLo ? c->haloBuf[2] : nullptr, pl.hasLo ? halo_move_bytes(pl.recvLo) : 0,
 	                                    pl.hasHi ? c->commRank + 1 : -1, pl.hasHi ? c->haloBuf[1] : nullptr, pl.hasHi ? halo_move_bytes(pl.sendHi) : 0,
 	                                    pl.hasHi ? c->haloBuf[3] : nullptr, pl.hasHi ? halo_move_bytes(pl.recvHi) : 0);
 	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange: " + c->be.error());
-	c->be.run_halo_moves(pl.hasLo ? &pl.recvLo : nullptr, pl.hasHi ? &pl.recvHi : nullptr, halo_view(c), alongY);
+	c->be.run_halo_moves(pl.hasLo ? &pl.recvLo : nullptr, pl.hasHi ? &pl.recvHi : nullptr, halo_view(c), mirror_state(c), alongY);
 	c->haveSurface = false;
 	return VX_OK;
 }
@@ -883,7 +898,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		if (!c) return VX_ERR_INVALID;
 		if (!halo_plan(c, plans[(size_t)i], why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: " + why);
 		if (plans[(size_t)i].hasLo != (i > 0) || plans[(size_t)i].hasHi != (i + 1 < count)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange_group: contexts must be the slabs of one grid in order");
-		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].sendLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].sendHi : nullptr, halo_view(c), c->slabAxis == 2);
+		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].sendLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].sendHi : nullptr, halo_view(c), mirror_state(c), c->slabAxis == 2);
 	}
 	for (int i = 0; i < count; ++i) { VX_ENTER(ctxs[i]); if (!ctxs[i]->be.sync_ok()) return fail(ctxs[i], VX_ERR_DEVICE, "vx_halo_exchange_group: pack failed: " + ctxs[i]->be.error()); }
 	for (int i = 0; i + 1 < count; ++i) {
@@ -898,7 +913,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		vx_ctx* c = ctxs[i];
 		VX_ENTER(c);
 		if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange_group: copy failed: " + c->be.error());
-		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].recvLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].recvHi : nullptr, halo_view(c), c->slabAxis == 2);
+		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].recvLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].recvHi : nullptr, halo_view(c), mirror_state(c), c->slabAxis == 2);
 		c->haveSurface = false;
 	}
 	return VX_OK;
