@@ -76,6 +76,13 @@ def fuzz_edits(oracle, p, budget, seed):
             if not (np.array_equal(got, ref_ids) and ok and np.array_equal(p.stats(), s.stats())):
                 print("INCREMENTAL MISMATCH seed %d args %s: %s" % (seed, args, msg))
                 sys.exit(1)
+        # a FULL run over the edited grid: the library's mirrors (bricks, lattice copies, sign summaries) followed the edits
+        full = oracle.execute(g)
+        p.execute()
+        ok, msg = fields.surface_equal(p.all_levels(), full.all_levels(), nrm_tol=0.0)
+        if not ok or not np.array_equal(p.stats(), full.stats()):
+            print("FULL RUN AFTER EDITS MISMATCH seed %d: %s" % (seed, msg))
+            sys.exit(1)
         chains += 1
         seed += 1
     print("edit fuzz ok: %d chains, %d edits" % (chains, edits))
