@@ -139,7 +139,6 @@ struct Backend {
 		for (u32 l = 0; l < levels; ++l) memset(p.levels[l].slotOf, 0xFF, (size_t)p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt * 4);
 	}
 	bool stage_timing_on() const { return true; } // the emulation always runs the serial order
-	template <typename P> void run_overlapped_level0(const P&) {}
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}

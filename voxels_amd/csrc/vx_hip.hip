@@ -19,6 +19,7 @@
 //
 // No MFMA: this is table-driven integer/byte work bound by HBM bandwidth and latency.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -1954,12 +1955,23 @@ struct Backend {
 		hipLaunchKernelGGL(k_gather_records, dim3((r.start[levels] + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, levels, out);
 		check(hipGetLastError(), "k_gather_records launch");
 	}
+	// A hand-over event between streams is attached to the kernel it follows (hipExtLaunchKernelGGL: the dispatch's own
+	// completion signal) instead of being recorded behind it: a recorded event is one more packet in the stream, and the
+	// next kernel of that stream starts ~8 us later.
+	hipEvent_t doneEvent = nullptr; // completion event of the next launch made through launch_with_event
+	template <typename K, typename... Args>
+	void launch_with_event(K kernel, dim3 grid, u32 lds, Args... args)
+	{
+		if (doneEvent) hipExtLaunchKernelGGL(kernel, grid, dim3(WG), lds, stream, nullptr, doneEvent, 0u, args...);
+		else hipLaunchKernelGGL(kernel, grid, dim3(WG), lds, stream, args...);
+		doneEvent = nullptr;
+	}
 	template <typename P>
 	void run_hierarchy(const P& p, u32 levels)
 	{
 		if (levels < 2) return;
 		const u32 grid = (p.levels[0].cap + WG - 1) / WG;
-		hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(WG), 0, stream, dev(p), levels);
+		launch_with_event(k_hierarchy, dim3(grid), 0u, dev(p), levels);
 		check(hipGetLastError(), "k_hierarchy launch");
 	}
 	template <typename P>
@@ -1968,7 +1980,7 @@ struct Backend {
 		const u32 cap = p.levels[level].cap;
 		if (!cap) return;
 		const u32 grid = std::min<u32>(cap, tune.matGrid ? tune.matGrid : (u32)cus * 8);
-		hipLaunchKernelGGL(k_material, dim3(grid), dim3(WG), 0, stream, dev(p), level);
+		launch_with_event(k_material, dim3(grid), 0u, dev(p), level);
 		check(hipGetLastError(), "k_material launch");
 	}
 	// Regular cells of the levels [levelBegin, levels): level 0 has its own kernel (vx_regular0.inl).  The 4096-cell
@@ -2010,18 +2022,20 @@ struct Backend {
 	//   side stream B : transition cells (after the material chain)
 	// The small, latency-bound material launches no longer leave the chip idle.
 	template <typename P>
-	void run_overlapped_level0(const P& p)
-	{
-		(void)hipEventRecord(evClassified, stream);
-		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		launch_regular(p, 0, 1, sideA);
-		(void)hipEventRecord(evSideA, sideA);
-	}
-	template <typename P>
 	void run_overlapped_tail(const P& p, u32 levels)
 	{
-		for (u32 L = 1; L < levels; ++L) run_material(p, L);
-		(void)hipEventRecord(evMaterial, stream);
+		// the hierarchy pass carries the event that releases the level-0 regular pass on side stream A (levels == 1: no
+		// hierarchy pass, the event is recorded)
+		if (levels >= 2) { doneEvent = evClassified; run_hierarchy(p, levels); }
+		else (void)hipEventRecord(evClassified, stream);
+		(void)hipStreamWaitEvent(sideA, evClassified, 0);
+		launch_regular(p, 0, 1, sideA);
+		(void)hipEventRecord(evSideA, sideA); // side streams: a recorded event (attached ones made the run slower there)
+		// the last material launch carries the event that releases the transition pass on side stream B
+		u32 lastMat = 0;
+		for (u32 L = 1; L < levels; ++L) if (p.levels[L].cap) lastMat = L;
+		for (u32 L = 1; L < levels; ++L) { if (L == lastMat) doneEvent = evMaterial; run_material(p, L); }
+		if (!lastMat) (void)hipEventRecord(evMaterial, stream);
 		(void)hipStreamWaitEvent(sideB, evMaterial, 0);
 		{
 			hipStream_t keep = stream;

@@ -380,11 +380,8 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	c->be.run_classify(p);
 	c->be.stage_mark(2);
 	if (!c->be.stage_timing_on()) {
-		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless); the level-0
-		// regular pass needs nothing of the hierarchy pass and is released right behind the classify pass
-		c->be.run_overlapped_level0(p);
-		c->be.run_hierarchy(p, levels);
-		c->be.run_overlapped_tail(p, levels);
+		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless)
+		c->be.run_overlapped_tail(p, levels); // hierarchy pass included
 		return;
 	}
 	c->be.run_hierarchy(p, levels);
