@@ -123,7 +123,6 @@ struct Globals {
 	u32 prevActive[MAX_LEVELS];       // dirty: slots >= prevActive[level] were created by this run
 	u32* largeBlocks;                 // number of classified blocks whose non-trivial cell count exceeds LARGE_THRESHOLD
 	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
-	u8* blockSummary;                 // bit0 = BF_Empty, bit1 = sign of the block's samples (an empty block has one sign)
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
 	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
 	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)

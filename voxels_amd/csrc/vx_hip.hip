@@ -2,7 +2,7 @@
 //
 // One polygonization = a handful of kernels on three streams of one context, no host round trip in between (work
 // lists and output offsets live in device memory):
-//   k_reset, k_block_summary, k_block_class   counters / slot maps; what the BF_Empty flags already say about a block
+//   k_run_reset, k_block_class   counters / slot maps; what the BF_Empty flags and the sign summaries say about a block
 //   k_classify    stream over the density field, skipping blocks the flags prove quiet: 16-byte coalesced loads, sign
 //                 bits packed to bit-masks in LDS, cells classified bit-parallel (256 per lane); emits the
 //                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block.
@@ -599,29 +599,13 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 	}
 }
 
-// ---- what the emptiness flags already say about a block (two tiny launches ahead of k_classify) ------------
-// summary: BF_Empty + the sign of one resident sample of the block (an empty block has a single sign).  The same launch
-// resets the run's counters and slot maps (independent work, one launch fewer at the head of every run).
-__global__ __launch_bounds__(WG) void k_block_summary(ExecParamsDev p, u32 zbLo, u32 zbHi, u32 ybLo, u32 ybHi, ResetRanges r)
+// ---- head of a full run: k_run_reset zeroes the run's counters, slot maps and classify-tile marks; k_block_class reads
+//      what the emptiness flags and the sign summaries already say about every block ------------------------------------
+__global__ __launch_bounds__(WG) void k_run_reset(ExecParamsDev p, ResetRanges r, u32 tiles)
 {
-	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
 	if (r.header) reset_words(p, r, i);
-	const u32 rowsY = ybHi - ybLo;
-	if (i >= L.cnt * rowsY * (zbHi - zbLo)) return;
-	const u32 bx = i % L.cnt, by = ybLo + (i / L.cnt) % rowsY, bz = zbLo + i / (L.cnt * rowsY);
-	const u32 id = block_coord_id(bx, by, bz, L.cnt);
-	u32 s = 0;
-	if (p.G.emptyFlags[id]) {
-		const GridView& g = p.G.grid;
-		// the neighbour slab below (in z or in y): only its last plane / row is resident, still inside the block
-		const int z = max((int)bz * 16, g.zOrigin), y = max((int)by * 16, g.yOrigin);
-		const i8 v = g.dist[dist_offset(g, (int)bx * 16, y, z)];
-		s = 1u | (((u32)(v >> 7) & 1u) << 1);
-	}
-	p.G.blockSummary[id] = (u8)s;
-	if ((bx & 15u) == 0 && by >= L.yb0 && by < L.yb1 && bz >= L.zb0 && bz < L.zb1)
-		p.G.tileWork[((bz - L.zb0) * (L.yb1 - L.yb0) + (by - L.yb0)) * ((L.cnt + 15u) / 16u) + bx / 16u] = 0;
+	if (i < tiles) p.G.tileWork[i] = 0;
 }
 
 __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
@@ -633,14 +617,14 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 	const u32 ii = inRange ? i : 0u;
 	const u32 bx = ii % L.cnt, by = L.yb0 + (ii / L.cnt) % rowsY, bz = L.zb0 + ii / (L.cnt * rowsY);
 	const u32 id = block_coord_id(bx, by, bz, L.cnt);
-	u32 all = 3u, any = 0u; // AND / OR over the 27 summaries (neighbour coordinates clamped like the reference's)
+	u32 all = 1u; // AND over the 27 BF_Empty flags (neighbour coordinates clamped like the reference's)
 #pragma unroll
 	for (int k = 0; k < 27; ++k) {
 		const u32 cx = (u32)clampi((int)bx + (k % 3) - 1, 0, (int)L.cnt - 1);
 		const u32 cy = (u32)clampi((int)by + ((k / 3) % 3) - 1, 0, (int)L.cnt - 1);
 		const u32 cz = (u32)clampi((int)bz + (k / 9) - 1, 0, (int)L.cnt - 1);
-		const u32 s = p.G.blockSummary[block_coord_id(cx, cy, cz, L.cnt)];
-		all &= s; any |= s;
+		const u32 s = p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)] ? 1u : 0u; // BF_Empty of the neighbour (the flag array covers the whole grid)
+		all &= s;
 	}
 	u32 c = (all & 1u) ? (u32)BC_SKIPPED : 0u;
 	// quiet: the block itself and the parts of its +x / +y / +z neighbours that its cells reach into (their first plane,
@@ -660,7 +644,7 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 	if (signAll == signAny && signAll != 0u) c |= BC_QUIET | (signAll == 2u ? (u32)BC_NEGATIVE : 0u);
 	if (inRange) {
 		p.G.blockClass[id] = (u8)c;
-		// classify tiles (TB blocks along x) that hold a block to read; zeroed by k_block_summary of the same run
+		// classify tiles (TB blocks along x) that hold a block to read; zeroed by k_run_reset of the same run
 		if (!(c & BC_QUIET)) p.G.tileWork[((bz - L.zb0) * rowsY + (by - L.yb0)) * ((L.cnt + 15u) / 16u) + bx / 16u] = 1;
 	}
 	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py);
@@ -1877,7 +1861,7 @@ struct Backend {
 		return ms;
 	}
 
-	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_block_summary)
+	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_run_reset)
 	ResetRanges pendingReset = {};
 	template <typename P>
 	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
@@ -1910,14 +1894,11 @@ struct Backend {
 		const u32 rowsY = L.yb1 - L.yb0;
 		const u32 grid = tilesX * rowsY * (L.zb1 - L.zb0);
 		if (!grid) return;
-		// summaries also for the neighbour layers of the slab (one block layer beyond it in z and in y)
-		const u32 zbLo = L.zb0 ? L.zb0 - 1 : 0, zbHi = std::min<u32>(L.zb1 + 1, L.cnt);
-		const u32 ybLo = L.yb0 ? L.yb0 - 1 : 0, ybHi = std::min<u32>(L.yb1 + 1, L.cnt);
 		{
 			const ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
-			const u32 lanes = std::max<u32>(L.cnt * (ybHi - ybLo) * (zbHi - zbLo), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
-			hipLaunchKernelGGL(k_block_summary, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), zbLo, zbHi, ybLo, ybHi, r);
+			const u32 lanes = std::max<u32>(grid, r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
+			hipLaunchKernelGGL(k_run_reset, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, grid);
 		}
 		hipLaunchKernelGGL(k_block_class, dim3((L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
 		const u32 rows = rowsY * (L.zb1 - L.zb0);

@@ -53,7 +53,7 @@ struct vx_ctx {
 	u32 distRows = 0, matRows = 0;       // rows per resident plane (n for a whole grid or a z-slab)
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
-	void *dBlockSummary = nullptr, *dBlockClass = nullptr; // per level-0 block scratch of the classify pass
+	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
 	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
@@ -263,10 +263,9 @@ bool ensure_level_tables(vx_ctx* c)
 		d.nActive = (u32*)c->dHeader + L;
 		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.listed || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 		if (!L) {
-			c->dBlockSummary = alloc(total);
 			c->dBlockClass = alloc(total);
 			c->dTileWork = alloc((size_t)((d.cnt + 15) / 16) * (d.yb1 - d.yb0) * (d.zb1 - d.zb0) + 16);
-			if (!c->dBlockSummary || !c->dBlockClass || !c->dTileWork) return false;
+			if (!c->dBlockClass || !c->dTileWork) return false;
 		}
 		// lattice copy of the distance samples of this level over the rank's rows / planes (one more than it owns: the far
 		// samples of its last block layer)
@@ -315,7 +314,6 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.stats = (u32*)c->dHeader + HDR_STATS;
 	p.G.workCount = (u32*)c->dHeader + HDR_WORK;
 	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
-	p.G.blockSummary = (u8*)c->dBlockSummary;
 	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.tileWork = (u8*)c->dTileWork;
 	p.G.blockSign = (const u16*)c->dBlockSign;
