@@ -142,6 +142,7 @@ def main():
     poly.set_materials(synth.default_lut())
     t_gen = time.perf_counter()
     slab = None
+    halo_transport = None
     if world == 1:
         poly.create_terrain(n, seed)
     else:
@@ -149,9 +150,20 @@ def main():
         slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
         slab.attach(poly)
         poly.fill_terrain(seed)
-        uid = torch.from_numpy(poly.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
-        dist_pkg.broadcast(uid, 0)
-        poly.comm_init(world, rank, uid.cpu().numpy())
+        # the exchange runs through the C ABI (vx_comm_init / vx_halo_exchange: RCCL bound by the library itself); if that
+        # communicator cannot be set up on this node every rank falls back to the torch.distributed transport of
+        # voxels_amd/slab.py (slower: the attached tensors are rewritten behind the library's back and attached again)
+        ok = 1
+        try:
+            uid = torch.from_numpy(poly.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+            dist_pkg.broadcast(uid, 0)
+            poly.comm_init(world, rank, uid.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: C-ABI communicator failed (%s), falling back to torch.distributed\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist_pkg.all_reduce(flag, op=dist_pkg.ReduceOp.MIN)
+        halo_transport = "c-abi-rccl" if int(flag.item()) == 1 else "torch-distributed"
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
@@ -160,7 +172,12 @@ def main():
         boundary block layers from the slab above — vx_halo_exchange: pack kernel, one grouped ncclSend/ncclRecv batch on the
         library's stream, unpack kernel; no host wait."""
         if world > 1:
-            poly.halo_exchange()
+            if halo_transport == "c-abi-rccl":
+                poly.halo_exchange()
+            else:
+                slab.gather_flags(dist_pkg)
+                slab.halo_exchange(dist_pkg)
+                slab.attach(poly)
 
     halo_exchange()
     torch.cuda.synchronize()
@@ -307,7 +324,7 @@ def main():
                                         "Mvoxels_per_s_over_surface_blocks": round(surface_blocks * 4096 / step_s / 1e6, 2),
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
-                       "halo_exchange_in_step": world > 1},
+                       "halo_exchange_in_step": world > 1, "halo_transport": halo_transport},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
