@@ -718,50 +718,67 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 		return (cls & BC_NEGATIVE) ? make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u) : make_uint4(0, 0, 0, 0);
 	};
 	{
+		// Two rounds of loads: the rows of blocks 0..7; then the rows of blocks 8..15 together with the rows y = 16 / z = 16
+		// (16 + 17 per block: 528 requests over 256 lanes) and the voxel right of the tile (289 bytes) — everything of a
+		// round is in flight before its first sign mask is formed.
 		const i8* tileBase = g.bDist + brick_base(g, (int)(tx * TB), (int)by, (int)bz);
 		const int row = tid; // the lane's voxel row of every block, in memory order
 		const int ry = ((row >> 3) & 3) * 4 + (row & 3), rz = (row >> 5) * 2 + ((row >> 2) & 1); // brick_local, inverted
-		batched_gather<256 * TB, uint4, 8>(
-			[&](int q) {
-				const int seg = q >> 8;
-				const u32 cls = blockCls[seg];
-				uint4 d = make_uint4(0, 0, 0, 0);
-				if (cls & BC_QUIET) d = quiet_fill(cls);
-				else if (seg * 16 < validCells) d = *(const uint4*)(tileBase + (size_t)seg * BRICK_BYTES + (size_t)row * 16);
-				return d;
-			},
-			[&](int q, uint4 d) { keep(q >> 8, ry, rz, d); });
-	}
-	batched_gather<16 * TB + 17 * TB, uint4, 3>(
-		[&](int q) {
-			int seg, ry, rz;
-			if (q < 16 * TB) { seg = q >> 4; ry = 16; rz = q & 15; }
-			else { const int e = q - 16 * TB; seg = e / 17; ry = e - seg * 17; rz = 16; }
+		const auto main_row = [&](int seg) {
+			const u32 cls = blockCls[seg];
+			uint4 d = make_uint4(0, 0, 0, 0);
+			if (cls & BC_QUIET) d = quiet_fill(cls);
+			else if (seg * 16 < validCells) d = *(const uint4*)(tileBase + (size_t)seg * BRICK_BYTES + (size_t)row * 16);
+			return d;
+		};
+		const auto far_where = [&](int q, int& seg, int& fy, int& fz) {
+			if (q < 16 * TB) { seg = q >> 4; fy = 16; fz = q & 15; }
+			else { const int e = q - 16 * TB; seg = e / 17; fy = e - seg * 17; fz = 16; }
+		};
+		const auto far_row = [&](int q) {
+			int seg, fy, fz;
+			far_where(min(q, 16 * TB + 17 * TB - 1), seg, fy, fz);
 			const u32 cls = blockCls[seg];
 			uint4 d = make_uint4(0, 0, 0, 0);
 			if (cls & BC_QUIET) d = quiet_fill(cls);
 			else if (seg * 16 < validCells) {
-				const int y = clampi((int)by * 16 + ry, 0, n - 1);
-				const int z = clampi((int)bz * 16 + rz, 0, n - 1);
+				const int y = clampi((int)by * 16 + fy, 0, n - 1);
+				const int z = clampi((int)bz * 16 + fz, 0, n - 1);
 				d = *(const uint4*)(g.bDist + brick_offset(g, x0 + seg * 16, y, z));
 			}
 			return d;
-		},
-		[&](int q, uint4 d) {
-			int seg, ry, rz;
-			if (q < 16 * TB) { seg = q >> 4; ry = 16; rz = q & 15; }
-			else { const int e = q - 16 * TB; seg = e / 17; ry = e - seg * 17; rz = 16; }
-			keep(seg, ry, rz, d);
-		});
-	batched_gather<289, i8, 2>(
-		[&](int r) {
-			const int ry = r % 17, rz = r / 17;
-			const int y = clampi((int)by * 16 + ry, 0, n - 1);
-			const int z = clampi((int)bz * 16 + rz, 0, n - 1);
+		};
+		const auto right_voxel = [&](int r) {
+			r = min(r, 288);
+			const int hy = r % 17, hz = r / 17;
+			const int y = clampi((int)by * 16 + hy, 0, n - 1);
+			const int z = clampi((int)bz * 16 + hz, 0, n - 1);
 			const int x = clampi(x0 + validCells, 0, n - 1);
 			return g.bDist[brick_offset(g, x, y, z)];
-		},
-		[&](int r, i8 v) { halo[r] = (u8)((u32)(v >> 7) & 1u); });
+		};
+		uint4 m[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) m[i] = main_row(i);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) keep(i, ry, rz, m[i]);
+		uint4 f[3];
+		i8 xv[2];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) m[i] = main_row(8 + i);
+#pragma unroll
+		for (int i = 0; i < 3; ++i) f[i] = far_row(tid + i * WG);
+#pragma unroll
+		for (int i = 0; i < 2; ++i) xv[i] = right_voxel(tid + i * WG);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) keep(8 + i, ry, rz, m[i]);
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			const int q = tid + i * WG;
+			if (q < 16 * TB + 17 * TB) { int seg, fy, fz; far_where(q, seg, fy, fz); keep(seg, fy, fz, f[i]); }
+		}
+#pragma unroll
+		for (int i = 0; i < 2; ++i) { const int r = tid + i * WG; if (r < 289) halo[r] = (u8)((u32)(xv[i] >> 7) & 1u); }
+	}
 	__syncthreads();
 
 	// ---- classify the 16*TB cells of one (y,z) row per thread, bit-parallel -----------------------------
