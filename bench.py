@@ -8,9 +8,10 @@ terrain, LOD levels 0..3 with transition cells and materials, on N MI355X GPUs o
 
 A step = one vx_polygonize over the resident grid (classify -> hierarchy -> material -> regular -> transition
 kernels, the device-built block lists, and the small header read-back that tells the host the counts).  With N > 1 the grid is sharded in slabs
-(along y by default: a terrain's surface lives in a few z-layers; strong scaling: the 1024^3 grid is fixed), and every
-step also re-exchanges the slab halo (1 distance layer down, 2 distance + 1 material + 1 blend layer up) over RCCL
-through the C ABI (vx_halo_exchange), as the path does after an edit.  Inputs are generated on the device
+(along y by default: a terrain's surface lives in a few z-layers; strong scaling: the 1024^3 grid is fixed); the slab
+halo (1 distance layer down, 2 distance + 1 material + 1 blend layer up) is exchanged over RCCL through the C ABI
+(vx_halo_exchange) once before the steps — a polygonization of an unchanged grid needs no exchange — or, with
+--halo-every-step, inside every step, as the path does after an edit.  Inputs are generated on the device
 (vx_grid_create_terrain / vx_grid_fill_terrain: the bytes of the host generator voxels_synth) and are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line.
 """
@@ -36,7 +37,9 @@ def parse():
     ap.add_argument("--levels", type=int, default=int(os.environ.get("VOXELS_BENCH_LEVELS", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab-axis", choices=["y", "z"], default="y", help="axis along which the grid is cut into one slab per GPU (y balances height-field terrains, whose surface sits in a few z-layers)")
-    ap.add_argument("--serialize", action="store_true", help="run the timed steps with the library's streams serialised (one kernel at a time), for per-kernel profiling")
+    ap.add_argument("--serialize", action="store_true", help="run EVERY launch of this process with the library's streams serialised (one kernel at a time), for per-kernel profiling: the end-to-end figures are skipped")
+    ap.add_argument("--allow-torch-transport", action="store_true", help="N > 1 only: if the C-ABI RCCL communicator (vx_comm_init) cannot be brought up, move the halo with torch.distributed instead of failing (such a run is no evidence for vx_halo_exchange)")
+    ap.add_argument("--halo-every-step", action="store_true", help="N > 1 only: exchange the slab halo inside every timed step (as after an edit) instead of once before the steps")
     return ap.parse_args()
 
 
@@ -150,20 +153,38 @@ def main():
         slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
         slab.attach(poly)
         poly.fill_terrain(seed)
-        # the exchange runs through the C ABI (vx_comm_init / vx_halo_exchange: RCCL bound by the library itself); if that
-        # communicator cannot be set up on this node every rank falls back to the torch.distributed transport of
-        # voxels_amd/slab.py (slower: the attached tensors are rewritten behind the library's back and attached again)
-        ok = 1
-        try:
-            uid = torch.from_numpy(poly.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
-            dist_pkg.broadcast(uid, 0)
-            poly.comm_init(world, rank, uid.cpu().numpy())
-        except Exception as e:  # noqa: BLE001
-            sys.stderr.write("rank %d: C-ABI communicator failed (%s), falling back to torch.distributed\n" % (rank, e))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist_pkg.all_reduce(flag, op=dist_pkg.ReduceOp.MIN)
-        halo_transport = "c-abi-rccl" if int(flag.item()) == 1 else "torch-distributed"
+        # The exchange runs through the C ABI (vx_comm_init / vx_halo_exchange: RCCL bound by the library itself).  Every rank
+        # walks through the SAME sequence of collectives whatever fails where: rank 0 broadcasts a status byte + the id
+        # (zeros when it could not make one), all ranks agree (MIN) before anybody enters ncclCommInitRank, and agree again
+        # on its outcome.  Without --allow-torch-transport a failure ends the run: a bench line must mean vx_halo_exchange.
+        msg = np.zeros(129, np.uint8)
+        why = ""
+        if rank == 0:
+            try:
+                msg[1:] = poly.comm_unique_id()
+                msg[0] = 1
+            except Exception as e:  # noqa: BLE001
+                why = str(e)
+        uid = torch.from_numpy(msg).to(dev)
+        dist_pkg.broadcast(uid, 0)
+        msg = uid.cpu().numpy()
+        ok = torch.tensor([int(msg[0])], dtype=torch.int32, device=dev)
+        dist_pkg.all_reduce(ok, op=dist_pkg.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            try:
+                poly.comm_init(world, rank, np.ascontiguousarray(msg[1:]))
+            except Exception as e:  # noqa: BLE001
+                why = str(e)
+                ok = torch.tensor([0], dtype=torch.int32, device=dev)
+            dist_pkg.all_reduce(ok, op=dist_pkg.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            halo_transport = "c-abi-rccl"
+        elif args.allow_torch_transport:
+            sys.stderr.write("rank %d: C-ABI communicator unavailable (%s): torch.distributed moves the halo\n" % (rank, why or "another rank failed"))
+            halo_transport = "torch-distributed"
+        else:
+            raise SystemExit("rank %d: the C-ABI RCCL communicator could not be brought up (%s); pass --allow-torch-transport to "
+                             "run with the torch.distributed transport instead" % (rank, why or "another rank failed"))
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
@@ -186,7 +207,10 @@ def main():
         poly.set_stage_timing(True)
 
     def step():
-        halo_exchange()
+        # a polygonization of an unchanged grid needs no exchange (the halo is resident since the one above); with
+        # --halo-every-step every step pays it, as a run after an edit would
+        if args.halo_every_step:
+            halo_exchange()
         return poly.execute(levels)
 
     def barrier():
@@ -224,7 +248,8 @@ def main():
         dev_ms += info.device_ms
     stage /= reps
     dev_ms /= reps
-    poly.set_stage_timing(False)
+    if not args.serialize:
+        poly.set_stage_timing(False)
     per_level = []
     for l in range(info.levels):
         lv = poly.level(l, with_data=False)
@@ -298,9 +323,11 @@ def main():
         poly.execute(levels)
         poly.all_levels()
 
-    e2e = {"polygonize_ms": timed(lambda: poly.execute(levels)),
-           "polygonize_plus_host_block_lists_ms": timed(run_and_lists),
-           "polygonize_plus_download_of_all_meshes_ms": timed(run_and_download, 2)}
+    # (--serialize: a profiling run; no overlapped launch may end up in its kernel trace)
+    e2e = None if args.serialize else {
+        "polygonize_ms": timed(lambda: poly.execute(levels)),
+        "polygonize_plus_host_block_lists_ms": timed(run_and_lists),
+        "polygonize_plus_download_of_all_meshes_ms": timed(run_and_download, 2)}
 
     if rank == 0:
         step_s = elapsed / args.steps
@@ -324,10 +351,10 @@ def main():
                                         "Mvoxels_per_s_over_surface_blocks": round(surface_blocks * 4096 / step_s / 1e6, 2),
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
-                       "halo_exchange_in_step": world > 1, "halo_transport": halo_transport},
+                       "halo_exchange_in_step": bool(world > 1 and args.halo_every_step), "halo_transport": halo_transport},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.serialize:
             de = dropin_e2e(poly)
             if de:
                 out["config"]["e2e_ms"]["libVoxels_Polygonizer_Execute"] = de

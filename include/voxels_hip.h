@@ -99,7 +99,8 @@ int vx_grid_read_block(vx_ctx* ctx, uint32_t block_id, int8_t* dist, uint8_t* ma
  * clamped.  d_empty_flags is the FULL (n/16)^3 flag array (neighbour layers of other ranks included). */
 /* The library keeps brick-ordered mirrors of the fields for its gathers and refreshes them where IT changes
  * the grid (vx_grid_fill_terrain, vx_halo_exchange*).  A caller that rewrites attached memory itself after a
- * polygonization has run must attach it again before the next one (attaching is cheap; the mirrors are then rebuilt). */
+ * polygonization has run must call vx_grid_invalidate (below) — or attach again — before the next one; otherwise that run
+ * silently polygonizes the OLD contents (nothing detects the staleness). */
 int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
                    const void* d_dist, int32_t dist_z0, const void* d_mat, const void* d_blend, int32_t mat_z0,
                    const void* d_empty_flags);
@@ -110,6 +111,11 @@ int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
 int vx_grid_attach_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end,
                      const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
                      const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_empty_flags);
+/* Tell the library that the caller rewrote the resident (attached) fields in place — the zero-copy use of
+ * vx_grid_attach*, where the application edits its own device tensors (the reference's Grid::Modify*BlockData on
+ * memory the library does not own).  The mirrors are rebuilt by the next polygonization; the emptiness flags stay the
+ * caller's business, as with vx_grid_attach. */
+int vx_grid_invalidate(vx_ctx* ctx);
 /* ---- generation on the device ------------------------------------------------------------------------------------------
  * Grid::Create(w, h, d, ..., VoxelSurface*) samples an application callback on the host (src/VoxelGrid.cpp:79-132) and
  * quantises the samples (:37-50).  For the benchmark's synthetic surface (include/voxels_synth.h, vxs_terrain) the same
@@ -214,7 +220,7 @@ int vx_device_block_table(vx_ctx* ctx, uint32_t level, const vx_listed_block** d
 int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
 
 /* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
- * ms[0..7] = reset, classify, hierarchy, material (all levels), regular cells of level 0, of the levels >= 1,
+ * ms[0..7] = reset + block classes, classify, hierarchy, material (all levels), regular cells of level 0, of the levels >= 1,
  * transition cells, block lists of the LAST run. */
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
 int vx_stage_times(vx_ctx* ctx, float ms[8]);

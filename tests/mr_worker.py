@@ -83,6 +83,7 @@ def main_rccl(out_dir, n, levels, axis, rank, world):
     else:
         slab.dist[:, 0].zero_(); slab.dist[:, -2:].zero_(); slab.mat[:, -1].zero_(); slab.blend[:, -1].zero_()
     torch.cuda.synchronize()
+    p.invalidate()                         # the attached tensors were rewritten behind the library's back
     p.halo_exchange()
     p.execute(levels)
     save(out_dir, rank, p)

@@ -350,6 +350,45 @@ def test_hip_config2_256_lod0_only(poly, port):
     assert ok, msg
 
 
+def widen_near_surface(d):
+    """Full-range distances for a clamped (+-4) field: every voxel nearer than the clamp gets |d| * 16 - r, r = a
+    position hash in [0, 15] (sign kept, zeros stay zero), so that t = (v1 << 8) / (v1 - v0) takes hundreds of values;
+    what Grid::ModifyBlockDistanceData lets an application write (no +-4 clamp, include/Grid.h:132)."""
+    n = d.shape[0]
+    ax = np.arange(n, dtype=np.int32)
+    r = ((ax.reshape(n, 1, 1) * 283 + ax.reshape(1, n, 1) * 179 + ax.reshape(1, 1, n) * 73) & 15).astype(np.int16)
+    a = np.abs(d.astype(np.int16))
+    wide = np.where((a > 0) & (a < 4), np.sign(d).astype(np.int16) * (a * 16 - r), d.astype(np.int16))
+    return wide.astype(np.int8)
+
+
+def test_hip_config3_512_three_levels(poly, port):
+    """BASELINE config 3: 512^3 terrain with materials, LOD levels 0..2 — level 2 is not the reference's last level
+    (TransVoxelImpl.cpp:523-525), so all of levels 1 and 2 carry transition cells — against the oracle; then once more
+    with full-range distances pushed through vx_grid_update_blocks (Grid::ModifyBlockDistanceData)."""
+    from voxels_amd import synth
+    n = 512
+    ref, flags = bench_oracle(port, n)
+    poly.create_terrain(n)
+    info = poly.execute(3)
+    assert info.levels == 3
+    got = poly.all_levels()
+    assert int(got[1].infos["n_tverts"].sum()) > 0 and int(got[2].infos["n_tverts"].sum()) > 0
+    ok, msg = fields.surface_equal(got, ref[:3], nrm_tol=NRM_TOL)
+    assert ok, msg
+    d, m, b = synth.terrain(n)
+    wide = widen_near_surface(d)
+    g = port.grid_from_dense(wide, m, b)
+    ref_wide = port.execute(g).all_levels()[:3]
+    ids, (dd, mm, bb) = fields.edited_blocks((d, m, b), (wide, m, b))
+    poly.update_blocks(ids, dd.view(np.int8), mm, bb, g.block_flags())
+    poly.execute(3)
+    ok, msg = fields.surface_equal(poly.all_levels(), ref_wide, nrm_tol=NRM_TOL)
+    assert ok, "full-range distances: " + msg
+    t_values = np.unique(np.abs(wide[np.abs(wide) < 64]))
+    assert len(t_values) > 40
+
+
 def test_hip_config5_512_carve_incremental(poly, port):
     """BASELINE config 5: 512^3 terrain, sphere carve (IT_Subtract, r = 20) at the surface, incremental re-polygonization
     of the dirty blocks; parity with the oracle doing the same two calls."""

@@ -80,6 +80,7 @@ class HipLibrary:
         lib.vx_grid_read_block.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        lib.vx_grid_invalidate.argtypes = [vp]
         lib.vx_material_lut.argtypes = [vp, vp, vp]
         lib.vx_polygonize.argtypes = [vp, u32, C.POINTER(ExecInfo)]
         lib.vx_polygonize_dirty.argtypes = [vp, vp, vp, C.POINTER(ExecInfo), vp, u32, C.POINTER(u32)]
@@ -254,7 +255,8 @@ class Polygonizer:
         return r
 
     def attach(self, n, z_begin, z_end, d_dist, dist_z0, d_mat, d_blend, mat_z0, d_flags):
-        """Device pointers (ints), e.g. torch tensors' data_ptr()."""
+        """Device pointers (ints), e.g. torch tensors' data_ptr().  The library mirrors the fields for its gathers: after
+        rewriting the tensors in place call invalidate() (or attach again), or the next execute() sees the old contents."""
         self._check(self._lib.vx_grid_attach(self._h, n, z_begin, z_end, C.c_void_p(d_dist), dist_z0,
                                              C.c_void_p(d_mat), C.c_void_p(d_blend), mat_z0, C.c_void_p(d_flags)),
                     "vx_grid_attach")
@@ -266,6 +268,11 @@ class Polygonizer:
                                                C.c_void_p(d_mat), C.c_void_p(d_blend), mat_y0, mat_rows, C.c_void_p(d_flags)),
                     "vx_grid_attach_y")
         self.n = n
+
+    def invalidate(self):
+        """The attached tensors were rewritten in place by the caller: the library's mirrors of them are rebuilt by the
+        next execute().  Without this call (or a new attach) a run after an in-place edit polygonizes the OLD contents."""
+        self._check(self._lib.vx_grid_invalidate(self._h), "vx_grid_invalidate")
 
     def update_blocks(self, block_ids, dist, mat, blend, empty_flags):
         block_ids = np.ascontiguousarray(block_ids, np.uint32)

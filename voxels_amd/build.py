@@ -35,6 +35,11 @@ def build_hip(force=False, verbose=True):
     # Policy: no kernel of the library spills or keeps arrays in scratch memory (a spilled variant of k_regular produced
     # wrong vertices now and then).  VX_ALLOW_SCRATCH=1 lifts the check for experiments.
     bad = [(k, v["ScratchSize"]) for k, v in table.items() if v.get("ScratchSize", 0)]
+    # the gate must not pass because the remark format changed and nothing was parsed
+    missing = [k for k in ("k_regular0", "k_regular", "k_transition", "k_classify", "k_material") if not any(k in name and "ScratchSize" in v for name, v in table.items())]
+    if missing:
+        os.remove(out)
+        raise RuntimeError("kernel resource remarks not found for %s: the no-scratch policy cannot be checked (hipcc remark format changed?)" % missing)
     with open(os.path.join(CSRC, "kernel_resources.txt"), "w") as f:
         f.write("%-72s %6s %8s %10s %10s\n" % ("kernel", "VGPRs", "scratch", "occupancy", "staticLDS"))
         for k, v in sorted(table.items()):

@@ -1807,7 +1807,7 @@ struct Backend {
 	{
 		if (!stageOn || !stageValid) return false;
 		if (hipEventSynchronize(stageEv[7]) != hipSuccess) return false;
-		// reset, classify, hierarchy, material | regular level 0, regular levels >= 1 | transition, block lists
+		// reset + block classes, classify, hierarchy, material | regular level 0, regular levels >= 1 | transition, block lists
 		static const int from[8] = { 0, 1, 2, 3, 4, 8, 5, 6 }, to[8] = { 1, 2, 3, 4, 8, 5, 6, 7 };
 		for (int i = 0; i < 8; ++i) { ms[i] = 0.f; (void)hipEventElapsedTime(&ms[i], stageEv[from[i]], stageEv[to[i]]); }
 		return true;
@@ -1925,6 +1925,7 @@ struct Backend {
 			while (rowGroup > 1 && rows % (8 * rowGroup)) rowGroup >>= 1;
 			if (!rowGroup) rowGroup = 1;
 		}
+		stage_mark(1); // stage times: [0] = reset + block classes, [1] = k_classify alone
 		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p), rowGroup);
 		check(hipGetLastError(), "k_classify launch");
 	}

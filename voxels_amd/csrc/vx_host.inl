@@ -374,8 +374,7 @@ void build_table_image(std::vector<u8>& img)
 // one pass of the device pipeline over the blocks listed in the level tables
 void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 {
-	c->be.stage_mark(1);
-	c->be.run_classify(p);
+	c->be.run_classify(p); // k_run_reset + k_block_class, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
 	c->be.stage_mark(2);
 	if (!c->be.stage_timing_on()) {
 		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless)
@@ -757,6 +756,17 @@ int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, co
 	return VX_OK;
 }
 
+int vx_grid_invalidate(vx_ctx* c)
+{
+	VX_ENTER(c);
+	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_grid_invalidate: no grid resident");
+	// the caller rewrote attached memory in place: the brick mirrors, lattice copies and sign summaries are rebuilt by the
+	// next polygonization, and whatever surface the context holds no longer describes the grid
+	c->bricksStale = true;
+	c->haveSurface = false;
+	return VX_OK;
+}
+
 namespace {
 
 // The four halo messages of an attached slab (see include/voxels_hip.h): which layers of which field go where.
@@ -868,7 +878,9 @@ int vx_halo_exchange(vx_ctx* c)
 	HaloPlan pl;
 	std::string why;
 	if (!halo_plan(c, pl, why)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: " + why);
-	if ((pl.hasLo && c->commRank == 0) || (pl.hasHi && c->commRank + 1 == c->commRanks)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: rank r must own the r-th slab");
+	// rank r owns the r-th slab: a rank that posts no message towards a neighbour that expects one (or the reverse) would
+	// leave its peer blocked in the grouped send / receive for ever
+	if (pl.hasLo != (c->commRank > 0) || pl.hasHi != (c->commRank + 1 < c->commRanks)) return fail(c, VX_ERR_INVALID, "vx_halo_exchange: rank r must own the r-th slab (first rank starts at 0, last rank ends at n, no other rank does)");
 	// pack -> one grouped send/recv batch -> unpack, all queued on the context's stream: nothing waits on the host
 	const bool alongY = c->slabAxis == 2;
 	c->be.run_halo_moves(pl.hasLo ? &pl.sendLo : nullptr, pl.hasHi ? &pl.sendHi : nullptr, halo_view(c), mirror_state(c), alongY);
