@@ -178,6 +178,7 @@ struct Backend {
 		}
 	}
 	bool stage_ms(float*) { return false; }
+	bool run_selftest(u32* out) { memset(out, 0, 8 * 4); return true; } // the device forms do not exist here
 
 	// classification of one level-0 block (portable form of k_classify)
 	template <typename P>
@@ -290,6 +291,12 @@ struct Backend {
 		const Tables T = tables_from_image(p.tables);
 		typedef RegStateT<CAP> ST;
 		ST* st = new ST;
+		// level 0 of a full run: blocks without a zero sample take the table-driven pass (tv_fast0.h), like k_regular0_fast
+		std::vector<unsigned long long> vrow(256, 0);
+		for (u32 code = 0; code < 256; ++code) memcpy(&vrow[code], p.tables + TAB_REG_VERT + code * 6, 6);
+		const F0Tables FT = f0_tables_from_image(p.tables, vrow.data());
+		Fast0State<640>* fst = new Fast0State<640>;
+		u32 fastBlocks = 0, generalBlocks = 0;
 		for (u32 level = 0; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];
 			for (u32 it = 0; it < item_count(p, level); ++it) {
@@ -300,6 +307,8 @@ struct Backend {
 				b.level = level; b.slot = slot; b.mult = L.mult;
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
 				if (ntc == 0 || (level == 0 && L.skip[slot])) { reg_write_empty_record(L, slot); continue; }
+				if (level == 0 && !p.G.dirty && CAP == 640 && !getenv("VX_EMU_NO_FAST0") && f0_block_serial(*fst, FT, p.G, L, p.P, slot, b.bx, b.by, b.bz, p.G.stats)) { ++fastBlocks; continue; }
+				if (level == 0) ++generalBlocks;
 				reg_phase_begin(*st, L, slot, 0, 1);
 				reg_phase_stage(*st, p.G, L, b, 0, 1);
 				for (int w = 0; w < 128; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
@@ -324,6 +333,8 @@ struct Backend {
 			}
 		}
 		delete st;
+		delete fst;
+		if (getenv("VX_EMU_TRACE") && (fastBlocks || generalBlocks)) fprintf(stderr, "[emu] level-0 blocks: %u through the fast pass, %u through the general pass (class <= %d cells)\n", fastBlocks, generalBlocks, CAP);
 	}
 
 	template <typename P>

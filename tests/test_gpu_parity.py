@@ -350,6 +350,14 @@ def test_hip_config2_256_lod0_only(poly, port):
     assert ok, msg
 
 
+def test_hip_device_arithmetic_exhaustive(poly):
+    """edge_t_crossing for all crossed int8 sample pairs, normalize_fix_zero for all 2^24 non-negative int8 gradients
+    (scaled and unscaled; against sqrtf + IEEE division), on the GPU (vx_selftest)."""
+    r = poly.selftest()
+    print("selftest:", r.tolist())
+    assert r[0] == 0 and r[1] == 0 and r[2] == 0, r.tolist()
+
+
 def widen_near_surface(d):
     """Full-range distances for a clamped (+-4) field: every voxel nearer than the clamp gets |d| * 16 - r, r = a
     position hash in [0, 15] (sign kept, zeros stay zero), so that t = (v1 << 8) / (v1 - v0) takes hundreds of values;

@@ -87,6 +87,7 @@ class HipLibrary:
         lib.vx_level_counts.argtypes = [vp, u32, C.POINTER(u32), vp]
         lib.vx_download_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         lib.vx_stats.argtypes = [vp, vp]
+        lib.vx_selftest.argtypes = [vp, vp]
         lib.vx_set_stage_timing.argtypes = [vp, C.c_int]
         lib.vx_stage_times.argtypes = [vp, vp]
         self.lib = lib
@@ -334,6 +335,12 @@ class Polygonizer:
         out = np.zeros(8, np.float32)
         self._check(self._lib.vx_stage_times(self._h, _ptr(out)), "vx_stage_times")
         return out
+
+    def selftest(self):
+        """vx_selftest: mismatch counts of the device arithmetic against its definition, exhaustively ([0..2] must be 0)."""
+        r = np.zeros(8, np.uint32)
+        self._check(self._lib.vx_selftest(self._h, _ptr(r)), "vx_selftest")
+        return r
 
     def stats(self):
         out = np.zeros(20, np.uint32)

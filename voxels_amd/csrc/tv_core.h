@@ -273,6 +273,19 @@ TV_HD void normal_from(const int s[6], float out[3])
 // the rounded quotient is exact (checked exhaustively over all 65280 int8 pairs in tests/test_core_math.py).
 TV_HD int edge_t(int v0, int v1) { return (int)((float)(v1 * 256) / (float)(v1 - v0)); }
 
+// edge_t for a crossed edge: v0 * v1 <= 0, v0 != v1 (the quotient lies in [0, 256]).  The device form multiplies by the
+// hardware reciprocal (1 ulp) instead of dividing: the product is off by less than 5e-5, an exact quotient is an integer
+// or at least 1/255 away from one, and a bias of 2^-10 puts every case on the right side of the truncation
+// (checked for all pairs on the device by tests/test_gpu_parity.py::test_hip_edge_t_crossing_exhaustive).
+TV_HD int edge_t_crossing(int v0, int v1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (int)__builtin_fmaf((float)(v1 * 256), __builtin_amdgcn_rcpf((float)(v1 - v0)), 0.0009765625f);
+#else
+	return edge_t(v0, v1);
+#endif
+}
+
 // Where edge_t lands without dividing, for the decisions that only ask "is the vertex on a corner, and which":
 // 0 <=> edge_t == 0 (v1 == 0: |v1 * 256| >= |v1 - v0| otherwise), 256 <=> edge_t == 256 (v0 == 0, the samples
 // of a crossed edge never share a strict sign), 1 = strictly inside the edge.  Same exhaustive test as edge_t.
@@ -346,26 +359,27 @@ TV_HD unsigned long long lut_row(const u8* lut, u32 materialId)
 TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVertex* out)
 {
 	const float k = 1.f / 256.f;
+	u32 f = r.flags;
+	if (f) f = (f >> 3) | ((f & 7u) << 3);
+#if defined(__HIP_DEVICE_COMPILE__)
+	// texture bytes {0, blend, Ids1[1], Ids0[1] | Ids1[2], Ids1[0], Ids0[2], Ids0[0]} picked out of the row with two
+	// byte permutes (selector 0..3 = low dword, 4..7 = high dword, 0x0C = constant 0); the vertex leaves as three
+	// aligned 16-byte stores (a member-wise copy is split at the member boundaries: 12 + 16 + 12 + 8 bytes)
+	const u32 lo = (u32)row, hi = (u32)(row >> 32);
+	const bool ok = ((hi >> 16) & 0xFFu) != 0;
+	u32 t0 = __builtin_amdgcn_perm(hi, lo, 0x01040C0Cu) | (((r.mat >> 8) & 0xFFu) << 8);
+	u32 t1 = __builtin_amdgcn_perm(hi, lo, 0x00020305u);
+	if (!ok) { t0 = 0; t1 = 0; }
+	uint4* dst = (uint4*)out;
+	dst[0] = make_uint4(__float_as_uint(r.p[0] * k), __float_as_uint(r.p[2] * k), __float_as_uint(r.p[1] * k), __float_as_uint(r.s[0] * k));
+	dst[1] = make_uint4(__float_as_uint(r.s[2] * k), __float_as_uint(r.s[1] * k), f, __float_as_uint(r.n[0]));
+	dst[2] = make_uint4(__float_as_uint(r.n[1]), __float_as_uint(r.n[2]), t0, t1);
+#else
 	PolyVertex o;
 	o.pos[0] = r.p[0] * k; o.pos[1] = r.p[2] * k; o.pos[2] = r.p[1] * k;
 	o.sec[0] = r.s[0] * k; o.sec[1] = r.s[2] * k; o.sec[2] = r.s[1] * k;
-	u32 f = r.flags;
-	if (f) f = (f >> 3) | ((f & 7u) << 3);
 	o.secW = f;
 	o.nrm[0] = r.n[0]; o.nrm[1] = r.n[1]; o.nrm[2] = r.n[2];
-#if defined(__HIP_DEVICE_COMPILE__)
-	{
-		// texture bytes {0, blend, Ids1[1], Ids0[1] | Ids1[2], Ids1[0], Ids0[2], Ids0[0]} picked out of the row with two
-		// byte permutes (selector 0..3 = low dword, 4..7 = high dword, 0x0C = constant 0)
-		const u32 lo = (u32)row, hi = (u32)(row >> 32);
-		const bool ok = ((hi >> 16) & 0xFFu) != 0;
-		u32 t0 = __builtin_amdgcn_perm(hi, lo, 0x01040C0Cu) | (((r.mat >> 8) & 0xFFu) << 8);
-		u32 t1 = __builtin_amdgcn_perm(hi, lo, 0x00020305u);
-		if (!ok) { t0 = 0; t1 = 0; }
-		memcpy(&o.tex[0], &t0, 4);
-		memcpy(&o.tex[4], &t1, 4);
-	}
-#else
 	u8 e[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) e[i] = (u8)(row >> (8 * i));
@@ -378,8 +392,8 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	o.tex[5] = ok ? e[3] : 0; // Upy = Ids1[0]
 	o.tex[6] = ok ? e[2] : 0; // Tny = Ids0[2]
 	o.tex[7] = ok ? e[0] : 0; // Tpy = Ids0[0]
-#endif
 	*out = o;
+#endif
 }
 
 TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out) { pack_vertex_row(r, lut_row(lut, r.mat), out); }

@@ -1,0 +1,261 @@
+// vx_fast0.inl — k_regular0_fast: the regular-cell pass of level 0 for blocks without a zero sample (tv_fast0.h has the
+// per-lane logic and the reason why it is exact), written for gfx950.  Included by vx_hip.hip behind vx_regular0.inl,
+// whose work distribution and register prefetch it shares: persistent workgroups stride over the level-0 slots, the
+// next block's 19^3 distances, 17^3 materials + blends and bitmap are requested into registers while the current block
+// emits.  A block in whose staged samples a lane finds a zero byte is appended to Globals::slowItems and left to
+// k_regular0<.., 2>, launched right behind on the same stream.
+//
+// Per block: deposit (+ zero test) | popcount prefix + compact cell list | cells: table-driven, no loop over table
+// vertices, wave-contiguous ranges, DPP scans | bases + pool reservations + vertex / triangle descriptors | one lane =
+// one vertex and one lane = one triangle (three indices).  5 barriers.
+namespace {
+
+constexpr u32 F0_TAB_FIXED = TAB_F0_BYTES - TAB_F0_CASE;   // case rows | triangle rows | edge infos | direction masks
+constexpr u32 F0_TAB_LDS = F0_TAB_FIXED + 2048;            // + the per-case vertex rows widened to 8 bytes
+
+__device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image)
+{
+	copy16(lds, image + TAB_F0_CASE, F0_TAB_FIXED);
+	for (u32 i = threadIdx.x; i < 256; i += WG) {
+		const u8* src = image + TAB_REG_VERT + i * 6;
+		unsigned long long row = 0;
+#pragma unroll
+		for (int b = 0; b < 6; ++b) row |= (unsigned long long)src[b] << (8 * b);
+		*(unsigned long long*)(lds + F0_TAB_FIXED + i * 8) = row;
+	}
+	return f0_tables_from_image(lds - TAB_F0_CASE, (const unsigned long long*)(lds + F0_TAB_FIXED));
+}
+
+// inclusive scan over the wave with DPP row shifts and row broadcasts (gfx9): no LDS traffic, six dependent adds
+__device__ __forceinline__ u32 wave_inclusive_scan_dpp(u32 v)
+{
+#if defined(VX_SCAN_SHFL)
+	return wave_inclusive_scan(v);
+#else
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+	return (u32)x;
+#endif
+}
+
+__device__ __forceinline__ u32 f0_has_zero_byte(u32 v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+
+// registers -> LDS (R0::deposit), and: does a staged distance sample equal zero?  (The rows y, z = -1 and 17 are looked
+// at as well: a zero there sends a block to the general pass without need, which costs time, never correctness.)
+template <typename ST>
+__device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Block& b, const R0Prefetch& pf)
+{
+	const int tid = R0<REG_CAP_SMALL>::opaque_tid();
+	const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
+	u32 zero = 0;
+	if (tid < 128) st.ntBits[tid] = pf.bits;
+#pragma unroll
+	for (int q = 0; q < 3; ++q) {
+		const int h = tid + q * WG;
+		if (h < 722) {
+			const int r = h >> 1, half = h & 1;
+			u32 a = half ? pf.dOwn[q].x : pf.dNb[q], bb = half ? pf.dOwn[q].y : pf.dOwn[q].x, c = half ? pf.dNb[q] : pf.dOwn[q].y;
+			if (!half && firstX) a = bb << 24;                          // no left neighbour: sample -1 = sample 0
+			if (half && lastX) c = (bb >> 24) * 0x01010101u;            // no right neighbour: samples 16, 17 = sample 15
+			u32* dst = (u32*)(st.samp + r * SROW + half * 12);
+			dst[0] = a; dst[1] = bb; dst[2] = c;
+			// half 0 holds x = -4..7, half 1 x = 8..19; the cells' corners are the columns 0..16
+			zero |= (half ? f0_has_zero_byte(a) : 0u) | f0_has_zero_byte(bb) | f0_has_zero_byte(half ? (c | 0xFFFFFF00u) : c);
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 3; ++q) {
+		const int t = tid + q * WG;
+		if (t < 578) {
+			const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
+			const int k = r / 17, j = r - k * 17;
+			u32* dst = (u32*)((arr ? st.blend : st.matId) + k * F0_MPLANE + j * F0_MROW);
+			dst[0] = pf.m[q].x; dst[1] = pf.m[q].y; dst[2] = pf.m[q].z; dst[3] = pf.m[q].w;
+			dst[4] = lastX ? (pf.mf[q] >> 24) : pf.mf[q];
+		}
+	}
+	return zero;
+}
+
+template <int CAP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p)
+{
+	static_assert(F0_MROW == R0_MROW, "the prefetch of vx_regular0.inl stages 20-byte material rows");
+	typedef Fast0State<CAP> ST;
+	typedef R0<CAP> K;
+	u8* tab = smem;
+	ST& st = *(ST*)(smem + F0_TAB_LDS);
+	__shared__ u32 wgStats[20];  // statistics of every block this workgroup handles, flushed once at the end
+	__shared__ u32 zeroFlag[2];  // "a lane met a zero sample", by parity of the workgroup's block counter
+
+	const LevelDesc& L = p.levels[0];
+	const u32 total = r0_uniform(*L.nActive);
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	const int tid = (int)threadIdx.x;
+	if (tid < 20) wgStats[tid] = 0;
+	if (tid < 2) zeroFlag[tid] = 0;
+	const F0Tables T = f0_stage_tables(tab, p.tables);
+	const GridView& g = p.G.grid;
+
+	u32 it = blockIdx.x;
+	R0Block cur, nxt;
+	R0Prefetch pf;
+	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
+	bool have = r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), cur);
+	if (have) K::request(g, L, cur, pf);
+	it += gridDim.x;
+	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), nxt);
+	u32 parity = 0;
+	while (have) {
+		const u32 candIt = it + gridDim.x;
+		R0Candidate cand;
+		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
+		{
+			const u32 z = f0_deposit(st, L, cur, pf);
+			if (__ballot(z != 0) && (tid & 63) == 0) zeroFlag[parity] = 1;
+			if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
+		}
+		__syncthreads();
+		const bool clean = r0_uniform(zeroFlag[parity]) == 0;
+		parity ^= 1u;
+		bool requested = false;
+		if (clean) {
+			// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
+			{
+				const int lane = tid & 63, wave = tid >> 6;
+				const u32 w0 = st.ntBits[lane], w1 = st.ntBits[lane + 64];
+				const u32 c0 = (u32)__popc(w0), c1 = (u32)__popc(w1);
+				const u32 i0 = wave_inclusive_scan_dpp(c0);
+				const u32 half = (u32)__shfl((int)i0, 63, 64);
+				const u32 i1 = wave_inclusive_scan_dpp(c1) + half;
+				const u32 e0 = i0 - c0, e1 = i1 - c1;
+				if (wave == 0) {
+					st.wordPrefix[lane] = (u16)e0; st.wordPrefix[lane + 64] = (u16)e1;
+					if (lane == 63) st.wordPrefix[128] = (u16)i1;
+				}
+				// row tid = cells [tid * 16, tid * 16 + 16): half of word tid >> 1, held by lane (tid >> 1) & 63 of either set
+				const int src = (tid >> 1) & 63;
+				const u32 wLo = (u32)__shfl((int)w0, src, 64), wHi = (u32)__shfl((int)w1, src, 64);
+				const u32 eLo = (u32)__shfl((int)e0, src, 64), eHi = (u32)__shfl((int)e1, src, 64);
+				const u32 word = (wave >= 2) ? wHi : wLo;
+				u32 kk = (wave >= 2) ? eHi : eLo;
+				u32 bits = word & 0xFFFFu;
+				if (tid & 1) { kk += (u32)__popc(bits); bits = word >> 16; }
+				while (bits) {
+					const u32 x = (u32)__builtin_ctz(bits);
+					bits &= bits - 1;
+					st.cellAN[kk++][0] = (u32)(tid * 16) + x;
+				}
+			}
+			__syncthreads();
+
+			// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
+			const u32 nt = r0_uniform(st.wordPrefix[128]);
+			const u32 Q = ((nt + WG - 1) / WG) * 64u;
+			const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
+			const u32 kBeg = r0_uniform(min(wave * Q, nt)), kEnd = r0_uniform(min(wave * Q + Q, nt));
+			{
+				u32 carry = 0;
+				for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
+					const u32 k = k0 + lane;
+					u32 cnt = 0;
+					if (k < kEnd) cnt = f0_cell(st, T, k, wgStats + 4);
+					const u32 incl = wave_inclusive_scan_dpp(cnt);
+					if (k < kEnd) st.cellC[k] = carry + incl - cnt;
+					carry += (u32)__shfl((int)incl, 63, 64);
+				}
+				if (lane == 0) st.waveTot[wave] = carry;
+			}
+			__syncthreads();
+			{
+				u32 waveBase = 0, tot = 0;
+#pragma unroll
+				for (u32 w = 0; w < (u32)(WG / 64); ++w) {
+					const u32 s = st.waveTot[w];
+					if (w < wave) waveBase += s;
+					tot += s;
+				}
+				const u32 vTotal = tot & 0xFFFFu, tTotal = tot >> 16;
+				// both pool reservations are requested now; their results are first needed after the descriptors are written.  The
+				// last lane makes them: its wave owns the tail of the compact list and is the first to run out of cells.
+				if (tid == WG - 1) {
+					st.vTotal = vTotal; st.tTotal = tTotal;
+					st.vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
+					st.iOff = atomicAdd(&p.P.cursors[CUR_I], tTotal * 3u);
+				}
+				for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
+					const u32 k = k0 + lane;
+					if (k < kEnd) {
+						const u32 base = st.cellC[k] + waveBase;
+						st.cellC[k] = base;
+						f0_describe(st, T, k, base, 0u, 0u);
+					}
+				}
+			}
+			__syncthreads();
+
+			const u32 vTotalU = r0_uniform(st.vTotal), tTotalU = r0_uniform(st.tTotal);
+			const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
+			const int ox = (int)(cur.bx * 16), oy = (int)(cur.by * 16), oz = (int)(cur.bz * 16);
+			// Vertices and indices leave in ONE loop, and the next block's inputs are requested inside its first trip (a loop
+			// with stores that is entered while loads are in flight makes the compiler drain the memory queue in front of it).
+			if (room) {
+				for (u32 chunk = 0; chunk == 0 || chunk * F0_VDESC < vTotalU || chunk * F0_TDESC < tTotalU; ++chunk) {
+					const u32 cv = chunk * F0_VDESC, ct = chunk * F0_TDESC;
+					if (chunk) {
+						__syncthreads();
+						for (u32 k = (u32)tid; k < nt; k += WG) f0_describe(st, T, k, st.cellC[k], cv, ct);
+						__syncthreads();
+					}
+					const u32 vEnd = cv < vTotalU ? min(vTotalU - cv, (u32)F0_VDESC) : 0u;
+					const u32 tEnd = ct < tTotalU ? min(tTotalU - ct, (u32)F0_TDESC) : 0u;
+					PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
+					u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
+					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
+						if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
+						const u32 j = base + (u32)tid;
+						if (j < vEnd) {
+							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
+							const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
+							f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), vOut + j);
+						}
+						if (j < tEnd) {
+							u32 ids[3];
+							f0_triangle(st, T, j, ids);
+							u32* o3 = iOut + j * 3u; // 12 bytes per lane, consecutive lanes consecutive triangles
+							o3[0] = ids[0]; o3[1] = ids[1]; o3[2] = ids[2];
+						}
+					}
+				}
+			}
+			if (tid == 0) {
+				BlockRecord& r = L.records[cur.slot];
+				r.coordId = cur.coord;
+				r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.tTotal * 3u : 0;
+				if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
+				r.degenerate = 0;
+				r.ntCells = nt;
+				r.pad = 0;
+				if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
+				wgStats[0] += nt;
+			}
+		} else if (tid == 0) {
+			// a zero sample: the general pass takes the block
+			p.G.slowItems[atomicAdd(p.G.slowCount, 1u)] = cur.slot;
+		}
+		if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); }
+		cur = nxt;
+		have = haveNext;
+		it = candIt;
+		haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, cand, nxt);
+	}
+	__syncthreads();
+	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+}
+
+} // namespace

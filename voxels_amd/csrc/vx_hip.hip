@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "tv_block.h"
+#include "tv_fast0.h"
 #include "vx_terrain_math.h"
 
 #define VX_BACKEND_NAME "hip:gfx950"
@@ -1216,6 +1217,7 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 } // namespace
 
 #include "vx_regular0.inl"
+#include "vx_fast0.inl"
 
 namespace {
 
@@ -1610,6 +1612,74 @@ __global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, Mir
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_selftest: the device forms of the exactness-critical arithmetic, checked exhaustively on the hardware they run on
+// (vx_selftest; tests/test_gpu_parity.py).  One lane per gradient (dx, dy, dz) in [0, 255]^3 — central differences
+// of int8 samples, up to sign — and, for the first 65536 lanes, per sample pair (v0, v1).
+//   out[0]  crossed sample pairs where edge_t_crossing differs from the truncated integer quotient
+//   out[1]  gradients whose normalised components differ between g and 0.5 g (tv_fast0.h drops the factor)
+//   out[2]  gradients where normalize_fix_zero differs from fp32 sqrtf + IEEE division as hipcc compiles them
+//   out[3+] candidates for cheaper forms (see below): components that differ from normalize_fix_zero
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float selftest_sqrt_newton(float x)
+{
+	// rsq + one Newton step with exact residual
+	const float y = __builtin_amdgcn_rsqf(x), s = x * y, h = 0.5f * y;
+	return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
+
+__global__ __launch_bounds__(WG) void k_selftest(u32* out)
+{
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (i < 65536u) {
+		const int v0 = (int)(i8)(i & 0xFFu), v1 = (int)(i8)(i >> 8);
+		if (v0 * v1 <= 0 && v0 != v1 && edge_t_crossing(v0, v1) != (v1 * 256) / (v1 - v0)) atomicAdd(&out[0], 1u);
+	}
+	const float g[3] = { (float)(i & 255u), (float)((i >> 8) & 255u), (float)(i >> 16) };
+	float a[3] = { g[0], g[1], g[2] }, b[3] = { g[0] * 0.5f, g[1] * 0.5f, g[2] * 0.5f };
+	normalize_fix_zero(a);
+	normalize_fix_zero(b);
+	if (__float_as_uint(a[0]) != __float_as_uint(b[0]) || __float_as_uint(a[1]) != __float_as_uint(b[1]) || __float_as_uint(a[2]) != __float_as_uint(b[2])) atomicAdd(&out[1], 1u);
+	const float len2 = (g[0] * g[0] + g[1] * g[1]) + g[2] * g[2];
+	{
+		const float len = sqrtf(len2);
+		float r[3] = { 0.f, 0.f, 0.f };
+		if (!(len <= 1.1920929e-07f)) { r[0] = g[0] / len; r[1] = g[1] / len; r[2] = g[2] / len; }
+		if (__float_as_uint(a[0]) != __float_as_uint(r[0]) || __float_as_uint(a[1]) != __float_as_uint(r[1]) || __float_as_uint(a[2]) != __float_as_uint(r[2])) atomicAdd(&out[2], 1u);
+	}
+	if (len2 > 0.f) {
+		// exact length as normalize_fix_zero finds it
+		float len = __builtin_amdgcn_sqrtf(len2);
+		{
+			const float down = __builtin_bit_cast(float, __builtin_bit_cast(int, len) - 1), up = __builtin_bit_cast(float, __builtin_bit_cast(int, len) + 1);
+			const float rDown = __builtin_fmaf(-down, len, len2), rUp = __builtin_fmaf(-up, len, len2);
+			len = (rDown <= 0.f) ? down : len;
+			len = (rUp > 0.f) ? up : len;
+		}
+		const float y0 = __builtin_amdgcn_rcpf(len), y = __builtin_fmaf(__builtin_fmaf(-len, y0, 1.0f), y0, y0);
+		u32 bad3 = 0, bad4 = 0, bad5 = 0, bad6 = 0, bad7 = 0;
+		const float lenN = selftest_sqrt_newton(len2);
+		if (__float_as_uint(lenN) != __float_as_uint(len)) bad4 = 1;                              // [4] length by rsq + Newton
+		if (__float_as_uint(__builtin_amdgcn_sqrtf(len2)) != __float_as_uint(len)) bad7 = 1;      // [7] raw v_sqrt_f32
+		const float yN0 = __builtin_amdgcn_rcpf(lenN), yN = __builtin_fmaf(__builtin_fmaf(-lenN, yN0, 1.0f), yN0, yN0);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const float n = g[c];
+			const float q0 = n * y, q1 = __builtin_fmaf(__builtin_fmaf(-len, q0, n), y, q0);
+			if (__float_as_uint(q1) != __float_as_uint(a[c])) bad3 = 1;                            // [3] one correction of the quotient instead of two
+			const float p0 = n * y0, p1 = __builtin_fmaf(__builtin_fmaf(-len, p0, n), y0, p0), p2 = __builtin_fmaf(__builtin_fmaf(-len, p1, n), y0, p1);
+			if (__float_as_uint(p2) != __float_as_uint(a[c])) bad5 = 1;                            // [5] unrefined reciprocal, two corrections
+			const float w0 = n * yN, w1 = __builtin_fmaf(__builtin_fmaf(-lenN, w0, n), yN, w0);
+			if (__float_as_uint(w1) != __float_as_uint(a[c])) bad6 = 1;                            // [6] Newton length + one correction
+		}
+		if (bad3) atomicAdd(&out[3], 1u);
+		if (bad4) atomicAdd(&out[4], 1u);
+		if (bad5) atomicAdd(&out[5], 1u);
+		if (bad6) atomicAdd(&out[6], 1u);
+		if (bad7) atomicAdd(&out[7], 1u);
+	}
+}
+
 // RCCL through its C API, bound at run time: a process that never shards a grid does not load the library
 struct Rccl {
 	typedef struct { char internal[128]; } UniqueId;
@@ -1681,7 +1751,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, fast0 = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -1702,6 +1772,7 @@ struct Backend {
 		tune.matGrid = env_u32("VX_MAT_GRID", 0);
 		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
+		tune.fast0 = env_u32("VX_FAST0", 1); // 0: every level-0 block through the general pass (A/B measurements)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -1719,10 +1790,13 @@ struct Backend {
 		const int regSmall = (int)(REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>)), regLarge = (int)(REG_TAB_LDS + sizeof(RegStateT<4096>));
 		const int trLds = (int)(TR_TAB_LDS + sizeof(TrState));
 		const int r0Small = (int)(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>)), r0Large = (int)(R0_TAB_LDS + sizeof(Reg0State<4096>));
-		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, incremental)")) {
+		const int f0Small = (int)(F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>));
+		if (!check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, incremental)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, handed on)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, f0Small), "hipFuncSetAttribute(k_regular0_fast)")) {
 			err = lastError;
 			return false;
 		}
@@ -1994,11 +2068,16 @@ struct Backend {
 			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
 			const u32 ldsS = R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), ldsL = R0_TAB_LDS + sizeof(Reg0State<4096>), gridL = std::min<u32>(cap, (u32)cus);
 			if (p.G.dirty) {
-				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, true>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
-				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, true>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 1>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+			} else if (tune.fast0) {
+				// blocks without a zero sample: the table-driven pass; the others are handed on through Globals::slowItems
+				hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p));
+				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(std::min<u32>(gridS, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
 			} else {
-				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, false>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
-				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, false>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 0>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
 			}
 			levelBegin = 1;
 			if (stageOn && on == stream) (void)hipEventRecord(stageEv[8], on);
@@ -2048,6 +2127,12 @@ struct Backend {
 		(void)hipStreamWaitEvent(stream, evSideB, 0);
 	}
 	bool stage_timing_on() const { return stageOn; }
+	bool run_selftest(u32* dOut)
+	{
+		if (!fill(dOut, 0, 8 * 4)) return false;
+		hipLaunchKernelGGL(k_selftest, dim3((1u << 24) / WG), dim3(WG), 0, stream, dOut);
+		return check(hipGetLastError(), "k_selftest launch");
+	}
 
 	// ---- halo messages of attached slabs (vx_halo_exchange*, vx_host.inl) -----------------------------------------------
 	// both messages of a direction (pack: what goes below / above; unpack: what came from below / above) in one launch;

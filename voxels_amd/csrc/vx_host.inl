@@ -9,6 +9,7 @@
 //   VX_BACKEND_NAME
 #include "../../include/voxels_hip.h"
 #include "tv_block.h"
+#include "tv_fast0.h"
 
 #include <algorithm>
 #include <chrono>
@@ -39,7 +40,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -54,6 +55,7 @@ struct vx_ctx {
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
+	void* dSlowItems = nullptr;                            // level-0 slots handed from the fast regular pass to the general one
 	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
@@ -264,6 +266,8 @@ bool ensure_level_tables(vx_ctx* c)
 		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.listed || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 		if (!L) {
 			c->dBlockClass = alloc(total);
+			c->dSlowItems = alloc(cap * 4 + 16);
+			if (!c->dSlowItems) return false;
 			c->dTileWork = alloc((size_t)((d.cnt + 15) / 16) * (d.yb1 - d.yb0) * (d.zb1 - d.zb0) + 16);
 			if (!c->dBlockClass || !c->dTileWork) return false;
 		}
@@ -317,6 +321,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.tileWork = (u8*)c->dTileWork;
 	p.G.blockSign = (const u16*)c->dBlockSign;
+	p.G.slowItems = (u32*)c->dSlowItems;
+	p.G.slowCount = (u32*)c->dHeader + HDR_SLOW;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
@@ -331,7 +337,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 
 void build_table_image(std::vector<u8>& img)
 {
-	img.assign(TAB_BYTES, 0);
+	img.assign(TAB_F0_BYTES, 0);
 	memcpy(&img[TAB_REG_CLASS], TVT_REG_CLASS, 256);
 	memcpy(&img[TAB_REG_CELL], TVT_REG_CELL, 256);
 	memcpy(&img[TAB_TR_CLASS], TVT_TR_CLASS, 512);
@@ -369,6 +375,8 @@ void build_table_image(std::vector<u8>& img)
 		memcpy(&img[TAB_TR_OWN + code * 2], &m, 2);
 	}
 	pack(TVT_TR_VERT, 512, TAB_TR_EDGE, TAB_TR_VERT);
+	static_assert((u32)TAB_F0_CASE == (u32)TAB_BYTES, "the fast-pass tables follow the image of tv_core.h");
+	f0_build_tables(img.data(), TVT_REG_CLASS, TVT_REG_CELL, TVT_REG_VERT, (const u16*)&img[TAB_REG_EDGE]);
 }
 
 // one pass of the device pipeline over the blocks listed in the level tables
@@ -472,10 +480,10 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	c->hostTiming = getenv("VX_HOST_TIMING") != nullptr;
 	std::vector<u8> img;
 	build_table_image(img);
-	c->dTables = c->be.alloc(TAB_BYTES);
+	c->dTables = c->be.alloc(TAB_F0_BYTES);
 	c->dLut = c->be.alloc(256 * 8);
 	c->dHeader = c->be.alloc(HDR_WORDS * 4);
-	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_BYTES)) {
+	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_F0_BYTES)) {
 		vx_ctx_destroy(c);
 		return VX_ERR_DEVICE;
 	}
@@ -1504,6 +1512,16 @@ int vx_debug_case_dump(vx_ctx* c, uint32_t level, uint32_t cap, uint32_t* coords
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_debug_case_dump: download failed");
 }
 #endif
+
+int vx_selftest(vx_ctx* c, uint32_t results[8])
+{
+	VX_ENTER(c);
+	if (!c || !results) return VX_ERR_INVALID;
+	void* d = c->be.alloc(8 * 4);
+	const bool ok = d && c->be.run_selftest((u32*)d) && c->be.d2h(results, d, 8 * 4);
+	c->be.free(d);
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_selftest: " + c->be.error());
+}
 
 int vx_set_stage_timing(vx_ctx* c, int enable)
 {

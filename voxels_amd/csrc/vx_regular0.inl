@@ -446,7 +446,9 @@ struct R0Candidate {
 	u32 valid, slot, ntc, skip, coord;
 };
 
-template <bool DIRTY>
+// MODE: which level-0 slots a launch works on — 0: all of them (full run), 1: the work list of an incremental run,
+// 2: the blocks the fast pass (vx_fast0.inl) handed on
+template <int MODE>
 __device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 it)
 {
 	// loads without conditions (see R0::request): an item beyond the list reads entry 0 and is marked invalid
@@ -455,7 +457,8 @@ __device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const Lev
 	c.valid = (it < ((total + 63u) & ~63u) && item < total) ? 1u : 0u;
 	if (!c.valid) item = 0;
 	c.slot = item;
-	if (DIRTY) c.slot = p.G.workItems[0][item]; // incremental runs list the slots to rebuild (a dependent load: compiled in only there)
+	if (MODE == 1) c.slot = p.G.workItems[0][item]; // incremental runs list the slots to rebuild (a dependent load: compiled in only there)
+	if (MODE == 2) c.slot = p.G.slowItems[item];
 	c.ntc = L.ntCount[c.slot];
 	c.skip = L.skip[c.slot];
 	c.coord = L.slotCoord[c.slot];
@@ -482,7 +485,7 @@ __device__ __forceinline__ bool r0_accept(const LevelDesc& L, u32 lo, const R0Ca
 }
 
 // next accepted item at or after `it` (stride gridDim.x), starting with an already requested candidate for `it`
-template <int CAP, bool DIRTY>
+template <int CAP, int MODE>
 __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32& it, R0Candidate c, R0Block& b)
 {
 	const u32 padded = (total + 63u) & ~63u;
@@ -490,7 +493,7 @@ __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const Level
 		if (r0_accept<CAP>(L, lo, c, b)) return true;
 		it += gridDim.x;
 		if (it >= padded) return false;
-		c = r0_peek<DIRTY>(p, L, total, it);
+		c = r0_peek<MODE>(p, L, total, it);
 	}
 }
 
@@ -502,7 +505,7 @@ __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const Level
 #define R0_TICK(i) do { } while (0)
 #endif
 
-template <int CAP, bool DIRTY>
+template <int CAP, int MODE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0(ExecParamsDev p, u32 lo)
 {
 #if defined(VX_R0_PROFILE)
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
 
 	const LevelDesc& L = p.levels[0];
-	const u32 total = r0_uniform(DIRTY ? p.G.workCount[0] : *L.nActive);
+	const u32 total = r0_uniform(MODE == 1 ? p.G.workCount[0] : (MODE == 2 ? *p.G.slowCount : *L.nActive));
 	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const int tid = (int)threadIdx.x;
 	if (tid < 20) wgStats[tid] = 0;
@@ -531,10 +534,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	// Two blocks are known ahead: `cur` (inputs requested, being processed) and `nxt` (accepted; inputs requested while
 	// `cur` writes its output).  The work list entry behind `nxt` is requested together with nxt's inputs and looked at
 	// when the iteration ends — all requests of an iteration sit in ONE place (see the output loop below).
-	bool have = r0_next_item<CAP, DIRTY>(p, L, total, lo, it, r0_peek<DIRTY>(p, L, total, it), cur);
+	bool have = r0_next_item<CAP, MODE>(p, L, total, lo, it, r0_peek<MODE>(p, L, total, it), cur);
 	if (have) K::request(g, L, cur, pf);
 	it += gridDim.x;
-	bool haveNext = have && r0_next_item<CAP, DIRTY>(p, L, total, lo, it, r0_peek<DIRTY>(p, L, total, it), nxt);
+	bool haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, it, r0_peek<MODE>(p, L, total, it), nxt);
 	while (have) {
 		const u32 candIt = it + gridDim.x;
 		R0Candidate cand;
@@ -637,14 +640,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
 				u32* iOut = p.P.idx + r0_uniform(st.iOff) + ci;
 				for (u32 base = 0; base < vEnd || base < iEnd; base += WG) {
-					if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<DIRTY>(p, L, total, candIt); requested = true; }
+					if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<MODE>(p, L, total, candIt); requested = true; }
 					const u32 j = base + (u32)tid;
 					if (j < vEnd) K::emit_vertex(st, RT, p.G, cur, j, vOut);
 					if (j < iEnd) K::flush_index(st, RT, j, iOut);
 				}
 			}
 		}
-		if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<DIRTY>(p, L, total, candIt); }
+		if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<MODE>(p, L, total, candIt); }
 		R0_TICK(7);
 		if (tid == 0) {
 			BlockRecord& r = L.records[cur.slot];
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		have = haveNext;
 		it = candIt;
 		R0_TICK(8);
-		haveNext = have && r0_next_item<CAP, DIRTY>(p, L, total, lo, it, cand, nxt);
+		haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, it, cand, nxt);
 	}
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
