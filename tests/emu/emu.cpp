@@ -12,6 +12,7 @@
 
 #include "../../voxels_amd/csrc/tv_block.h"
 #include "../../voxels_amd/csrc/tv_fast0.h"
+#include "../../voxels_amd/csrc/tv_fast1.h"
 #include "../../voxels_amd/csrc/vx_terrain_math.h"
 
 #define VX_BACKEND_NAME "emu:cpu (tests only)"

@@ -296,7 +296,8 @@ struct Backend {
 		for (u32 code = 0; code < 256; ++code) memcpy(&vrow[code], p.tables + TAB_REG_VERT + code * 6, 6);
 		const F0Tables FT = f0_tables_from_image(p.tables, vrow.data());
 		Fast0State<640>* fst = new Fast0State<640>;
-		u32 fastBlocks = 0, generalBlocks = 0;
+		Fast1State<640>* fst1 = new Fast1State<640>;
+		u32 fastBlocks = 0, generalBlocks = 0, fastCoarse = 0, generalCoarse = 0;
 		for (u32 level = 0; level < levels; ++level) {
 			const LevelDesc& L = p.levels[level];
 			for (u32 it = 0; it < item_count(p, level); ++it) {
@@ -308,7 +309,8 @@ struct Backend {
 				block_coords(L.slotCoord[slot], L.cnt, b.bx, b.by, b.bz);
 				if (ntc == 0 || (level == 0 && L.skip[slot])) { reg_write_empty_record(L, slot); continue; }
 				if (level == 0 && !p.G.dirty && CAP == 640 && !getenv("VX_EMU_NO_FAST0") && f0_block_serial(*fst, FT, p.G, L, p.P, slot, b.bx, b.by, b.bz, p.G.stats)) { ++fastBlocks; continue; }
-				if (level == 0) ++generalBlocks;
+				if (level >= 1 && level < PYRAMID_LEVELS && !p.G.dirty && CAP == 640 && !getenv("VX_EMU_NO_FAST1") && f1_block_serial(*fst1, FT, p.G, L, p.P, level, slot, b.bx, b.by, b.bz, p.G.stats)) { ++fastCoarse; continue; }
+				if (level == 0) ++generalBlocks; else ++generalCoarse;
 				reg_phase_begin(*st, L, slot, 0, 1);
 				reg_phase_stage(*st, p.G, L, b, 0, 1);
 				for (int w = 0; w < 128; ++w) st->wordPrefix[w] = (u16)TV_POPC(st->ntBits[w]);
@@ -334,7 +336,9 @@ struct Backend {
 		}
 		delete st;
 		delete fst;
+		delete fst1;
 		if (getenv("VX_EMU_TRACE") && (fastBlocks || generalBlocks)) fprintf(stderr, "[emu] level-0 blocks: %u through the fast pass, %u through the general pass (class <= %d cells)\n", fastBlocks, generalBlocks, CAP);
+		if (getenv("VX_EMU_TRACE") && (fastCoarse || generalCoarse)) fprintf(stderr, "[emu] level >= 1 blocks: %u through the fast pass, %u through the general pass (class <= %d cells)\n", fastCoarse, generalCoarse, CAP);
 	}
 
 	template <typename P>

@@ -28,24 +28,32 @@ __global__ void k_rate(unsigned long long* out, unsigned* sink, int iters)
 		if (WHICH == 7) { BODY("v_cndmask_b32") }
 	}
 	const unsigned long long t1 = __builtin_readcyclecounter();
-	if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+	if ((threadIdx.x & 63) == 0) atomicMax(&out[blockIdx.x], t1 - t0); // the slowest wave of the block (the arbiter favours the oldest)
 	sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
 template <int WHICH>
 void run(const char* name)
 {
-	const int iters = 2000, blocks = 256;
+	const int iters = 2000;
 	unsigned long long* dOut; unsigned* dSink;
-	hipMalloc(&dOut, blocks * 8); hipMalloc(&dSink, blocks * 1024 * 4);
+	hipMalloc(&dOut, 512 * 8); hipMalloc(&dSink, 512 * 1024 * 4);
 	printf("%-16s", name);
-	for (int threads : { 64, 256, 512, 1024 }) { // 1 wave per CU .. 4 waves per SIMD (one block per CU)
-		hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, dOut, dSink, iters);
+	for (int threads : { 64, 256, 512, 1024, 2048 }) { // 1 wave per CU .. 8 waves per SIMD (2048: two blocks of 1024 per CU)
+		const int blocks = threads == 2048 ? 512 : 256, tpb = threads == 2048 ? 1024 : threads;
+		hipMemset(dOut, 0, 512 * 8);
+		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+		hipEventRecord(e0, 0);
+		hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(tpb), 0, 0, dOut, dSink, iters);
+		hipEventRecord(e1, 0);
 		hipDeviceSynchronize();
+		float ms = 0; hipEventElapsedTime(&ms, e0, e1);
 		std::vector<unsigned long long> h(blocks);
 		hipMemcpy(h.data(), dOut, blocks * 8, hipMemcpyDeviceToHost);
 		double sum = 0; for (auto v : h) sum += (double)v;
-		printf("  %4d thr/CU: %6.2f cyc/inst/wave", threads, sum / blocks / (iters * 64.0));
+		// SIMD throughput from the wall clock: wave-instructions per SIMD / kernel time
+		const double perSimd = (double)threads / 64.0 / 4.0 * iters * 64.0;
+		printf(" | %4d thr/CU: %5.2f cyc/inst (slowest wave), %5.1f ns per inst per SIMD", threads, sum / blocks / (iters * 64.0), ms * 1e6 / (perSimd > 0 ? perSimd : 1));
 	}
 	printf("\n");
 	hipFree(dOut); hipFree(dSink);

@@ -127,9 +127,10 @@ struct Globals {
 	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
 	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)
 	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
-	// full runs, level 0: slots of the blocks the fast pass (tv_fast0.h) hands on to the general pass (a zero sample)
-	u32* slowItems;                   // [cap of level 0]
-	u32* slowCount;
+	// full runs: blocks the fast regular passes (tv_fast0.h, tv_fast1.h) hand on to the general pass (a zero sample, a LOD
+	// chain ending on a voxel).  [0]: level-0 slots; [1]: level << 24 | slot for the levels >= 1
+	u32* slowItems[2];
+	u32* slowCount;                   // [2]
 };
 
 // BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the

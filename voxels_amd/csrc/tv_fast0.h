@@ -30,16 +30,19 @@ enum { F0_VDESC = 1024, F0_TDESC = 1024 };                                    //
 enum : u32 {
 	TAB_F0_CASE = 9232,      // 256 x 3 dwords, see f0_build_tables
 	TAB_F0_TRI = 12304,      // 16 x u64: the 15 triangle-corner nibbles of a class
-	TAB_F0_EDGE = 12432,     // 16 x (u32, u32): per edge index, see F0Edge
-	TAB_F0_DIRS = 12560,     // 8 bytes: reuse directions 1..6 (bit d-1) a reuseValidityMask allows, + padding to 16
-	TAB_F0_BYTES = 12576
+	TAB_F0_EDGE = 12432,     // 16 x 16 bytes: per edge index, see F0Edge
+	TAB_F0_DIRS = 12688,     // 8 bytes: reuse directions 1..6 (bit d-1) a reuseValidityMask allows, + padding to 16
+	TAB_F0_BYTES = 12704
 };
 
 // what a vertex / an index needs to know about cell edge `e` (index into the regular edge-word table)
-struct F0Edge {
-	u32 x; // offset of corner v0 from the cell's base sample in the staged distances | step to corner v1 << 16
+struct alignas(16) F0Edge {
+	u32 x; // offset of corner v0 from the cell's base sample in the staged distances of level 0 | step to corner v1 << 16
 	u32 y; // the same in the staged materials: offset | step << 10; v0 << 20 | axis << 23 | reuse direction << 25 | reuse slot << 29
+	u32 z; // like x for the 17^3 staging of the levels >= 1 (tv_fast1.h: rows of F1_SROW bytes)
+	u32 w; // unused
 };
+enum { F1_SROW = 20, F1_SPLANE = 17 * F1_SROW, F1_SBYTES = 17 * F1_SPLANE }; // levels >= 1: sample (i,j,k) at k * F1_SPLANE + j * F1_SROW + i
 
 struct F0Tables {
 	const u32* caseRow;                 // [256][3]
@@ -72,15 +75,16 @@ inline void f0_build_tables(u8* img, const unsigned char* regClass, const unsign
 	}
 	for (u32 e = 0; e < 16; ++e) {
 		const u32 w = edgeWords[e], v0 = (w >> 4) & 15u, v1 = w & 15u, dir = w >> 12, slot = (w >> 8) & 15u;
-		F0Edge info = { 0, 0 };
+		F0Edge info = { 0, 0, 0, 0 };
 		if (w) {
 			const u32 d = v1 - v0, axis = d == 1u ? 0u : (d == 2u ? 1u : 2u);
 			const u32 sOff = (v0 & 1u) + ((v0 >> 1) & 1u) * SROW + (v0 >> 2) * SPLANE, sStep = axis == 0 ? 1u : (axis == 1 ? (u32)SROW : (u32)SPLANE);
 			const u32 mOff = (v0 & 1u) + ((v0 >> 1) & 1u) * F0_MROW + (v0 >> 2) * F0_MPLANE, mStep = axis == 0 ? 1u : (axis == 1 ? (u32)F0_MROW : (u32)F0_MPLANE);
 			info.x = sOff | (sStep << 16);
 			info.y = mOff | (mStep << 10) | (v0 << 20) | (axis << 23) | ((dir & 15u) << 25) | ((slot & 3u) << 29);
+			info.z = ((v0 & 1u) + ((v0 >> 1) & 1u) * F1_SROW + (v0 >> 2) * F1_SPLANE) | ((axis == 0 ? 1u : (axis == 1 ? (u32)F1_SROW : (u32)F1_SPLANE)) << 16);
 		}
-		memcpy(img + TAB_F0_EDGE + e * 8, &info, 8);
+		memcpy(img + TAB_F0_EDGE + e * 16, &info, 16);
 	}
 	for (u32 m = 0; m < 8; ++m) {
 		u32 a = 0;
@@ -118,25 +122,38 @@ struct Fast0State {
 	u32 vOff, iOff, vTotal, tTotal, zero;
 };
 
+// Where a pass keeps the samples and the cell materials (level 0: 19^3 distances + 17^3 voxel materials, the material of
+// a cell being the voxel at its base corner, :755-760; levels >= 1: 17^3 lattice samples + the block's material cache)
+struct F0Layout {
+	enum { SR = SROW, SP = SPLANE };
+	template <typename ST> static TV_HD const i8* base_sample(const ST& st, int cx, int cy, int cz) { return st.samp + samp_index(cx, cy, cz); }
+	// bit d-1: the cell in reuse direction d (x-1 | y-1 << 1 | z-1 << 2) has this cell's material id
+	template <typename ST> static TV_HD u32 same_material(const ST& st, u32, int cx, int cy, int cz)
+	{
+		const u8* mp = st.matId + (cz * F0_MPLANE + cy * F0_MROW + cx);
+		const u32 mine = mp[0];
+		return (mp[-1] == mine ? 1u : 0u) | (mp[-F0_MROW] == mine ? 2u : 0u) | (mp[-F0_MROW - 1] == mine ? 4u : 0u)
+		     | (mp[-F0_MPLANE] == mine ? 8u : 0u) | (mp[-F0_MPLANE - 1] == mine ? 16u : 0u) | (mp[-F0_MPLANE - F0_MROW] == mine ? 32u : 0u);
+	}
+};
+
 // ---- one compact cell: case, reuse resolution, counts (returns created vertices | triangles << 16) ---------------------
-template <typename ST>
-TV_HD u32 f0_cell(ST& st, const F0Tables& T, u32 k, u32* classCount)
+template <typename LAY, typename ST>
+TV_HD u32 fx_cell(ST& st, const F0Tables& T, u32 k, u32* classCount)
 {
 	const u32 c = st.cellAN[k][0] & 0xFFFu;
 	const int cx = (int)(c & 15u), cy = (int)((c >> 4) & 15u), cz = (int)(c >> 8);
-	const i8* sp = st.samp + samp_index(cx, cy, cz);
+	const i8* sp = LAY::base_sample(st, cx, cy, cz);
+	enum { SR = LAY::SR, SP = LAY::SP };
 	// the sign of a sign-extended byte fills bits 7..31: bit 8 + i of corner i's sample is bit i of the case code
-	const int v0 = sp[0], v1 = sp[1], v2 = sp[SROW], v3 = sp[SROW + 1], v4 = sp[SPLANE], v5 = sp[SPLANE + 1], v6 = sp[SPLANE + SROW], v7 = sp[SPLANE + SROW + 1];
+	const int v0 = sp[0], v1 = sp[1], v2 = sp[SR], v3 = sp[SR + 1], v4 = sp[SP], v5 = sp[SP + 1], v6 = sp[SP + SR], v7 = sp[SP + SR + 1];
 	const u32 code = (((u32)v0 & 0x100u) | ((u32)v1 & 0x200u) | ((u32)v2 & 0x400u) | ((u32)v3 & 0x800u)
 	                | ((u32)v4 & 0x1000u) | ((u32)v5 & 0x2000u) | ((u32)v6 & 0x4000u) | ((u32)v7 & 0x8000u)) >> 8;
 	const u32* row = T.caseRow + code * 3u;
 	const u32 w0 = row[0], w1 = row[1], w2 = row[2];
 	const u32 nv = (w0 >> 12) & 15u, ntri = w0 >> 28, cls = (w1 >> 12) & 15u;
-	// materials of this cell and of the six cells its non-owned edges come from (direction d: x-1 | y-1 << 1 | z-1 << 2)
-	const u8* mp = st.matId + (cz * F0_MPLANE + cy * F0_MROW + cx);
-	const u32 mine = mp[0];
-	const u32 eq = (mp[-1] == mine ? 1u : 0u) | (mp[-F0_MROW] == mine ? 2u : 0u) | (mp[-F0_MROW - 1] == mine ? 4u : 0u)
-	             | (mp[-F0_MPLANE] == mine ? 8u : 0u) | (mp[-F0_MPLANE - 1] == mine ? 16u : 0u) | (mp[-F0_MPLANE - F0_MROW] == mine ? 32u : 0u);
+	// materials of this cell and of the six cells its non-owned edges come from
+	const u32 eq = LAY::same_material(st, c, cx, cy, cz);
 	// reuseValidityMask from the bitmap (TransVoxelImpl.cpp:1543-1548, :1742-1748): a non-trivial cell earlier in the
 	// row / in an earlier row of the slice / in an earlier slice
 	const u32 rowId = (u32)((cz << 4) | cy);
@@ -163,10 +180,14 @@ TV_HD u32 f0_cell(ST& st, const F0Tables& T, u32 k, u32* classCount)
 	return (u32)TV_POPC(newMask) | (ntri << 16);
 }
 
+template <typename ST>
+TV_HD u32 f0_cell(ST& st, const F0Tables& T, u32 k, u32* classCount) { return fx_cell<F0Layout>(st, T, k, classCount); }
+
 // descriptors of cell k's new vertices and triangles that fall into the given chunks; base = vertex base | triangle base << 16
 template <typename ST>
 TV_HD void f0_describe(ST& st, const F0Tables& T, u32 k, u32 base, u32 chunkV, u32 chunkT)
 {
+	const u32 F0_VDESC = (u32)(sizeof(st.vdesc) / sizeof(st.vdesc[0])), F0_TDESC = (u32)(sizeof(st.tdesc) / sizeof(st.tdesc[0])); // (shadow the level-0 capacities)
 	const u32 a = st.cellAN[k][0];
 	u32 m = st.cellAN[k][1] & 0xFFFu;
 	u32 j = base & 0xFFFFu;

@@ -1,8 +1,7 @@
 // vx_fast0.inl — k_regular0_fast: the regular-cell pass of level 0 for blocks without a zero sample (tv_fast0.h has the
 // per-lane logic and the reason why it is exact), written for gfx950.  Included by vx_hip.hip behind vx_regular0.inl,
-// whose work distribution and register prefetch it shares: persistent workgroups stride over the level-0 slots, the
-// next block's 19^3 distances, 17^3 materials + blends and bitmap are requested into registers while the current block
-// emits.  A block in whose staged samples a lane finds a zero byte is appended to Globals::slowItems and left to
+// whose work distribution it shares: persistent workgroups stride over the level-0 slots, the next block's 19^3
+// distances, 17^3 materials + blends and bitmap are requested into registers while the current block emits.  A block in whose staged samples a lane finds a zero byte is appended to Globals::slowItems[0] and left to
 // k_regular0<.., 2>, launched right behind on the same stream.
 //
 // Per block: deposit (+ zero test) | popcount prefix + compact cell list | cells: table-driven, no loop over table
@@ -45,38 +44,113 @@ __device__ __forceinline__ u32 wave_inclusive_scan_dpp(u32 v)
 
 __device__ __forceinline__ u32 f0_has_zero_byte(u32 v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
 
-// registers -> LDS (R0::deposit), and: does a staged distance sample equal zero?  (The rows y, z = -1 and 17 are looked
-// at as well: a zero there sends a block to the general pass without need, which costs time, never correctness.)
-template <typename ST>
-__device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Block& b, const R0Prefetch& pf)
+// What a workgroup holds of the NEXT block while it finishes the current one.  Lanes are mapped so that most of a
+// row's address is a per-lane constant of the block:
+//   distances: lane = (jj = tid % 19, group = tid / 19), rows (jj, kk = group + 13 q), q = 0, 1 — the 19 samples x = -1..17
+//              of row (y, z) = (by * 16 - 1 + jj, bz * 16 - 1 + kk): the row's 16 bytes in its own brick + the dwords left and
+//              right of them in the x-neighbour bricks (bricks of x-neighbour blocks follow each other);
+//   materials: lane = (j = tid % 17, group = tid / 17), rows (j, k = group + 15 q), q = 0, 1 — samples 0..16 of the
+//              material AND the blend row (same offset in both mirrors).
+struct F0Prefetch {
+	uint4 d[2]; u32 dl[2], dr[2];
+	uint4 m[2], b[2]; u32 mf[2], bf[2];
+	u32 bits;         // one word of the non-trivial bitmap (lanes < 128)
+};
+
+__device__ __forceinline__ int f0_opaque_tid()
 {
-	const int tid = R0<REG_CAP_SMALL>::opaque_tid();
+	int t = (int)threadIdx.x;
+	asm volatile("" : "+v"(t)); // keeps the lane's task decomposition from being hoisted out of the block loop (registers)
+	return t;
+}
+
+// byte offset, relative to the block's own brick, of the brick row that holds voxel row (y, z) given as block-relative
+// coordinates ry, rz in [-1, 17] (clamped to the grid by the caller through lo / hi = the valid range of ry / rz)
+__device__ __forceinline__ int f0_row_part(int r, int lo, int hi, int brickStride, bool isZ)
+{
+	r = max(lo, min(r, hi));
+	const int q = r >> 4, l = r & 15; // q in {-1, 0, 1}
+	return q * brickStride + (isZ ? (((l >> 1) << 9) | ((l & 1) << 6)) : (((l >> 2) << 7) | ((l & 3) << 4)));
+}
+
+__device__ __forceinline__ void f0_request(const GridView& g, const LevelDesc& L, const R0Block& b, F0Prefetch& pf)
+{
+	const int tid = f0_opaque_tid();
+	const int n = g.n, cnt = (int)L.cnt;
+	// every lane loads (indices clamped into range): a conditional load with a default value makes the compiler wait for
+	// the data right behind the load, and these requests must stay in flight
+	pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
+	const int brickRow = (n >> 4) * BRICK_BYTES, brickPlane = g.bRowsY * brickRow; // next block along y / z
+	const size_t own = brick_base(g, (int)b.bx, (int)b.by, (int)b.bz);
+	const bool firstX = b.bx == 0, lastX = (int)b.bx + 1 == cnt;
+	// block-relative coordinates that stay inside the grid (the reference clamps every fetch, :1194-1201)
+	const int yLo = -min((int)b.by * 16, 1), yHi = min(n - 1 - (int)b.by * 16, 17), zLo = -min((int)b.bz * 16, 1), zHi = min(n - 1 - (int)b.bz * 16, 17);
+	{
+		const i8* base = g.bDist + own;
+		const int jj = min(tid % 19, 18), group = tid / 19;
+		const int yPart = f0_row_part(jj - 1, yLo, yHi, brickRow, false);
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int kk = min(group + 13 * q, 18);
+			const int row = yPart + f0_row_part(kk - 1, zLo, zHi, brickPlane, true);
+			pf.d[q] = *(const uint4*)(base + row);
+			pf.dl[q] = *(const u32*)(base + row + (firstX ? 0 : 12 - BRICK_BYTES));
+			pf.dr[q] = *(const u32*)(base + row + (lastX ? 12 : BRICK_BYTES));
+		}
+	}
+	{
+		const u8* mbase = g.bMat + own;
+		const u8* bbase = g.bBlend + own;
+		const int j = min(tid % 17, 16), group = tid / 17;
+		const int yPart = f0_row_part(j, 0, yHi, brickRow, false);
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int k = min(group + 15 * q, 16);
+			const int row = yPart + f0_row_part(k, 0, zHi, brickPlane, true);
+			const int far = row + (lastX ? 12 : BRICK_BYTES); // sample 16 in byte 0; at the grid's edge the row's last dword (see deposit)
+			pf.m[q] = *(const uint4*)(mbase + row);
+			pf.b[q] = *(const uint4*)(bbase + row);
+			pf.mf[q] = *(const u32*)(mbase + far);
+			pf.bf[q] = *(const u32*)(bbase + far);
+		}
+	}
+}
+
+// registers -> LDS, and: does a staged distance sample equal zero?  (The rows y, z = -1 and 17 are looked at as well: a
+// zero there sends a block to the general pass without need, which costs time, never correctness.)
+template <typename ST>
+__device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Block& b, const F0Prefetch& pf)
+{
+	const int tid = f0_opaque_tid();
 	const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
 	u32 zero = 0;
 	if (tid < 128) st.ntBits[tid] = pf.bits;
+	{
+		const int jj = tid % 19, group = tid / 19;
 #pragma unroll
-	for (int q = 0; q < 3; ++q) {
-		const int h = tid + q * WG;
-		if (h < 722) {
-			const int r = h >> 1, half = h & 1;
-			u32 a = half ? pf.dOwn[q].x : pf.dNb[q], bb = half ? pf.dOwn[q].y : pf.dOwn[q].x, c = half ? pf.dNb[q] : pf.dOwn[q].y;
-			if (!half && firstX) a = bb << 24;                          // no left neighbour: sample -1 = sample 0
-			if (half && lastX) c = (bb >> 24) * 0x01010101u;            // no right neighbour: samples 16, 17 = sample 15
-			u32* dst = (u32*)(st.samp + r * SROW + half * 12);
-			dst[0] = a; dst[1] = bb; dst[2] = c;
-			// half 0 holds x = -4..7, half 1 x = 8..19; the cells' corners are the columns 0..16
-			zero |= (half ? f0_has_zero_byte(a) : 0u) | f0_has_zero_byte(bb) | f0_has_zero_byte(half ? (c | 0xFFFFFF00u) : c);
+		for (int q = 0; q < 2; ++q) {
+			const int kk = group + 13 * q;
+			if (kk < 19 && tid < 19 * 13) {
+				u32 left = pf.dl[q], right = pf.dr[q];
+				if (firstX) left = pf.d[q].x << 24;                       // no left neighbour: sample -1 = sample 0
+				if (lastX) right = (pf.d[q].w >> 24) * 0x01010101u;       // no right neighbour: samples 16, 17 = sample 15
+				u32* dst = (u32*)(st.samp + kk * SPLANE + jj * SROW);       // bytes 0..3: x = -4..-1, 4..19: x = 0..15, 20..23: x = 16..19
+				dst[0] = left; dst[1] = pf.d[q].x; dst[2] = pf.d[q].y; dst[3] = pf.d[q].z; dst[4] = pf.d[q].w; dst[5] = right;
+				zero |= f0_has_zero_byte(pf.d[q].x) | f0_has_zero_byte(pf.d[q].y) | f0_has_zero_byte(pf.d[q].z) | f0_has_zero_byte(pf.d[q].w) | f0_has_zero_byte(right | 0xFFFFFF00u);
+			}
 		}
 	}
+	{
+		const int j = tid % 17, group = tid / 17;
 #pragma unroll
-	for (int q = 0; q < 3; ++q) {
-		const int t = tid + q * WG;
-		if (t < 578) {
-			const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
-			const int k = r / 17, j = r - k * 17;
-			u32* dst = (u32*)((arr ? st.blend : st.matId) + k * F0_MPLANE + j * F0_MROW);
-			dst[0] = pf.m[q].x; dst[1] = pf.m[q].y; dst[2] = pf.m[q].z; dst[3] = pf.m[q].w;
-			dst[4] = lastX ? (pf.mf[q] >> 24) : pf.mf[q];
+		for (int q = 0; q < 2; ++q) {
+			const int k = group + 15 * q;
+			if (k < 17 && tid < 17 * 15) {
+				u32* dm = (u32*)(st.matId + k * F0_MPLANE + j * F0_MROW);
+				u32* db = (u32*)(st.blend + k * F0_MPLANE + j * F0_MROW);
+				dm[0] = pf.m[q].x; dm[1] = pf.m[q].y; dm[2] = pf.m[q].z; dm[3] = pf.m[q].w; dm[4] = lastX ? (pf.mf[q] >> 24) : pf.mf[q];
+				db[0] = pf.b[q].x; db[1] = pf.b[q].y; db[2] = pf.b[q].z; db[3] = pf.b[q].w; db[4] = lastX ? (pf.bf[q] >> 24) : pf.bf[q];
+			}
 		}
 	}
 	return zero;
@@ -104,10 +178,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
 	u32 it = blockIdx.x;
 	R0Block cur, nxt;
-	R0Prefetch pf;
+	F0Prefetch pf;
 	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
 	bool have = r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), cur);
-	if (have) K::request(g, L, cur, pf);
+	if (have) f0_request(g, L, cur, pf);
 	it += gridDim.x;
 	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), nxt);
 	u32 parity = 0;
@@ -164,7 +238,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
 					const u32 k = k0 + lane;
 					u32 cnt = 0;
-					if (k < kEnd) cnt = f0_cell(st, T, k, wgStats + 4);
+					if (k < kEnd) {
+						cnt = f0_cell(st, T, k, wgStats + 4);
+#if defined(VX_CASE_DUMP)
+						L.caseDump[(size_t)cur.slot * BLOCK_CELLS + (st.cellAN[k][0] & 0xFFFu)] = (u8)((st.cellAN[k][0] >> 12) & 0xFFu);
+#endif
+					}
 					const u32 incl = wave_inclusive_scan_dpp(cnt);
 					if (k < kEnd) st.cellC[k] = carry + incl - cnt;
 					carry += (u32)__shfl((int)incl, 63, 64);
@@ -217,7 +296,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 					PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
 					u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
-						if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
+						if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
 						if (j < vEnd) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
@@ -246,9 +325,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			}
 		} else if (tid == 0) {
 			// a zero sample: the general pass takes the block
-			p.G.slowItems[atomicAdd(p.G.slowCount, 1u)] = cur.slot;
+			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;
 		}
-		if (!requested) { if (haveNext) K::request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); }
+		if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); }
 		cur = nxt;
 		have = haveNext;
 		it = candIt;

@@ -32,6 +32,7 @@
 
 #include "tv_block.h"
 #include "tv_fast0.h"
+#include "tv_fast1.h"
 #include "vx_terrain_math.h"
 
 #define VX_BACKEND_NAME "hip:gfx950"
@@ -1218,6 +1219,7 @@ __device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* ima
 
 #include "vx_regular0.inl"
 #include "vx_fast0.inl"
+#include "vx_fast1.inl"
 
 namespace {
 
@@ -1227,7 +1229,9 @@ namespace {
 #if !defined(VX_REG_WAVES)
 #define VX_REG_WAVES 4
 #endif
-template <int CAP>
+// MODE 0: the slots of the levels [levelBegin, levels) (or the work lists of an incremental run); MODE 2: the blocks the
+// fast pass of the levels >= 1 (vx_fast1.inl) handed on (Globals::slowItems[1])
+template <int CAP, int MODE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CAP_SMALL ? 1 : VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
 {
 	typedef RegStateT<CAP> ST;
@@ -1243,6 +1247,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CA
 		u32 run = 0;
 		for (u32 l = 0; l < levels; ++l) { wl.start[l] = run; if (l >= levelBegin) run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive; }
 		for (u32 l = levels; l <= MAX_LEVELS; ++l) wl.start[l] = run;
+		if (MODE == 2) wl.start[MAX_LEVELS] = p.G.slowCount[1];
 	}
 	__syncthreads();
 	const u32 total = wl.start[MAX_LEVELS];
@@ -1261,8 +1266,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CA
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
 		RegBlockCtx b;
-		decode_item(wl, levels, item, b.level, b.slot);
-		if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
+		if (MODE == 2) {
+			const u32 packed = p.G.slowItems[1][item];
+			b.level = packed >> 24; b.slot = packed & 0xFFFFFFu;
+		} else {
+			decode_item(wl, levels, item, b.level, b.slot);
+			if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
+		}
 		const LevelDesc& L = p.levels[b.level];
 		const u32 ntc = L.ntCount[b.slot];
 		if ((lo && ntc <= lo) || ntc > (u32)CAP) continue;   // the first class (lo == 0) also owns empty blocks
@@ -1751,7 +1761,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, fast0 = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -1773,6 +1783,7 @@ struct Backend {
 		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
 		tune.fast0 = env_u32("VX_FAST0", 1); // 0: every level-0 block through the general pass (A/B measurements)
+		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -1800,8 +1811,10 @@ struct Backend {
 			err = lastError;
 			return false;
 		}
-		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
+		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small, handed on)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>))), "hipFuncSetAttribute(k_regular1_fast)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")) {
 			err = lastError;
 			return false;
@@ -2085,9 +2098,23 @@ struct Backend {
 		u32 cap = 0;
 		for (u32 l = levelBegin; l < levels; ++l) cap += p.levels[l].cap;
 		if (cap) {
-			const u32 gridS = std::min<u32>(cap, (u32)cus * tune.regWgsPerCu);
-			hipLaunchKernelGGL(k_regular<REG_CAP_SMALL>, dim3(gridS), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>), on, dev(p), levelBegin, levels, 0u);
-			if (largeClass) hipLaunchKernelGGL(k_regular<4096>, dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
+			const u32 ldsS = REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>);
+			u32 generalBegin = levelBegin;
+			// levels with a lattice copy: blocks without a zero lattice sample take the table-driven pass; what it hands on
+			// (Globals::slowItems[1]) and the coarser levels go through the general pass.  (32-bit voxel offsets: mirrors < 4 GiB.)
+			const u32 fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
+			const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
+			if (!p.G.dirty && tune.fast1 && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
+				u32 capFast = 0;
+				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
+				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.regWgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd);
+				hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
+				generalBegin = fastEnd;
+			}
+			u32 capGeneral = 0;
+			for (u32 l = generalBegin; l < levels; ++l) capGeneral += p.levels[l].cap;
+			if (capGeneral) hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 0>), dim3(std::min<u32>(capGeneral, (u32)cus * tune.regWgsPerCu)), dim3(WG), ldsS, on, dev(p), generalBegin, levels, 0u);
+			if (largeClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
 		}
 		check(hipGetLastError(), "k_regular launch");
 	}

@@ -10,6 +10,7 @@
 #include "../../include/voxels_hip.h"
 #include "tv_block.h"
 #include "tv_fast0.h"
+#include "tv_fast1.h"
 
 #include <algorithm>
 #include <chrono>
@@ -55,7 +56,7 @@ struct vx_ctx {
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
-	void* dSlowItems = nullptr;                            // level-0 slots handed from the fast regular pass to the general one
+	void* dSlowItems[2] = { nullptr, nullptr };            // blocks handed from the fast regular passes to the general one (level 0 | levels >= 1)
 	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
@@ -266,8 +267,8 @@ bool ensure_level_tables(vx_ctx* c)
 		if (!d.slotOf || !d.slotCoord || !d.ntBits || !d.records || !d.listed || !d.ntCount || (L && !d.cache) || (!L && !d.skip)) return false;
 		if (!L) {
 			c->dBlockClass = alloc(total);
-			c->dSlowItems = alloc(cap * 4 + 16);
-			if (!c->dSlowItems) return false;
+			c->dSlowItems[0] = alloc(cap * 4 + 16);
+			if (!c->dSlowItems[0]) return false;
 			c->dTileWork = alloc((size_t)((d.cnt + 15) / 16) * (d.yb1 - d.yb0) * (d.zb1 - d.zb0) + 16);
 			if (!c->dBlockClass || !c->dTileWork) return false;
 		}
@@ -283,6 +284,12 @@ bool ensure_level_tables(vx_ctx* c)
 			P.data = (i8*)alloc((size_t)P.bricksX * P.bricksY * bricksZ * BRICK_BYTES + 64);
 			if (!P.data) return false;
 		}
+	}
+	{
+		size_t coarse = 0;
+		for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) coarse += c->lv[L].cap;
+		c->dSlowItems[1] = alloc(coarse * 4 + 16);
+		if (!c->dSlowItems[1]) return false;
 	}
 	{
 		size_t wgs = 0;
@@ -321,7 +328,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.blockClass = (u8*)c->dBlockClass;
 	p.G.tileWork = (u8*)c->dTileWork;
 	p.G.blockSign = (const u16*)c->dBlockSign;
-	p.G.slowItems = (u32*)c->dSlowItems;
+	p.G.slowItems[0] = (u32*)c->dSlowItems[0];
+	p.G.slowItems[1] = (u32*)c->dSlowItems[1];
 	p.G.slowCount = (u32*)c->dHeader + HDR_SLOW;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;

@@ -458,7 +458,7 @@ __device__ __forceinline__ R0Candidate r0_peek(const ExecParamsDev& p, const Lev
 	if (!c.valid) item = 0;
 	c.slot = item;
 	if (MODE == 1) c.slot = p.G.workItems[0][item]; // incremental runs list the slots to rebuild (a dependent load: compiled in only there)
-	if (MODE == 2) c.slot = p.G.slowItems[item];
+	if (MODE == 2) c.slot = p.G.slowItems[0][item];
 	c.ntc = L.ntCount[c.slot];
 	c.skip = L.skip[c.slot];
 	c.coord = L.slotCoord[c.slot];
