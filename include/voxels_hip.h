@@ -223,8 +223,10 @@ int vx_stats(vx_ctx* ctx, uint32_t stats[20]);
  * this arithmetic on the host: t = (v1 << 8) / (v1 - v0), src/TransVoxelImpl.cpp:1591; normalizeFixZero, :93-103):
  * results[0] = crossed int8 sample pairs whose t differs from the truncated quotient, results[1] = gradients whose normal
  * changes when the gradient is scaled by 0.5, results[2] = gradients whose normal differs from fp32 sqrt + division;
- * all three must be 0.  results[3..7] count mismatches of cheaper candidate forms (informational). */
-int vx_selftest(vx_ctx* ctx, uint32_t results[8]);
+ * results[11] = gradients whose normal differs between normalize_gradient (the cheaper form the fast passes use for the
+ * end-point normals, valid for integer gradients only) and normalizeFixZero; all four must be 0.  results[3..10] count
+ * mismatches of other candidate forms (informational). */
+int vx_selftest(vx_ctx* ctx, uint32_t results[16]);
 
 /* Optional per-stage device timing (HIP events between the kernels of vx_polygonize; adds a few event records).
  * ms[0..7] = reset + block classes, classify, hierarchy, material (all levels), regular cells of level 0, of the levels >= 1,

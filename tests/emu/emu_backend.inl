@@ -178,7 +178,7 @@ struct Backend {
 		}
 	}
 	bool stage_ms(float*) { return false; }
-	bool run_selftest(u32* out) { memset(out, 0, 8 * 4); return true; } // the device forms do not exist here
+	bool run_selftest(u32* out) { memset(out, 0, 16 * 4); return true; } // the device forms do not exist here
 
 	// classification of one level-0 block (portable form of k_classify)
 	template <typename P>

@@ -355,7 +355,7 @@ def test_hip_device_arithmetic_exhaustive(poly):
     (scaled and unscaled; against sqrtf + IEEE division), on the GPU (vx_selftest)."""
     r = poly.selftest()
     print("selftest:", r.tolist())
-    assert r[0] == 0 and r[1] == 0 and r[2] == 0, r.tolist()
+    assert r[0] == 0 and r[1] == 0 and r[2] == 0 and r[11] == 0, r.tolist()
 
 
 def widen_near_surface(d):

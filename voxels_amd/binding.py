@@ -30,7 +30,9 @@ class ExecInfo(C.Structure):
 
 
 def hip_library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvoxels_hip.so")
+    """The in-tree HIP build.  VOXELS_HIP_LIBRARY names another build of the SAME library (A/B measurements of kernel
+    variants compiled from the same sources with different -D switches, tools/ab_build.py) — never a different backend."""
+    return os.environ.get("VOXELS_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libvoxels_hip.so")
 
 
 def _ptr(a):
@@ -337,8 +339,8 @@ class Polygonizer:
         return out
 
     def selftest(self):
-        """vx_selftest: mismatch counts of the device arithmetic against its definition, exhaustively ([0..2] must be 0)."""
-        r = np.zeros(8, np.uint32)
+        """vx_selftest: mismatch counts of the device arithmetic against its definition, exhaustively ([0..2], [11] must be 0)."""
+        r = np.zeros(16, np.uint32)
         self._check(self._lib.vx_selftest(self._h, _ptr(r)), "vx_selftest")
         return r
 

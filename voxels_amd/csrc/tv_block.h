@@ -29,7 +29,7 @@ template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v;
 namespace tv {
 
 enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
-enum { CUR_V = 0, CUR_I = 32, CUR_OVF = 64 };
+enum { CUR_V = 0, CUR_I = 1, CUR_OVF = 64 }; // the two pool cursors share an aligned 64-bit word: one atomic reserves both ranges of a mesh
 enum { LIST_WG = 256 }; // block coordinates per workgroup of the list kernels
 enum { LARGE_THRESHOLD = 640 }; // blocks with more non-trivial cells use the 4096-cell LDS class of the regular pass // hot device counters live in separate cache lines (atomics serialise per line)
 
@@ -83,7 +83,7 @@ struct LevelDesc {
 struct Pools {
 	PolyVertex* verts;
 	u32* idx;
-	u32* cursors;       // [CUR_V] vertices used, [CUR_I] indices used, [CUR_OVF] overflow flag — one 128-byte line each
+	u32* cursors;       // [CUR_V] vertices used, [CUR_I] indices used (one 64-bit word), [CUR_OVF] overflow flag (its own 128-byte line)
 	u32 vertCap, idxCap;
 };
 

@@ -218,6 +218,30 @@ TV_HD void normalize_fix_zero(float v[3])
 #endif
 }
 
+// normalize_fix_zero for a vector of INTEGER components in [-255, 255] (a central difference of int8 samples, scaled or
+// not by a power of two): same bits, fewer operations.  On the device the length comes from rsq + one Newton step and
+// every quotient gets one correction instead of two — for these 2^24 inputs (up to signs) both are exact, checked
+// exhaustively on the hardware itself (vx_selftest, results[4], [6], [11]); arbitrary vectors (an interpolated normal)
+// keep normalize_fix_zero.
+TV_HD void normalize_gradient(float v[3])
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VX_EXACT_NORMALS_ONLY)
+	const float len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+	if (!(len2 > 0.f)) { v[0] = v[1] = v[2] = 0.f; return; } // integer components: the length is 0 or at least 1
+	const float r = __builtin_amdgcn_rsqf(len2), s = len2 * r, h = 0.5f * r;
+	const float len = __builtin_fmaf(__builtin_fmaf(-s, s, len2), h, s);
+	const float y0 = __builtin_amdgcn_rcpf(len);
+	const float y = __builtin_fmaf(__builtin_fmaf(-len, y0, 1.0f), y0, y0);
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		const float n = v[i], q0 = n * y;
+		v[i] = __builtin_fmaf(__builtin_fmaf(-len, q0, n), y, q0);
+	}
+#else
+	normalize_fix_zero(v);
+#endif
+}
+
 // distance sampler reading the dense field in HBM (global coordinates, clamped like every reference fetch)
 struct GlobalDist {
 	const GridView* g;

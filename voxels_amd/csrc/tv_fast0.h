@@ -242,8 +242,8 @@ TV_HD void f0_vertex(const ST& st, const F0Tables& T, u32 desc, int ox, int oy, 
 	rv.p[0] = (float)px; rv.p[1] = (float)py; rv.p[2] = (float)pz;
 	rv.s[0] = rv.p[0]; rv.s[1] = rv.p[1]; rv.s[2] = rv.p[2];
 	rv.flags = 0;
-	normalize_fix_zero(N0);
-	normalize_fix_zero(N1);
+	normalize_gradient(N0);
+	normalize_gradient(N1);
 	// blend (t * b0 + u * b1) / 256 truncated (:1699): the fp32 expression is exact integer arithmetic (sum <= 256 * 255)
 	if (id0 == id1 && id0 == cellId) rv.mat = id0 | (((((u32)t & 0x1FFu) * b0 + uu * b1) >> 8) << 8);
 	else rv.mat = cellId | (cellBlend << 8);

@@ -106,8 +106,8 @@ TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, u32 desc, 
 	rv.p[0] = (float)((x0 << 8) + (int)(ax ? uu : 0u)); rv.p[1] = (float)((y0 << 8) + (int)(ay ? uu : 0u)); rv.p[2] = (float)((z0 << 8) + (int)(az ? uu : 0u));
 	// central differences, components ordered x, z, y (CalcNormal, :1239-1246; the factor 0.5 does not survive normalising)
 	float N0[3] = { (float)(a0 - a1), (float)(a2 - a3), (float)(a4 - a5) }, N1[3] = { (float)(b0 - b1), (float)(b2 - b3), (float)(b4 - b5) };
-	normalize_fix_zero(N0);
-	normalize_fix_zero(N1);
+	normalize_gradient(N0);
+	normalize_gradient(N1);
 	const int v1 = (int)v0 | (1 << axis);
 	rv.flags = boundary_mask(cx, cy, cz, mult, (int)v0, v1);
 	if ((M0 & 0xFFu) == (M1 & 0xFFu) && (M0 & 0xFFu) == (cellMat & 0xFFu)) rv.mat = (M0 & 0xFFu) | (((((u32)t & 0x1FFu) * (M0 >> 8) + uu * (M1 >> 8)) >> 8) << 8);

@@ -177,8 +177,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 			if (tid == WG - 1) {
 				const u32 vTotal = tot & 0xFFFFu, tTotal = tot >> 16;
 				st.vTotal = vTotal; st.tTotal = tTotal;
-				st.vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
-				st.iOff = atomicAdd(&p.P.cursors[CUR_I], tTotal * 3u);
+				reserve_both(p.P.cursors, vTotal, tTotal * 3u, st.vOff, st.iOff);
 			}
 			for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
 				const u32 k = k0 + lane;

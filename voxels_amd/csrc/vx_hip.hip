@@ -90,6 +90,21 @@ __device__ u32 block_exclusive_scan_u16(u16* a, u32 n, u32* scratch)
 	return total;
 }
 
+// both output ranges of a mesh with ONE returning atomic: the cursors are the halves of an aligned 64-bit word (the pools
+// hold fewer than 2^32 elements, so the vertex half never carries into the index half).  Every block of every pass
+// reserves through the same two addresses — about 30 reservations per microsecond during a 1024^3 run, a third of
+// what one address sustains — so the number of round trips matters more than the bytes.
+__device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indices, u32& vOff, u32& iOff)
+{
+#if defined(VX_SEPARATE_RESERVE)
+	vOff = atomicAdd(&cursors[CUR_V], verts);
+	iOff = atomicAdd(&cursors[CUR_I], indices);
+#else
+	const unsigned long long r = atomicAdd((unsigned long long*)cursors, (unsigned long long)verts | ((unsigned long long)indices << 32));
+	vOff = (u32)r; iOff = (u32)(r >> 32);
+#endif
+}
+
 __device__ __forceinline__ void stage_tables(u8* dst, const u8* src)
 {
 	const uint4* s = (const uint4*)src;
@@ -1464,8 +1479,7 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 					const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
 					if (tid == 0) {
 						st.vTotal = vt; st.iTotal = it2;
-						st.vOff = atomicAdd(&p.P.cursors[CUR_V], vt);
-						st.iOff = atomicAdd(&p.P.cursors[CUR_I], it2);
+						reserve_both(p.P.cursors, vt, it2, st.vOff, st.iOff);
 					}
 				}
 				__syncthreads(); TR_TICK(10);
@@ -1629,7 +1643,8 @@ __global__ __launch_bounds__(WG) void k_halo_move(HaloPair pair, GridView g, Mir
 //   out[0]  crossed sample pairs where edge_t_crossing differs from the truncated integer quotient
 //   out[1]  gradients whose normalised components differ between g and 0.5 g (tv_fast0.h drops the factor)
 //   out[2]  gradients where normalize_fix_zero differs from fp32 sqrtf + IEEE division as hipcc compiles them
-//   out[3+] candidates for cheaper forms (see below): components that differ from normalize_fix_zero
+//   out[3..10] candidates for cheaper forms (see below): gradients with a component that differs from normalize_fix_zero
+//   out[11] gradients where normalize_gradient (the form the fast passes use for end-point normals) differs from it
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float selftest_sqrt_newton(float x)
 {
@@ -1681,6 +1696,28 @@ __global__ __launch_bounds__(WG) void k_selftest(u32* out)
 			if (__float_as_uint(p2) != __float_as_uint(a[c])) bad5 = 1;                            // [5] unrefined reciprocal, two corrections
 			const float w0 = n * yN, w1 = __builtin_fmaf(__builtin_fmaf(-lenN, w0, n), yN, w0);
 			if (__float_as_uint(w1) != __float_as_uint(a[c])) bad6 = 1;                            // [6] Newton length + one correction
+		}
+		{
+			// [8] Newton length, unrefined reciprocal, one correction; [9] the same with the reciprocal taken from rsq(len2)
+			const float yR = __builtin_amdgcn_rsqf(len2);
+			u32 bad8 = 0, bad9 = 0, bad10 = 0;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float n = g[c];
+				const float w0 = n * yN0, w1 = __builtin_fmaf(__builtin_fmaf(-lenN, w0, n), yN0, w0);
+				if (__float_as_uint(w1) != __float_as_uint(a[c])) bad8 = 1;
+				const float r0 = n * yR, r1 = __builtin_fmaf(__builtin_fmaf(-lenN, r0, n), yR, r0);
+				if (__float_as_uint(r1) != __float_as_uint(a[c])) bad9 = 1;
+				const float r2 = __builtin_fmaf(__builtin_fmaf(-lenN, r1, n), yR, r1);
+				if (__float_as_uint(r2) != __float_as_uint(a[c])) bad10 = 1;                          // [10] [9] with two corrections
+			}
+			if (bad8) atomicAdd(&out[8], 1u);
+			if (bad9) atomicAdd(&out[9], 1u);
+			if (bad10) atomicAdd(&out[10], 1u);
+			// [11] what the fast passes use: normalize_gradient
+			float q[3] = { g[0], g[1], g[2] };
+			normalize_gradient(q);
+			if (__float_as_uint(q[0]) != __float_as_uint(a[0]) || __float_as_uint(q[1]) != __float_as_uint(a[1]) || __float_as_uint(q[2]) != __float_as_uint(a[2])) atomicAdd(&out[11], 1u);
 		}
 		if (bad3) atomicAdd(&out[3], 1u);
 		if (bad4) atomicAdd(&out[4], 1u);
@@ -2156,7 +2193,7 @@ struct Backend {
 	bool stage_timing_on() const { return stageOn; }
 	bool run_selftest(u32* dOut)
 	{
-		if (!fill(dOut, 0, 8 * 4)) return false;
+		if (!fill(dOut, 0, 16 * 4)) return false;
 		hipLaunchKernelGGL(k_selftest, dim3((1u << 24) / WG), dim3(WG), 0, stream, dOut);
 		return check(hipGetLastError(), "k_selftest launch");
 	}

@@ -1521,12 +1521,12 @@ int vx_debug_case_dump(vx_ctx* c, uint32_t level, uint32_t cap, uint32_t* coords
 }
 #endif
 
-int vx_selftest(vx_ctx* c, uint32_t results[8])
+int vx_selftest(vx_ctx* c, uint32_t results[16])
 {
 	VX_ENTER(c);
 	if (!c || !results) return VX_ERR_INVALID;
-	void* d = c->be.alloc(8 * 4);
-	const bool ok = d && c->be.run_selftest((u32*)d) && c->be.d2h(results, d, 8 * 4);
+	void* d = c->be.alloc(16 * 4);
+	const bool ok = d && c->be.run_selftest((u32*)d) && c->be.d2h(results, d, 16 * 4);
 	c->be.free(d);
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_selftest: " + c->be.error());
 }

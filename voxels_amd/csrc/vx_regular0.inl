@@ -607,8 +607,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			// run out of cells and can afford to wait for the two atomics while the others write their descriptors
 			if (tid == WG - 1) {
 				st.vTotal = vTotal; st.iTotal = iTotal;
-				st.vOff = atomicAdd(&p.P.cursors[CUR_V], vTotal);
-				st.iOff = atomicAdd(&p.P.cursors[CUR_I], iTotal);
+				reserve_both(p.P.cursors, vTotal, iTotal, st.vOff, st.iOff);
 			}
 			u32 run = waveBase + incl - sum;
 			for (u32 k = kBeg; k < kEnd; ++k) {
