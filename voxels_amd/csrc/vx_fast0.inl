@@ -156,48 +156,6 @@ __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Bl
 	return zero;
 }
 
-#if defined(VX_F0_OLD_PREFETCH)
-// A/B builds only (tools): the lane mapping of vx_regular0.inl (R0::request, three half rows + three material rows per lane)
-template <typename ST>
-__device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Block& b, const R0Prefetch& pf)
-{
-	const int tid = f0_opaque_tid();
-	const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
-	u32 zero = 0;
-	if (tid < 128) st.ntBits[tid] = pf.bits;
-#pragma unroll
-	for (int q = 0; q < 3; ++q) {
-		const int h = tid + q * WG;
-		if (h < 722) {
-			const int r = h >> 1, half = h & 1;
-			u32 a = half ? pf.dOwn[q].x : pf.dNb[q], bb = half ? pf.dOwn[q].y : pf.dOwn[q].x, c = half ? pf.dNb[q] : pf.dOwn[q].y;
-			if (!half && firstX) a = bb << 24;
-			if (half && lastX) c = (bb >> 24) * 0x01010101u;
-			u32* dst = (u32*)(st.samp + r * SROW + half * 12);
-			dst[0] = a; dst[1] = bb; dst[2] = c;
-			zero |= (half ? f0_has_zero_byte(a) : 0u) | f0_has_zero_byte(bb) | f0_has_zero_byte(half ? (c | 0xFFFFFF00u) : c);
-		}
-	}
-#pragma unroll
-	for (int q = 0; q < 3; ++q) {
-		const int t = tid + q * WG;
-		if (t < 578) {
-			const int arr = t >= 289 ? 1 : 0, r = t - arr * 289;
-			const int k = r / 17, j = r - k * 17;
-			u32* dst = (u32*)((arr ? st.blend : st.matId) + k * F0_MPLANE + j * F0_MROW);
-			dst[0] = pf.m[q].x; dst[1] = pf.m[q].y; dst[2] = pf.m[q].z; dst[3] = pf.m[q].w;
-			dst[4] = lastX ? (pf.mf[q] >> 24) : pf.mf[q];
-		}
-	}
-	return zero;
-}
-#define F0_PREFETCH_T R0Prefetch
-#define F0_REQUEST(blk) K::request(g, L, blk, pf)
-#else
-#define F0_PREFETCH_T F0Prefetch
-#define F0_REQUEST(blk) f0_request(g, L, blk, pf)
-#endif
-
 template <int CAP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p)
 {
@@ -220,10 +178,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
 	u32 it = blockIdx.x;
 	R0Block cur, nxt;
-	F0_PREFETCH_T pf;
+	F0Prefetch pf;
 	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
 	bool have = r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), cur);
-	if (have) F0_REQUEST(cur);
+	if (have) f0_request(g, L, cur, pf);
 	it += gridDim.x;
 	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), nxt);
 	u32 parity = 0;
@@ -337,7 +295,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 					PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
 					u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
-						if (!requested) { if (haveNext) F0_REQUEST(nxt); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
+						if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
 						if (j < vEnd) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
@@ -368,7 +326,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			// a zero sample: the general pass takes the block
 			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;
 		}
-		if (!requested) { if (haveNext) F0_REQUEST(nxt); cand = r0_peek<0>(p, L, total, candIt); }
+		if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); }
 		cur = nxt;
 		have = haveNext;
 		it = candIt;

@@ -1074,7 +1074,9 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	if (!c->vertCap) {
 		// first guess: ~3 vertices and ~12 indices per surface voxel column; grown on demand (exact need is known after a run)
 		const u32 area = c->n * c->n;
-		if (!ensure_pools(c, std::max(1u << 16, area * 6), std::max(1u << 18, area * 24))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
+		const char* ev = getenv("VX_POOL_VERTS"); // (experiments: pools large enough for any layout from the start)
+		const char* ei = getenv("VX_POOL_INDICES");
+		if (!ensure_pools(c, std::max<u32>(std::max(1u << 16, area * 6), ev ? (u32)atoll(ev) : 0u), std::max<u32>(std::max(1u << 18, area * 24), ei ? (u32)atoll(ei) : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
 	}
 	u32 retries = 0;
 	float ms = 0.f;
