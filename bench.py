@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab-axis", choices=["y", "z"], default="y", help="axis along which the grid is cut into one slab per GPU (y balances height-field terrains, whose surface sits in a few z-layers)")
     ap.add_argument("--serialize", action="store_true", help="run EVERY launch of this process with the library's streams serialised (one kernel at a time), for per-kernel profiling: the end-to-end figures are skipped")
+    ap.add_argument("--no-extra", action="store_true", help="skip the second ('caves') workload reported under config.extra")
     ap.add_argument("--allow-torch-transport", action="store_true", help="N > 1 only: if the C-ABI RCCL communicator (vx_comm_init) cannot be brought up, move the halo with torch.distributed instead of failing (such a run is no evidence for vx_halo_exchange)")
     ap.add_argument("--halo-every-step", action="store_true", help="N > 1 only: exchange the slab halo inside every timed step (as after an edit) instead of once before the steps")
     return ap.parse_args()
@@ -66,22 +67,29 @@ def cpu_baseline(n, seed):
     cores = os.cpu_count() or 1
     big = n if (mem_available_gb() >= 40 and cores >= 16) else (512 if cores >= 16 else 256)
 
-    def run(size, threads, reps):
+    counts = {}
+
+    def run(size, threads, reps, count=False):
         d, m, b = synth.terrain(size, 0, size, seed)
         g = oracle.grid_from_dense(d, m, b)
         del d, m, b
         best = None
-        for _ in range(reps):
+        for r in range(reps):
             t = time.perf_counter()
             s = oracle.execute(g, threads=threads)
             dt = time.perf_counter() - t
+            if count and r == reps - 1:  # what the reference produced (all its levels): checked against the drop-in run of the same grid
+                lv = s.all_levels()
+                counts["levels"] = len(lv)
+                counts["verts"] = int(sum(len(l.verts) for l in lv))
+                counts["indices"] = int(sum(len(l.idx) for l in lv))
             s.destroy()
             best = dt if best is None else min(best, dt)
         return best
 
-    t_all = run(big, cores, 2)
+    t_all = run(big, cores, 2, count=(big == n))
     t_one = run(256, 1, 1)
-    return {"value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": oracle.kind,
+    return {"value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": oracle.kind, "counts": counts or None,
             "one_thread": {"value": round(256 ** 3 / t_one / 1e6, 3), "unit": "Mvoxels/s", "cores": 1,
                            "sample": "256^3 sub-world of the same seeded terrain, all 5 reference LOD levels, 1 run of %.1f s" % t_one},
             "sample": "%s of the same seeded terrain, all %d reference LOD levels (the reference cannot limit levels; the GPU "
@@ -329,6 +337,60 @@ def main():
         "polygonize_plus_host_block_lists_ms": timed(run_and_lists),
         "polygonize_plus_download_of_all_meshes_ms": timed(run_and_download, 2)}
 
+    # ---- what the timed step leaves out: the library's mirrors of the grid (brick order, lattice copies, sign summaries)
+    #      are built where the grid changes, not by a polygonization.  A caller that changes the whole grid and runs once
+    #      pays them: cold = mirrors + run, measured by declaring the resident grid changed (vx_grid_invalidate). ----------
+    cold = None
+    if not args.serialize:
+        best = None
+        for _ in range(3):
+            poly.invalidate()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            ci = poly.execute(levels)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t) * 1e3
+            if best is None or wall < best[0]:
+                best = (wall, float(ci.mirror_ms), float(ci.device_ms))
+        vox = n * n * planes
+        mirror_bytes = 6 * vox + sum(vox >> (3 * l) for l in range(1, 4))  # three fields read + written, lattice copies of levels 1..3 written
+        cold = {"cold_execute_ms": round(best[0], 4), "mirror_build_ms": round(best[1], 4), "device_ms_after_mirrors": round(best[2], 4),
+                "Mvoxels_per_s_cold": round(n ** 3 / (best[0] * 1e-3) / 1e6, 2),
+                "mirror_roofline": {"kernel": "k_rebrick", "bytes": int(mirror_bytes), "achieved_GBps": round(mirror_bytes / (best[1] * 1e-3) / 1e9, 1),
+                                    "frac_of_8TBps": round(mirror_bytes / (best[1] * 1e-3) / 8e12, 4)},
+                "note": "the headline step runs on a resident, unchanged grid (SURVEY.md §8(d)); after a change of the whole grid "
+                        "the first run also rebuilds the mirrors - the one place where all n^3 samples of the three fields are read"}
+
+    # ---- a second workload whose figure does not rest on a sparse surface: the "caves" style of the generator puts surface
+    #      into a large share of all blocks (parity-tested like the terrain, tests/test_gpu_parity.py) ---------------------
+    extra = None
+
+    def extra_workload():
+        poly.create_terrain(n, seed, 1)
+        for _ in range(2):
+            xi = poly.execute(levels)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        k = 10
+        for _ in range(k):
+            xi = poly.execute(levels)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / k * 1e3
+        tot = np.zeros(4, np.uint64)
+        for l in range(xi.levels):
+            lv = poly.level(l, with_data=False)
+            tot += np.array([lv.infos["n_verts"].sum(), lv.infos["n_idx"].sum(), lv.infos["n_tverts"].sum(), lv.infos["n_tidx"].sum()], np.uint64)
+        sb = int(xi.active_blocks[0])
+        out_bytes = 48 * (int(tot[0]) + int(tot[2])) + 4 * (int(tot[1]) + int(tot[3]))
+        need = 4096 * int(xi.blocks_read) + 2 * 4096 * sb + out_bytes
+        return {"workload": "%d^3 'caves' style of the same generator (seed %d): 3-D noise isosurfaces in a band around the terrain height, "
+                            "materials, LOD levels 0..%d with transition cells" % (n, seed, levels - 1),
+                "ms_per_step": round(ms, 4), "Mvoxels_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 2),
+                "surface_blocks": sb, "surface_block_share": round(sb / ((n // 16) ** 3), 4),
+                "Mvoxels_per_s_over_surface_blocks": round(sb * 4096 / (ms * 1e-3) / 1e6, 2),
+                "verts": int(tot[0]), "indices": int(tot[1]), "tverts": int(tot[2]), "tindices": int(tot[3]),
+                "bytes_actually_touched": int(need), "achieved_GBps": round(need / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(need / (ms * 1e-3) / 8e12, 4)}
+
     if rank == 0:
         step_s = elapsed / args.steps
         out = {
@@ -351,7 +413,8 @@ def main():
                                         "Mvoxels_per_s_over_surface_blocks": round(surface_blocks * 4096 / step_s / 1e6, 2),
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
-                       "halo_exchange_in_step": bool(world > 1 and args.halo_every_step), "halo_transport": halo_transport},
+                       "halo_exchange_in_step": bool(world > 1 and args.halo_every_step), "halo_transport": halo_transport,
+                       "cold": cold},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not args.serialize:
@@ -361,6 +424,17 @@ def main():
             cb = cpu_baseline(n, seed)
             if cb:
                 out["cpu_baseline"] = cb
+                # the reference and the drop-in library polygonized the same grid in this run: their counts must agree
+                rc = cb.get("counts")
+                if rc and de and "verts" in de:
+                    if (rc["levels"], rc["verts"], rc["indices"]) != (de["levels"], de["verts"], de["indices"]):
+                        raise SystemExit("drop-in library and CPU reference disagree on the %d^3 grid: reference %s, libVoxels.so %s" % (n, rc, {k: de[k] for k in ("levels", "verts", "indices")}))
+                    out["config"]["e2e_ms"]["libVoxels_Polygonizer_Execute"]["counts_equal_reference"] = True
+        if world == 1 and not args.serialize and not args.no_extra:
+            try:
+                out["config"]["extra"] = extra_workload()
+            except Exception as e:  # noqa: BLE001
+                out["config"]["extra"] = {"error": str(e)[-300:]}
         print(json.dumps(out))
     if world > 1:
         dist_pkg.destroy_process_group()

@@ -59,7 +59,9 @@ typedef struct vx_exec_info {
 	uint64_t algorithmic_bytes; /* n^3 + 2*4096*surface blocks + 48*V + 4*I */
 	uint32_t blocks_read;       /* level-0 blocks whose distance samples the run had to read (the others are proven
 	                               surface-free by the BF_Empty flags of their 27-neighbourhood); 0 for incremental runs */
-	uint32_t reserved;
+	float mirror_ms;            /* device time this call spent bringing the library's mirrors of the grid up to date (brick
+	                               order, lattice copies, sign summaries: the one place where all n^3 samples are read) —
+	                               0 when the grid did not change since the last run; not part of device_ms */
 } vx_exec_info;
 
 /* ---- context ------------------------------------------------------------------------------------------- */
@@ -126,6 +128,8 @@ int vx_grid_invalidate(vx_ctx* ctx);
  * inside the grid (the halo included) and the BF_Empty flags of the rank's own blocks (the neighbours' flag layers come
  * with vx_halo_exchange). */
 int vx_grid_create_terrain(vx_ctx* ctx, uint32_t n, uint32_t seed);
+/* style as in vxs_terrain_ex (include/voxels_synth.h): 0 = the terrain, 1 = "caves" (surface in a large share of all blocks) */
+int vx_grid_create_terrain_ex(vx_ctx* ctx, uint32_t n, uint32_t seed, uint32_t style);
 int vx_grid_fill_terrain(vx_ctx* ctx, uint32_t seed);
 
 /* ---- multi-GPU: halo exchange of attached slabs -------------------------------------------

@@ -99,13 +99,13 @@ struct Backend {
 		for (u32 id = 0; id < nb * nb * nb; ++id) flags[id] = edit_block_empty(g, id % nb, (id / nb) % nb, id / (nb * nb));
 	}
 	bool d2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
-	void run_terrain(const GridView& g, u32 seed, float* height, const int dr[4], const int mr[4], u8* flags, const u32* ids, u32 count)
+	void run_terrain(const GridView& g, u32 seed, float* height, const int dr[4], const int mr[4], u8* flags, const u32* ids, u32 count, u32 style)
 	{
 		const u32 n = (u32)g.n, nb = n / 16;
 		for (u32 y = 0; y < n; ++y) for (u32 x = 0; x < n; ++x) height[(size_t)y * n + x] = vxt::height(n, x, y, seed);
 		for (int z = dr[0]; z < dr[1]; ++z) for (int y = dr[2]; y < dr[3]; ++y) for (u32 x = 0; x < n; ++x) {
 			i8 d; u8 m, b;
-			vxt::voxel(x, (u32)y, (u32)z, height[(size_t)y * n + x], seed, d, m, b);
+			vxt::voxel(x, (u32)y, (u32)z, height[(size_t)y * n + x], seed, d, m, b, style);
 			const_cast<i8*>(g.dist)[dist_offset(g, (int)x, y, z)] = d;
 			if (z >= mr[0] && z < mr[1] && y >= mr[2] && y < mr[3]) { const size_t o = mat_offset(g, (int)x, y, z); const_cast<u8*>(g.mat)[o] = m; const_cast<u8*>(g.blend)[o] = b; }
 		}

@@ -494,3 +494,22 @@ def test_emu_halo_exchange_group(emu, world, axis):
 def test_emu_device_terrain(emu):
     import torch
     fields.check_device_terrain(lambda: make_poly(emu), torch, torch.device("cpu"), 64, seed=11)
+
+
+def test_emu_caves_style_matches_host_generator_and_oracle(emu):
+    """The "caves" style of the synthetic generator (bench.py's second workload): device path of the emulation = host
+    generator byte for byte, surface = the oracle's."""
+    from voxels_amd import synth
+    n = 64
+    d, m, b = synth.terrain(n, style=1)
+    dev = make_poly(emu)
+    dev.create_terrain(n, 1337, 1)
+    host = make_poly(emu)
+    host.upload(d, m, b, synth.block_empty_flags(d))
+    assert np.array_equal(dev.pack(), host.pack())
+    port = vxo.load_port()
+    s = port.execute(port.grid_from_dense(d, m, b))
+    dev.execute()
+    ok, msg = fields.surface_equal(dev.all_levels(), s.all_levels())
+    assert ok, msg
+

@@ -397,6 +397,26 @@ def test_hip_config3_512_three_levels(poly, port):
     assert len(t_values) > 40
 
 
+def test_hip_caves_workload_256(poly, port):
+    """The second bench workload (bench.py config.extra): the "caves" style of the generator — surface in most blocks, many
+    blocks near the 640-cell class boundary — generated on the device (bytes = the host generator's) and polygonized,
+    LOD levels 0..3, against the oracle."""
+    from voxels_amd import Polygonizer, synth
+    n = 256
+    d, m, b = synth.terrain(n, style=1)
+    g = port.grid_from_dense(d, m, b)
+    ref = port.execute(g).all_levels()[:4]
+    poly.create_terrain(n, 1337, 1)
+    host = Polygonizer(device=0)
+    host.upload(d, m, b, g.block_flags())
+    assert np.array_equal(poly.pack(), host.pack())
+    host.close()
+    info = poly.execute(4)
+    assert info.active_blocks[0] > 0.5 * (n // 16) ** 3
+    ok, msg = fields.surface_equal(poly.all_levels(), ref, nrm_tol=NRM_TOL)
+    assert ok, msg
+
+
 def test_hip_config5_512_carve_incremental(poly, port):
     """BASELINE config 5: 512^3 terrain, sphere carve (IT_Subtract, r = 20) at the surface, incremental re-polygonization
     of the dirty blocks; parity with the oracle doing the same two calls."""

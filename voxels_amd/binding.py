@@ -26,7 +26,7 @@ class ExecInfo(C.Structure):
     _fields_ = [("levels", C.c_uint32), ("retries", C.c_uint32), ("device_ms", C.c_float),
                 ("total_verts", C.c_uint64), ("total_indices", C.c_uint64),
                 ("active_blocks", C.c_uint32 * 8), ("algorithmic_bytes", C.c_uint64),
-                ("blocks_read", C.c_uint32), ("reserved", C.c_uint32)]
+                ("blocks_read", C.c_uint32), ("mirror_ms", C.c_float)]
 
 
 def hip_library_path():
@@ -69,6 +69,7 @@ class HipLibrary:
         lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
         lib.vx_grid_create_heightmap.argtypes = [vp, u32, vp]
         lib.vx_grid_create_terrain.argtypes = [vp, u32, u32]
+        lib.vx_grid_create_terrain_ex.argtypes = [vp, u32, u32, u32]
         lib.vx_grid_fill_terrain.argtypes = [vp, u32]
         lib.vx_grid_inject_ball.argtypes = [vp, vp, vp, C.c_float, C.c_int, vp, vp]
         lib.vx_grid_inject_material.argtypes = [vp, vp, vp, C.c_uint8, C.c_int, vp, vp]
@@ -208,9 +209,9 @@ class Polygonizer:
         self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
         return dv.value, di.value, nv.value, ni.value
 
-    def create_terrain(self, n, seed=1337):
+    def create_terrain(self, n, seed=1337, style=0):
         """The synthetic noise terrain (voxels_amd.synth.terrain) generated on the device into a grid the context owns."""
-        self._check(self._lib.vx_grid_create_terrain(self._h, int(n), int(seed)), "vx_grid_create_terrain")
+        self._check(self._lib.vx_grid_create_terrain_ex(self._h, int(n), int(seed), int(style)), "vx_grid_create_terrain_ex")
         self.n = n
 
     def fill_terrain(self, seed=1337):

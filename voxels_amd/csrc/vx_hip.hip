@@ -442,7 +442,7 @@ __global__ __launch_bounds__(WG) void k_terrain_height(u32 n, u32 seed, float* h
 	if (i < n * n) height[i] = vxt::height(n, i % n, i / n, seed);
 }
 
-__global__ __launch_bounds__(WG) void k_terrain_fill(GridView g, u32 seed, const float* height, TerrainRange dr, TerrainRange mr)
+__global__ __launch_bounds__(WG) void k_terrain_fill(GridView g, u32 seed, const float* height, TerrainRange dr, TerrainRange mr, u32 style)
 {
 	const u32 n = (u32)g.n, segs = n >> 4;
 	const u32 rows = (u32)(dr.y1 - dr.y0);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(WG) void k_terrain_fill(GridView g, u32 seed, const
 	const u32 sx = (u32)(q % segs), y = (u32)dr.y0 + (u32)((q / segs) % rows), z = (u32)dr.z0 + (u32)(q / ((size_t)segs * rows));
 	i8 d[16]; u8 m[16], b[16];
 #pragma unroll 4
-	for (u32 i = 0; i < 16; ++i) vxt::voxel(sx * 16 + i, y, z, height[(size_t)y * n + sx * 16 + i], seed, d[i], m[i], b[i]);
+	for (u32 i = 0; i < 16; ++i) vxt::voxel(sx * 16 + i, y, z, height[(size_t)y * n + sx * 16 + i], seed, d[i], m[i], b[i], style);
 	uint4 v;
 	memcpy(&v, d, 16);
 	*(uint4*)(const_cast<i8*>(g.dist) + dist_offset(g, (int)(sx * 16), (int)y, (int)z)) = v;
@@ -1398,13 +1398,16 @@ __device__ __forceinline__ void tr_face_store(i8* plane, int tid, const i8 (&v)[
 	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) plane[r] = faceOn ? v[q] : (i8)0; }
 }
 
-__global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_transition(ExecParamsDev p, u32 levels)
 {
 	u8* tab = smem;
 	TrState& st = *(TrState*)(smem + TR_TAB_LDS);
 	__shared__ WorkList wl;
 	__shared__ u32 scanScratch[8];
+	__shared__ u32 quietFaces[2];
+	u32 quietParity = 0;
 
+	if (threadIdx.x < 2) quietFaces[threadIdx.x] = 0;
 	if (threadIdx.x == 0) {
 		u32 run = 0;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
@@ -1445,15 +1448,54 @@ __global__ __launch_bounds__(WG) void k_transition(ExecParamsDev p, u32 levels)
 				const FaceGeom fg = face_geom(f);
 				if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
 			}
+			// A boundary plane whose samples all have one sign holds no transition cell.  The sign summaries of the level-0
+			// blocks (MirrorState::blockSign: "every voxel of the block's plane x = 0 / y = 0 / z = 0 is >= 0 / < 0") decide
+			// that without reading the plane: the face covers (mult + 1)^2 of those block planes, its far edge included.
+			// Faces found quiet are treated like faces without a neighbour block: not staged, no cells.
+			if (p.G.blockSign) {
+				const u32 cnt0 = p.levels[0].cnt, m1 = b.mult + 1u;
+				u32 quiet = 0;
+#pragma unroll
+				for (int f = 0; f < 6; ++f) { // (unrolled: the face's axes are compile-time constants)
+					if ((f & 3) != (tid >> 6) || !((on >> f) & 1u)) continue; // one wave per face; uniform per wave
+					const FaceGeom fg = face_geom(f);
+					const u32 field = fg.axis == 0 ? 1u : (fg.axis == 1 ? 2u : 4u);
+					u32 seen = 0; // bit 0: a plane of samples >= 0, bit 1: a plane of samples < 0, bit 2: a mixed or unknown plane
+					for (u32 i = (u32)tid & 63u; i < m1 * m1; i += 64u) {
+						const u32 du = i % m1, dv = i / m1;
+						const u32 qa = (fg.positive ? bc[fg.axis] + 1u : bc[fg.axis]) * b.mult;
+						const u32 qu = min(bc[fg.ua] * b.mult + du, cnt0 - 1u), qv = min(bc[fg.va] * b.mult + dv, cnt0 - 1u);
+						int q[3];
+						face_scatter(fg, (int)qu, (int)qv, (int)qa, q);
+						const u32 sg = ((u32)p.G.blockSign[block_coord_id((u32)q[0], (u32)q[1], (u32)q[2], cnt0)] >> (2u * field)) & 3u;
+						seen |= sg == 1u ? 1u : (sg == 2u ? 2u : 4u);
+					}
+					const bool pos = __ballot((seen & 1u) != 0) != 0, neg = __ballot((seen & 2u) != 0) != 0, mixed = __ballot((seen & 4u) != 0) != 0;
+					if (!mixed && !(pos && neg)) quiet |= 1u << f;
+				}
+				if ((tid & 63) == 0 && quiet) atomicOr(&quietFaces[quietParity], quiet);
+			}
 			__syncthreads(); TR_TICK(2);
+			on &= ~quietFaces[quietParity];
+			if (tid == 0) quietFaces[quietParity ^ 1u] = 0; // the other word is next written behind this barrier and read behind the next item's
+			quietParity ^= 1u;
 			if (tid == 0) st.faceOn = on;
 			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
 			// 33 x 33 samples per face; three faces (15 loads per lane) are in flight together
+			// (a face that is off — uniform over the workgroup — is neither requested nor stored: nothing reads its plane)
 			i8 v[3][5];
-			tr_face_request<0>(p.G.grid, b, on, tid, v[0]); tr_face_request<1>(p.G.grid, b, on, tid, v[1]); tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
-			tr_face_store(st.plane[0], tid, v[0], (on & 1u) != 0); tr_face_store(st.plane[1], tid, v[1], (on & 2u) != 0); tr_face_store(st.plane[2], tid, v[2], (on & 4u) != 0);
-			tr_face_request<3>(p.G.grid, b, on, tid, v[0]); tr_face_request<4>(p.G.grid, b, on, tid, v[1]); tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
-			tr_face_store(st.plane[3], tid, v[0], (on & 8u) != 0); tr_face_store(st.plane[4], tid, v[1], (on & 16u) != 0); tr_face_store(st.plane[5], tid, v[2], (on & 32u) != 0);
+			if (on & 1u) tr_face_request<0>(p.G.grid, b, on, tid, v[0]);
+			if (on & 2u) tr_face_request<1>(p.G.grid, b, on, tid, v[1]);
+			if (on & 4u) tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
+			if (on & 1u) tr_face_store(st.plane[0], tid, v[0], true);
+			if (on & 2u) tr_face_store(st.plane[1], tid, v[1], true);
+			if (on & 4u) tr_face_store(st.plane[2], tid, v[2], true);
+			if (on & 8u) tr_face_request<3>(p.G.grid, b, on, tid, v[0]);
+			if (on & 16u) tr_face_request<4>(p.G.grid, b, on, tid, v[1]);
+			if (on & 32u) tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
+			if (on & 8u) tr_face_store(st.plane[3], tid, v[0], true);
+			if (on & 16u) tr_face_store(st.plane[4], tid, v[1], true);
+			if (on & 32u) tr_face_store(st.plane[5], tid, v[2], true);
 		}
 		__syncthreads(); TR_TICK(3);
 		tr_phase_classify(st, tid, WG);
@@ -1967,13 +2009,13 @@ struct Backend {
 		check(hipGetLastError(), "k_heightmap launch");
 	}
 	// the synthetic terrain into the resident fields (dist over dr, material + blend over mr), BF_Empty of the listed blocks
-	void run_terrain(const GridView& g, u32 seed, float* height, const int dr[4], const int mr[4], u8* flags, const u32* ids, u32 count)
+	void run_terrain(const GridView& g, u32 seed, float* height, const int dr[4], const int mr[4], u8* flags, const u32* ids, u32 count, u32 style)
 	{
 		const u32 n = (u32)g.n;
 		TerrainRange d = { dr[0], dr[1], dr[2], dr[3] }, m = { mr[0], mr[1], mr[2], mr[3] };
 		hipLaunchKernelGGL(k_terrain_height, dim3((n * n + WG - 1) / WG), dim3(WG), 0, stream, n, seed, height);
 		const size_t segs = (size_t)(n / 16) * (size_t)(d.y1 - d.y0) * (size_t)(d.z1 - d.z0);
-		if (segs) hipLaunchKernelGGL(k_terrain_fill, dim3((u32)((segs + WG - 1) / WG)), dim3(WG), 0, stream, g, seed, (const float*)height, d, m);
+		if (segs) hipLaunchKernelGGL(k_terrain_fill, dim3((u32)((segs + WG - 1) / WG)), dim3(WG), 0, stream, g, seed, (const float*)height, d, m, style);
 		if (count) hipLaunchKernelGGL(k_edit_flags, dim3(count), dim3(WG), 0, stream, g, flags, ids, count);
 		check(hipGetLastError(), "k_terrain launch");
 	}

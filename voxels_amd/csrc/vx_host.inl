@@ -583,7 +583,7 @@ int vx_grid_create_heightmap(vx_ctx* c, uint32_t n, const int8_t* heightmap)
 namespace {
 
 // the synthetic terrain over everything resident (own layers + halo, clamped to the grid) + flags of the own blocks
-int generate_terrain(vx_ctx* c, u32 seed, const char* what)
+int generate_terrain(vx_ctx* c, u32 seed, u32 style, const char* what)
 {
 	const u32 n = c->n, nb = n / 16;
 	const int zb = (int)c->zBegin, ze = (int)c->zEnd, yb = (int)c->yBegin, ye = (int)c->yEnd;
@@ -595,7 +595,7 @@ int generate_terrain(vx_ctx* c, u32 seed, const char* what)
 	void* dIds = c->be.alloc(ids.size() * 4 + 16);
 	bool ok = dHeight && dIds && c->be.h2d(dIds, ids.data(), ids.size() * 4);
 	if (ok) {
-		c->be.run_terrain(resident_view(c), seed, (float*)dHeight, dr, mr, (u8*)c->dFlags, (const u32*)dIds, (u32)ids.size());
+		c->be.run_terrain(resident_view(c), seed, (float*)dHeight, dr, mr, (u8*)c->dFlags, (const u32*)dIds, (u32)ids.size(), style);
 		ok = c->be.sync_ok();
 	}
 	c->be.free(dHeight); c->be.free(dIds);
@@ -606,7 +606,9 @@ int generate_terrain(vx_ctx* c, u32 seed, const char* what)
 
 } // namespace
 
-int vx_grid_create_terrain(vx_ctx* c, uint32_t n, uint32_t seed)
+int vx_grid_create_terrain(vx_ctx* c, uint32_t n, uint32_t seed) { return vx_grid_create_terrain_ex(c, n, seed, 0); }
+
+int vx_grid_create_terrain_ex(vx_ctx* c, uint32_t n, uint32_t seed, uint32_t style)
 {
 	VX_ENTER(c);
 	if (!c || n < 16 || (n & 15) || n > VX_MAX_GRID) return fail(c, VX_ERR_INVALID, "vx_grid_create_terrain: n must be a multiple of 16 up to 2048");
@@ -619,14 +621,14 @@ int vx_grid_create_terrain(vx_ctx* c, uint32_t n, uint32_t seed)
 	}
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
-	return generate_terrain(c, seed, "vx_grid_create_terrain");
+	return generate_terrain(c, seed, style, "vx_grid_create_terrain");
 }
 
 int vx_grid_fill_terrain(vx_ctx* c, uint32_t seed)
 {
 	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist || !c->slabAxis) return fail(c, VX_ERR_INVALID, "vx_grid_fill_terrain: needs a slab attached with vx_grid_attach / vx_grid_attach_y");
-	return generate_terrain(c, seed, "vx_grid_fill_terrain");
+	return generate_terrain(c, seed, 0, "vx_grid_fill_terrain");
 }
 
 int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
@@ -1061,7 +1063,13 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
 	if (!ensure_level_tables(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: level table allocation failed: " + c->be.error());
-	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: brick mirror allocation failed: " + c->be.error());
+	float mirrorMs = 0.f;
+	{
+		const bool stale = c->bricksStale;
+		if (stale) c->be.begin_timing();
+		if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: brick mirror allocation failed: " + c->be.error());
+		if (stale) mirrorMs = c->be.end_timing_ms(); // (waits for the copy: only a run on a changed grid pays this)
+	}
 	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
 	const u32 slabPlanes = c->zEnd - c->zBegin, slabRows = c->yEnd - c->yBegin;
 	{
@@ -1200,6 +1208,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		for (u32 L = 0; L < levels && L < 8; ++L) info->active_blocks[L] = c->hdr[L];
 		info->algorithmic_bytes = (uint64_t)c->n * slabRows * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
 		info->blocks_read = c->hdr[HDR_LARGE + 1];
+		info->mirror_ms = mirrorMs;
 	}
 	return VX_OK;
 }

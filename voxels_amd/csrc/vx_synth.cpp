@@ -18,6 +18,11 @@ extern "C" {
 
 void vxs_terrain(uint32_t n, uint32_t z0, uint32_t z1, uint32_t seed, int8_t* dist, uint8_t* mat, uint8_t* blend)
 {
+	vxs_terrain_ex(n, z0, z1, seed, 0, dist, mat, blend);
+}
+
+void vxs_terrain_ex(uint32_t n, uint32_t z0, uint32_t z1, uint32_t seed, uint32_t style, int8_t* dist, uint8_t* mat, uint8_t* blend)
+{
 	std::vector<float> height((size_t)n * n);
 	#pragma omp parallel for schedule(static)
 	for (int64_t y = 0; y < (int64_t)n; ++y)
@@ -30,7 +35,7 @@ void vxs_terrain(uint32_t n, uint32_t z0, uint32_t z1, uint32_t seed, int8_t* di
 		for (uint32_t x = 0; x < n; ++x) {
 			const size_t i = plane + (size_t)y * n + x;
 			int8_t d; uint8_t m, b;
-			vxt::voxel(x, y, z, height[(size_t)y * n + x], seed, d, m, b);
+			vxt::voxel(x, y, z, height[(size_t)y * n + x], seed, d, m, b, style);
 			dist[i] = d;
 			if (mat) mat[i] = m;
 			if (blend) blend[i] = b;

@@ -15,19 +15,21 @@ def _load():
             raise RuntimeError("%s not found: run __graft_entry__.build()" % _PATH)
         _lib = C.CDLL(_PATH)
         _lib.vxs_terrain.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3
+        _lib.vxs_terrain_ex.argtypes = [C.c_uint32] * 5 + [C.c_void_p] * 3
         _lib.vxs_sphere.argtypes = [C.c_uint32] * 3 + [C.c_float, C.c_void_p]
         _lib.vxs_block_empty_flags.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     return _lib
 
 
-def terrain(n, z0=0, z1=None, seed=1337, materials=True):
-    """(dist int8, mat u8, blend u8) of planes [z0, z1) of the n^3 noise terrain, each shaped [z1-z0, n, n]."""
+def terrain(n, z0=0, z1=None, seed=1337, materials=True, style=0):
+    """(dist int8, mat u8, blend u8) of planes [z0, z1) of the n^3 noise terrain, each shaped [z1-z0, n, n].
+    style 1 = "caves": surface in a large share of all blocks (include/voxels_synth.h)."""
     z1 = n if z1 is None else z1
     lib = _load()
     d = np.zeros((z1 - z0, n, n), np.int8)
     m = np.zeros((z1 - z0, n, n), np.uint8) if materials else None
     b = np.zeros((z1 - z0, n, n), np.uint8) if materials else None
-    lib.vxs_terrain(n, z0, z1, seed, d.ctypes.data, m.ctypes.data if materials else None, b.ctypes.data if materials else None)
+    lib.vxs_terrain_ex(n, z0, z1, seed, style, d.ctypes.data, m.ctypes.data if materials else None, b.ctypes.data if materials else None)
     return d, m, b
 
 
