@@ -111,8 +111,14 @@ def dropin_e2e(poly):
         f.write(blob.tobytes())
         path = f.name
     try:
-        r = subprocess.run([exe, path, "2"], capture_output=True, text=True, timeout=600)
-        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "rc %d" % r.returncode)[-200:]}
+        r = subprocess.run([exe, path, "3"], capture_output=True, text=True, timeout=600, env=dict(os.environ, VOXELS_TRACE="1"))
+        if r.returncode != 0 or not r.stdout.strip():
+            return {"error": (r.stderr or "rc %d" % r.returncode)[-200:]}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        # VOXELS_TRACE: where the last Execute spent its time (grid to device | vx_polygonize | meshes to host)
+        laps = [l.split("]", 1)[1].rsplit(None, 2) for l in r.stderr.splitlines() if l.startswith("[Voxels]")]
+        out["last_run_breakdown_ms"] = {what.strip(): float(ms) for what, ms, _ in laps[-3:]}
+        return out
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)[-200:]}
     finally:
@@ -328,6 +334,19 @@ def main():
             poly.level_ranges(l)
 
     def run_and_download():
+        # every mesh on the host, addressable per block: both pools in one DMA into a (recycled) page-locked arena
+        # (vx_host_meshes_acquire) + per level the block infos and the blocks' ranges in the pools
+        poly.execute(levels)
+        hm = poly.host_meshes()
+        for l in range(levels):
+            poly.level(l, with_data=False)
+            poly.level_ranges(l)
+        got = (hm.verts.size, hm.indices.size)
+        hm.release()
+        return got
+
+    def run_and_copy_levels():
+        # the older interface: per level four caller-owned arrays (vx_download_level), i.e. one more host copy
         poly.execute(levels)
         poly.all_levels()
 
@@ -335,7 +354,9 @@ def main():
     e2e = None if args.serialize else {
         "polygonize_ms": timed(lambda: poly.execute(levels)),
         "polygonize_plus_host_block_lists_ms": timed(run_and_lists),
-        "polygonize_plus_download_of_all_meshes_ms": timed(run_and_download, 2)}
+        "polygonize_plus_download_of_all_meshes_ms": timed(run_and_download, 3),
+        "polygonize_plus_vx_download_level_copies_ms": timed(run_and_copy_levels, 2),
+        "mesh_bytes": int(poly.info.total_verts) * 48 + int(poly.info.total_indices) * 4}
 
     # ---- what the timed step leaves out: the library's mirrors of the grid (brick order, lattice copies, sign summaries)
     #      are built where the grid changes, not by a polygonization.  A caller that changes the whole grid and runs once

@@ -204,6 +204,25 @@ typedef struct vx_block_ranges {
 } vx_block_ranges;
 int vx_device_meshes(vx_ctx* ctx, const vx_vertex** d_verts, const uint32_t** d_indices, uint64_t* n_verts, uint64_t* n_indices);
 int vx_level_ranges(vx_ctx* ctx, uint32_t level, vx_block_ranges* ranges /* one per block, vx_download_level order */);
+/* Host copy of both pools in ONE step (what BlockPolygons::GetVertices / GetIndices, include/Voxels.h:210-231, hand out —
+ * per-block arrays — as views: block k of a level owns verts[ranges[k].v_off ..] etc., with vx_level_ranges /
+ * vx_download_level(infos only) giving offsets and counts).  The copy lands in page-locked memory at DMA speed and is
+ * not copied again: the caller owns `arena` (and with it verts / indices) until vx_host_meshes_release, independent of
+ * later runs and of the context's lifetime.  Released arenas are recycled by the next acquire (page-locking memory is
+ * slow; a steady caller never pays it twice).
+ * in/out: meshes->arena == NULL asks for a fresh copy; an arena returned by an earlier acquire on the same context is
+ * brought up to date instead (after incremental runs only the appended part of the pools travels; it may be exchanged
+ * for a larger one - always use the returned pointers). */
+typedef struct vx_host_meshes {
+	const vx_vertex* verts;
+	const uint32_t* indices;
+	uint64_t n_verts, n_indices;
+	void* arena;
+} vx_host_meshes;
+int vx_host_meshes_acquire(vx_ctx* ctx, vx_host_meshes* meshes);
+void vx_host_meshes_release(void* arena);
+/* frees the recycled arenas of this process (optional; e.g. before unloading the library) */
+void vx_host_meshes_trim(void);
 /* The same lists as a device-resident table: what PushBlocksToResult (src/TransVoxelImpl.cpp:1266-1293) assembles per
  * block — ranges of its 1 + 6 meshes in the pools, id (:149-152), Y-up corners (:1283-1293) — for the blocks of one level
  * in GetBlockForLevel order (:395-401; blocks without a regular vertex are left out, :1274).  A full run writes the

@@ -30,6 +30,12 @@ struct Backend {
 	bool d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void* alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
 	void free_pinned(void* p) { ::free(p); }
+	static void release_pinned(void* p) { ::free(p); }
+	bool d2h_bulk(void* const* dst, const void* const* src, const size_t* bytes, int count)
+	{
+		for (int i = 0; i < count; ++i) if (bytes[i]) memcpy(dst[i], src[i], bytes[i]);
+		return true;
+	}
 	void begin_timing() {}
 	float end_timing_ms() { return 0.f; }
 	// Grid file format v1 expanded block by block (the HIP backend does this in k_decode_grid)

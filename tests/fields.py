@@ -176,3 +176,20 @@ def check_device_terrain(make_poly, torch, device, n, seed=1337, world=2):
                 assert np.array_equal(fl_got[own], fl_want[own]), (axis, r)
             else:
                 assert np.array_equal(fl_got[:, own], fl_want[:, own]), (axis, r)
+
+
+def check_host_meshes(poly, hm):
+    """The one-step host copy (vx_host_meshes_acquire) holds exactly what vx_download_level copies out block by block."""
+    for l, lev in enumerate(poly.all_levels()):
+        r = poly.level_ranges(l)
+        ov = oi = otv = oti = 0
+        for k, info in enumerate(lev.infos):
+            nv, ni = int(info["n_verts"]), int(info["n_idx"])
+            assert np.array_equal(hm.verts[r["v_off"][k]:r["v_off"][k] + nv], lev.verts[ov:ov + nv]), (l, k)
+            assert np.array_equal(hm.indices[r["i_off"][k]:r["i_off"][k] + ni], lev.idx[oi:oi + ni]), (l, k)
+            ov += nv; oi += ni
+            for f in range(6):
+                nv, ni = int(info["n_tverts"][f]), int(info["n_tidx"][f])
+                assert np.array_equal(hm.verts[r["tv_off"][k][f]:r["tv_off"][k][f] + nv], lev.tverts[otv:otv + nv]), (l, k, f)
+                assert np.array_equal(hm.indices[r["ti_off"][k][f]:r["ti_off"][k][f] + ni], lev.tidx[oti:oti + ni]), (l, k, f)
+                otv += nv; oti += ni

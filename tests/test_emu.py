@@ -219,6 +219,8 @@ def test_emu_repeated_edits_vs_port(emu, port):
     pre = g.read_dense()
     p.upload(*pre, g.block_flags())
     p.execute()
+    hm = p.host_meshes()
+    fields.check_host_meshes(p, hm)
     for t, pos, ext, r in ((2, (30.0, 33.5, 31.25), (20, 20, 20), 7.0), (0, (40, 20, 25), (16, 16, 16), 6.0),
                            (2, (3.0, 60.0, 30.0), (12, 12, 12), 5.0), (2, (31.0, 33.0, 31.0), (10, 10, 10), 4.0)):
         mn, mx = g.inject_ball(pos, ext, r, t)
@@ -232,6 +234,21 @@ def test_emu_repeated_edits_vs_port(emu, port):
         ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
         assert ok, msg
         assert np.array_equal(p.stats(), s.stats())
+        hm = p.host_meshes(previous=hm)  # only what the run appended travels
+        fields.check_host_meshes(p, hm)
+    # an arena outlives the surface it was filled from (and the context); a released one is handed out again
+    keep = hm.verts.copy()
+    p.execute()
+    assert np.array_equal(hm.verts, keep)
+    p._lib.vx_host_meshes_trim()  # (earlier tests left arenas in the recycling list)
+    fresh = p.host_meshes()
+    fields.check_host_meshes(p, fresh)
+    addr = fresh.verts.ctypes.data
+    fresh.release()
+    again = [p.host_meshes(), p.host_meshes()]  # (the first may be the copy vx_download_level made for check_host_meshes)
+    assert addr in [a.verts.ctypes.data for a in again]
+    for a in again:
+        fields.check_host_meshes(p, a)
 
 
 def test_emu_transition_face_batches(emu, port):

@@ -320,6 +320,8 @@ def test_hip_repeated_edits_vs_port(poly, port, n):
     pre = g.read_dense()
     poly.upload(*pre, g.block_flags())
     poly.execute()
+    hm = poly.host_meshes()  # the one-DMA host copy of the pools, kept up to date across the incremental runs
+    fields.check_host_meshes(poly, hm)
     c = n / 2.0
     edits = ((2, (c - 2.0, c + 1.5, c - 0.75), (20, 20, 20), 7.0), (0, (c + 8, c - 12, c - 7), (16, 16, 16), 6.0),
              (2, (3.0, n - 4.0, c - 2), (12, 12, 12), 5.0), (2, (c - 1.0, c + 1.0, c - 1.0), (10, 10, 10), 4.0))
@@ -335,6 +337,15 @@ def test_hip_repeated_edits_vs_port(poly, port, n):
         ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
         assert ok, msg
         assert np.array_equal(poly.stats(), s.stats())
+        hm = poly.host_meshes(previous=hm)
+        fields.check_host_meshes(poly, hm)
+    for lanes, piece in ((1, 32), (3, 1), (4, 7)):  # the same copy cut differently (VX_D2H_STREAMS / VX_D2H_PIECE_MB)
+        os.environ["VX_D2H_STREAMS"], os.environ["VX_D2H_PIECE_MB"] = str(lanes), str(piece)
+        try:
+            other = poly.host_meshes()
+        finally:
+            del os.environ["VX_D2H_STREAMS"], os.environ["VX_D2H_PIECE_MB"]
+        assert np.array_equal(other.verts, hm.verts) and np.array_equal(other.indices, hm.indices)
 
 
 def test_hip_config2_256_lod0_only(poly, port):

@@ -22,6 +22,39 @@ class VoxelsHipError(RuntimeError):
     pass
 
 
+class _HostMeshesStruct(C.Structure):
+    _fields_ = [("verts", C.c_void_p), ("indices", C.c_void_p), ("n_verts", C.c_uint64), ("n_indices", C.c_uint64),
+                ("arena", C.c_void_p)]
+
+
+class HostMeshes:
+    """Owner of one arena (include/voxels_hip.h vx_host_meshes): .verts / .indices are views into page-locked memory,
+    valid until release() (or garbage collection of this object)."""
+
+    def __init__(self, lib, m):
+        self._lib, self._arena = lib, m.arena
+        nv, ni = int(m.n_verts), int(m.n_indices)
+        self.verts = (np.ctypeslib.as_array(C.cast(m.verts, C.POINTER(C.c_uint8)), (nv * VERTEX_DTYPE.itemsize,)).view(VERTEX_DTYPE)
+                      if nv else np.zeros(0, VERTEX_DTYPE))
+        self.indices = (np.ctypeslib.as_array(C.cast(m.indices, C.POINTER(C.c_uint32)), (ni,)) if ni else np.zeros(0, np.uint32))
+
+    def _take(self):
+        a, self._arena = self._arena, None
+        self.verts = self.indices = None
+        return a
+
+    def release(self):
+        a = self._take()
+        if a:
+            self._lib.vx_host_meshes_release(a)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class ExecInfo(C.Structure):
     _fields_ = [("levels", C.c_uint32), ("retries", C.c_uint32), ("device_ms", C.c_float),
                 ("total_verts", C.c_uint64), ("total_indices", C.c_uint64),
@@ -89,6 +122,11 @@ class HipLibrary:
         lib.vx_polygonize_dirty.argtypes = [vp, vp, vp, C.POINTER(ExecInfo), vp, u32, C.POINTER(u32)]
         lib.vx_level_counts.argtypes = [vp, u32, C.POINTER(u32), vp]
         lib.vx_download_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        lib.vx_host_meshes_acquire.argtypes = [vp, vp]
+        lib.vx_host_meshes_release.argtypes = [vp]
+        lib.vx_host_meshes_release.restype = None
+        lib.vx_host_meshes_trim.argtypes = []
+        lib.vx_host_meshes_trim.restype = None
         lib.vx_stats.argtypes = [vp, vp]
         lib.vx_selftest.argtypes = [vp, vp]
         lib.vx_set_stage_timing.argtypes = [vp, C.c_int]
@@ -325,6 +363,16 @@ class Polygonizer:
         self._check(self._lib.vx_download_level(self._h, lvl, _ptr(infos), _ptr(verts), _ptr(idx), _ptr(tverts), _ptr(tidx)),
                     "vx_download_level")
         return Level(infos, verts, idx, tverts, tidx)
+
+    def host_meshes(self, previous=None):
+        """vx_host_meshes_acquire: both pools on the host (page-locked, one DMA), as numpy views.  Block k of level l owns
+        verts[level_ranges(l)[k]['v_off'] : ... + level(l, False).infos[k]['n_verts']] etc.  `previous`: a HostMeshes of an
+        earlier acquire on this context, brought up to date instead (incremental runs); do not use it afterwards."""
+        m = _HostMeshesStruct()
+        if previous is not None:
+            m.arena = previous._take()
+        self._check(self._lib.vx_host_meshes_acquire(self._h, C.byref(m)), "vx_host_meshes_acquire")
+        return HostMeshes(self._lib, m)
 
     def all_levels(self):
         return [self.level(l) for l in range(self.info.levels)]

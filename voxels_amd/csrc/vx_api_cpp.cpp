@@ -13,7 +13,9 @@
 #include "vx_grid_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -149,35 +151,39 @@ void Grid::ModifyBlockMaterialData(const float3& c, const MaterialId* materials,
 namespace
 {
 
+// A block's seven meshes are views into the surface's page-locked copy of the two pools (vx_host_meshes_acquire): no
+// per-block arrays are allocated or filled.
 struct BlockImpl : public BlockPolygons
 {
 	unsigned Id = 0;
 	float3 MinCorner, MaxCorner;
-	std::vector<PolygonVertex> Vertices;
-	std::vector<unsigned> Indices;
-	std::vector<PolygonVertex> TVertices[6];
-	std::vector<unsigned> TIndices[6];
+	const PolygonVertex* Vertices = nullptr;
+	const unsigned* Indices = nullptr;
+	unsigned VertexCount = 0, IndexCount = 0;
+	const PolygonVertex* TVertices[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	const unsigned* TIndices[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	unsigned TVertexCount[6] = { 0, 0, 0, 0, 0, 0 }, TIndexCount[6] = { 0, 0, 0, 0, 0, 0 };
 
 	unsigned GetId() const override { return Id; }
 	const PolygonVertex* GetVertices(unsigned* count) const override
 	{
-		if (count) *count = (unsigned)Vertices.size();
-		return Vertices.empty() ? nullptr : Vertices.data();
+		if (count) *count = VertexCount;
+		return VertexCount ? Vertices : nullptr;
 	}
 	const unsigned* GetIndices(unsigned* count) const override
 	{
-		if (count) *count = (unsigned)Indices.size();
-		return Indices.empty() ? nullptr : Indices.data();
+		if (count) *count = IndexCount;
+		return IndexCount ? Indices : nullptr;
 	}
 	const PolygonVertex* GetTransitionVertices(TransitionFaceId face, unsigned* count) const override
 	{
-		if (count) *count = (unsigned)TVertices[face].size();
-		return TVertices[face].empty() ? nullptr : TVertices[face].data();
+		if (count) *count = TVertexCount[face];
+		return TVertexCount[face] ? TVertices[face] : nullptr;
 	}
 	const unsigned* GetTransitionIndices(TransitionFaceId face, unsigned* count) const override
 	{
-		if (count) *count = (unsigned)TIndices[face].size();
-		return TIndices[face].empty() ? nullptr : TIndices[face].data();
+		if (count) *count = TIndexCount[face];
+		return TIndexCount[face] ? TIndices[face] : nullptr;
 	}
 	float3 GetMinimalCorner() const override { return MinCorner; }
 	float3 GetMaximalCorner() const override { return MaxCorner; }
@@ -186,18 +192,20 @@ struct BlockImpl : public BlockPolygons
 struct SurfaceImpl : public PolygonSurface
 {
 	float3 Extents;
-	std::vector<std::vector<std::unique_ptr<BlockImpl> > > Levels;
+	std::vector<std::vector<BlockImpl> > Levels;
+	vx_host_meshes Meshes = { nullptr, nullptr, 0, 0, nullptr }; // owned: released with the surface
 	PolygonizationStatistics Stats;
 	unsigned GridSize = 0;
 	vx_ctx* Owner = nullptr; // context whose device caches belong to this surface (needed by Modification)
 
+	~SurfaceImpl() { if (Meshes.arena) vx_host_meshes_release(Meshes.arena); }
 	float3 GetExtents() const override { return Extents; }
 	unsigned GetLevelsCount() const override { return (unsigned)Levels.size(); }
 	unsigned GetBlocksForLevelCount(unsigned level) const override { return (unsigned)Levels[level].size(); }
 	const BlockPolygons* GetBlockForLevel(unsigned level, unsigned id) const override
 	{
 		if (id >= Levels[level].size()) return nullptr;
-		return Levels[level][id].get();
+		return &Levels[level][id];
 	}
 	const PolygonizationStatistics* GetStatistics() const override { return &Stats; }
 	unsigned GetCacheSizeBytes() const override
@@ -217,7 +225,7 @@ struct SurfaceImpl : public PolygonSurface
 	{
 		size_t r = 0;
 		for (const auto& lvl : Levels)
-			for (const auto& b : lvl) r += b->Vertices.size() * sizeof(PolygonVertex) + b->Indices.size() * sizeof(unsigned) + 12 * sizeof(std::vector<unsigned>);
+			for (const auto& b : lvl) r += (size_t)b.VertexCount * sizeof(PolygonVertex) + (size_t)b.IndexCount * sizeof(unsigned) + 12 * sizeof(std::vector<unsigned>);
 		return (unsigned)r;
 	}
 	void Destroy() override { delete this; }
@@ -234,34 +242,40 @@ struct ModificationImpl : public Modification
 	void Destroy() override { delete this; }
 };
 
-// copies one level out of the context into host-owned blocks
-bool FetchLevel(vx_ctx* ctx, unsigned level, std::vector<std::unique_ptr<BlockImpl> >& out)
+// Brings the surface's host copy of the pools up to date (one DMA into page-locked memory; after an incremental run only
+// what the run appended) and rebuilds the per-block views of all levels.
+bool FetchSurface(vx_ctx* ctx, unsigned levels, SurfaceImpl& s)
 {
-	uint32_t nb = 0;
-	uint64_t tot[4];
-	if (vx_level_counts(ctx, level, &nb, tot) != VX_OK) return false;
-	std::vector<vx_block_info> infos(nb);
-	std::vector<vx_vertex> v(tot[0]), tv(tot[2]);
-	std::vector<uint32_t> i(tot[1]), ti(tot[3]);
-	if (vx_download_level(ctx, level, infos.data(), v.data(), i.data(), tv.data(), ti.data()) != VX_OK) return false;
-	out.clear();
-	out.reserve(nb);
-	size_t ov = 0, oi = 0, otv = 0, oti = 0;
-	for (uint32_t k = 0; k < nb; ++k) {
-		const vx_block_info& in = infos[k];
-		std::unique_ptr<BlockImpl> b(new BlockImpl);
-		b->Id = in.id;
-		b->MinCorner = float3(in.min_corner[0], in.min_corner[1], in.min_corner[2]);
-		b->MaxCorner = float3(in.max_corner[0], in.max_corner[1], in.max_corner[2]);
-		const PolygonVertex* pv = (const PolygonVertex*)v.data();
-		const PolygonVertex* ptv = (const PolygonVertex*)tv.data();
-		b->Vertices.assign(pv + ov, pv + ov + in.n_verts); ov += in.n_verts;
-		b->Indices.assign(i.begin() + oi, i.begin() + oi + in.n_idx); oi += in.n_idx;
-		for (int f = 0; f < 6; ++f) {
-			b->TVertices[f].assign(ptv + otv, ptv + otv + in.n_tverts[f]); otv += in.n_tverts[f];
-			b->TIndices[f].assign(ti.begin() + oti, ti.begin() + oti + in.n_tidx[f]); oti += in.n_tidx[f];
+	if (vx_host_meshes_acquire(ctx, &s.Meshes) != VX_OK) return false;
+	const PolygonVertex* pv = (const PolygonVertex*)s.Meshes.verts;
+	const unsigned* pi = s.Meshes.indices;
+	s.Levels.resize(levels);
+	std::vector<vx_block_info> infos;
+	std::vector<vx_block_ranges> ranges;
+	for (unsigned level = 0; level < levels; ++level) {
+		uint32_t nb = 0;
+		if (vx_level_counts(ctx, level, &nb, nullptr) != VX_OK) return false;
+		infos.resize(nb);
+		ranges.resize(nb);
+		if (nb && (vx_download_level(ctx, level, infos.data(), nullptr, nullptr, nullptr, nullptr) != VX_OK
+		           || vx_level_ranges(ctx, level, ranges.data()) != VX_OK)) return false;
+		std::vector<BlockImpl>& out = s.Levels[level];
+		out.clear();
+		out.resize(nb);
+		for (uint32_t k = 0; k < nb; ++k) {
+			const vx_block_info& in = infos[k];
+			const vx_block_ranges& r = ranges[k];
+			BlockImpl& b = out[k];
+			b.Id = in.id;
+			b.MinCorner = float3(in.min_corner[0], in.min_corner[1], in.min_corner[2]);
+			b.MaxCorner = float3(in.max_corner[0], in.max_corner[1], in.max_corner[2]);
+			b.Vertices = pv + r.v_off; b.VertexCount = in.n_verts;
+			b.Indices = pi + r.i_off; b.IndexCount = in.n_idx;
+			for (int f = 0; f < 6; ++f) {
+				b.TVertices[f] = pv + r.tv_off[f]; b.TVertexCount[f] = in.n_tverts[f];
+				b.TIndices[f] = pi + r.ti_off[f]; b.TIndexCount[f] = in.n_tidx[f];
+			}
 		}
-		out.push_back(std::move(b));
 	}
 	return true;
 }
@@ -350,20 +364,30 @@ public:
 	{
 		VoxelGrid* g = grid.GetInternalRepresentation();
 		if (!g || !EnsureContext()) return nullptr;
+		// VOXELS_TRACE=1: where a call spends its time (stderr)
+		static const bool trace = getenv("VOXELS_TRACE") != nullptr;
+		auto t0 = std::chrono::steady_clock::now();
+		auto lap = [&](const char* what) {
+			if (!trace) return;
+			const auto t1 = std::chrono::steady_clock::now();
+			fprintf(stderr, "[Voxels] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+			t0 = t1;
+		};
 		if (!SyncGrid(*g) || !SyncMaterials(materials)) {
 			Log(LS_Error, vx_last_error(Ctx));
 			return nullptr;
 		}
+		lap("grid + materials to device");
 		vx_exec_info info;
 		if (!modification) {
 			if (vx_polygonize(Ctx, 0, &info) != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+			lap("vx_polygonize");
 			SurfaceImpl* s = new SurfaceImpl;
 			s->GridSize = g->Size();
 			s->Owner = Ctx;
 			s->Extents = float3((float)g->Size(), (float)g->Size(), (float)g->Size());
-			s->Levels.resize(info.levels);
-			for (unsigned l = 0; l < info.levels; ++l)
-				if (!FetchLevel(Ctx, l, s->Levels[l])) { Log(LS_Error, vx_last_error(Ctx)); delete s; return nullptr; }
+			if (!FetchSurface(Ctx, info.levels, *s)) { Log(LS_Error, vx_last_error(Ctx)); delete s; return nullptr; }
+			lap("meshes to host + block views");
 			FillStats(Ctx, s->Stats);
 			return s;
 		}
@@ -388,8 +412,7 @@ public:
 		}
 		if (rc != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
 		mod->ModifiedBlocks.insert(mod->ModifiedBlocks.end(), ids.begin(), ids.begin() + count);
-		for (unsigned l = 0; l < info.levels && l < s->Levels.size(); ++l)
-			if (!FetchLevel(Ctx, l, s->Levels[l])) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+		if (!FetchSurface(Ctx, std::min<unsigned>(info.levels, (unsigned)s->Levels.size()), *s)) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
 		FillStats(Ctx, s->Stats);
 		return s;
 	}
@@ -419,6 +442,7 @@ extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage lo
 
 extern "C" void DeinitializeVoxels()
 {
+	vx_host_meshes_trim();
 	Voxels::Log(Voxels::LS_Info, "Voxels library deinitialized");
 	Voxels::g_Logger = nullptr;
 	Voxels::g_Initialized = false;

@@ -1832,6 +1832,8 @@ struct Backend {
 	hipStream_t ownStream = nullptr, stream = nullptr;
 	hipStream_t sideA = nullptr, sideB = nullptr;      // level-0 regular pass / transition pass run beside the material chain
 	hipEvent_t evClassified = nullptr, evMaterial = nullptr, evSideA = nullptr, evSideB = nullptr;
+	hipStream_t copyStream[4] = { nullptr, nullptr, nullptr, nullptr }; // d2h_bulk
+	hipEvent_t evCopy = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	hipEvent_t stageEv[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; // [8]: between the level-0 and the level >= 1 regular pass
 	bool stageOn = false, stageValid = false;
@@ -1905,6 +1907,8 @@ struct Backend {
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		for (int i = 0; i < 9; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
+		for (hipStream_t& cs : copyStream) if (cs) { (void)hipStreamDestroy(cs); cs = nullptr; }
+		if (evCopy) (void)hipEventDestroy(evCopy);
 		if (sideA) (void)hipStreamDestroy(sideA);
 		if (sideB) (void)hipStreamDestroy(sideB);
 		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB }) if (e) (void)hipEventDestroy(e);
@@ -1957,6 +1961,38 @@ struct Backend {
 		return p;
 	}
 	void free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+	static void release_pinned(void* p) { if (p) (void)hipHostFree(p); } // arenas outlive their context
+	// Large device -> page-locked host copies, after everything queued on the run's stream: cut into pieces that
+	// can alternate between copy streams (VX_D2H_STREAMS > 1).  Measured on MI355X (tools/d2h_time.py, 499 MB): one stream
+	// 57 GB/s, 2-4 streams 53-56 GB/s - the link is the limit, so one stream is the default.
+	bool d2h_bulk(void* const* dst, const void* const* src, const size_t* bytes, int count)
+	{
+		const u32 lanes = std::min<u32>(4, std::max<u32>(1, env_u32("VX_D2H_STREAMS", 1)));
+		const size_t piece = (size_t)std::max<u32>(1, env_u32("VX_D2H_PIECE_MB", 32)) << 20;
+		size_t total = 0;
+		for (int i = 0; i < count; ++i) total += bytes[i];
+		if (!total) return true;
+		if (lanes == 1 || total <= piece) {
+			for (int i = 0; i < count; ++i)
+				if (bytes[i] && !check(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")) return false;
+			return check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		}
+		for (u32 l = 0; l < lanes; ++l)
+			if (!copyStream[l] && !check(hipStreamCreateWithFlags(&copyStream[l], hipStreamNonBlocking), "hipStreamCreate(copy)")) return false;
+		if (!evCopy && !check(hipEventCreateWithFlags(&evCopy, hipEventDisableTiming), "hipEventCreate(copy)")) return false;
+		if (!check(hipEventRecord(evCopy, stream), "hipEventRecord(copy)")) return false;
+		for (u32 l = 0; l < lanes; ++l) if (!check(hipStreamWaitEvent(copyStream[l], evCopy, 0), "hipStreamWaitEvent(copy)")) return false;
+		u32 next = 0;
+		bool ok = true;
+		for (int i = 0; i < count && ok; ++i)
+			for (size_t off = 0; off < bytes[i] && ok; off += piece) {
+				const size_t len = std::min(piece, bytes[i] - off);
+				ok = check(hipMemcpyAsync((char*)dst[i] + off, (const char*)src[i] + off, len, hipMemcpyDeviceToHost, copyStream[next]), "hipMemcpyAsync(D2H)");
+				next = (next + 1) % lanes;
+			}
+		for (u32 l = 0; l < lanes; ++l) ok = check(hipStreamSynchronize(copyStream[l]), "hipStreamSynchronize(copy)") && ok;
+		return ok;
+	}
 	void stage_enable(bool on)
 	{
 		stageOn = on;

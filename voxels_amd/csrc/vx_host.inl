@@ -19,10 +19,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 namespace {
+
+struct HostArena;
 
 #include "tv_tables.inc"
 
@@ -89,9 +92,8 @@ struct vx_ctx {
 	bool haveSurface = false;
 	u32 nextId = 0;
 	std::vector<EmittedBlock> blocks[MAX_LEVELS];
-	std::vector<PolyVertex> hVerts;
-	std::vector<u32> hIdx;
-	u32 hostVerts = 0, hostIdx = 0; // how much of the (append-only between full runs) pools the host mirror already holds
+	HostArena* hostArena = nullptr; // page-locked host copy of the pools (vx_download_level; handed out by vx_host_meshes_acquire)
+	uint64_t poolLineage = 0;             // changes whenever the pools are rewritten (a host copy of another lineage is useless)
 	bool listsReady = false;
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
@@ -417,20 +419,117 @@ void block_corners(const LevelDesc& d, u32 coordId, float mn[3], float mx[3])
 }
 
 // host mirror of the output pools; between full runs the pools only grow, so only the new tail is copied
-bool fetch_pools(vx_ctx* c)
+// ---- page-locked host copies of the pools ("arenas") --------------------------------------------------------------
+// One block of page-locked memory: vertices first, indices behind them.  Arenas outlive contexts (a PolygonSurface of
+// the drop-in API owns one) and are recycled through a process-wide list: page-locking some 100 MB costs far more than
+// copying into them.
+struct HostArena {
+	void* mem = nullptr;
+	PolyVertex* verts = nullptr;
+	u32* idx = nullptr;
+	size_t capVerts = 0, capIdx = 0;
+	u32 haveVerts = 0, haveIdx = 0; // prefix of the pools it holds...
+	uint64_t lineage = 0;           // ...of this vx_ctx::poolLineage
+	void (*release_mem)(void*) = nullptr;
+};
+
+std::mutex g_arenaLock;
+std::vector<HostArena*> g_arenaFree;
+uint64_t g_lineage = 0;
+
+uint64_t next_lineage()
 {
-	if (c->hostVerts < c->poolVerts) {
-		c->hVerts.resize(c->poolVerts);
-		if (!c->be.d2h(c->hVerts.data() + c->hostVerts, (const PolyVertex*)c->dVerts + c->hostVerts, (size_t)(c->poolVerts - c->hostVerts) * sizeof(PolyVertex))) return false;
-		c->hostVerts = c->poolVerts;
+	std::lock_guard<std::mutex> g(g_arenaLock);
+	return ++g_lineage;
+}
+
+void arena_destroy(HostArena* a)
+{
+	if (!a) return;
+	if (a->mem && a->release_mem) a->release_mem(a->mem);
+	delete a;
+}
+
+void arena_recycle(HostArena* a)
+{
+	if (!a) return;
+	a->haveVerts = a->haveIdx = 0; a->lineage = 0;
+	HostArena* drop = nullptr;
+	{
+		std::lock_guard<std::mutex> g(g_arenaLock);
+		g_arenaFree.push_back(a);
+		if (g_arenaFree.size() > 4) { // keep the larger ones
+			size_t k = 0;
+			for (size_t i = 1; i < g_arenaFree.size(); ++i) if (g_arenaFree[i]->capVerts < g_arenaFree[k]->capVerts) k = i;
+			drop = g_arenaFree[k];
+			g_arenaFree.erase(g_arenaFree.begin() + k);
+		}
 	}
-	if (c->hostIdx < c->poolIdx) {
-		c->hIdx.resize(c->poolIdx);
-		if (!c->be.d2h(c->hIdx.data() + c->hostIdx, (const u32*)c->dIdx + c->hostIdx, (size_t)(c->poolIdx - c->hostIdx) * 4)) return false;
-		c->hostIdx = c->poolIdx;
+	arena_destroy(drop);
+}
+
+HostArena* arena_get(vx_ctx* c, size_t needVerts, size_t needIdx)
+{
+	{
+		std::lock_guard<std::mutex> g(g_arenaLock);
+		size_t best = g_arenaFree.size();
+		for (size_t i = 0; i < g_arenaFree.size(); ++i) {
+			const HostArena* a = g_arenaFree[i];
+			if (a->capVerts < needVerts || a->capIdx < needIdx) continue;
+			if (best == g_arenaFree.size() || a->capVerts < g_arenaFree[best]->capVerts) best = i;
+		}
+		if (best != g_arenaFree.size()) {
+			HostArena* a = g_arenaFree[best];
+			g_arenaFree.erase(g_arenaFree.begin() + best);
+			return a;
+		}
 	}
+	// some slack: the next run of a similar grid, or an incremental run's appended blocks, fit without a new arena
+	const size_t capV = needVerts + needVerts / 8 + 4096, capI = needIdx + needIdx / 8 + 16384;
+	const size_t vBytes = (capV * sizeof(PolyVertex) + 255) & ~size_t(255);
+	std::unique_ptr<HostArena> a(new HostArena);
+	a->mem = c->be.alloc_pinned(vBytes + capI * 4);
+	if (!a->mem) return nullptr;
+	a->release_mem = &Backend::release_pinned;
+	a->verts = (PolyVertex*)a->mem;
+	a->idx = (u32*)((char*)a->mem + vBytes);
+	a->capVerts = capV; a->capIdx = capI;
+	return a.release();
+}
+
+// make `a` hold the pools of the current surface; only what it does not hold yet travels
+bool arena_fill(vx_ctx* c, HostArena*& a)
+{
+	if (a && (a->lineage != c->poolLineage || a->capVerts < c->poolVerts || a->capIdx < c->poolIdx)) {
+		if (a->lineage == c->poolLineage && a->haveVerts <= c->poolVerts && a->haveIdx <= c->poolIdx) {
+			// grown beyond its capacity: move what it holds to a larger one (host copy; no second trip over the bus)
+			HostArena* b = arena_get(c, (size_t)c->poolVerts + c->poolVerts / 4, (size_t)c->poolIdx + c->poolIdx / 4);
+			if (!b) return false;
+			memcpy(b->verts, a->verts, (size_t)a->haveVerts * sizeof(PolyVertex));
+			memcpy(b->idx, a->idx, (size_t)a->haveIdx * 4);
+			b->haveVerts = a->haveVerts; b->haveIdx = a->haveIdx; b->lineage = a->lineage;
+			arena_recycle(a);
+			a = b;
+		} else {
+			a->haveVerts = a->haveIdx = 0;
+			a->lineage = c->poolLineage;
+			if (a->capVerts < c->poolVerts || a->capIdx < c->poolIdx) { arena_recycle(a); a = nullptr; }
+		}
+	}
+	if (!a) {
+		a = arena_get(c, c->poolVerts, c->poolIdx);
+		if (!a) return false;
+		a->lineage = c->poolLineage;
+	}
+	void* dst[2] = { a->verts + a->haveVerts, a->idx + a->haveIdx };
+	const void* src[2] = { (const PolyVertex*)c->dVerts + a->haveVerts, (const u32*)c->dIdx + a->haveIdx };
+	const size_t bytes[2] = { (size_t)(c->poolVerts - a->haveVerts) * sizeof(PolyVertex), (size_t)(c->poolIdx - a->haveIdx) * 4 };
+	if (!c->be.d2h_bulk(dst, src, bytes, 2)) return false;
+	a->haveVerts = c->poolVerts; a->haveIdx = c->poolIdx;
 	return true;
 }
+
+bool fetch_pools(vx_ctx* c) { return arena_fill(c, c->hostArena); }
 
 // grow the pools of an incremental run: what earlier runs wrote stays valid
 bool grow_pools_keeping(vx_ctx* c, u32 needVerts, u32 needIdx)
@@ -515,6 +614,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
+	arena_recycle(c->hostArena);
 	for (void* hb : c->haloBuf) c->be.free(hb);
 	c->be.comm_destroy();
 	c->be.free_pinned(c->hdrPinned);
@@ -1143,7 +1243,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	c->largeHint = c->hdr[HDR_LARGE] != 0;
 	c->levelsRun = levels;
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
-	c->hostVerts = 0; c->hostIdx = 0; // the pools were rewritten
+	c->poolLineage = next_lineage(); // the pools were rewritten
 	c->haveSurface = true;
 	c->listsReady = false; // the host copy of the block lists is fetched on first access
 	c->deviceLists = true;
@@ -1268,7 +1368,7 @@ int vx_compact_pools(vx_ctx* c)
 	c->dVerts = newV; c->dIdx = newI; c->vertCap = capV; c->idxCap = capI;
 	c->deviceLists = false;
 	c->poolVerts = nv; c->poolIdx = ni;
-	c->hostVerts = 0; c->hostIdx = 0; // the host mirror describes the old layout
+	c->poolLineage = next_lineage(); // host copies describe the old layout
 	for (u32 L = 0; L < c->levelsRun; ++L) c->blocks[L].swap(moved[L]);
 	return VX_OK;
 }
@@ -1455,14 +1555,14 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 			memcpy(b.min_corner, e.minc, 12); memcpy(b.max_corner, e.maxc, 12);
 		}
 		++k;
-		if (verts && r.vCount) memcpy(verts + ov, c->hVerts.data() + r.vOff, (size_t)r.vCount * 48);
+		if (verts && r.vCount) memcpy(verts + ov, c->hostArena->verts + r.vOff, (size_t)r.vCount * 48);
 		ov += r.vCount;
-		if (idx && r.iCount) memcpy(idx + oi, c->hIdx.data() + r.iOff, (size_t)r.iCount * 4);
+		if (idx && r.iCount) memcpy(idx + oi, c->hostArena->idx + r.iOff, (size_t)r.iCount * 4);
 		oi += r.iCount;
 		for (int f = 0; f < 6; ++f) {
-			if (tverts && r.tvCount[f]) memcpy(tverts + otv, c->hVerts.data() + r.tvOff[f], (size_t)r.tvCount[f] * 48);
+			if (tverts && r.tvCount[f]) memcpy(tverts + otv, c->hostArena->verts + r.tvOff[f], (size_t)r.tvCount[f] * 48);
 			otv += r.tvCount[f];
-			if (tidx && r.tiCount[f]) memcpy(tidx + oti, c->hIdx.data() + r.tiOff[f], (size_t)r.tiCount[f] * 4);
+			if (tidx && r.tiCount[f]) memcpy(tidx + oti, c->hostArena->idx + r.tiOff[f], (size_t)r.tiCount[f] * 4);
 			oti += r.tiCount[f];
 		}
 	}
@@ -1478,6 +1578,33 @@ int vx_device_meshes(vx_ctx* c, const vx_vertex** dVerts, const uint32_t** dIdx,
 	if (nVerts) *nVerts = c->poolVerts;
 	if (nIdx) *nIdx = c->poolIdx;
 	return VX_OK;
+}
+
+int vx_host_meshes_acquire(vx_ctx* c, vx_host_meshes* m)
+{
+	VX_ENTER(c);
+	if (!c || !c->haveSurface || !m) return fail(c, VX_ERR_INVALID, "vx_host_meshes_acquire: no surface");
+	HostArena* a = (HostArena*)m->arena;
+	if (!a) { a = c->hostArena; c->hostArena = nullptr; } // what vx_download_level may have fetched already is handed over
+	const bool ok = arena_fill(c, a);
+	m->arena = a;
+	m->verts = a ? (const vx_vertex*)a->verts : nullptr;
+	m->indices = a ? a->idx : nullptr;
+	m->n_verts = a ? a->haveVerts : 0;
+	m->n_indices = a ? a->haveIdx : 0;
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_host_meshes_acquire: " + (c->be.error().empty() ? std::string("page-locked allocation failed") : c->be.error()));
+}
+
+void vx_host_meshes_release(void* arena) { arena_recycle((HostArena*)arena); }
+
+void vx_host_meshes_trim(void)
+{
+	std::vector<HostArena*> all;
+	{
+		std::lock_guard<std::mutex> g(g_arenaLock);
+		all.swap(g_arenaFree);
+	}
+	for (HostArena* a : all) arena_destroy(a);
 }
 
 int vx_level_ranges(vx_ctx* c, uint32_t level, vx_block_ranges* ranges)
