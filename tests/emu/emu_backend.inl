@@ -383,7 +383,7 @@ struct Backend {
 						st->iOff = TV_ATOMIC_ADD(&p.P.cursors[CUR_I], st->iTotal);
 						for (u32 chunk = 0; chunk == 0 || chunk < st->vTotal; chunk += VDESC_CAP) {
 							tr_phase_describe(*st, chunk, 0, 1);
-							tr_phase_emit_vertices(*st, T, p.G, p.P, b, chunk, 0, 1);
+							tr_phase_emit_vertices(*st, T, p.G, F1HostSampler{ &p.G.grid }, p.P, b, chunk, 0, 1);
 						}
 						for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
 							tr_phase_stage_indices(*st, T, chunk, 0, 1);

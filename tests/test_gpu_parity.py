@@ -65,6 +65,24 @@ def test_hip_matches_reference_fixture(poly, name):
     assert np.array_equal(st, gold.stats)
 
 
+def test_hip_wide_offset_variants_match_reference_fixture():
+    """The kernels' 64-bit-offset variants (grids beyond 1024^3, whose mirrors exceed 4 GiB) forced onto a fixture
+    (VX_FORCE_WIDE is read when the context is created)."""
+    from voxels_amd import Polygonizer
+    os.environ["VX_FORCE_WIDE"] = "1"
+    try:
+        p = Polygonizer(device=0)
+    finally:
+        del os.environ["VX_FORCE_WIDE"]
+    p.set_materials(vxo.default_lut())
+    for name in ("noise64_fullrange_mat", "terrain32_mat"):
+        gold = Golden(name)
+        lv, st = run_hip(p, gold.dist, gold.mat, gold.blend, gold.flags)
+        ok, msg = fields.surface_equal(lv, gold.levels, nrm_tol=NRM_TOL)
+        assert ok, name + ": " + msg
+        assert np.array_equal(st, gold.stats)
+
+
 def test_hip_known_answer_hash(poly):
     gold = Golden("sphere64")
     lv, _ = run_hip(poly, gold.dist, gold.mat, gold.blend, gold.flags)

@@ -1,0 +1,13 @@
+run() { # name lib env...
+  name=$1; lib=$2; shift 2
+  env "$@" VOXELS_HIP_LIBRARY=$lib timeout 300 python bench.py --steps 8 --warmup 2 --no-extra --no-cpu-baseline --serialize > $out/bench_$name.json 2> $out/bench_$name.err
+  python - $out/bench_$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    s = d["config"]["stage_ms_serialized"]
+    print(sys.argv[2], "regular(L>=1)", s["k_regular"], "transition", s["k_transition"], "regular0", s["k_regular0"], "material", s["k_material"])
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+}

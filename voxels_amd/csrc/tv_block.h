@@ -107,6 +107,8 @@ TV_HD size_t pyramid_offset(const PyramidLevel& P, int X, int Y, int Z)
 	return (((size_t)(z >> 4) * P.bricksY + (size_t)(y >> 4)) * P.bricksX + (size_t)((u32)X >> 4)) * BRICK_BYTES + brick_local((u32)X & 15u, y & 15u, z & 15u);
 }
 
+struct __attribute__((aligned(16))) FlatItem { u32 where, coordId, ntCells, pad; }; // Globals::flatItems
+
 // stats[0] = non-trivial cells, [1] = degenerate triangles removed, [2] = level-0 blocks processed,
 // stats[4..19] = per-class cell counts
 struct Globals {
@@ -131,6 +133,12 @@ struct Globals {
 	// chain ending on a voxel).  [0]: level-0 slots; [1]: level << 24 | slot for the levels >= 1
 	u32* slowItems[2];
 	u32* slowCount;                   // [2]
+	// full runs: the active blocks of the levels >= 1 as one list in level order, written by the material pass (which
+	// visits every one of them): { level << 24 | slot, block coordinate id, non-trivial cells, 0 }.  The passes over
+	// those blocks index it by work item instead of turning the item into (level, slot) and then fetching the slot's
+	// coordinate and cell count - one dependent round trip less at the head of every block.
+	struct FlatItem* flatItems;
+	const u32* slotCounts;            // [MAX_LEVELS] active blocks per level (LevelDesc::nActive of all levels, contiguous)
 };
 
 // BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the
@@ -974,13 +982,13 @@ TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const Re
 // ---------------------------------------------------------------------------------------------------------
 // Transition pass state: all 6 faces of a block at once; cell id = f * 256 + row * 16 + col
 // ---------------------------------------------------------------------------------------------------------
-enum { TR_CELLS = 6 * 256, TR_CAP = 512 };
+enum { TR_CELLS = 6 * 256, TR_CAP = 512, TR_PROW = 48 }; // TR_PROW: bytes per staged plane row (33 samples; 16-byte pieces stay aligned)
 
 // The six faces of a block are independent (reuse never crosses a face, every face has its own output ranges), so
 // the per-cell state is sized for TR_CAP non-trivial cells and a block is handled in batches of consecutive faces
 // whose non-trivial cells fit: nearly always one batch; any two faces (2 x 256 cells) always fit.
 struct TrState {
-	i8 plane[6][PLANE + 7];   // 33 x 33 full-resolution samples of each boundary plane, index v * 33 + u
+	__attribute__((aligned(16))) i8 plane[6][33 * TR_PROW]; // 33 x 33 full-resolution samples of each boundary plane, index v * TR_PROW + u
 	u32 ntAll[48];            // non-trivial transition cells of all faces
 	u32 ntBits[48];           // ... of the faces of the current batch
 	u16 wordPrefix[50];       // [48] = number of non-trivial transition cells of the batch
@@ -1040,17 +1048,17 @@ TV_HD void tr_phase_load(TrState& st, const Globals& G, const LevelDesc& L, cons
 		p[fg.ua] = (int)(bc[fg.ua] * 16 * b.mult) + (r % 33) * half;
 		p[fg.va] = (int)(bc[fg.va] * 16 * b.mult) + (r / 33) * half;
 		p[fg.axis] = (int)((bc[fg.axis] * 16 + (fg.positive ? 16 : 0)) * b.mult);
-		st.plane[f][r] = (i8)dist_at(G.grid, p[0], p[1], p[2]);
+		st.plane[f][(r / 33) * TR_PROW + r % 33] = (i8)dist_at(G.grid, p[0], p[1], p[2]);
 	}
 }
 
 TV_HD void tr_cell_values(const TrState& st, int f, int row, int col, i8 v9[9])
 {
-	const i8* p = st.plane[f] + (row * 2) * 33 + col * 2;
+	const i8* p = st.plane[f] + (row * 2) * TR_PROW + col * 2;
 #pragma unroll
 	for (int j = 0; j < 3; ++j)
 #pragma unroll
-		for (int i = 0; i < 3; ++i) v9[j * 3 + i] = p[j * 33 + i];
+		for (int i = 0; i < 3; ++i) v9[j * 3 + i] = p[j * TR_PROW + i];
 }
 
 TV_HD void tr_phase_classify(TrState& st, int tid, int nth)
@@ -1170,8 +1178,9 @@ TV_HD void tr_phase_describe(TrState& st, u32 chunkBase, int tid, int nth)
 	}
 }
 
-// one lane = one new transition vertex of the chunk
-TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
+// one lane = one new transition vertex of the chunk; `smp` reads the voxels around it (tr_new_vertex)
+template <typename SMP>
+TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G, const SMP& smp, const Pools& P, const RegBlockCtx& b, u32 chunkBase, int tid, int nth)
 {
 	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
 	const u32 end = (st.vTotal - chunkBase < (u32)VDESC_CAP) ? st.vTotal - chunkBase : (u32)VDESC_CAP;
@@ -1191,9 +1200,12 @@ TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G
 		r.endpoint = endpoint ? 1 : 0; r.dir = (u8)dir; r.slot = (u8)slot; r.kind = RK_NEW_EDGE; r.store = NO_SLOT;
 		TrCellGeom geo;
 		tr_cell_geom(fg, b, row, col, geo);
+		// the vertex's material id is the low-res cell's whatever the end points hold (tr_new_vertex), so its row of the
+		// material table is requested before the voxel fetches instead of behind them (one round trip less)
+		const unsigned long long lut = lut_row(G.lut, st.cellMat[k]);
 		RawVertex rv;
-		tr_new_vertex(G.grid, fg, geo, v, w, r, st.cellMat[k], rv);
-		pack_vertex(rv, G.lut, P.verts + st.vOff + chunkBase + j);
+		tr_new_vertex(smp, fg, geo, v, w, r, st.cellMat[k], rv);
+		pack_vertex_row(rv, lut, P.verts + st.vOff + chunkBase + j);
 	}
 }
 

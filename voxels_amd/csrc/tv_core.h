@@ -36,6 +36,13 @@
 #define TV_HD inline
 #endif
 
+// keeps the compiler's scheduler from moving instructions across (device code; nothing on the host)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TV_SCHED_FENCE() do { } while (0)
+#endif
+
 namespace tv {
 
 typedef uint8_t u8;
@@ -300,6 +307,16 @@ TV_HD void normal_from(const int s[6], float out[3])
 	out[1] = (float)(s[2] - s[3]) * 0.5f;
 	out[2] = (float)(s[4] - s[5]) * 0.5f;
 	normalize_fix_zero(out);
+}
+
+// the same for the transition vertices: the halved differences of int8 samples are exact in fp32 and normalize_gradient
+// gives normalize_fix_zero's bits for them (its comment; vx_selftest)
+TV_HD void gradient_from(const int s[6], float out[3])
+{
+	out[0] = (float)(s[0] - s[1]) * 0.5f;
+	out[1] = (float)(s[2] - s[3]) * 0.5f;
+	out[2] = (float)(s[4] - s[5]) * 0.5f;
+	normalize_gradient(out);
 }
 
 // (v1 << 8) / (v1 - v0) with C truncation.  Evaluated as a correctly rounded fp32 division: for |v| <= 128 the
@@ -844,11 +861,15 @@ TV_HD void tr_sample_pos(const FaceGeom& fg, const TrCellGeom& c, int k, int P[3
 	P[0] = c.lowBase[0] + off[0]; P[1] = c.lowBase[1] + off[1]; P[2] = c.lowBase[2] + off[2];
 }
 
-TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom& c, const i8 v[13], u32 w,
+// `smp` addresses voxels as sums of one term per axis (tv_fast1.h: F1HostSampler for the dense fields, the kernels'
+// F1BrickSampler for the brick mirrors): every edge of a transition cell runs along one axis, so the LOD chain and the two
+// stencils need a handful of terms instead of a full address computation per fetch.
+template <typename SMP>
+TV_HD void tr_new_vertex(const SMP& smp, const FaceGeom& fg, const TrCellGeom& c, const i8 v[13], u32 w,
                          const TrResolution& r, u32 lowMat, RawVertex& o)
 {
+	typedef typename SMP::Off Off;
 	const int v0 = (w >> 4) & 15, v1 = w & 15;
-	const GlobalDist d{ &g };
 	int I0[3], I1[3];
 	tr_sample_pos(fg, c, v0, I0);
 	tr_sample_pos(fg, c, v1, I1);
@@ -868,31 +889,58 @@ TV_HD void tr_new_vertex(const GridView& g, const FaceGeom& fg, const TrCellGeom
 		p1 = (int)(i8)((w1 >> ((v1 & 3) * 8)) & 0xFFu);
 	}
 	if (!r.endpoint) {
+		// FindBestVertexInLODChain (:1484-1509): the end points differ along one axis by a power of two; every step
+		// halves the (signed) distance, keeping the half that holds the sign change (one fetch per step)
 		const int lodOfEdge = (v0 >= 9) ? c.level : c.level - 1;
-		if (lodOfEdge > 0) lod_chain(d, lodOfEdge, I0, I1, p0, p1);
+		for (int lev = lodOfEdge; lev > 0; --lev) {
+			const int mx = I0[0] + (I1[0] - I0[0]) / 2, my = I0[1] + (I1[1] - I0[1]) / 2, mz = I0[2] + (I1[2] - I0[2]) / 2;
+			const int midV = smp.dist(smp.tx(mx) + smp.ty(my) + smp.tz(mz));
+			if (p0 * midV <= 0) { I1[0] = mx; I1[1] = my; I1[2] = mz; p1 = midV; }
+			else { I0[0] = mx; I0[1] = my; I0[2] = mz; p0 = midV; }
+		}
 	}
 	// both stencils and both materials in one round trip (an end-point vertex uses one of the two normals; the other
 	// stencil is read all the same: no second dependent trip, no branch around loads)
-	EndpointSamples es;
-	gather_endpoints(d, GridMaterials{ &g }, I0, I1, es);
+	int a[6], bb[6];
+	u32 M0, M1;
+	{
+		// x+1, x-1, z+1, z-1, y+1, y-1 around P0 / P1 (CalcNormal's order, :1239-1246); P0's requests are issued before
+		// P1's address terms are computed (fewer values alive at once: the kernel runs at its register limit)
+		{
+			const Off x0 = smp.tx(I0[0]), x0m = smp.tx(I0[0] - 1), x0p = smp.tx(I0[0] + 1);
+			const Off y0 = smp.ty(I0[1]), y0m = smp.ty(I0[1] - 1), y0p = smp.ty(I0[1] + 1);
+			const Off z0 = smp.tz(I0[2]), z0m = smp.tz(I0[2] - 1), z0p = smp.tz(I0[2] + 1);
+			const Off yz0 = y0 + z0, xy0 = x0 + y0, xz0 = x0 + z0;
+			a[0] = smp.dist(x0p + yz0); a[1] = smp.dist(x0m + yz0); a[2] = smp.dist(xy0 + z0p); a[3] = smp.dist(xy0 + z0m); a[4] = smp.dist(xz0 + y0p); a[5] = smp.dist(xz0 + y0m);
+			M0 = smp.mat(x0 + yz0, I0[0], I0[1], I0[2]);
+		}
+		TV_SCHED_FENCE();
+		{
+			const Off x1 = smp.tx(I1[0]), x1m = smp.tx(I1[0] - 1), x1p = smp.tx(I1[0] + 1);
+			const Off y1 = smp.ty(I1[1]), y1m = smp.ty(I1[1] - 1), y1p = smp.ty(I1[1] + 1);
+			const Off z1 = smp.tz(I1[2]), z1m = smp.tz(I1[2] - 1), z1p = smp.tz(I1[2] + 1);
+			const Off yz1 = y1 + z1, xy1 = x1 + y1, xz1 = x1 + z1;
+			bb[0] = smp.dist(x1p + yz1); bb[1] = smp.dist(x1m + yz1); bb[2] = smp.dist(xy1 + z1p); bb[3] = smp.dist(xy1 + z1m); bb[4] = smp.dist(xz1 + y1p); bb[5] = smp.dist(xz1 + y1m);
+			M1 = smp.mat(x1 + yz1, I1[0], I1[1], I1[2]);
+		}
+	}
 	if (r.endpoint) {
 		if (t == 0) {
 			u = 256;
-			normal_from(es.b, N1);
+			gradient_from(bb, N1);
 			if (v1 >= 9) { const int cid = low_corner_id(fg, v1 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		} else {
 			u = 0; t = 256;
-			normal_from(es.a, N0);
+			gradient_from(a, N0);
 			if (v0 >= 9) { const int cid = low_corner_id(fg, v0 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		}
 	} else {
 		t = (p0 != p1) ? edge_t(p0, p1) : 0;
 		u = 256 - t;
-		normal_from(es.a, N0);
-		normal_from(es.b, N1);
+		gradient_from(a, N0);
+		gradient_from(bb, N1);
 		if (v0 >= 9 && v1 >= 9) adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, low_corner_id(fg, v0 - 9), low_corner_id(fg, v1 - 9));
 	}
-	const u32 M0 = es.M0, M1 = es.M1;
 	float P0[3] = { (float)I0[0], (float)I0[1], (float)I0[2] }, P1[3] = { (float)I1[0], (float)I1[1], (float)I1[2] };
 	float S0[3] = { P0[0], P0[1], P0[2] }, S1[3] = { P1[0], P1[1], P1[2] };
 	if (v0 >= 9 || v1 >= 9) {

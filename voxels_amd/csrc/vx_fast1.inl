@@ -12,28 +12,30 @@ namespace {
 
 // voxel addresses in the brick mirrors as sums of one term per axis (tv_core.h brick_offset, split): 32-bit offsets,
 // valid while a mirror is smaller than 4 GiB (grids up to 1024^3; the host launches the general pass beyond)
-struct F1BrickSampler {
+template <typename OFF>
+struct BrickSamplerT {
 	const i8* bDist;
 	const u8* bMat;
 	const u8* bBlend;
 	int last;          // n - 1
 	u32 nb, rowsY;     // blocks per row, resident block rows per block plane
 	int yb0, zb0;      // first resident block row / plane
-	typedef u32 Off;
-	__device__ __forceinline__ Off tx(int x) const { x = max(0, min(x, last)); return ((u32)(x >> 4) << 12) | ((u32)x & 15u); }
+	typedef OFF Off;
+	__device__ __forceinline__ Off tx(int x) const { x = max(0, min(x, last)); return ((Off)((u32)x >> 4) << 12) | ((u32)x & 15u); }
 	__device__ __forceinline__ Off ty(int y) const
 	{
 		y = max(0, min(y, last));
-		return (__umul24((u32)((y >> 4) - yb0), nb) << 12) | ((((u32)y >> 2) & 3u) << 7) | (((u32)y & 3u) << 4);
+		return ((Off)__umul24((u32)((y >> 4) - yb0), nb) << 12) | ((((u32)y >> 2) & 3u) << 7) | (((u32)y & 3u) << 4);
 	}
 	__device__ __forceinline__ Off tz(int z) const
 	{
 		z = max(0, min(z, last));
-		return (__umul24(__umul24((u32)((z >> 4) - zb0), rowsY), nb) << 12) | ((((u32)z >> 1) & 7u) << 9) | (((u32)z & 1u) << 6);
+		return ((Off)__umul24(__umul24((u32)((z >> 4) - zb0), rowsY), nb) << 12) | ((((u32)z >> 1) & 7u) << 9) | (((u32)z & 1u) << 6);
 	}
 	__device__ __forceinline__ int dist(Off o) const { return bDist[o]; }
 	__device__ __forceinline__ u32 mat(Off o, int, int, int) const { return (u32)bMat[o] | ((u32)bBlend[o] << 8); }
 };
+typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller than 4 GiB
 
 template <int CAP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular1_fast(ExecParamsDev p, u32 levelEnd)
@@ -42,22 +44,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	typedef R0<CAP> K;
 	u8* tab = smem;
 	ST& st = *(ST*)(smem + F0_TAB_LDS);
-	__shared__ WorkList wl;
 	__shared__ u32 wgStats[20];
 	__shared__ u32 zeroFlag[2];
 
 	const int tid = (int)threadIdx.x;
 	if (tid < 20) wgStats[tid] = 0;
 	if (tid < 2) zeroFlag[tid] = 0;
-	if (tid == 0) {
-		u32 run = 0;
-		for (u32 l = 0; l <= MAX_LEVELS; ++l) { wl.start[l] = run; if (l >= 1 && l < levelEnd) run += *p.levels[l].nActive; }
-		st.suspect = 0;
-	}
-	__syncthreads();
-	const u32 total = r0_uniform(wl.start[MAX_LEVELS]);
-	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	if (tid == 0) st.suspect = 0;
 	const F0Tables T = f0_stage_tables(tab, p.tables); // visible after the first barrier of the item loop
+	// the work items are the first entries of the run's list of active blocks of the levels >= 1 (Globals::flatItems, in
+	// level order): those of the levels below levelEnd.  Counts and the item's entry come in one round trip.
+	u32 total = 0;
+	for (u32 l = 1; l < levelEnd; ++l) total += p.G.slotCounts[l];
+	total = r0_uniform(total);
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const GridView& g = p.G.grid;
 	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
 	const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
@@ -66,13 +66,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
-		u32 level, slot;
-		decode_item(wl, levelEnd, item, level, slot);
-		level = r0_uniform(level); slot = r0_uniform(slot);
+		const FlatItem fi = p.G.flatItems[item];
+		const u32 level = r0_uniform(fi.where >> 24), slot = r0_uniform(fi.where & 0xFFFFFFu);
 		const LevelDesc& L = p.levels[level];
-		const u32 ntc = r0_uniform(L.ntCount[slot]);
+		const u32 ntc = r0_uniform(fi.ntCells);
 		if (ntc > (u32)CAP) continue;                       // the 4096-cell class of the general pass owns those
-		const u32 coord = r0_uniform(L.slotCoord[slot]);
+		const u32 coord = r0_uniform(fi.coordId);
 		if (ntc == 0) {                                     // (uniform) a surface-bearing block without a non-trivial coarse cell
 			if (tid == 0) reg_write_empty_record(L, slot);
 			continue;
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 						u32 ids[3];
 						f0_triangle(st, T, j, ids);
 						u32* o3 = iOut + j * 3u;
-						o3[0] = ids[0]; o3[1] = ids[1]; o3[2] = ids[2];
+						{ o3[0] = ids[0]; o3[1] = ids[1]; o3[2] = ids[2]; }
 					}
 				}
 			}

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "tv_block.h"
@@ -1086,6 +1087,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_
 				const u32 cnt = st.ntTotal;
 				L.ntCount[slot] = (u16)cnt;
 				if (cnt > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
+				if (!p.G.dirty) { // (the slot counts of all levels are final since k_hierarchy)
+					u32 before = 0;
+					for (u32 l = 1; l < level; ++l) before += p.G.slotCounts[l];
+					FlatItem e;
+					e.where = (level << 24) | slot; e.coordId = L.slotCoord[slot]; e.ntCells = cnt; e.pad = 0;
+					p.G.flatItems[before + slot] = e;
+				}
 			}
 		}
 		__syncthreads();
@@ -1395,10 +1403,113 @@ __device__ __forceinline__ void tr_face_request(const GridView& g, const RegBloc
 __device__ __forceinline__ void tr_face_store(i8* plane, int tid, const i8 (&v)[5], bool faceOn)
 {
 #pragma unroll
-	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) plane[r] = faceOn ? v[q] : (i8)0; }
+	for (int q = 0; q < 5; ++q) { const int r = tid + q * WG; if (r < PLANE) { const int vv = r / 33; plane[vv * TR_PROW + (r - vv * 33)] = faceOn ? v[q] : (i8)0; } }
 }
 
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_transition(ExecParamsDev p, u32 levels)
+// The boundary planes of a level-L block are 33 x 33 points of the level L-1 lattice, and that lattice is resident in
+// brick order: the lattice copy of level L-1, or the grid's own mirror for L = 1.  Addresses are sums of one term per
+// axis (tv_core.h brick_local, pyramid_offset).  `last` = largest valid coordinate: n - 1 in the grid's mirror, n >> l in
+// a lattice copy (which holds the clamped far sample).
+template <typename OFF>
+struct TrLatticeT {
+	const i8* base;
+	u32 bricksX, bricksY;
+	int yOrg, zOrg, last;
+	__device__ __forceinline__ OFF tx(int X) const { return ((OFF)((u32)X >> 4) << 12) | ((u32)X & 15u); }
+	__device__ __forceinline__ OFF ty(int Y) const
+	{
+		const u32 y = (u32)(Y - yOrg);
+		return ((OFF)__umul24(y >> 4, bricksX) << 12) | (((y >> 2) & 3u) << 7) | ((y & 3u) << 4);
+	}
+	__device__ __forceinline__ OFF tz(int Z) const
+	{
+		const u32 z = (u32)(Z - zOrg);
+		return ((OFF)__umul24(__umul24(z >> 4, bricksY), bricksX) << 12) | (((z >> 1) & 7u) << 9) | ((z & 1u) << 6);
+	}
+};
+
+// false: the lattice the block's planes lie in has no resident copy (levels beyond the lattice copies; shards without them)
+template <typename OFF>
+__device__ __forceinline__ bool tr_lattice_of(const Globals& G, u32 level, TrLatticeT<OFF>& lat)
+{
+	const GridView& g = G.grid;
+	if (level == 1) {
+		lat.base = g.bDist; lat.bricksX = (u32)g.n >> 4; lat.bricksY = (u32)g.bRowsY;
+		lat.yOrg = g.bYb0 * 16; lat.zOrg = g.bZb0 * 16; lat.last = g.n - 1;
+		return true;
+	}
+	if (level - 1u >= (u32)PYRAMID_LEVELS || !G.pyr[level - 1u].data) return false;
+	const PyramidLevel& P = G.pyr[level - 1u];
+	lat.base = P.data; lat.bricksX = P.bricksX; lat.bricksY = P.bricksY;
+	lat.yOrg = P.yOrigin; lat.zOrg = P.zOrigin; lat.last = g.n >> (level - 1u);
+	return true;
+}
+
+// All planes of one block: the four faces whose rows run along x (z and y faces) are read row by row - two 16-byte pieces
+// and the far sample per row, 132 rows, one lane each; the two x faces sample by sample (one byte of every 16-byte voxel
+// row they cross).  Nothing is conditional on a face being on (a branch around loads ends with a wait for them; and which
+// faces are on is only known once the sign summaries, requested right behind the planes, have arrived): faces that turn
+// out to be off were read from clamped addresses and are not stored.
+template <typename OFF>
+__device__ __forceinline__ void tr_planes_request(const TrLatticeT<OFF>& lat, const RegBlockCtx& b, int tid, uint4& r0, uint4& r1, i8& rFar, i8 (&g)[9])
+{
+	// (the lane's row / sample indices do not depend on the block: left alone the compiler computes them once before the
+	// item loop and keeps some twenty registers occupied through every other phase - which then spill)
+	asm volatile("" : "+v"(tid));
+	const int X0 = (int)b.bx * 32, Y0 = (int)b.by * 32, Z0 = (int)b.bz * 32;
+	// ---- rows along x ----
+	{
+		const int row = min(tid, 131), fi = row / 33, rowV = row - fi * 33; // faces 0, 1, 3, 4
+		const bool zFace = (fi & 1) == 0, positive = fi >= 2;
+		const int A = min((zFace ? Z0 : Y0) + (positive ? 32 : 0), lat.last);
+		const int V = min((zFace ? Y0 : Z0) + rowV, lat.last);
+		const OFF yz = lat.ty(zFace ? V : A) + lat.tz(zFace ? A : V);
+		const i8* src = lat.base + yz + lat.tx(X0);
+		r0 = *(const uint4*)src;
+		r1 = *(const uint4*)(src + BRICK_BYTES);
+		rFar = lat.base[yz + lat.tx(min(X0 + 32, lat.last))];
+	}
+	// ---- the x faces (2: x = X0, 5: x = X0 + 32): samples (u, v) = (y, z) ----
+	const OFF xNeg = lat.tx(X0), xPos = lat.tx(min(X0 + 32, lat.last));
+#pragma unroll
+	for (int q = 0; q < 9; ++q) {
+		const int t = min(tid + q * WG, 2 * PLANE - 1);
+		const int fi = t >= PLANE ? 1 : 0, r = t - fi * PLANE;
+		const int vv = r / 33, uu = r - vv * 33;
+		g[q] = lat.base[(fi ? xPos : xNeg) + lat.ty(min(Y0 + uu, lat.last)) + lat.tz(min(Z0 + vv, lat.last))];
+	}
+}
+
+__device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1, i8 rFar, const i8 (&g)[9], u32 on, int tid, TrState& st)
+{
+	asm volatile("" : "+v"(tid));
+	if (tid < 132) {
+		const int fi = tid / 33, rowV = tid - fi * 33, rowFace = fi + (fi >= 2 ? 1 : 0);
+		if ((on >> rowFace) & 1u) {
+			i8* dst = st.plane[rowFace] + rowV * TR_PROW;
+			*(uint4*)dst = r0;
+			*(uint4*)(dst + 16) = r1;
+			dst[32] = rFar;
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 9; ++q) {
+		const int t = tid + q * WG;
+		if (t < 2 * PLANE) {
+			const int fi = t >= PLANE ? 1 : 0, r = t - fi * PLANE;
+			const int vv = r / 33, uu = r - vv * 33;
+			if ((on >> (fi ? 5 : 2)) & 1u) st.plane[fi ? 5 : 2][vv * TR_PROW + uu] = g[q];
+		}
+	}
+}
+
+#if !defined(VX_TR_WAVES)
+#define VX_TR_WAVES 5
+#endif
+// WIDE: a brick mirror of 4 GiB or more (grids beyond 1024^3): 64-bit voxel offsets around the vertices
+// (three waves per SIMD there: the 64-bit address terms do not fit the 128 registers of four)
+template <bool WIDE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : VX_TR_WAVES))) void k_transition(ExecParamsDev p, u32 levels)
 {
 	u8* tab = smem;
 	TrState& st = *(TrState*)(smem + TR_TAB_LDS);
@@ -1407,20 +1518,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	__shared__ u32 quietFaces[2];
 	u32 quietParity = 0;
 
-	if (threadIdx.x < 2) quietFaces[threadIdx.x] = 0;
-	if (threadIdx.x == 0) {
-		u32 run = 0;
-		for (u32 l = 0; l < MAX_LEVELS; ++l) {
-			wl.start[l] = run;
-			if (l < levels && p.levels[l].hasTransitions) run += p.G.dirty ? p.G.workCount[l] : *p.levels[l].nActive;
-		}
-		wl.start[MAX_LEVELS] = run;
-	}
-	__syncthreads();
-	const u32 total = wl.start[MAX_LEVELS];
-	if (blockIdx.x >= ((total + 63u) & ~63u)) return;
+	// (requested first: the copy is in flight while thread 0 fetches the level counts)
 	const Tables T = stage_transition_tables(tab, p.tables); // visible after the first barrier of the item loop
-	const int tid = threadIdx.x;
+	if (threadIdx.x < 2) quietFaces[threadIdx.x] = 0;
+	// Full runs: the work items are the leading entries of the run's list of active blocks of the levels >= 1
+	// (Globals::flatItems, level order) - the levels with transition cells are 1 .. refLevels - 2.  Incremental runs walk
+	// their per-level work lists.
+	u32 total = 0;
+	if (p.G.dirty) { // (uniform)
+		if (threadIdx.x == 0) {
+			u32 run = 0;
+			for (u32 l = 0; l < MAX_LEVELS; ++l) {
+				wl.start[l] = run;
+				if (l < levels && p.levels[l].hasTransitions) run += p.G.workCount[l];
+			}
+			wl.start[MAX_LEVELS] = run;
+		}
+		__syncthreads();
+		total = wl.start[MAX_LEVELS];
+	} else {
+		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) total += p.G.slotCounts[l];
+	}
+	total = __builtin_amdgcn_readfirstlane(total);
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return;
+	const int tid0 = threadIdx.x;
+	const GridView& gv = p.G.grid;
+	const BrickSamplerT<typename std::conditional<WIDE, size_t, u32>::type> smp = { gv.bDist, gv.bMat, gv.bBlend, gv.n - 1, (u32)gv.n >> 4, (u32)gv.bRowsY, gv.bYb0, gv.bZb0 };
 
 #if defined(VX_TR_PROFILE)
 	u32 prof[24] = { 0 };
@@ -1432,14 +1555,29 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
+		// Opaque per iteration: everything a lane derives from its index alone (row and sample coordinates, addresses in the
+		// LDS state ...) is the same for every item, and the compiler would compute it all once in front of this loop and
+		// keep it in registers through every phase - dozens of them, in a kernel at its register limit, for a loop that
+		// nearly always runs once.
+		int tid = tid0;
+		asm volatile("" : "+v"(tid));
 		RegBlockCtx b;
-		b.level = 0;
-		for (u32 l = 1; l < MAX_LEVELS; ++l) if (item >= wl.start[l] && wl.start[l + 1] > wl.start[l]) b.level = l;
-		b.slot = item - wl.start[b.level];
-		if (p.G.dirty) b.slot = p.G.workItems[b.level][b.slot];
+		u32 coordId;
+		if (p.G.dirty) { // (uniform)
+			b.level = 0;
+			for (u32 l = 1; l < MAX_LEVELS; ++l) if (item >= wl.start[l] && wl.start[l + 1] > wl.start[l]) b.level = l;
+			b.slot = p.G.workItems[b.level][item - wl.start[b.level]];
+			coordId = p.levels[b.level].slotCoord[b.slot];
+		} else {
+			const FlatItem fi = p.G.flatItems[item];
+			b.level = fi.where >> 24; b.slot = fi.where & 0xFFFFFFu;
+			coordId = fi.coordId;
+		}
+		b.level = __builtin_amdgcn_readfirstlane(b.level); b.slot = __builtin_amdgcn_readfirstlane(b.slot);
 		const LevelDesc& L = p.levels[b.level];
 		b.mult = L.mult;
-		block_coords(L.slotCoord[b.slot], L.cnt, b.bx, b.by, b.bz);
+		block_coords(__builtin_amdgcn_readfirstlane(coordId), L.cnt, b.bx, b.by, b.bz);
+		TR_TICK(0);
 
 		{
 			u32 on = 0;
@@ -1448,28 +1586,45 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				const FaceGeom fg = face_geom(f);
 				if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
 			}
+			// the planes are requested before the sign summaries below are looked at: both arrive in one round trip, and what
+			// the summaries say only decides which planes are stored
+			// (32-bit offsets: a lattice copy is at most an eighth of the grid; the grid's own mirror - level-1 planes - only
+			// qualifies while it is smaller than 4 GiB)
+			TrLatticeT<u32> lat;
+			uint4 rowLo = { 0, 0, 0, 0 }, rowHi = { 0, 0, 0, 0 };
+			i8 rowFar = 0, xFace[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			const bool haveLattice = !(WIDE && b.level == 1u) && tr_lattice_of(p.G, b.level, lat); // (uniform)
+			if (haveLattice) tr_planes_request(lat, b, tid, rowLo, rowHi, rowFar, xFace);
+			TR_TICK(1);
 			// A boundary plane whose samples all have one sign holds no transition cell.  The sign summaries of the level-0
 			// blocks (MirrorState::blockSign: "every voxel of the block's plane x = 0 / y = 0 / z = 0 is >= 0 / < 0") decide
 			// that without reading the plane: the face covers (mult + 1)^2 of those block planes, its far edge included.
 			// Faces found quiet are treated like faces without a neighbour block: not staged, no cells.
-			if (p.G.blockSign) {
-				const u32 cnt0 = p.levels[0].cnt, m1 = b.mult + 1u;
+			if (p.G.blockSign && b.mult <= 8u) {
+				const u32 cnt0 = p.levels[0].cnt, m1 = b.mult + 1u; // m1 <= 9: lane -> (du, dv) = (lane & 15, lane >> 4 + 4 * pass)
 				u32 quiet = 0;
 #pragma unroll
 				for (int f = 0; f < 6; ++f) { // (unrolled: the face's axes are compile-time constants)
 					if ((f & 3) != (tid >> 6) || !((on >> f) & 1u)) continue; // one wave per face; uniform per wave
 					const FaceGeom fg = face_geom(f);
 					const u32 field = fg.axis == 0 ? 1u : (fg.axis == 1 ? 2u : 4u);
-					u32 seen = 0; // bit 0: a plane of samples >= 0, bit 1: a plane of samples < 0, bit 2: a mixed or unknown plane
-					for (u32 i = (u32)tid & 63u; i < m1 * m1; i += 64u) {
-						const u32 du = i % m1, dv = i / m1;
-						const u32 qa = (fg.positive ? bc[fg.axis] + 1u : bc[fg.axis]) * b.mult;
-						const u32 qu = min(bc[fg.ua] * b.mult + du, cnt0 - 1u), qv = min(bc[fg.va] * b.mult + dv, cnt0 - 1u);
+					const u32 du = (u32)tid & 15u;
+					const u32 qa = (fg.positive ? bc[fg.axis] + 1u : bc[fg.axis]) * b.mult;
+					const u32 qu = min(bc[fg.ua] * b.mult + du, cnt0 - 1u);
+					u32 sg[3];
+#pragma unroll
+					for (u32 pass = 0; pass < 3; ++pass) { // all (at most three) summaries of a lane are requested together
+						const u32 dv = (((u32)tid >> 4) & 3u) + 4u * pass;
+						const u32 qv = min(bc[fg.va] * b.mult + dv, cnt0 - 1u);
 						int q[3];
 						face_scatter(fg, (int)qu, (int)qv, (int)qa, q);
-						const u32 sg = ((u32)p.G.blockSign[block_coord_id((u32)q[0], (u32)q[1], (u32)q[2], cnt0)] >> (2u * field)) & 3u;
-						seen |= sg == 1u ? 1u : (sg == 2u ? 2u : 4u);
+						const u32 id = block_coord_id((u32)q[0], (u32)q[1], (u32)q[2], cnt0);
+						const u32 word = p.G.blockSign[id]; // (the coordinates are clamped: every lane reads a valid entry)
+						sg[pass] = (du < m1 && dv < m1) ? (word >> (2u * field)) & 3u : 3u; // 3: outside the face
 					}
+					u32 seen = 0; // bit 0: a plane of samples >= 0, bit 1: a plane of samples < 0, bit 2: a mixed or unknown plane
+#pragma unroll
+					for (u32 pass = 0; pass < 3; ++pass) seen |= sg[pass] == 1u ? 1u : (sg[pass] == 2u ? 2u : (sg[pass] == 3u ? 0u : 4u));
 					const bool pos = __ballot((seen & 1u) != 0) != 0, neg = __ballot((seen & 2u) != 0) != 0, mixed = __ballot((seen & 4u) != 0) != 0;
 					if (!mixed && !(pos && neg)) quiet |= 1u << f;
 				}
@@ -1481,21 +1636,26 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			quietParity ^= 1u;
 			if (tid == 0) st.faceOn = on;
 			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
-			// 33 x 33 samples per face; three faces (15 loads per lane) are in flight together
-			// (a face that is off — uniform over the workgroup — is neither requested nor stored: nothing reads its plane)
-			i8 v[3][5];
-			if (on & 1u) tr_face_request<0>(p.G.grid, b, on, tid, v[0]);
-			if (on & 2u) tr_face_request<1>(p.G.grid, b, on, tid, v[1]);
-			if (on & 4u) tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
-			if (on & 1u) tr_face_store(st.plane[0], tid, v[0], true);
-			if (on & 2u) tr_face_store(st.plane[1], tid, v[1], true);
-			if (on & 4u) tr_face_store(st.plane[2], tid, v[2], true);
-			if (on & 8u) tr_face_request<3>(p.G.grid, b, on, tid, v[0]);
-			if (on & 16u) tr_face_request<4>(p.G.grid, b, on, tid, v[1]);
-			if (on & 32u) tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
-			if (on & 8u) tr_face_store(st.plane[3], tid, v[0], true);
-			if (on & 16u) tr_face_store(st.plane[4], tid, v[1], true);
-			if (on & 32u) tr_face_store(st.plane[5], tid, v[2], true);
+			if (haveLattice) {
+				tr_planes_store(rowLo, rowHi, rowFar, xFace, on, tid, st);
+			} else {
+				// no resident lattice for these planes: sample by sample from the grid's mirror; 33 x 33 samples per face, three
+				// faces (15 loads per lane) in flight together (a face that is off - uniform over the workgroup - is neither
+				// requested nor stored: nothing reads its plane)
+				i8 v[3][5];
+				if (on & 1u) tr_face_request<0>(p.G.grid, b, on, tid, v[0]);
+				if (on & 2u) tr_face_request<1>(p.G.grid, b, on, tid, v[1]);
+				if (on & 4u) tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
+				if (on & 1u) tr_face_store(st.plane[0], tid, v[0], true);
+				if (on & 2u) tr_face_store(st.plane[1], tid, v[1], true);
+				if (on & 4u) tr_face_store(st.plane[2], tid, v[2], true);
+				if (on & 8u) tr_face_request<3>(p.G.grid, b, on, tid, v[0]);
+				if (on & 16u) tr_face_request<4>(p.G.grid, b, on, tid, v[1]);
+				if (on & 32u) tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
+				if (on & 8u) tr_face_store(st.plane[3], tid, v[0], true);
+				if (on & 16u) tr_face_store(st.plane[4], tid, v[1], true);
+				if (on & 32u) tr_face_store(st.plane[5], tid, v[2], true);
+			}
 		}
 		__syncthreads(); TR_TICK(3);
 		tr_phase_classify(st, tid, WG);
@@ -1529,7 +1689,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 					if (chunk) __syncthreads(); TR_TICK(11);
 					tr_phase_describe(st, chunk, tid, WG);
 					__syncthreads(); TR_TICK(12);
-					tr_phase_emit_vertices(st, T, p.G, p.P, b, chunk, tid, WG);
+					tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
 				}
 				for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
 					__syncthreads(); TR_TICK(13);
@@ -1544,7 +1704,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		__syncthreads(); TR_TICK(15);
 	}
 #if defined(VX_TR_PROFILE)
-	if (tid == 0) for (int i = 0; i < 24; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[16 + i], prof[i] >> 6); // header words 192..215
+	if (tid0 == 0) for (int i = 0; i < 24; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[16 + i], prof[i] >> 6); // header words 192..215
 #endif
 }
 
@@ -1842,7 +2002,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -1862,9 +2022,11 @@ struct Backend {
 		tune.classifyRowGroup = env_u32("VX_CLASSIFY_ROWGROUP", 4);
 		tune.matGrid = env_u32("VX_MAT_GRID", 0);
 		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
+		tune.f1WgsPerCu = std::max<u32>(1, env_u32("VX_F1_WGS_PER_CU", 20));
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
 		tune.fast0 = env_u32("VX_FAST0", 1); // 0: every level-0 block through the general pass (A/B measurements)
 		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
+		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -1896,7 +2058,8 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>))), "hipFuncSetAttribute(k_regular1_fast)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
-		    || !check(hipFuncSetAttribute((const void*)k_transition, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
+		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")) {
 			err = lastError;
 			return false;
 		}
@@ -2222,7 +2385,7 @@ struct Backend {
 			if (!p.G.dirty && tune.fast1 && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
 				u32 capFast = 0;
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
-				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.regWgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd);
+				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd);
 				hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
 				generalBegin = fastEnd;
 			}
@@ -2355,8 +2518,12 @@ struct Backend {
 		u32 cap = 0;
 		for (u32 l = 1; l < levels; ++l) if (p.levels[l].hasTransitions) cap += p.levels[l].cap;
 		if (!cap) return;
-		const u32 grid = std::min<u32>(cap, tune.trGrid ? tune.trGrid : (u32)cus * 12);
-		hipLaunchKernelGGL(k_transition, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
+		// five resident workgroups per CU, each striding over its items (measured at 1024^3: 1280 workgroups 0.107 ms,
+		// 1024: 0.117, 1536: 0.126, one workgroup per block: 0.109 - a workgroup's start costs about as much as its planes)
+		const u32 grid = std::min<u32>(cap, tune.trGrid ? tune.trGrid : (u32)cus * 5);
+		const bool wide = (size_t)p.G.grid.n * p.G.grid.n * p.G.grid.n >= ((size_t)1 << 32) || tune.forceWide;
+		if (wide) hipLaunchKernelGGL(k_transition<true>, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
+		else hipLaunchKernelGGL(k_transition<false>, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		check(hipGetLastError(), "k_transition launch");
 	}
 };

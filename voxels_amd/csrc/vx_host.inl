@@ -59,6 +59,7 @@ struct vx_ctx {
 	bool ownsGrid = false;
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
+	void* dFlatItems = nullptr;                            // active blocks of the levels >= 1 in level order (Globals::flatItems)
 	void* dSlowItems[2] = { nullptr, nullptr };            // blocks handed from the fast regular passes to the general one (level 0 | levels >= 1)
 	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
@@ -292,6 +293,8 @@ bool ensure_level_tables(vx_ctx* c)
 		for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) coarse += c->lv[L].cap;
 		c->dSlowItems[1] = alloc(coarse * 4 + 16);
 		if (!c->dSlowItems[1]) return false;
+		c->dFlatItems = alloc(coarse * 16 + 16);
+		if (!c->dFlatItems) return false;
 	}
 	{
 		size_t wgs = 0;
@@ -333,6 +336,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.slowItems[0] = (u32*)c->dSlowItems[0];
 	p.G.slowItems[1] = (u32*)c->dSlowItems[1];
 	p.G.slowCount = (u32*)c->dHeader + HDR_SLOW;
+	p.G.flatItems = (FlatItem*)c->dFlatItems;
+	p.G.slotCounts = (const u32*)c->dHeader;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
