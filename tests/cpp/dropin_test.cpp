@@ -106,7 +106,10 @@ static void LogSink(LogSeverity sev, const char* msg) { if (sev >= LS_Error) fpr
 
 int main(int argc, char** argv)
 {
-	if (argc < 3) { fprintf(stderr, "usage: %s <grid edge> <out file>\n", argv[0]); return 2; }
+	if (argc < 3) { fprintf(stderr, "usage: %s <grid edge> <out file> [B]\n", argv[0]); return 2; }
+	// "B": the Modification is executed by a SECOND Polygonizer, after the first one has been reused for a full run on
+	// another grid (the reference keeps a surface's caches in the PolygonSurface, so any Polygonizer can update it)
+	const bool second = argc > 3 && argv[3][0] == 'B';
 	const unsigned n = (unsigned)atoi(argv[1]);
 	FILE* f = fopen(argv[2], "wb");
 	if (!f) return 2;
@@ -132,7 +135,18 @@ int main(int argc, char** argv)
 	mod->Map = surface;
 	mod->MinCornerModified = box.first;
 	mod->MaxCornerModified = box.second;
-	PolygonSurface* updated = poly.Execute(*grid, &mats, mod);
+	Polygonizer polyB;
+	if (second) {
+		Ball other; other.r = n * 0.2f;
+		Grid* g2 = Grid::Create(n / 2, n / 2, n / 2, 0.f, 0.f, 0.f, 1.f, &other);
+		if (!g2) return 4;
+		PolygonSurface* s2 = poly.Execute(*g2, &mats);
+		if (!s2) return 5;
+		Dump(f, s2);
+		s2->Destroy();
+		g2->Destroy();
+	}
+	PolygonSurface* updated = (second ? polyB : poly).Execute(*grid, &mats, mod);
 	if (updated != surface) { fprintf(stderr, "Modification did not update the surface in place\n"); return 6; }
 	unsigned mc = 0;
 	const unsigned* ids = mod->GetModifiedBlocks(&mc);

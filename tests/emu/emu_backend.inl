@@ -203,8 +203,9 @@ struct Backend {
 		publish_level0_block(p.G, p.levels[0], bx, by, bz, bits, cnt, accumulate);
 	}
 
+	template <typename P> bool classify_activates_ancestors(const P&) const { return false; }
 	template <typename P>
-	void run_classify(const P& p)
+	void run_classify(const P& p, bool)
 	{
 		const LevelDesc& L = p.levels[0];
 		std::vector<i8> samp(SAMPLES + 7);
@@ -251,7 +252,7 @@ struct Backend {
 	static u32 item_slot(const P& p, u32 level, u32 i) { return p.G.dirty ? p.G.workItems[level][i] : i; }
 
 	template <typename P>
-	void run_hierarchy(const P& p, u32 levels)
+	void run_hierarchy(const P& p, u32 levels, bool = false)
 	{
 		const LevelDesc& L0 = p.levels[0];
 		for (u32 s = 0; s < *L0.nActive; ++s) {

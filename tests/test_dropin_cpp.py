@@ -22,16 +22,19 @@ def test_public_headers_compile_standalone(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [64, 128])
-def test_same_application_same_bytes(tmp_path, n):
+@pytest.mark.parametrize("n,variant", [(64, ""), (128, ""), (64, "B")])
+def test_same_application_same_bytes(tmp_path, n, variant):
+    """variant "B": the Modification runs on a second Polygonizer after the first was reused on another grid - a surface
+    carries its caches (src/TransVoxelImpl.h:81-95), whoever updates it."""
     from voxels_amd import build
     build.build_cpp_api()
     build.build_dropin_tests()
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/dropin_ref not built (needs /root/reference at build time)")
     a, b = str(tmp_path / "ours.bin"), str(tmp_path / "ref.bin")
-    subprocess.check_call([OURS, str(n), a])
-    subprocess.check_call([REF, str(n), b])
+    extra = [variant] if variant else []
+    subprocess.check_call([OURS, str(n), a] + extra)
+    subprocess.check_call([REF, str(n), b] + extra)
     da, db = open(a, "rb").read(), open(b, "rb").read()
     assert len(da) == len(db), (len(da), len(db))
     if da != db:

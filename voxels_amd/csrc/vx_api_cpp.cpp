@@ -148,6 +148,8 @@ void Grid::ModifyBlockMaterialData(const float3& c, const MaterialId* materials,
 }
 
 // ------------------------------------------------------------------------------------------------ surface
+struct DeviceState; // below: the device context a surface shares with the Polygonizer that made it
+
 namespace
 {
 
@@ -196,7 +198,7 @@ struct SurfaceImpl : public PolygonSurface
 	vx_host_meshes Meshes = { nullptr, nullptr, 0, 0, nullptr }; // owned: released with the surface
 	PolygonizationStatistics Stats;
 	unsigned GridSize = 0;
-	vx_ctx* Owner = nullptr; // context whose device caches belong to this surface (needed by Modification)
+	std::shared_ptr<DeviceState> Device; // the context whose device caches describe this surface: kept alive by the surface, usable by any Polygonizer (Modification)
 
 	~SurfaceImpl() { if (Meshes.arena) vx_host_meshes_release(Meshes.arena); }
 	float3 GetExtents() const override { return Extents; }
@@ -291,25 +293,26 @@ Modification* Modification::Create()
 
 Modification::~Modification() {}
 
-// ------------------------------------------------------------------------------------------------ polygonizer
-class TransVoxelImpl
+// One device context with the grid mirrored in it and the caches of the last surface it produced (the reference keeps
+// those caches - consistency bitmaps, material caches, slot maps - inside the PolygonSurface, src/TransVoxelImpl.h:81-95;
+// here they live in HBM, owned jointly by the Polygonizer that made the surface and by the surface itself).
+struct DeviceState
 {
-public:
 	vx_ctx* Ctx = nullptr;
 	uint64_t ResidentGridUid = 0; // VoxelGrid::Uid of the grid mirrored in HBM (0 = none; never compare addresses: they get reused)
 	uint64_t ResidentGeneration = 0;
 
-	~TransVoxelImpl() { if (Ctx) vx_ctx_destroy(Ctx); }
+	~DeviceState() { if (Ctx) vx_ctx_destroy(Ctx); }
 
-	bool EnsureContext()
+	static std::shared_ptr<DeviceState> Create()
 	{
-		if (Ctx) return true;
-		if (vx_ctx_create(0, &Ctx) != VX_OK) {
-			Ctx = nullptr;
+		std::shared_ptr<DeviceState> d(new DeviceState);
+		if (vx_ctx_create(0, &d->Ctx) != VX_OK) {
+			d->Ctx = nullptr;
 			Log(LS_CriticalError, "Voxels: no usable HIP device (libvoxels_hip has no CPU fallback)");
-			return false;
+			return nullptr;
 		}
-		return true;
+		return d;
 	}
 
 	// mirror the host grid into HBM: whole grid the first time, edited blocks afterwards
@@ -328,7 +331,7 @@ public:
 			ResidentGridUid = g.Uid();
 		} else if (ResidentGeneration != g.Generation()) {
 			std::vector<uint32_t> ids;
-			g.DirtySince(ResidentGeneration, ids); // per-consumer: another Polygonizer mirroring the same grid is not affected
+			g.DirtySince(ResidentGeneration, ids); // per-consumer: another mirror of the same grid is not affected
 			std::vector<int8_t> d(ids.size() * 4096);
 			std::vector<uint8_t> m(ids.size() * 4096), b(ids.size() * 4096);
 			const uint32_t nb = g.BlocksPerAxis();
@@ -351,6 +354,13 @@ public:
 		}
 		return vx_material_lut(Ctx, lut, valid) == VX_OK;
 	}
+};
+
+// ------------------------------------------------------------------------------------------------ polygonizer
+class TransVoxelImpl
+{
+public:
+	std::shared_ptr<DeviceState> Device; // where this Polygonizer's full runs happen
 
 	static void FillStats(vx_ctx* ctx, PolygonizationStatistics& st)
 	{
@@ -363,7 +373,7 @@ public:
 	PolygonSurface* Execute(const Grid& grid, const MaterialMap* materials, Modification* modification)
 	{
 		VoxelGrid* g = grid.GetInternalRepresentation();
-		if (!g || !EnsureContext()) return nullptr;
+		if (!g) return nullptr;
 		// VOXELS_TRACE=1: where a call spends its time (stderr)
 		static const bool trace = getenv("VOXELS_TRACE") != nullptr;
 		auto t0 = std::chrono::steady_clock::now();
@@ -373,31 +383,38 @@ public:
 			fprintf(stderr, "[Voxels] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
 			t0 = t1;
 		};
-		if (!SyncGrid(*g) || !SyncMaterials(materials)) {
-			Log(LS_Error, vx_last_error(Ctx));
-			return nullptr;
-		}
-		lap("grid + materials to device");
-		vx_exec_info info;
 		if (!modification) {
-			if (vx_polygonize(Ctx, 0, &info) != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+			// A surface that is still alive shares the device state it was made in (its caches are there, and a later
+			// Modification needs them): a new full run then gets a context of its own instead of overwriting them.
+			if (!Device || Device.use_count() > 1) Device = DeviceState::Create();
+			if (!Device) return nullptr;
+			vx_ctx* ctx = Device->Ctx;
+			if (!Device->SyncGrid(*g) || !Device->SyncMaterials(materials)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
+			lap("grid + materials to device");
+			vx_exec_info info;
+			if (vx_polygonize(ctx, 0, &info) != VX_OK) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 			lap("vx_polygonize");
 			SurfaceImpl* s = new SurfaceImpl;
 			s->GridSize = g->Size();
-			s->Owner = Ctx;
+			s->Device = Device;
 			s->Extents = float3((float)g->Size(), (float)g->Size(), (float)g->Size());
-			if (!FetchSurface(Ctx, info.levels, *s)) { Log(LS_Error, vx_last_error(Ctx)); delete s; return nullptr; }
+			if (!FetchSurface(ctx, info.levels, *s)) { Log(LS_Error, vx_last_error(ctx)); delete s; return nullptr; }
 			lap("meshes to host + block views");
-			FillStats(Ctx, s->Stats);
+			FillStats(ctx, s->Stats);
 			return s;
 		}
-		// incremental run over the modification's dirty box: the same Map object is updated in place
+		// Incremental run over the modification's dirty box: the same Map object is updated in place, in the device state
+		// the surface carries - whichever Polygonizer is asked to do it (the reference's caches travel with the
+		// PolygonSurface the same way, src/TransVoxelImpl.cpp:362-364).
 		SurfaceImpl* s = static_cast<SurfaceImpl*>(modification->Map);
 		ModificationImpl* mod = static_cast<ModificationImpl*>(modification);
-		if (!s || s->Owner != Ctx) {
-			Log(LS_Error, "Modification: the surface was not produced by this Polygonizer's last full Execute");
+		if (!s || !s->Device) {
+			Log(LS_Error, "Modification: no surface to update (Modification::Map)");
 			return nullptr;
 		}
+		DeviceState& dev = *s->Device;
+		vx_ctx* ctx = dev.Ctx;
+		if (!dev.SyncGrid(*g) || !dev.SyncMaterials(materials)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 		const float mn[3] = { modification->MinCornerModified.x, modification->MinCornerModified.y, modification->MinCornerModified.z };
 		const float mx[3] = { modification->MaxCornerModified.x, modification->MaxCornerModified.y, modification->MaxCornerModified.z };
 		// room for every block of every level: the run cannot report more, so it never has to be repeated for space
@@ -405,15 +422,16 @@ public:
 		for (uint32_t cnt = g->Size() / 16; cnt; cnt >>= 1) allBlocks += (size_t)cnt * cnt * cnt;
 		std::vector<uint32_t> ids(allBlocks + 1);
 		uint32_t count = 0;
-		int rc = vx_polygonize_dirty(Ctx, mn, mx, &info, ids.data(), (uint32_t)ids.size(), &count);
+		vx_exec_info info;
+		int rc = vx_polygonize_dirty(ctx, mn, mx, &info, ids.data(), (uint32_t)ids.size(), &count);
 		if (rc == VX_OK && count > ids.size()) {
 			Log(LS_Error, "Modification: too many modified blocks");
 			return nullptr;
 		}
-		if (rc != VX_OK) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
+		if (rc != VX_OK) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 		mod->ModifiedBlocks.insert(mod->ModifiedBlocks.end(), ids.begin(), ids.begin() + count);
-		if (!FetchSurface(Ctx, std::min<unsigned>(info.levels, (unsigned)s->Levels.size()), *s)) { Log(LS_Error, vx_last_error(Ctx)); return nullptr; }
-		FillStats(Ctx, s->Stats);
+		if (!FetchSurface(ctx, std::min<unsigned>(info.levels, (unsigned)s->Levels.size()), *s)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
+		FillStats(ctx, s->Stats);
 		return s;
 	}
 };

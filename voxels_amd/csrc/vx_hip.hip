@@ -678,7 +678,7 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
 constexpr int TW = TB / 2;        // 32-bit words of sign bits per tile row
 
-__global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
+__global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, u32 activateAncestors)
 {
 	__shared__ __attribute__((aligned(16))) u16 sgn[289 * TB];  // sign masks: row r = rz*17+ry, TB x 16 voxels
 	__shared__ u8 halo[292];                                     // sign of the voxel right of the tile, per row
@@ -860,6 +860,21 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup)
 			if (blockCnt[tid] > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
 			blockSkipped[tid] = skipped ? 1u : 0u;
 			blockSlot[tid] = (int)slot;
+			// Small block ranges (128^3 grids, the slabs of an 8-rank run): the block's ancestors become active on the levels
+			// 1 .. levels-1 right here (whoever marks an ancestor first gives it its slot and goes on upwards) - one launch and
+			// its hand-over less on a run's critical path (128^3: kernels done after 147 us instead of 173).  With many active
+			// blocks the chains of dependent atomics at the tail of the workgroups cost more than that (1024^3: +21 us on
+			// k_classify against 9 us for k_hierarchy, where every block has a lane of its own).
+			for (u32 l = 1; activateAncestors && l < p.G.levels; ++l) {
+				const LevelDesc& A = p.levels[l];
+				const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+				if (px >= A.cnt || py >= A.cnt || pz >= A.cnt) break;
+				const u32 aid = block_coord_id(px, py, pz, A.cnt);
+				if (atomicCAS(&A.slotOf[aid], -1, -2) != -1) break; // somebody else owns this ancestor chain
+				const u32 aslot = atomicAdd(A.nActive, 1u);
+				A.slotCoord[aslot] = aid;
+				A.slotOf[aid] = (int)aslot; // visible to the next kernel
+			}
 		}
 	}
 	__syncthreads();
@@ -2002,7 +2017,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2026,6 +2041,7 @@ struct Backend {
 		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
 		tune.fast0 = env_u32("VX_FAST0", 1); // 0: every level-0 block through the general pass (A/B measurements)
 		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
+		tune.foldBlocks = env_u32("VX_FOLD_BLOCKS", 65536); // level-0 blocks up to which k_classify also activates the ancestors
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -2268,8 +2284,16 @@ struct Backend {
 		return d;
 	}
 
+	// full runs over few level-0 blocks: k_classify does k_hierarchy's work (see there)
 	template <typename P>
-	void run_classify(const P& p)
+	bool classify_activates_ancestors(const P& p) const
+	{
+		const LevelDesc& L = p.levels[0];
+		return (size_t)L.cnt * (L.yb1 - L.yb0) * (L.zb1 - L.zb0) <= (size_t)tune.foldBlocks;
+	}
+	// carryClassified: the classify launch carries the event that releases the level-0 regular pass on side stream A
+	template <typename P>
+	void run_classify(const P& p, bool carryClassified)
 	{
 		const LevelDesc& L = p.levels[0];
 		const u32 tilesX = (L.cnt + TB - 1) / TB;
@@ -2291,7 +2315,8 @@ struct Backend {
 			if (!rowGroup) rowGroup = 1;
 		}
 		stage_mark(1); // stage times: [0] = reset + block classes, [1] = k_classify alone
-		hipLaunchKernelGGL(k_classify, dim3(grid), dim3(WG), 0, stream, dev(p), rowGroup);
+		if (carryClassified) doneEvent = evClassified;
+		launch_with_event(k_classify, dim3(grid), 0u, dev(p), rowGroup, classify_activates_ancestors(p) ? 1u : 0u);
 		check(hipGetLastError(), "k_classify launch");
 	}
 	template <typename P>
@@ -2331,10 +2356,11 @@ struct Backend {
 		doneEvent = nullptr;
 	}
 	template <typename P>
-	void run_hierarchy(const P& p, u32 levels)
+	void run_hierarchy(const P& p, u32 levels, bool carryClassified = false)
 	{
-		if (levels < 2) return;
+		if (levels < 2) { if (carryClassified) (void)hipEventRecord(evClassified, stream); return; }
 		const u32 grid = (p.levels[0].cap + WG - 1) / WG;
+		if (carryClassified) doneEvent = evClassified;
 		launch_with_event(k_hierarchy, dim3(grid), 0u, dev(p), levels);
 		check(hipGetLastError(), "k_hierarchy launch");
 	}
@@ -2407,10 +2433,7 @@ struct Backend {
 	template <typename P>
 	void run_overlapped_tail(const P& p, u32 levels)
 	{
-		// the hierarchy pass carries the event that releases the level-0 regular pass on side stream A (levels == 1: no
-		// hierarchy pass, the event is recorded)
-		if (levels >= 2) { doneEvent = evClassified; run_hierarchy(p, levels); }
-		else (void)hipEventRecord(evClassified, stream);
+		// (the classify launch carried the event that releases the level-0 regular pass on side stream A)
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
 		launch_regular(p, 0, 1, sideA);
 		(void)hipEventRecord(evSideA, sideA); // side streams: a recorded event (attached ones made the run slower there)

@@ -397,14 +397,19 @@ void build_table_image(std::vector<u8>& img)
 // one pass of the device pipeline over the blocks listed in the level tables
 void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 {
-	c->be.run_classify(p); // k_run_reset + k_block_class, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
+	const bool overlapped = !c->be.stage_timing_on();
+	const bool ancestorsDone = c->be.classify_activates_ancestors(p);
+	c->be.run_classify(p, overlapped && ancestorsDone); // k_run_reset + k_block_class, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
 	c->be.stage_mark(2);
-	if (!c->be.stage_timing_on()) {
+	// (the HIP backend's classify pass also activates the ancestors of the blocks it finds; the hierarchy pass remains the
+	// second step of an incremental run, and of the CPU emulation)
+	if (overlapped) {
 		// normal operation: independent stages overlap on side streams (per-stage times are then meaningless)
-		c->be.run_overlapped_tail(p, levels); // hierarchy pass included
+		if (!ancestorsDone) c->be.run_hierarchy(p, levels, true); // (carries the event that releases side stream A)
+		c->be.run_overlapped_tail(p, levels);
 		return;
 	}
-	c->be.run_hierarchy(p, levels);
+	if (!ancestorsDone) c->be.run_hierarchy(p, levels, false);
 	c->be.stage_mark(3);
 	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
 	c->be.stage_mark(4);
