@@ -79,7 +79,7 @@ def build_hip_casedump(force=False):
 def build_synth(force=False):
     """Host-side synthetic input generator (include/voxels_synth.h)."""
     out = os.path.join(CSRC, "libvoxels_synth.so")
-    srcs = [os.path.join(CSRC, "vx_synth.cpp"), os.path.join(ROOT, "include", "voxels_synth.h")]
+    srcs = [os.path.join(CSRC, "vx_synth.cpp"), os.path.join(CSRC, "vx_terrain_math.h"), os.path.join(ROOT, "include", "voxels_synth.h")]
     if not force and not _newer(out, srcs):
         return out
     subprocess.check_call(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-o", out,

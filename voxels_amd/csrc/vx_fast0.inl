@@ -157,8 +157,9 @@ __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Bl
 }
 
 template <int CAP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p, u32 lo)
 {
+	if (lo && *p.G.largeBlocks == 0) return; // nothing for the capacity classes above the first (uniform over the grid)
 	static_assert(F0_MROW == R0_MROW, "the prefetch of vx_regular0.inl stages 20-byte material rows");
 	typedef Fast0State<CAP> ST;
 	typedef R0<CAP> K;
@@ -180,10 +181,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	R0Block cur, nxt;
 	F0Prefetch pf;
 	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
-	bool have = r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), cur);
+	bool have = r0_next_item<CAP, 0>(p, L, total, lo, it, r0_peek<0>(p, L, total, it), cur);
 	if (have) f0_request(g, L, cur, pf);
 	it += gridDim.x;
-	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, r0_peek<0>(p, L, total, it), nxt);
+	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, lo, it, r0_peek<0>(p, L, total, it), nxt);
 	u32 parity = 0;
 	while (have) {
 		const u32 candIt = it + gridDim.x;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		cur = nxt;
 		have = haveNext;
 		it = candIt;
-		haveNext = have && r0_next_item<CAP, 0>(p, L, total, 0u, it, cand, nxt);
+		haveNext = have && r0_next_item<CAP, 0>(p, L, total, lo, it, cand, nxt);
 	}
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);

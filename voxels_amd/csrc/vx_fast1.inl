@@ -38,8 +38,9 @@ struct BrickSamplerT {
 typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller than 4 GiB
 
 template <int CAP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular1_fast(ExecParamsDev p, u32 levelEnd)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular1_fast(ExecParamsDev p, u32 levelEnd, u32 lo)
 {
+	if (lo && *p.G.largeBlocks == 0) return; // nothing for the capacity classes above the first (uniform over the grid)
 	typedef Fast1State<CAP> ST;
 	typedef R0<CAP> K;
 	u8* tab = smem;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 		const u32 level = r0_uniform(fi.where >> 24), slot = r0_uniform(fi.where & 0xFFFFFFu);
 		const LevelDesc& L = p.levels[level];
 		const u32 ntc = r0_uniform(fi.ntCells);
-		if (ntc > (u32)CAP) continue;                       // the 4096-cell class of the general pass owns those
+		if (ntc > (u32)CAP || (lo && ntc <= lo)) continue;   // another capacity class owns those (the first class, lo == 0, also owns the empty blocks)
 		const u32 coord = r0_uniform(fi.coordId);
 		if (ntc == 0) {                                     // (uniform) a surface-bearing block without a non-trivial coarse cell
 			if (tid == 0) reg_write_empty_record(L, slot);

@@ -50,6 +50,7 @@ struct ExecParamsDev {
 
 constexpr int WG = 256;
 constexpr int REG_CAP_SMALL = LARGE_THRESHOLD; // LDS capacity class of the regular pass that covers ordinary surfaces
+constexpr int REG_CAP_MID = 1536;               // second class of the table-driven passes (dense surfaces: three workgroups per CU instead of one in the 4096-cell class)
 
 // ------------------------------------------------------------------------------------------------------
 // workgroup helpers
@@ -2066,13 +2067,17 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, incremental)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, incremental)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, handed on)")
-		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, f0Small), "hipFuncSetAttribute(k_regular0_fast)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, f0Small), "hipFuncSetAttribute(k_regular0_fast)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>))), "hipFuncSetAttribute(k_regular0_fast mid)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, handed on)")) {
 			err = lastError;
 			return false;
 		}
 		if (!check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>))), "hipFuncSetAttribute(k_regular1_fast)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>))), "hipFuncSetAttribute(k_regular1_fast mid)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")) {
@@ -2389,9 +2394,15 @@ struct Backend {
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
 			} else if (tune.fast0) {
 				// blocks without a zero sample: the table-driven pass; the others are handed on through Globals::slowItems
-				hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p));
+				// (dense surfaces: a second table-driven class up to REG_CAP_MID cells; beyond that, and for what either class
+				// hands on, the general pass in its two classes)
+				hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p), 0u);
+				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_MID>), dim3(std::min<u32>(cap, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>), on, dev(p), (u32)REG_CAP_SMALL);
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(std::min<u32>(gridS, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 0u);
-				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+				if (largeClass) {
+					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
+					hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
+				}
 			} else {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 0>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
@@ -2411,14 +2422,20 @@ struct Backend {
 			if (!p.G.dirty && tune.fast1 && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
 				u32 capFast = 0;
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
-				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd);
+				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
+				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), on, dev(p), fastEnd, (u32)REG_CAP_SMALL);
 				hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
+				if (largeClass) {
+					const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
+					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
+					hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
+				}
 				generalBegin = fastEnd;
 			}
 			u32 capGeneral = 0;
 			for (u32 l = generalBegin; l < levels; ++l) capGeneral += p.levels[l].cap;
 			if (capGeneral) hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 0>), dim3(std::min<u32>(capGeneral, (u32)cus * tune.regWgsPerCu)), dim3(WG), ldsS, on, dev(p), generalBegin, levels, 0u);
-			if (largeClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(cap, (u32)cus)), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), levelBegin, levels, (u32)REG_CAP_SMALL);
+			if (largeClass && capGeneral) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capGeneral, (u32)cus)), dim3(WG), REG_TAB_LDS + sizeof(RegStateT<4096>), on, dev(p), generalBegin, levels, (u32)REG_CAP_SMALL);
 		}
 		check(hipGetLastError(), "k_regular launch");
 	}

@@ -82,15 +82,15 @@ VXT_HD float height(uint32_t n, uint32_t x, uint32_t y, uint32_t seed)
 
 // one voxel: quantised distance, material id, blend
 // style 0: the height-field terrain with overhangs (the benchmark's headline workload); style 1: "caves" — the same
-// heights, but the distance falls off 32 times slower and the 3-D noise term dominates, so that an isosurface network
-// fills a band of about +-190 voxels around the terrain height: a workload where a large share of ALL blocks carries
+// heights, but the distance falls off 64 times slower and the 3-D noise term dominates, so that an isosurface network
+// fills a band of about +-380 voxels around the terrain height: a workload where a large share of ALL blocks carries
 // surface (the reference has no generator at all: surfaces are application callbacks, include/VoxelSurface.h)
 VXT_HD void voxel(uint32_t x, uint32_t y, uint32_t z, float h, uint32_t seed, int8_t& dist, uint8_t& mat, uint8_t& blend, uint32_t style = 0)
 {
 	const float CAVE_AMP = style ? 6.0f : 5.0f;
 	const float caveFreq = 1.0f / 24.0f;
 	float d = (float)z - h;
-	if (style) d = d * (1.0f / 32.0f) - CAVE_AMP * noise3((float)x * caveFreq, (float)y * caveFreq, (float)z * caveFreq, seed + 977u);
+	if (style) d = d * (1.0f / 64.0f) - CAVE_AMP * noise3((float)x * caveFreq, (float)y * caveFreq, (float)z * caveFreq, seed + 977u);
 	else if (d > 4.0f + CAVE_AMP) d = 100.f;       // far above: clamped to +4 anyway
 	else if (d < -(4.0f + CAVE_AMP)) d = -100.f;   // far below
 	else d = d - CAVE_AMP * noise3((float)x * caveFreq, (float)y * caveFreq, (float)z * caveFreq, seed + 977u);
