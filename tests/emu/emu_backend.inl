@@ -137,6 +137,7 @@ struct Backend {
 		}
 	}
 	void end_timing_record() {}
+	void end_overlapped() {}
 	float elapsed_ms() { return 0.f; }
 	template <typename P>
 	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)

@@ -35,10 +35,13 @@ def main():
             slab.attach(p)
             for _ in range(5):
                 p.execute(levels)
-            t = time.perf_counter()
-            for _ in range(30):
-                info = p.execute(levels)
-            dt = (time.perf_counter() - t) / 30
+            dt = None
+            for _ in range(3):  # best of three batches (a single slow call would otherwise decide the maximum over ranks)
+                t = time.perf_counter()
+                for _ in range(20):
+                    info = p.execute(levels)
+                batch = (time.perf_counter() - t) / 20
+                dt = batch if dt is None else min(dt, batch)
             res.append((dt * 1e3, info.device_ms, int(info.active_blocks[0])))
             p.close()
             del slab

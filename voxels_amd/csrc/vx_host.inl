@@ -1235,10 +1235,11 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		c->be.end_timing_record();
 		// the header travels right behind the kernels: one host wait per run
 		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned(HDR_WORDS * 4);
-		if (!c->hdrPinned) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed");
+		if (!c->hdrPinned) { c->be.sync(); c->be.end_overlapped(); return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed"); }
 		bool okRun = c->be.d2h_async(c->hdrPinned, c->dHeader, HDR_WORDS * 4);
 		t1 = tNow();
 		okRun = okRun && c->be.sync_ok();
+		c->be.end_overlapped(); // (the tail of an overlapped run was queued on a side stream)
 		t2 = tNow();
 		if (!okRun) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
 		ms = c->be.elapsed_ms();
