@@ -2007,6 +2007,10 @@ __global__ __launch_bounds__(WG) void k_gather_records(ExecParamsDev p, DirtyRan
 struct Backend {
 	hipStream_t ownStream = nullptr, stream = nullptr;
 	hipStream_t sideA = nullptr, sideB = nullptr;      // level-0 regular pass / transition pass run beside the material chain
+	hipStream_t sideC = nullptr;                       // dense surfaces: the capacity classes above the first of level 0 (few workgroups per CU, long-running: beside the first class, not behind it); those of the levels >= 1 follow the transition pass on side stream B (a fifth stream would share a hardware queue with this one and wait behind it)
+	hipEvent_t evMidC = nullptr, evMidD = nullptr, evSideC = nullptr, evSideD = nullptr;
+	bool spreadC = false, spreadD = false;           // this run queued work on side stream C / D
+	bool overlappedTail = false;                     // inside run_overlapped_tail
 	hipEvent_t evClassified = nullptr, evMaterial = nullptr, evSideA = nullptr, evSideB = nullptr, evMain = nullptr;
 	hipStream_t mainKeep = nullptr; // set while the tail of an overlapped run is queued on side stream A
 	hipStream_t copyStream[4] = { nullptr, nullptr, nullptr, nullptr }; // d2h_bulk
@@ -2051,6 +2055,11 @@ struct Backend {
 		stream = ownStream;
 		if (!check(hipStreamCreateWithFlags(&sideA, hipStreamNonBlocking), "hipStreamCreate(side A)")
 		    || !check(hipStreamCreateWithFlags(&sideB, hipStreamNonBlocking), "hipStreamCreate(side B)")
+		    || !check(hipStreamCreateWithFlags(&sideC, hipStreamNonBlocking), "hipStreamCreate(side C)")
+		    || !check(hipEventCreateWithFlags(&evMidC, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evMidD, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evSideC, hipEventDisableTiming), "hipEventCreate")
+		    || !check(hipEventCreateWithFlags(&evSideD, hipEventDisableTiming), "hipEventCreate")
 		    || !check(hipEventCreateWithFlags(&evClassified, hipEventDisableTiming), "hipEventCreate")
 		    || !check(hipEventCreateWithFlags(&evMaterial, hipEventDisableTiming), "hipEventCreate")
 		    || !check(hipEventCreateWithFlags(&evSideA, hipEventDisableTiming), "hipEventCreate")
@@ -2097,6 +2106,8 @@ struct Backend {
 		if (evCopy) (void)hipEventDestroy(evCopy);
 		if (sideA) (void)hipStreamDestroy(sideA);
 		if (sideB) (void)hipStreamDestroy(sideB);
+		if (sideC) (void)hipStreamDestroy(sideC);
+		for (hipEvent_t e : { evMidC, evMidD, evSideC, evSideD }) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { evClassified, evMaterial, evSideA, evSideB, evMain }) if (e) (void)hipEventDestroy(e);
 		if (ownStream) (void)hipStreamDestroy(ownStream);
 	}
@@ -2398,12 +2409,25 @@ struct Backend {
 				// blocks without a zero sample: the table-driven pass; the others are handed on through Globals::slowItems
 				// (dense surfaces: a second table-driven class up to REG_CAP_MID cells; beyond that, and for what either class
 				// hands on, the general pass in its two classes)
+				// Overlapped runs put the upper classes on a stream of their own (side C, released like this one by the
+				// classification): with three or one workgroup per CU they run long and leave room, so they belong beside the
+				// first class, not behind it (second bench workload: 3.84 -> 3.69 ms).  What the two table-driven classes hand
+				// on is only complete when both are done.
+				const bool spread = largeClass && on == sideA;
+				hipStream_t upper = spread ? sideC : on;
+				if (spread) { (void)hipStreamWaitEvent(sideC, evClassified, 0); spreadC = true; }
 				hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p), 0u);
-				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_MID>), dim3(std::min<u32>(cap, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>), on, dev(p), (u32)REG_CAP_SMALL);
+				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_MID>), dim3(std::min<u32>(cap, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>), upper, dev(p), (u32)REG_CAP_SMALL);
+				if (spread) {
+					(void)hipEventRecord(evMidC, sideC);
+					hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, sideC, dev(p), (u32)REG_CAP_MID);
+					(void)hipEventRecord(evSideC, sideC);
+					(void)hipStreamWaitEvent(on, evMidC, 0);
+				}
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(std::min<u32>(gridS, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
-					hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
+					if (!spread) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
 				}
 			} else {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 0>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
@@ -2424,13 +2448,25 @@ struct Backend {
 			if (!p.G.dirty && tune.fast1 && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
 				u32 capFast = 0;
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
+				// (as on level 0: the upper classes beside the first one when the run is overlapped, i.e. when this is the main
+				// stream of run_overlapped_tail - on side stream B, behind the transition pass)
+				const bool spread = largeClass && overlappedTail && on == stream;
+				hipStream_t sideD = sideB;
+				hipStream_t upper = spread ? sideD : on;
+				const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
+				if (spread) { (void)hipStreamWaitEvent(sideD, evMaterial, 0); spreadD = true; }
 				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
-				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), on, dev(p), fastEnd, (u32)REG_CAP_SMALL);
+				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), upper, dev(p), fastEnd, (u32)REG_CAP_SMALL);
+				if (spread) {
+					(void)hipEventRecord(evMidD, sideD);
+					hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, sideD, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
+					(void)hipEventRecord(evSideD, sideD);
+					(void)hipStreamWaitEvent(on, evMidD, 0);
+				}
 				hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
 				if (largeClass) {
-					const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
-					hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
+					if (!spread) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
 				}
 				generalBegin = fastEnd;
 			}
@@ -2453,6 +2489,8 @@ struct Backend {
 	void run_overlapped_tail(const P& p, u32 levels)
 	{
 		// (the classify launch carried the event that releases the level-0 regular pass on side stream A)
+		overlappedTail = true;
+		spreadC = spreadD = false;
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
 		launch_regular(p, 0, 1, sideA);
 		// the last material launch carries the event that releases the transition pass on side stream B
@@ -2472,9 +2510,12 @@ struct Backend {
 		// What follows the three branches (block lists, header read-back) runs on side stream A: on large grids the level-0
 		// pass there is the last to finish, and a stream that waits for events which have already fired loses nothing,
 		// whereas the main stream would start ~15 us after the event it waits for (1024^3: 0.53 -> 0.51 ms).
+		overlappedTail = false;
 		(void)hipEventRecord(evMain, stream);
 		(void)hipStreamWaitEvent(sideA, evMain, 0);
 		(void)hipStreamWaitEvent(sideA, evSideB, 0);
+		if (spreadC) (void)hipStreamWaitEvent(sideA, evSideC, 0);
+		if (spreadD) (void)hipStreamWaitEvent(sideA, evSideD, 0);
 		mainKeep = stream;
 		stream = sideA;
 	}
