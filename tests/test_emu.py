@@ -236,6 +236,12 @@ def test_emu_repeated_edits_vs_port(emu, port):
         assert np.array_equal(p.stats(), s.stats())
         hm = p.host_meshes(previous=hm)  # only what the run appended travels
         fields.check_host_meshes(p, hm)
+    # compaction rewrites the pools: an arena of the old layout is refilled as a whole, not patched
+    p.compact_pools()
+    hm = p.host_meshes(previous=hm)
+    fields.check_host_meshes(p, hm)
+    ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+    assert ok, msg
     # an arena outlives the surface it was filled from (and the context); a released one is handed out again
     keep = hm.verts.copy()
     p.execute()

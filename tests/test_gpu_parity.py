@@ -357,6 +357,11 @@ def test_hip_repeated_edits_vs_port(poly, port, n):
         assert np.array_equal(poly.stats(), s.stats())
         hm = poly.host_meshes(previous=hm)
         fields.check_host_meshes(poly, hm)
+    poly.compact_pools()  # the pools are rewritten: an arena of the old layout is refilled as a whole
+    hm = poly.host_meshes(previous=hm)
+    fields.check_host_meshes(poly, hm)
+    ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+    assert ok, msg
     for lanes, piece in ((1, 32), (3, 1), (4, 7)):  # the same copy cut differently (VX_D2H_STREAMS / VX_D2H_PIECE_MB)
         os.environ["VX_D2H_STREAMS"], os.environ["VX_D2H_PIECE_MB"] = str(lanes), str(piece)
         try:
