@@ -107,6 +107,18 @@ TV_HD size_t pyramid_offset(const PyramidLevel& P, int X, int Y, int Z)
 	return (((size_t)(z >> 4) * P.bricksY + (size_t)(y >> 4)) * P.bricksX + (size_t)((u32)X >> 4)) * BRICK_BYTES + brick_local((u32)X & 15u, y & 15u, z & 15u);
 }
 
+// The yz-planes X = 32 k of the level-l lattice (l = 0..2: the planes the x faces of the transition pass of level l + 1
+// lie in; k = 0 .. (n >> l) / 32, the last one being the clamped far plane), bytes [k][z][y] with y fastest, z and y over
+// 0 .. n >> l (far entries included).  In brick order such a plane costs one access per sample (one byte of every
+// 16-byte voxel row); here a face row is 33 contiguous bytes like the rows of the other four faces.  A fourth mirror,
+// written by the same kernels as the lattice copies.
+enum { XPLANE_LEVELS = 3 };
+struct XPlanes {
+	i8* data;          // nullptr: no copy of this level
+	u32 rows, stride;  // entries along z; bytes per row (a multiple of 16, >= entries along y)
+};
+TV_HD size_t xplane_offset(const XPlanes& P, u32 plane, u32 Z, u32 Y) { return ((size_t)plane * P.rows + Z) * P.stride + Y; }
+
 struct __attribute__((aligned(16))) FlatItem { u32 where, coordId, ntCells, pad; }; // Globals::flatItems
 
 // stats[0] = non-trivial cells, [1] = degenerate triangles removed, [2] = level-0 blocks processed,
@@ -129,6 +141,7 @@ struct Globals {
 	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
 	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)
 	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
+	XPlanes xp[XPLANE_LEVELS];        // yz-planes of the lattices 0..2 at every 32nd x (the x faces of the transition pass)
 	// full runs: blocks the fast regular passes (tv_fast0.h, tv_fast1.h) hand on to the general pass (a zero sample, a LOD
 	// chain ending on a voxel).  [0]: level-0 slots; [1]: level << 24 | slot for the levels >= 1
 	u32* slowItems[2];
@@ -150,6 +163,7 @@ struct Globals {
 // What the mirrors of a grid carry beside the bricks (handed to the kernels that keep them current)
 struct MirrorState {
 	PyramidLevel pyr[PYRAMID_LEVELS];
+	XPlanes xp[XPLANE_LEVELS];
 	u16* blockSign;                 // per level-0 block: field f = dx | dy << 1 | dz << 2 (2 bits each) summarises the voxels with x = 0 (dx), y = 0 (dy), z = 0 (dz): 1 = all >= 0, 2 = all < 0, 0 = mixed or not all resident
 	int yBegin, yEnd, zBegin, zEnd; // the rank's own rows / planes
 };

@@ -507,11 +507,30 @@ __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, i
 //     sample n of every level;
 //   * blockSign[id]: 1 = every distance sample of the block is >= 0, 2 = every sample is < 0, 0 = mixed or not all resident.
 
+// The same segment for the x-plane copies (XPlanes, tv_block.h): its first voxel if the segment starts on a plane
+// X = 32 k of a lattice, its last voxel (n - 1) as the clamped far plane.  y / z may be n like above.
+__device__ __forceinline__ void xplane_write_segment(const XPlanes* xp, int n, int xs, int y, int z, uint4 d)
+{
+#pragma unroll
+	for (int l = 0; l < XPLANE_LEVELS; ++l) {
+		const XPlanes& P = xp[l];
+		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
+		if (!(xs & ((32 << l) - 1))) P.data[xplane_offset(P, (u32)(xs >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)(d.x & 0xFFu);
+		if (xs + 16 == n) P.data[xplane_offset(P, (u32)(n >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)(d.w >> 24);
+	}
+}
+
 __device__ __forceinline__ void lattice_rows_of(const MirrorState& X, int n, int xs, int y, int z, uint4 d)
 {
-	if (!X.pyr[1].data && !X.pyr[2].data && !X.pyr[3].data) return;
 	if (y < X.yBegin || y > X.yEnd || z < X.zBegin || z > X.zEnd) return;
 	const bool yFar = y == n - 1, zFar = z == n - 1;
+	if (X.xp[0].data || X.xp[1].data || X.xp[2].data) {
+		xplane_write_segment(X.xp, n, xs, y, z, d);
+		if (yFar) xplane_write_segment(X.xp, n, xs, n, z, d);
+		if (zFar) xplane_write_segment(X.xp, n, xs, y, n, d);
+		if (yFar && zFar) xplane_write_segment(X.xp, n, xs, n, n, d);
+	}
+	if (!X.pyr[1].data && !X.pyr[2].data && !X.pyr[3].data) return;
 	if (!((y | z) & 1)) pyramid_write_segment(X.pyr, n, xs, y, z, d);
 	if (yFar && !(z & 1)) pyramid_write_segment(X.pyr, n, xs, n, z, d);
 	if (zFar && !(y & 1)) pyramid_write_segment(X.pyr, n, xs, y, n, d);
@@ -1431,6 +1450,8 @@ struct TrLatticeT {
 	const i8* base;
 	u32 bricksX, bricksY;
 	int yOrg, zOrg, last;
+	const i8* xp;        // the lattice's x-plane copy (XPlanes), or nullptr: the x faces are gathered from the bricks
+	u32 xpRows, xpStride;
 	__device__ __forceinline__ OFF tx(int X) const { return ((OFF)((u32)X >> 4) << 12) | ((u32)X & 15u); }
 	__device__ __forceinline__ OFF ty(int Y) const
 	{
@@ -1452,12 +1473,16 @@ __device__ __forceinline__ bool tr_lattice_of(const Globals& G, u32 level, TrLat
 	if (level == 1) {
 		lat.base = g.bDist; lat.bricksX = (u32)g.n >> 4; lat.bricksY = (u32)g.bRowsY;
 		lat.yOrg = g.bYb0 * 16; lat.zOrg = g.bZb0 * 16; lat.last = g.n - 1;
+		lat.xp = G.xp[0].data; lat.xpRows = G.xp[0].rows; lat.xpStride = G.xp[0].stride;
 		return true;
 	}
 	if (level - 1u >= (u32)PYRAMID_LEVELS || !G.pyr[level - 1u].data) return false;
 	const PyramidLevel& P = G.pyr[level - 1u];
 	lat.base = P.data; lat.bricksX = P.bricksX; lat.bricksY = P.bricksY;
 	lat.yOrg = P.yOrigin; lat.zOrg = P.zOrigin; lat.last = g.n >> (level - 1u);
+	const bool haveXp = level - 1u < (u32)XPLANE_LEVELS;
+	lat.xp = haveXp ? G.xp[level - 1u].data : nullptr;
+	lat.xpRows = haveXp ? G.xp[level - 1u].rows : 0u; lat.xpStride = haveXp ? G.xp[level - 1u].stride : 0u;
 	return true;
 }
 
@@ -1473,19 +1498,31 @@ __device__ __forceinline__ void tr_planes_request(const TrLatticeT<OFF>& lat, co
 	// item loop and keeps some twenty registers occupied through every other phase - which then spill)
 	asm volatile("" : "+v"(tid));
 	const int X0 = (int)b.bx * 32, Y0 = (int)b.by * 32, Z0 = (int)b.bz * 32;
-	// ---- rows along x ----
+	// ---- rows: lanes 0..131 the faces 0, 1, 3, 4 (rows along x in the bricks); with an x-plane copy of the lattice lanes
+	//      132..197 the faces 2 and 5 (rows along y of the planes X0 / 32 and X0 / 32 + 1) ----
 	{
-		const int row = min(tid, 131), fi = row / 33, rowV = row - fi * 33; // faces 0, 1, 3, 4
-		const bool zFace = (fi & 1) == 0, positive = fi >= 2;
-		const int A = min((zFace ? Z0 : Y0) + (positive ? 32 : 0), lat.last);
-		const int V = min((zFace ? Y0 : Z0) + rowV, lat.last);
-		const OFF yz = lat.ty(zFace ? V : A) + lat.tz(zFace ? A : V);
-		const i8* src = lat.base + yz + lat.tx(X0);
+		const int row = min(tid, lat.xp ? 197 : 131), fi = row / 33, rowV = row - fi * 33;
+		const i8 *src, *hi, *far;
+		if (fi < 4) {
+			const bool zFace = (fi & 1) == 0, positive = fi >= 2;
+			const int A = min((zFace ? Z0 : Y0) + (positive ? 32 : 0), lat.last);
+			const int V = min((zFace ? Y0 : Z0) + rowV, lat.last);
+			const OFF yz = lat.ty(zFace ? V : A) + lat.tz(zFace ? A : V);
+			src = lat.base + yz + lat.tx(X0);
+			hi = src + BRICK_BYTES;
+			far = lat.base + yz + lat.tx(min(X0 + 32, lat.last));
+		} else {
+			// (a plane of the copy covers the lattice's whole y / z extent with its far entries: Y0 + 32 and Z0 + rowV exist)
+			src = lat.xp + ((size_t)((u32)(X0 >> 5) + (fi == 5 ? 1u : 0u)) * lat.xpRows + (u32)(Z0 + rowV)) * lat.xpStride + (u32)Y0;
+			hi = src + 16;
+			far = src + 32;
+		}
 		r0 = *(const uint4*)src;
-		r1 = *(const uint4*)(src + BRICK_BYTES);
-		rFar = lat.base[yz + lat.tx(min(X0 + 32, lat.last))];
+		r1 = *(const uint4*)hi;
+		rFar = *far;
 	}
-	// ---- the x faces (2: x = X0, 5: x = X0 + 32): samples (u, v) = (y, z) ----
+	if (lat.xp) return; // (uniform)
+	// ---- the x faces (2: x = X0, 5: x = X0 + 32) sample by sample from the bricks: samples (u, v) = (y, z) ----
 	const OFF xNeg = lat.tx(X0), xPos = lat.tx(min(X0 + 32, lat.last));
 #pragma unroll
 	for (int q = 0; q < 9; ++q) {
@@ -1496,11 +1533,11 @@ __device__ __forceinline__ void tr_planes_request(const TrLatticeT<OFF>& lat, co
 	}
 }
 
-__device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1, i8 rFar, const i8 (&g)[9], u32 on, int tid, TrState& st)
+__device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1, i8 rFar, const i8 (&g)[9], bool xRows, u32 on, int tid, TrState& st)
 {
 	asm volatile("" : "+v"(tid));
-	if (tid < 132) {
-		const int fi = tid / 33, rowV = tid - fi * 33, rowFace = fi + (fi >= 2 ? 1 : 0);
+	if (tid < (xRows ? 198 : 132)) {
+		const int fi = tid / 33, rowV = tid - fi * 33, rowFace = fi < 4 ? fi + (fi >= 2 ? 1 : 0) : (fi == 4 ? 2 : 5);
 		if ((on >> rowFace) & 1u) {
 			i8* dst = st.plane[rowFace] + rowV * TR_PROW;
 			*(uint4*)dst = r0;
@@ -1508,6 +1545,7 @@ __device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1
 			dst[32] = rFar;
 		}
 	}
+	if (xRows) return; // (uniform)
 #pragma unroll
 	for (int q = 0; q < 9; ++q) {
 		const int t = tid + q * WG;
@@ -1653,7 +1691,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : V
 			if (tid == 0) st.faceOn = on;
 			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
 			if (haveLattice) {
-				tr_planes_store(rowLo, rowHi, rowFar, xFace, on, tid, st);
+				tr_planes_store(rowLo, rowHi, rowFar, xFace, lat.xp != nullptr, on, tid, st);
 			} else {
 				// no resident lattice for these planes: sample by sample from the grid's mirror; 33 x 33 samples per face, three
 				// faces (15 loads per lane) in flight together (a face that is off - uniform over the workgroup - is neither

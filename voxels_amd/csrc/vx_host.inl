@@ -63,6 +63,7 @@ struct vx_ctx {
 	void* dSlowItems[2] = { nullptr, nullptr };            // blocks handed from the fast regular passes to the general one (level 0 | levels >= 1)
 	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
+	XPlanes xp[XPLANE_LEVELS];                           // yz-planes of the lattices 0..2 at every 32nd x
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
 	// planes [brickZb0, +brickPlanesZ); stale = everything has to be copied again before the next polygonization
 	void* dBrick[3] = { nullptr, nullptr, nullptr };
@@ -182,6 +183,7 @@ MirrorState mirror_state(const vx_ctx* c)
 {
 	MirrorState ms;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) ms.pyr[L] = c->pyr[L];
+	for (u32 L = 0; L < XPLANE_LEVELS; ++L) ms.xp[L] = c->xp[L];
 	ms.blockSign = (u16*)c->dBlockSign;
 	ms.yBegin = (int)c->yBegin; ms.yEnd = (int)c->yEnd; ms.zBegin = (int)c->zBegin; ms.zEnd = (int)c->zEnd;
 	return ms;
@@ -288,6 +290,18 @@ bool ensure_level_tables(vx_ctx* c)
 			if (!P.data) return false;
 		}
 	}
+	// x-plane copies of the lattices 0..2 (whole extent in y and z: 35 MB at 1024^3; a slab only ever fills and reads its
+	// own rows).  Part of the mirrors: filled by the next rebrick.
+	for (u32 l = 0; l < XPLANE_LEVELS; ++l) {
+		XPlanes& X = c->xp[l];
+		X.data = nullptr; X.rows = X.stride = 0;
+		const u32 nl = c->n >> l;
+		if (!c->be.wants_pyramid() || nl < 32 || l + 1 >= c->refLevels) continue;
+		X.rows = nl + 1;
+		X.stride = (nl + 1 + 15u) & ~15u;
+		X.data = (i8*)alloc((size_t)(nl / 32 + 1) * X.rows * X.stride + 64);
+		if (!X.data) return false;
+	}
 	{
 		size_t coarse = 0;
 		for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) coarse += c->lv[L].cap;
@@ -339,6 +353,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.flatItems = (FlatItem*)c->dFlatItems;
 	p.G.slotCounts = (const u32*)c->dHeader;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
+	for (u32 L = 0; L < XPLANE_LEVELS; ++L) p.G.xp[L] = c->xp[L];
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
