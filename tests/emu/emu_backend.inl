@@ -138,6 +138,7 @@ struct Backend {
 	}
 	void end_timing_record() {}
 	void end_overlapped() {}
+	u32 head_partials() const { return 0; } // the emulation counts the block classes into the header itself
 	float elapsed_ms() { return 0.f; }
 	template <typename P>
 	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)

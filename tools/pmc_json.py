@@ -6,7 +6,7 @@ import re
 import sys
 
 CLASSES = {"k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular0": "k_regular0",
-           "k_regular": "k_regular", "k_run_reset": "k_classify", "k_block_class": "k_classify", "k_list": "k_lists"}
+           "k_regular": "k_regular", "k_run_head": "k_classify", "k_run_reset": "k_classify", "k_block_class": "k_classify", "k_list": "k_lists"}
 
 
 def parse(path):

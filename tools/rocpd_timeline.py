@@ -7,7 +7,7 @@ import sys
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    first = sys.argv[2] if len(sys.argv) > 2 else "k_run_reset"
+    first = sys.argv[2] if len(sys.argv) > 2 else "k_run_head"
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if "kernel_dispatch" in t][0]
     ks = [t for t in tabs if "kernel_symbol" in t][0]

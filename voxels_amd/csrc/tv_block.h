@@ -138,7 +138,6 @@ struct Globals {
 	u32* largeBlocks;                 // number of classified blocks whose non-trivial cell count exceeds LARGE_THRESHOLD
 	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
-	u8* tileWork;                     // per classify tile (16 blocks along x) of the rank's block rows: holds a block to read
 	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)
 	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
 	XPlanes xp[XPLANE_LEVELS];        // yz-planes of the lattices 0..2 at every 32nd x (the x faces of the transition pass)

@@ -2,7 +2,7 @@
 //
 // One polygonization = a handful of kernels on three streams of one context, no host round trip in between (work
 // lists and output offsets live in device memory):
-//   k_run_reset, k_block_class   counters / slot maps; what the BF_Empty flags and the sign summaries say about a block
+//   k_run_head      counters / slot maps reset; what the BF_Empty flags and the sign summaries say about a block
 //   k_classify    stream over the density field, skipping blocks the flags prove quiet: 16-byte coalesced loads, sign
 //                 bits packed to bit-masks in LDS, cells classified bit-parallel (256 per lane); emits the
 //                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block.
@@ -617,6 +617,8 @@ __global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, Mir
 struct ResetRanges {
 	u32* header;
 	u32 headerWords;
+	u32* partials;            // [workgroups of k_run_head]: block-class statistics (behind the header, copied with it)
+	u32 partialCount;
 	u32 start[MAX_LEVELS + 1]; // word ranges of the flat index space: [0, headerWords) header, then slotOf of level 0, 1, ...
 };
 
@@ -637,19 +639,15 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 	}
 }
 
-// ---- head of a full run: k_run_reset zeroes the run's counters, slot maps and classify-tile marks; k_block_class reads
-//      what the emptiness flags and the sign summaries already say about every block ------------------------------------
-__global__ __launch_bounds__(WG) void k_run_reset(ExecParamsDev p, ResetRanges r, u32 tiles)
-{
-	const u32 i = blockIdx.x * WG + threadIdx.x;
-	if (r.header) reset_words(p, r, i);
-	if (i < tiles) p.G.tileWork[i] = 0;
-}
-
-__global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
+// ---- head of a full run, one launch: the run's counters = 0 and block -> slot maps = -1 (four words per lane), and per
+//      level-0 block what the emptiness flags and the sign summaries already say about it (one block per lane).  The two
+//      halves touch different memory, so one kernel can do both; the statistics of the classes are counted at the end of the
+//      run (k_list_count), when the header is long since zero. --------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r)
 {
 	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (r.header) reset_words(p, r, i);
 	const u32 rowsY = L.yb1 - L.yb0;
 	const bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
 	const u32 ii = inRange ? i : 0u;
@@ -680,19 +678,14 @@ __global__ __launch_bounds__(WG) void k_block_class(ExecParamsDev p)
 		signAll &= sg; signAny |= sg;
 	}
 	if (signAll == signAny && signAll != 0u) c |= BC_QUIET | (signAll == 2u ? (u32)BC_NEGATIVE : 0u);
-	if (inRange) {
-		p.G.blockClass[id] = (u8)c;
-		// classify tiles (TB blocks along x) that hold a block to read; zeroed by k_run_reset of the same run
-		if (!(c & BC_QUIET)) p.G.tileWork[((bz - L.zb0) * rowsY + (by - L.yb0)) * ((L.cnt + 15u) / 16u) + bx / 16u] = 1;
-	}
-	// blocks the classify pass will read: what "every distance sample once" amounts to for this grid (reported, bench.py);
-	// one atomic per workgroup (one per wave on a single address serialised the whole launch)
+	if (inRange) p.G.blockClass[id] = (u8)c;
+	// Two statistics, as per-workgroup partial sums that travel with the header (no atomics: the header is being zeroed by
+	// this very launch): blocks the classify pass will read - what "every distance sample once" amounts to for this grid
+	// (reported, bench.py) - and the reference's "blocks calculated" on level 0: every block its emptiness rule does not
+	// skip (:1511-1527), whether the classify pass has to read it or not.
 	const int readers = __syncthreads_count(inRange && !(c & BC_QUIET));
-	if (threadIdx.x == 0 && readers) atomicAdd(&p.G.largeBlocks[1], (u32)readers);
-	// the reference's "blocks calculated" on level 0: every block its emptiness rule does not skip (:1511-1527), whether
-	// the classify pass has to read it or not
 	const int calculated = __syncthreads_count(inRange && !(c & BC_SKIPPED));
-	if (threadIdx.x == 0 && calculated) atomicAdd(&p.G.stats[2], (u32)calculated);
+	if (threadIdx.x == 0 && r.partials) r.partials[blockIdx.x] = (u32)readers | ((u32)calculated << 16);
 }
 
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
@@ -733,15 +726,22 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 	const int validCells = (n - x0) < 16 * TB ? (n - x0) : 16 * TB; // multiple of 16
 	const int tid = threadIdx.x;
 
-	// what the flags say: quiet blocks are not read at all, a tile of quiet blocks is done (most tiles of a terrain: the
-	// test is one uniform byte per workgroup, written by k_block_class)
-	if (!p.G.tileWork[tile]) return;
+	// what the flags say (the classes of the tile's 16 blocks, written by k_run_head): quiet blocks are not read at all, a
+	// tile of quiet blocks is done - most tiles of a terrain
 	u32 myClass = BC_SKIPPED | BC_QUIET;
-	if (tid < TB) {
-		const u32 bx = tx * TB + (u32)tid;
+	if ((L.cnt & (TB - 1u)) == 0u) {
+		// whole tiles: the 16 classes are 16 aligned bytes at a workgroup-uniform address (a scalar load)
+		const uint4 cls = *(const uint4*)(p.G.blockClass + block_coord_id(tx * TB, by, bz, L.cnt));
+		const u32 quietAll = cls.x & cls.y & cls.z & cls.w & 0x01010101u * (u32)BC_QUIET;
+		if (quietAll == 0x01010101u * (u32)BC_QUIET) return;
+		const u32 word = ((u32)tid & 12u) == 0u ? cls.x : (((u32)tid & 12u) == 4u ? cls.y : (((u32)tid & 12u) == 8u ? cls.z : cls.w));
+		myClass = (word >> (((u32)tid & 3u) * 8u)) & 0xFFu;
+	} else {
+		const u32 bx = tx * TB + ((u32)tid & (TB - 1u));
 		if (bx < L.cnt) myClass = p.G.blockClass[block_coord_id(bx, by, bz, L.cnt)];
-		blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockCls[tid] = myClass;
+		if (__ballot(!(myClass & BC_QUIET)) == 0ull) return; // (every wave holds the 16 classes four times over: uniform over the workgroup)
 	}
+	if (tid < TB) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockCls[tid] = myClass; }
 	__syncthreads();
 
 	// ---- load from the brick mirror: the TB blocks of a tile are 64 KB of consecutive addresses, lane t takes the 16-byte
@@ -2315,14 +2315,16 @@ struct Backend {
 		return ms;
 	}
 
-	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_run_reset)
+	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_run_head)
 	ResetRanges pendingReset = {};
+	u32 headWorkgroups = 0; // of the last k_run_head launch: that many block-class partial sums sit behind the header
 	template <typename P>
 	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
 	{
 		ResetRanges r;
 		u32 run = headerWords;
 		r.header = header; r.headerWords = headerWords;
+		r.partials = header + headerWords; r.partialCount = 0;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
 			r.start[l] = run;
 			if (l < levels) run += p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt;
@@ -2359,10 +2361,10 @@ struct Backend {
 		{
 			const ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
-			const u32 lanes = std::max<u32>(grid, r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
-			hipLaunchKernelGGL(k_run_reset, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, grid);
+			const u32 lanes = std::max<u32>(L.cnt * rowsY * (L.zb1 - L.zb0), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
+			headWorkgroups = (lanes + WG - 1) / WG;
+			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r);
 		}
-		hipLaunchKernelGGL(k_block_class, dim3((L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p));
 		const u32 rows = rowsY * (L.zb1 - L.zb0);
 		u32 rowGroup = 0; // 0 = no remap
 		if ((rows & 7u) == 0) {
@@ -2558,6 +2560,7 @@ struct Backend {
 		stream = sideA;
 	}
 	// behind the host's wait for the run: the main stream is the current one again
+	u32 head_partials() const { return headWorkgroups; }
 	void end_overlapped()
 	{
 		if (mainKeep) { stream = mainKeep; mainKeep = nullptr; }

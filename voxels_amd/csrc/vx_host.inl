@@ -44,7 +44,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -61,7 +61,6 @@ struct vx_ctx {
 	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
 	void* dFlatItems = nullptr;                            // active blocks of the levels >= 1 in level order (Globals::flatItems)
 	void* dSlowItems[2] = { nullptr, nullptr };            // blocks handed from the fast regular passes to the general one (level 0 | levels >= 1)
-	void* dTileWork = nullptr;                             // per classify tile: any block to read
 	PyramidLevel pyr[PYRAMID_LEVELS];                    // lattice copies of the distance field for levels 1..3
 	XPlanes xp[XPLANE_LEVELS];                           // yz-planes of the lattices 0..2 at every 32nd x
 	// brick mirrors of the three fields (tv_core.h GridView): resident block rows [brickYb0, +brickRowsY) of the block
@@ -274,8 +273,7 @@ bool ensure_level_tables(vx_ctx* c)
 			c->dBlockClass = alloc(total);
 			c->dSlowItems[0] = alloc(cap * 4 + 16);
 			if (!c->dSlowItems[0]) return false;
-			c->dTileWork = alloc((size_t)((d.cnt + 15) / 16) * (d.yb1 - d.yb0) * (d.zb1 - d.zb0) + 16);
-			if (!c->dBlockClass || !c->dTileWork) return false;
+			if (!c->dBlockClass) return false;
 		}
 		// lattice copy of the distance samples of this level over the rank's rows / planes (one more than it owns: the far
 		// samples of its last block layer)
@@ -345,7 +343,6 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.workCount = (u32*)c->dHeader + HDR_WORK;
 	p.G.largeBlocks = (u32*)c->dHeader + HDR_LARGE;
 	p.G.blockClass = (u8*)c->dBlockClass;
-	p.G.tileWork = (u8*)c->dTileWork;
 	p.G.blockSign = (const u16*)c->dBlockSign;
 	p.G.slowItems[0] = (u32*)c->dSlowItems[0];
 	p.G.slowItems[1] = (u32*)c->dSlowItems[1];
@@ -414,7 +411,7 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 {
 	const bool overlapped = !c->be.stage_timing_on();
 	const bool ancestorsDone = c->be.classify_activates_ancestors(p);
-	c->be.run_classify(p, overlapped && ancestorsDone); // k_run_reset + k_block_class, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
+	c->be.run_classify(p, overlapped && ancestorsDone); // k_run_head, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
 	c->be.stage_mark(2);
 	// (the HIP backend's classify pass also activates the ancestors of the blocks it finds; the hierarchy pass remains the
 	// second step of an incremental run, and of the CPU emulation)
@@ -614,7 +611,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	build_table_image(img);
 	c->dTables = c->be.alloc(TAB_F0_BYTES);
 	c->dLut = c->be.alloc(256 * 8);
-	c->dHeader = c->be.alloc(HDR_WORDS * 4);
+	c->dHeader = c->be.alloc((HDR_WORDS + HDR_PARTIALS) * 4); // header + the block-class partial sums of k_run_head (one word per workgroup)
 	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_F0_BYTES)) {
 		vx_ctx_destroy(c);
 		return VX_ERR_DEVICE;
@@ -1249,9 +1246,10 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		}
 		c->be.end_timing_record();
 		// the header travels right behind the kernels: one host wait per run
-		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned(HDR_WORDS * 4);
+		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned((HDR_WORDS + HDR_PARTIALS) * 4);
 		if (!c->hdrPinned) { c->be.sync(); c->be.end_overlapped(); return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed"); }
-		bool okRun = c->be.d2h_async(c->hdrPinned, c->dHeader, HDR_WORDS * 4);
+		const u32 partials = std::min<u32>(c->be.head_partials(), (u32)HDR_PARTIALS);
+		bool okRun = c->be.d2h_async(c->hdrPinned, c->dHeader, (HDR_WORDS + partials) * 4);
 		t1 = tNow();
 		okRun = okRun && c->be.sync_ok();
 		c->be.end_overlapped(); // (the tail of an overlapped run was queued on a side stream)
@@ -1259,6 +1257,12 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		if (!okRun) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
 		ms = c->be.elapsed_ms();
 		memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
+		if (partials) { // the block-class statistics arrive as per-workgroup partial sums behind the header (k_run_head)
+			u32 readers = 0, calculated = 0;
+			for (u32 i = 0; i < partials; ++i) { readers += c->hdrPinned[HDR_WORDS + i] & 0xFFFFu; calculated += c->hdrPinned[HDR_WORDS + i] >> 16; }
+			c->hdr[HDR_LARGE + 1] = readers;
+			c->hdr[HDR_STATS + 2] = calculated;
+		}
 		t3 = tNow();
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (c->hdr[HDR_LARGE] && !c->be.largeClass) { c->be.largeClass = true; continue; } // blocks of the large class showed up: once more, with it
