@@ -141,7 +141,7 @@ struct Backend {
 	u32 head_partials() const { return 0; } // the emulation counts the block classes into the header itself
 	float elapsed_ms() { return 0.f; }
 	template <typename P>
-	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32*, u32)
 	{
 		memset(header, 0, (size_t)headerWords * 4);
 		for (u32 l = 0; l < levels; ++l) memset(p.levels[l].slotOf, 0xFF, (size_t)p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt * 4);

@@ -62,6 +62,8 @@ struct LevelDesc {
 	int* slotOf;        // [cnt^3] block coordinate id -> active slot, -1 = none
 	u32* slotCoord;     // [cap] slot -> coordinate id
 	u32* nActive;       // number of slots in use
+	u32* listCounts;    // [ceil(cnt^3 / LIST_WG)] blocks with a regular mesh per LIST_WG block coordinates: counted where a block's
+	                    //          record is written, consumed by the list kernel of a full run (zeroed with the run's counters)
 	u32* ntBits;        // [cap][128] non-trivial cell bitmap of the block (current geometry)
 	u32* consBits;      // level 0: [cap][128] the reference's Level0ConsistencyCache: bits of every cell that was ever
 	                    //          polygonized as non-trivial (only set, never cleared, TransVoxelImpl.cpp:757)
@@ -215,6 +217,12 @@ TV_HD void listed_block_fill(ListedBlock& out, const LevelDesc& L, u32 coordId, 
 }
 
 // does block coordinate `id` of level L appear in the level's list?  (-1: no, else its slot)
+// a block whose record says it has a regular mesh will be listed (listed_block_slot): its group of LIST_WG coordinates counts it
+TV_HD void count_listed_block(const LevelDesc& L, u32 coordId, u32 vCount)
+{
+	if (vCount && L.listCounts) TV_ATOMIC_ADD(&L.listCounts[coordId / LIST_WG], 1u);
+}
+
 TV_HD int listed_block_slot(const LevelDesc& L, u32 id)
 {
 	if (id >= L.cnt * L.cnt * L.cnt) return -1;
@@ -982,6 +990,7 @@ TV_HD void reg_phase_record(const ST& st, u32* acc, const LevelDesc& L, const Re
 	r.coordId = L.slotCoord[b.slot];
 	const bool ok = st.vOff + st.vTotal <= P.vertCap && st.iOff + st.iTotal <= P.idxCap;
 	r.vOff = st.vOff; r.vCount = ok ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = ok ? st.iTotal : 0;
+	count_listed_block(L, r.coordId, r.vCount);
 	if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
 	r.degenerate = st.degenerate;
 	r.ntCells = st.wordPrefix[128];

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				BlockRecord& r = L.records[cur.slot];
 				r.coordId = cur.coord;
 				r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.tTotal * 3u : 0;
+				count_listed_block(L, r.coordId, r.vCount);
 				if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
 				r.degenerate = 0;
 				r.ntCells = nt;

@@ -619,6 +619,8 @@ struct ResetRanges {
 	u32 headerWords;
 	u32* partials;            // [workgroups of k_run_head]: block-class statistics (behind the header, copied with it)
 	u32 partialCount;
+	u32* listCounts;          // [listWgs] listed blocks per LIST_WG block coordinates (LevelDesc::listCounts): zeroed here
+	u32 listWgs;
 	u32 start[MAX_LEVELS + 1]; // word ranges of the flat index space: [0, headerWords) header, then slotOf of level 0, 1, ...
 };
 
@@ -641,13 +643,13 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 
 // ---- head of a full run, one launch: the run's counters = 0 and block -> slot maps = -1 (four words per lane), and per
 //      level-0 block what the emptiness flags and the sign summaries already say about it (one block per lane).  The two
-//      halves touch different memory, so one kernel can do both; the statistics of the classes are counted at the end of the
-//      run (k_list_count), when the header is long since zero. --------------------------------------------------------------
+//      halves touch different memory, so one kernel can do both; the statistics of the classes leave as partial sums. ---------
 __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r)
 {
 	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
 	if (r.header) reset_words(p, r, i);
+	if (r.header && i < r.listWgs) r.listCounts[i] = 0;
 	const u32 rowsY = L.yb1 - L.yb0;
 	const bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
 	const u32 ii = inRange ? i : 0u;
@@ -1791,9 +1793,10 @@ __global__ __launch_bounds__(WG) void k_classify_blocks(ExecParamsDev p, const u
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_list_count / k_list_write: the result's block lists (ListedBlock, tv_block.h) built where the records are.
-// Coordinate order = index order of the block -> slot maps, so the lists are an ordered compaction of them: counts per
-// workgroup, then every workgroup adds up the counts before it (at most ~1200 of them) and writes its blocks.
+// k_list_write: the result's block lists (ListedBlock, tv_block.h) built where the records are.  Coordinate order =
+// index order of the block -> slot maps, so the lists are an ordered compaction of them: the passes that write a block's
+// record count it into its group of LIST_WG coordinates (LevelDesc::listCounts); every workgroup here adds up the counts
+// before it (at most ~1200 of them) and writes its blocks.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 list_level_of(const ListPlan& plan, u32 levels, u32 w)
 {
@@ -1802,6 +1805,8 @@ __device__ __forceinline__ u32 list_level_of(const ListPlan& plan, u32 levels, u
 	return l;
 }
 
+// (large block ranges: the counts come from a launch of their own - an atomic per block record in the regular passes
+// cost the level-0 pass more there than this launch costs the tail)
 __global__ __launch_bounds__(LIST_WG) void k_list_count(ExecParamsDev p, ListPlan plan, u32 levels)
 {
 	const u32 w = blockIdx.x, l = list_level_of(plan, levels, w);
@@ -2319,12 +2324,13 @@ struct Backend {
 	ResetRanges pendingReset = {};
 	u32 headWorkgroups = 0; // of the last k_run_head launch: that many block-class partial sums sit behind the header
 	template <typename P>
-	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords)
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32* listCounts, u32 listWgs)
 	{
 		ResetRanges r;
 		u32 run = headerWords;
 		r.header = header; r.headerWords = headerWords;
 		r.partials = header + headerWords; r.partialCount = 0;
+		r.listCounts = listCounts; r.listWgs = listWgs;
 		for (u32 l = 0; l < MAX_LEVELS; ++l) {
 			r.start[l] = run;
 			if (l < levels) run += p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt;
@@ -2361,7 +2367,7 @@ struct Backend {
 		{
 			const ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
-			const u32 lanes = std::max<u32>(L.cnt * rowsY * (L.zb1 - L.zb0), r.header ? (r.start[MAX_LEVELS] + 3) / 4 : 0u);
+			const u32 lanes = std::max<u32>(L.cnt * rowsY * (L.zb1 - L.zb0), r.header ? std::max<u32>((r.start[MAX_LEVELS] + 3) / 4, r.listWgs) : 0u);
 			headWorkgroups = (lanes + WG - 1) / WG;
 			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r);
 		}
@@ -2641,7 +2647,7 @@ struct Backend {
 	{
 		const u32 wgs = plan.wgStart[levels];
 		if (!wgs) return;
-		hipLaunchKernelGGL(k_list_count, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
+		if (!p.levels[0].listCounts) hipLaunchKernelGGL(k_list_count, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
 		hipLaunchKernelGGL(k_list_write, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
 		check(hipGetLastError(), "k_list launch");
 	}

@@ -69,7 +69,8 @@ struct vx_ctx {
 	void* dBlockSign = nullptr;          // per level-0 block: sign summary of its samples (MirrorState)
 	u32 brickN = 0, brickYb0 = 0, brickZb0 = 0, brickRowsY = 0, brickPlanesZ = 0;
 	bool bricksStale = true;
-	void* dListCounts = nullptr;                         // per-workgroup counts of the list kernels
+	void* dListCounts = nullptr;                         // listed blocks per LIST_WG block coordinates, all levels (LevelDesc::listCounts)
+	u32 listWgs = 0;
 	void* haloBuf[4] = { nullptr, nullptr, nullptr, nullptr }; // staging of the halo messages: send below, send above, receive from below, receive from above
 	size_t haloCap[4] = { 0, 0, 0, 0 };
 	int slabAxis = 0;                                    // how the grid was attached: 0 = not attached, 1 = slab of z-planes, 2 = slab of y-rows
@@ -313,6 +314,12 @@ bool ensure_level_tables(vx_ctx* c)
 		for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) wgs += ((size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt + LIST_WG - 1) / LIST_WG;
 		c->dListCounts = alloc(wgs * 4 + 16);
 		if (!c->dListCounts) return false;
+		c->listWgs = (u32)wgs;
+		size_t at = 0; // every level's segment of the counts (the list kernel's workgroups are laid out the same way, ListPlan::wgStart)
+		for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) {
+			c->lv[L].listCounts = (u32*)c->dListCounts + at;
+			at += ((size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt + LIST_WG - 1) / LIST_WG;
+		}
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1; c->tablesYb0 = yb0; c->tablesYb1 = yb1;
 	return true;
@@ -354,6 +361,8 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
+	// listed blocks are counted where their records are written only on small block ranges (k_list_count otherwise)
+	if (!c->be.classify_activates_ancestors(p)) for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L].listCounts = nullptr;
 	p.P.verts = (PolyVertex*)c->dVerts;
 	p.P.idx = (u32*)c->dIdx;
 	p.P.cursors = (u32*)c->dHeader + HDR_CURSORS;
@@ -579,7 +588,7 @@ bool grow_pools_keeping(vx_ctx* c, u32 needVerts, u32 needIdx)
 int ensure_lists(vx_ctx* c)
 {
 	if (c->listsReady) return VX_OK;
-	// the tables were written by the run itself (k_list_count / k_list_write): one copy per level, nothing to sort
+	// the tables were written by the run itself (k_list_write): one copy per level, nothing to sort
 	for (u32 L = 0; L < c->levelsRun; ++L) {
 		const u32 count = c->hdr[HDR_LISTS + L];
 		std::vector<EmittedBlock>& out = c->blocks[L];
@@ -1221,7 +1230,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		fill_params(c, p, levels);
 		c->be.begin_timing();
 		c->be.stage_mark(0);
-		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS); // header = 0, slot maps = -1
+		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS, (u32*)c->dListCounts, c->listWgs); // header = 0, slot maps = -1, list counts = 0
 #if defined(VX_CASE_DUMP)
 		for (u32 L = 0; L < levels; ++L) { c->be.fill(c->lv[L].caseDump, 0, (size_t)c->lv[L].cap * BLOCK_CELLS); c->be.fill(c->lv[L].trCaseDump, 0, (size_t)c->lv[L].cap * TR_CELLS * 2); }
 #endif
