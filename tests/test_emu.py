@@ -536,3 +536,17 @@ def test_emu_caves_style_matches_host_generator_and_oracle(emu):
     ok, msg = fields.surface_equal(dev.all_levels(), s.all_levels())
     assert ok, msg
 
+
+
+def test_emu_empty_surface_host_meshes(emu):
+    """A grid without any surface: no blocks, empty pools, and the one-step host copy hands out empty arrays."""
+    n = 32
+    d = np.full((n, n, n), 50, np.int8)
+    z = np.zeros((n, n, n), np.uint8)
+    p = make_poly(emu)
+    p.upload(d, z, z, np.ones((n // 16) ** 3, np.uint8))
+    info = p.execute()
+    hm = p.host_meshes()
+    assert hm.verts.size == 0 and hm.indices.size == 0
+    assert all(p.level(l).totals() == (0, 0, 0, 0, 0) for l in range(info.levels))
+    hm.release()
