@@ -249,6 +249,23 @@ def main():
         elapsed = float(te.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # N > 1: the other variant as well - a step that includes the halo exchange (what a run after an edit pays) when the
+    # timed steps above ran without it, and the other way round.  Every rank runs the same sequence (no collective is
+    # conditional on a rank's own state).
+    ms_other = None
+    if world > 1:
+        k = max(1, min(args.steps, 10))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            if not args.halo_every_step:
+                halo_exchange()
+            poly.execute(levels)
+        barrier()
+        to = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist_pkg.all_reduce(to, op=dist_pkg.ReduceOp.MAX)
+        ms_other = float(to.item()) / k * 1e3
+
     # ---- per-kernel device timing (HIP events on the stream the kernels run on).  With stage timing enabled the
     #      library serialises its streams so that every kernel's duration is its own; the timed steps above ran the
     #      normal, overlapped pipeline (level-0 regular pass and transition pass beside the material chain). ----
@@ -435,6 +452,7 @@ def main():
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
                        "halo_exchange_in_step": bool(world > 1 and args.halo_every_step), "halo_transport": halo_transport,
+                       ("ms_per_step_without_halo_exchange" if args.halo_every_step else "ms_per_step_with_halo_exchange"): (round(ms_other, 4) if ms_other is not None else None),
                        "cold": cold},
             "roofline": roofline,
         }
