@@ -966,7 +966,7 @@ TV_HD void reg_phase_flush_indices(const ST& st, const Tables& T, const Pools& P
 			const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
 			id = (u32)st.vbase[k2] + ((st.info[k2] >> (slot * 4)) & 0xFu);
 		}
-		out[j] = id;
+		TV_STREAM_STORE(&out[j], id);
 	}
 }
 
@@ -1276,7 +1276,7 @@ TV_HD void tr_phase_flush_indices(const TrState& st, const Tables& T, const Pool
 			const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
 			id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
 		}
-		out[j] = id;
+		TV_STREAM_STORE(&out[j], id);
 	}
 }
 

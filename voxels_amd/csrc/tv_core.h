@@ -42,6 +42,12 @@
 #else
 #define TV_SCHED_FENCE() do { } while (0)
 #endif
+// a store of data the run does not read again (mesh vertices, indices): streaming on the device, plain on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TV_STREAM_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
+#else
+#define TV_STREAM_STORE(ptr, value) (*(ptr) = (value))
+#endif
 
 namespace tv {
 
@@ -421,10 +427,17 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	u32 t0 = __builtin_amdgcn_perm(hi, lo, 0x01040C0Cu) | (((r.mat >> 8) & 0xFFu) << 8);
 	u32 t1 = __builtin_amdgcn_perm(hi, lo, 0x00020305u);
 	if (!ok) { t0 = 0; t1 = 0; }
-	uint4* dst = (uint4*)out;
-	dst[0] = make_uint4(__float_as_uint(r.p[0] * k), __float_as_uint(r.p[2] * k), __float_as_uint(r.p[1] * k), __float_as_uint(r.s[0] * k));
-	dst[1] = make_uint4(__float_as_uint(r.s[2] * k), __float_as_uint(r.s[1] * k), f, __float_as_uint(r.n[0]));
-	dst[2] = make_uint4(__float_as_uint(r.n[1]), __float_as_uint(r.n[2]), t0, t1);
+	typedef u32 __attribute__((ext_vector_type(4))) v4u;
+	v4u* dst = (v4u*)out;
+	const v4u a = { __float_as_uint(r.p[0] * k), __float_as_uint(r.p[2] * k), __float_as_uint(r.p[1] * k), __float_as_uint(r.s[0] * k) };
+	const v4u b = { __float_as_uint(r.s[2] * k), __float_as_uint(r.s[1] * k), f, __float_as_uint(r.n[0]) };
+	const v4u c = { __float_as_uint(r.n[1]), __float_as_uint(r.n[2]), t0, t1 };
+	// The meshes are written once and not read again by the run: streaming (non-temporal) stores keep them from
+	// displacing the voxel lines the neighbouring blocks are about to read.  Measured at 1024^3: level-0 pass 0.196 ->
+	// 0.181 ms, levels >= 1 0.128 -> 0.115, the whole step 0.498 -> 0.463.
+	TV_STREAM_STORE(&dst[0], a);
+	TV_STREAM_STORE(&dst[1], b);
+	TV_STREAM_STORE(&dst[2], c);
 #else
 	PolyVertex o;
 	o.pos[0] = r.p[0] * k; o.pos[1] = r.p[2] * k; o.pos[2] = r.p[1] * k;

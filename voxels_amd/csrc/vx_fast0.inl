@@ -307,7 +307,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 							u32 ids[3];
 							f0_triangle(st, T, j, ids);
 							u32* o3 = iOut + j * 3u; // 12 bytes per lane, consecutive lanes consecutive triangles
-							o3[0] = ids[0]; o3[1] = ids[1]; o3[2] = ids[2];
+							TV_STREAM_STORE(&o3[0], ids[0]); TV_STREAM_STORE(&o3[1], ids[1]); TV_STREAM_STORE(&o3[2], ids[2]);
 						}
 					}
 				}

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 						u32 ids[3];
 						f0_triangle(st, T, j, ids);
 						u32* o3 = iOut + j * 3u;
-						{ o3[0] = ids[0]; o3[1] = ids[1]; o3[2] = ids[2]; }
+						TV_STREAM_STORE(&o3[0], ids[0]); TV_STREAM_STORE(&o3[1], ids[1]); TV_STREAM_STORE(&o3[2], ids[2]);
 					}
 				}
 			}

@@ -434,7 +434,7 @@ struct R0 {
 				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
 				id = (st.cellC[k2] & 0xFFFFu) + (((u32)st.ords[k2] >> (slot * 4u)) & 0xFu);
 			}
-			out[j] = id;
+			TV_STREAM_STORE(&out[j], id);
 		}
 	}
 };
