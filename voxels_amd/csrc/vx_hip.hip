@@ -2,17 +2,22 @@
 //
 // One polygonization = a handful of kernels on three streams of one context, no host round trip in between (work
 // lists and output offsets live in device memory):
-//   k_run_head      counters / slot maps reset; what the BF_Empty flags and the sign summaries say about a block
+//   k_run_head    counters / slot maps reset; what the BF_Empty flags and the sign summaries say about a block
 //   k_classify    stream over the density field, skipping blocks the flags prove quiet: 16-byte coalesced loads, sign
 //                 bits packed to bit-masks in LDS, cells classified bit-parallel (256 per lane); emits the
-//                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block.
-//   k_hierarchy   marks the ancestors of active blocks on the coarser LOD levels.
-//   k_material    (per level >= 1, serial) per-cell material vote over the 8 children -> material cache.
-//   k_regular     one surface-bearing block per workgroup pass (grid oversubscribed, the dispatcher balances):
-//                 19^3 samples + Transvoxel tables in LDS, reuse resolution, wavefront prefix sums for vertex/index
-//                 offsets, one atomicAdd per mesh to reserve its range of the output pools (per-block stream
-//                 compaction), one lane per new vertex.  Level 0 runs beside the material chain on a side stream.
-//   k_transition  same for the 6 x 16 x 16 transition cells of the blocks of levels 1..last-1 (third stream).
+//                 non-trivial-cell bitmap and an active slot for every surface-bearing level-0 block (small block
+//                 ranges: also the ancestors' slots).
+//   k_hierarchy   marks the ancestors of active blocks on the coarser LOD levels (large ranges, incremental runs).
+//   k_material    (per level >= 1, serial) per-cell material vote over the 8 children -> material cache; flat list of
+//                 the active blocks of the levels >= 1.
+//   k_regular0_fast, k_regular1_fast (vx_fast0.inl, vx_fast1.inl)   the regular cells of level 0 / of the levels 1..3 for
+//                 blocks without a zero sample: table-driven cells and triangles, one lane per vertex and per triangle,
+//                 one 64-bit atomicAdd per mesh to reserve its ranges of the output pools (per-block stream
+//                 compaction), streaming stores.  Level 0 runs beside the material chain on a side stream.
+//   k_regular0, k_regular (vx_regular0.inl, here)   the general pass: what the table-driven passes hand on (zero samples,
+//                 LOD chains ending on a voxel), the 4096-cell class, levels beyond the lattice copies, incremental runs.
+//   k_transition  the 6 x 16 x 16 transition cells of the blocks of levels 1..last-1 (third stream).
+//   k_list_count, k_list_write   the result's block tables.
 //   k_classify_blocks, k_build_worklist, k_gather_records   incremental (Modification) runs.
 //   k_decode_grid Grid file format v1 -> dense fields (vx_grid_upload_packed).
 // The per-cell logic is tv_core.h / tv_block.h (shared with the CPU emulation used by the tests).
