@@ -24,7 +24,7 @@ enum { F1_VDESC = 768, F1_TDESC = 768 };
 template <int CAP>
 struct Fast1State {
 	i8 samp[F1_SBYTES + 12];   // 17 x 17 rows of F1_SROW bytes (+ padding: the cache block below is copied in 16-byte pieces)
-	__attribute__((aligned(16))) u16 cache[BLOCK_CELLS]; // the block's LevelMaterialCache entries: id | blend << 8
+	__attribute__((aligned(16))) u8 cacheId[BLOCK_CELLS]; // material ids of the block's LevelMaterialCache entries (the cell pass compares ids; a vertex reads its cell's whole entry, id | blend << 8, from the cache in HBM with its voxel fetches: 4 KB of LDS less per workgroup, which matters to the level-0 pass running beside this one)
 	u32 ntBits[128];
 	u16 wordPrefix[132];
 	__attribute__((aligned(8))) u32 cellAN[CAP][2];
@@ -41,10 +41,10 @@ struct F1Layout {
 	template <typename ST> static TV_HD const i8* base_sample(const ST& st, int cx, int cy, int cz) { return st.samp + (cz * F1_SPLANE + cy * F1_SROW + cx); }
 	template <typename ST> static TV_HD u32 same_material(const ST& st, u32 c, int, int, int)
 	{
-		const u16* mp = st.cache + c; // neighbours outside the block are never asked for (their mask bit is 0): any value will do
-		const u32 mine = mp[0] & 0xFFu;
-		return ((mp[-1] & 0xFFu) == mine ? 1u : 0u) | ((mp[-16] & 0xFFu) == mine ? 2u : 0u) | ((mp[-17] & 0xFFu) == mine ? 4u : 0u)
-		     | ((mp[-256] & 0xFFu) == mine ? 8u : 0u) | ((mp[-257] & 0xFFu) == mine ? 16u : 0u) | ((mp[-272] & 0xFFu) == mine ? 32u : 0u);
+		const u8* mp = st.cacheId + c; // neighbours outside the block are never asked for (their mask bit is 0): any value will do
+		const u32 mine = mp[0];
+		return (mp[-1] == mine ? 1u : 0u) | (mp[-16] == mine ? 2u : 0u) | (mp[-17] == mine ? 4u : 0u)
+		     | (mp[-256] == mine ? 8u : 0u) | (mp[-257] == mine ? 16u : 0u) | (mp[-272] == mine ? 32u : 0u);
 	}
 };
 
@@ -62,7 +62,7 @@ struct F1HostSampler {
 // ---- one lane = one new vertex (reg_edge_vertex of tv_core.h, for a cell without zero corner samples) ---------------
 // desc = cell id | edge index << 12; (ox,oy,oz) = the block's origin in voxels; returns "strictly inside its level-0 edge"
 template <typename ST, typename SMP>
-TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, u32 desc, int level, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
+TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16* blockCache, u32 desc, int level, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
 {
 	typedef typename SMP::Off Off;
 	const u32 c = desc & 0xFFFu;
@@ -97,7 +97,7 @@ TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, u32 desc, 
 	const int a0 = smp.dist(txp + yz0), a1 = smp.dist(txm + yz0), a2 = smp.dist(xy0 + tzp), a3 = smp.dist(xy0 + tzm), a4 = smp.dist(xz0 + typ), a5 = smp.dist(xz0 + tym);
 	const int b0 = smp.dist(tx1p + yz1), b1 = smp.dist(tx1m + yz1), b2 = smp.dist(xy1 + tz1p), b3 = smp.dist(xy1 + tz1m), b4 = smp.dist(xz1 + ty1p), b5 = smp.dist(xz1 + ty1m);
 	const u32 M0 = smp.mat(tx0 + yz0, x0, y0, z0), M1 = smp.mat(tx1 + yz1, x0 + ax, y0 + ay, z0 + az);
-	const u32 cellMat = st.cache[c];
+	const u32 cellMat = blockCache[c]; // (requested with the fetches above)
 	const bool interior = p0 * p1 < 0; // samples of strictly opposite sign: 0 < t < 256, vertex strictly inside its edge
 	const int t = (p0 != p1) ? edge_t(p0, p1) : 0, u = 256 - t; // (:1671-1678)
 	const u32 uu = (u32)u & 0x1FFu;
@@ -133,7 +133,8 @@ inline bool f1_block_serial(Fast1State<CAP>& st, const F0Tables& T, const Global
 		if (v == 0) return false;
 		st.samp[k * F1_SPLANE + j * F1_SROW + i] = (i8)v;
 	}
-	memcpy(st.cache, L.cache + (size_t)slot * BLOCK_CELLS, BLOCK_CELLS * 2);
+	const u16* blockCache = L.cache + (size_t)slot * BLOCK_CELLS;
+	for (u32 c = 0; c < (u32)BLOCK_CELLS; ++c) st.cacheId[c] = (u8)(blockCache[c] & 0xFFu);
 	u32 nt = 0;
 	for (int w = 0; w < 128; ++w) { st.ntBits[w] = L.ntBits[(size_t)slot * 128 + w]; st.wordPrefix[w] = (u16)nt; nt += (u32)TV_POPC(st.ntBits[w]); }
 	st.wordPrefix[128] = (u16)nt;
@@ -152,7 +153,7 @@ inline bool f1_block_serial(Fast1State<CAP>& st, const F0Tables& T, const Global
 		const u32 tEnd = ct < tTotal ? (tTotal - ct < (u32)F1_TDESC ? tTotal - ct : (u32)F1_TDESC) : 0u;
 		for (u32 j = 0; j < vEnd; ++j) {
 			const u32 desc = st.vdesc[j];
-			if (!f1_vertex(st, T, smp, desc, (int)level, ox, oy, oz, lut_row(G.lut, st.cache[desc & 0xFFFu]), P.verts + vOff + cv + j)) suspect = true;
+			if (!f1_vertex(st, T, smp, blockCache, desc, (int)level, ox, oy, oz, lut_row(G.lut, st.cacheId[desc & 0xFFFu]), P.verts + vOff + cv + j)) suspect = true;
 		}
 		for (u32 t = 0; t < tEnd; ++t) f0_triangle(st, T, t, P.idx + iOff + (ct + t) * 3u);
 	}

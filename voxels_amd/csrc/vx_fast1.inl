@@ -95,7 +95,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 				const int r = min(tid + q * WG, 288), k = r / 17, j = r - k * 17;
 				rows[q] = pyramid_row17(P, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
 			}
-			((uint4*)st.cache)[tid] = c0; ((uint4*)st.cache)[tid + WG] = c1;
+			// (the ids = the low bytes of the 16-bit entries: lane tid holds the entries [8 tid, 8 tid + 8) and [8 (tid + 256), ...))
+			((uint2*)st.cacheId)[tid] = make_uint2(__builtin_amdgcn_perm(c0.y, c0.x, 0x06040200u), __builtin_amdgcn_perm(c0.w, c0.z, 0x06040200u));
+			((uint2*)st.cacheId)[tid + WG] = make_uint2(__builtin_amdgcn_perm(c1.y, c1.x, 0x06040200u), __builtin_amdgcn_perm(c1.w, c1.z, 0x06040200u));
 #pragma unroll
 			for (int q = 0; q < 2; ++q) {
 				const int r = tid + q * WG;
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 					const u32 j = base + (u32)tid;
 					if (j < vEnd) {
 						const u32 desc = st.vdesc[j];
-						const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cache[desc & 0xFFFu] & 0xFFu);
-						if (!f1_vertex(st, T, smp, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
+						const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
+						if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
 					}
 					if (j < tEnd) {
 						u32 ids[3];
