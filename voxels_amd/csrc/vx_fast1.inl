@@ -2,12 +2,14 @@
 // blocks without a zero lattice sample (tv_fast1.h has the per-lane logic), written for gfx950.  Included by vx_hip.hip
 // behind vx_fast0.inl, whose table staging, list building and scans it shares.
 //
-// One workgroup per (level, slot) item at a time: 17^3 lattice samples (17 contiguous bytes per row of the level's
-// lattice copy) + the block's 8 KB material cache + bitmap into LDS (32 KB in all: five workgroups per CU hide the
-// latency of the voxel fetches around the vertices, nothing is prefetched) | compact cell list | table-driven cells |
-// bases + reservations + descriptors | one lane = one vertex (LOD chain, then 16 fetches with per-axis address terms)
-// and one lane = one triangle.  A block with a zero sample, or whose chains end on a voxel, goes to k_regular<.., 2>
-// through Globals::slowItems[1].
+// One workgroup per item of the run's flat list of active blocks (Globals::flatItems: level, slot, coordinate and cell
+// count in one load) at a time: 17^3 lattice samples (17 contiguous bytes per row of the level's lattice copy) + the
+// material ids of the block's cache + bitmap into LDS (27 KB in all; nothing is prefetched: the workgroups beside it hide
+// the latency of the voxel fetches around the vertices - and every KB held here is one the level-0 pass on the other
+// stream cannot use) | compact cell list | table-driven cells | bases + reservations +
+// descriptors | one lane = one vertex (LOD chain, then 17 fetches with per-axis address terms) and one lane = one
+// triangle, both through streaming stores.  A block with a zero sample, or whose chains end on a voxel, goes to
+// k_regular<.., 2> through Globals::slowItems[1]; blocks above the capacity class to the next one (`lo`).
 namespace {
 
 // voxel addresses in the brick mirrors as sums of one term per axis (tv_core.h brick_offset, split): 32-bit offsets,
