@@ -266,6 +266,40 @@ def main():
         dist_pkg.all_reduce(to, op=dist_pkg.ReduceOp.MAX)
         ms_other = float(to.item()) / k * 1e3
 
+    # ---- N > 1: the correctness bit of a sharded run.  Every rank digests the blocks it produced
+    #      (voxels_amd/digest.py: per-level totals + an order-independent 64-bit hash over every byte of every mesh, the block
+    #      ids, corners and counts), the digests are summed over the ranks, and rank 0 polygonizes the WHOLE grid in a second
+    #      context on its own GPU (6.6 GB at 1024^3) and compares.  A difference ends the run with a non-zero exit code on
+    #      every rank: a SCALE record either carries "multi_gpu_check": "equal" or does not exist. ---------------------------
+    multi_gpu_check = None
+    if world > 1:
+        from voxels_amd import digest
+        poly.execute(levels)
+        mine = digest.surface_digest(poly.all_levels())
+        tsum = torch.from_numpy(digest.pack(mine)).to(dev)
+        dist_pkg.all_reduce(tsum, op=dist_pkg.ReduceOp.SUM)
+        summed = digest.unpack(tsum.cpu().numpy(), levels)
+        verdict = torch.zeros(1, dtype=torch.int32, device=dev)
+        if rank == 0:
+            whole_poly = Polygonizer(device=local_rank)
+            whole_poly.set_materials(synth.default_lut())
+            whole_poly.create_terrain(n, seed)
+            whole_poly.execute(levels)
+            ref = digest.surface_digest(whole_poly.all_levels())
+            whole_poly.close()
+            equal = digest.digests_equal(summed, ref)
+            verdict[0] = 1 if equal else 0
+            multi_gpu_check = {"result": "equal" if equal else "DIFFERENT",
+                               "totals_per_level_blocks_verts_indices_tverts_tindices": summed[0].tolist(),
+                               "hash": "%016x" % int(summed[1]), "reference": "whole-grid run of the same library on rank 0's GPU",
+                               "reference_totals": ref[0].tolist(), "reference_hash": "%016x" % int(ref[1])}
+        dist_pkg.broadcast(verdict, 0)
+        if int(verdict.item()) != 1:
+            if rank == 0:
+                sys.stderr.write("multi-GPU self-check FAILED: %s\n" % json.dumps(multi_gpu_check))
+            dist_pkg.destroy_process_group()
+            raise SystemExit(3)
+
     # ---- per-kernel device timing (HIP events on the stream the kernels run on).  With stage timing enabled the
     #      library serialises its streams so that every kernel's duration is its own; the timed steps above ran the
     #      normal, overlapped pipeline (level-0 regular pass and transition pass beside the material chain). ----
@@ -452,6 +486,10 @@ def main():
                                         "note": "a height-field terrain keeps its surface in %d of %d level-0 blocks; `value` counts every voxel of the grid, as the metric defines it" % (surface_blocks, (n // 16) ** 2 * (planes // 16))},
                        "stage_ms_serialized": stage_ms, "whole_execute": whole, "e2e_ms": e2e, "device_gen_s": round(t_gen, 3),
                        "halo_exchange_in_step": bool(world > 1 and args.halo_every_step), "halo_transport": halo_transport,
+                       "step_definition": "r03+: one vx_polygonize per step on a resident grid; with N > 1 the slab halo is exchanged once before "
+                                          "the steps (vx_halo_exchange) unless --halo-every-step (r01/r02 exchanged it inside every step: "
+                                          "compare those rounds with ms_per_step_with_halo_exchange)",
+                       "multi_gpu_check": (multi_gpu_check["result"] if multi_gpu_check else None), "multi_gpu_check_detail": multi_gpu_check,
                        ("ms_per_step_without_halo_exchange" if args.halo_every_step else "ms_per_step_with_halo_exchange"): (round(ms_other, 4) if ms_other is not None else None),
                        "cold": cold},
             "roofline": roofline,

@@ -19,7 +19,7 @@ extern "C" {
  * may be NULL. */
 void vxs_terrain(uint32_t n, uint32_t z0, uint32_t z1, uint32_t seed, int8_t* dist, uint8_t* mat, uint8_t* blend);
 /* The same with a surface style: 0 = the terrain above; 1 = "caves": the 3-D noise term dominates and an isosurface
- * network fills a band of about +-190 voxels around the terrain height (a workload with surface in a large share of all
+ * network fills a band of about +-380 voxels around the terrain height (|z - h| / 64 < 6, vx_terrain_math.h) (a workload with surface in a large share of all
  * blocks, for throughput figures that do not depend on a sparse surface). */
 void vxs_terrain_ex(uint32_t n, uint32_t z0, uint32_t z1, uint32_t seed, uint32_t style, int8_t* dist, uint8_t* mat, uint8_t* blend);
 

@@ -40,21 +40,20 @@ def main():
     p.set_materials(vxo.default_lut())
     slab.attach(p)
     p.execute(levels)
-    out = {"stats": p.stats()}
-    for li, lv in enumerate(p.all_levels()):
-        out["L%d_infos" % li] = lv.infos
-        out["L%d_verts" % li] = lv.verts
-        out["L%d_idx" % li] = lv.idx
-        out["L%d_tverts" % li] = lv.tverts
-        out["L%d_tidx" % li] = lv.tidx
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    save(out_dir, rank, p)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def save(out_dir, rank, p):
-    out = {"stats": p.stats()}
-    for li, lv in enumerate(p.all_levels()):
+    """the rank's levels + the digest of the whole sharded run as bench.py --gpus N forms it: every rank's digest
+    (voxels_amd/digest.py), packed and summed with all_reduce"""
+    from voxels_amd import digest
+    all_levels = p.all_levels()
+    packed = torch.from_numpy(digest.pack(digest.surface_digest(all_levels)))
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    out = {"stats": p.stats(), "digest_sum": packed.numpy()}
+    for li, lv in enumerate(all_levels):
         out["L%d_infos" % li] = lv.infos
         out["L%d_verts" % li] = lv.verts
         out["L%d_idx" % li] = lv.idx

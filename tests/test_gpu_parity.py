@@ -301,6 +301,11 @@ def test_hip_config4_1024_eight_slabs(port, axis):
     del slabs
     ok, msg = fields.surface_equal(merge_rank_levels(parts), ref, nrm_tol=NRM_TOL)
     assert ok, msg
+    # the correctness bit `bench.py --gpus 8` prints (single-GPU emulation of it): the ranks' digests, packed and summed as
+    # its all_reduce does, equal the digest of the whole surface - here the oracle's
+    from voxels_amd import digest
+    summed = digest.unpack(sum(digest.pack(digest.surface_digest(part)) for part in parts), levels)
+    assert digest.digests_equal(summed, digest.surface_digest(ref)), "summed rank digests vs oracle digest"
 
 
 @pytest.mark.parametrize("seed", [300, 304, 317])

@@ -31,9 +31,10 @@ def test_two_ranks_equal_one(tmp_path, axis, port):
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"), str(tmp_path), str(n), str(levels), axis], env=e))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    parts, stats = [], np.zeros(20, np.uint64)
+    parts, stats, digest_sums = [], np.zeros(20, np.uint64), []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        digest_sums.append(z["digest_sum"])
         parts.append([Level(z["L%d_infos" % l], z["L%d_verts" % l], z["L%d_idx" % l], z["L%d_tverts" % l], z["L%d_tidx" % l]) for l in range(levels)])
         stats += z["stats"]
     d, m, b = synth.terrain(n, seed=5)
@@ -49,4 +50,8 @@ def test_two_ranks_equal_one(tmp_path, axis, port):
     assert ok, "2 ranks vs oracle: " + msg
     ok, msg = fields.surface_equal(merged, whole.all_levels())
     assert ok, msg
+    # the correctness bit of bench.py --gpus N: the all-reduced digest equals the digest of the whole surface
+    from voxels_amd import digest
+    for ds in digest_sums:
+        assert digest.digests_equal(digest.unpack(ds, levels), digest.surface_digest(ref)), "all-reduced digest vs oracle"
     assert np.array_equal(stats.astype(np.uint32), whole.stats())

@@ -1,5 +1,6 @@
 """Two ranks on two GPUs through the C ABI (row b8): vx_grid_fill_terrain + vx_comm_init + vx_halo_exchange over RCCL, one
-process per GPU, merged and compared with the single-context result.  Needs two GPUs (skipped otherwise: RCCL refuses
+process per GPU, merged and compared with the ORACLE's surface of the whole grid (oracle/port.cpp, pinned against the
+unmodified reference) - and the all-reduced digest that bench.py --gpus N prints as its correctness bit with the oracle's.  Needs two GPUs (skipped otherwise: RCCL refuses
 two ranks on one device); the same path with in-process transport runs on one GPU in
 tests/test_gpu_parity.py::test_hip_halo_exchange_group."""
 import os
@@ -35,9 +36,15 @@ def test_two_gpus_rccl_equal_one(tmp_path, axis, port):
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         parts.append([Level(z["L%d_infos" % l], z["L%d_verts" % l], z["L%d_idx" % l], z["L%d_tverts" % l], z["L%d_tidx" % l]) for l in range(levels)])
-    whole = Polygonizer(device=0)
-    whole.set_materials(synth.default_lut())
-    whole.create_terrain(n, 5)
-    whole.execute(levels)
-    ok, msg = fields.surface_equal(merge_rank_levels(parts), whole.all_levels())
-    assert ok, msg
+    import vxo
+    port = vxo.load_port()
+    assert port is not None, "oracle/libvoxels_port.so missing (run __graft_entry__.build())"
+    d, m, b = synth.terrain(n, seed=5)
+    ref = port.execute(port.grid_from_dense(d, m, b)).all_levels()[:levels]
+    merged = merge_rank_levels(parts)
+    ok, msg = fields.surface_equal(merged, ref, nrm_tol=1e-5)
+    assert ok, "2 GPUs over RCCL vs oracle: " + msg
+    from voxels_amd import digest
+    for r in range(world):
+        ds = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["digest_sum"]
+        assert digest.digests_equal(digest.unpack(ds, levels), digest.surface_digest(ref)), "all-reduced digest vs oracle"

@@ -371,7 +371,13 @@ class Polygonizer:
         m = _HostMeshesStruct()
         if previous is not None:
             m.arena = previous._take()
-        self._check(self._lib.vx_host_meshes_acquire(self._h, C.byref(m)), "vx_host_meshes_acquire")
+        rc = self._lib.vx_host_meshes_acquire(self._h, C.byref(m))
+        if rc != 0 and m.arena:
+            # the C side always writes the arena back (possibly a different one): nothing owns it on this path, so it goes
+            # back to the library's recycling list instead of leaking page-locked memory (`previous` is spent either way)
+            self._lib.vx_host_meshes_release(m.arena)
+            m.arena = None
+        self._check(rc, "vx_host_meshes_acquire")
         return HostMeshes(self._lib, m)
 
     def all_levels(self):

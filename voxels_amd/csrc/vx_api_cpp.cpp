@@ -245,24 +245,26 @@ struct ModificationImpl : public Modification
 };
 
 // Brings the surface's host copy of the pools up to date (one DMA into page-locked memory; after an incremental run only
-// what the run appended) and rebuilds the per-block views of all levels.
+// what the run appended) and rebuilds the per-block views of all levels.  The views are built aside and swapped in only
+// when everything succeeded; on a failure the surface keeps NO views (vx_host_meshes_acquire may already have exchanged
+// the arena the old views pointed into for a larger one: a stale view would be a use-after-free waiting to happen).
 bool FetchSurface(vx_ctx* ctx, unsigned levels, SurfaceImpl& s)
 {
-	if (vx_host_meshes_acquire(ctx, &s.Meshes) != VX_OK) return false;
+	std::vector<std::vector<BlockImpl>> built(levels);
+	const auto fail = [&]() { s.Levels.clear(); s.Levels.resize(levels); return false; };
+	if (vx_host_meshes_acquire(ctx, &s.Meshes) != VX_OK) return fail();
 	const PolygonVertex* pv = (const PolygonVertex*)s.Meshes.verts;
 	const unsigned* pi = s.Meshes.indices;
-	s.Levels.resize(levels);
 	std::vector<vx_block_info> infos;
 	std::vector<vx_block_ranges> ranges;
 	for (unsigned level = 0; level < levels; ++level) {
 		uint32_t nb = 0;
-		if (vx_level_counts(ctx, level, &nb, nullptr) != VX_OK) return false;
+		if (vx_level_counts(ctx, level, &nb, nullptr) != VX_OK) return fail();
 		infos.resize(nb);
 		ranges.resize(nb);
 		if (nb && (vx_download_level(ctx, level, infos.data(), nullptr, nullptr, nullptr, nullptr) != VX_OK
-		           || vx_level_ranges(ctx, level, ranges.data()) != VX_OK)) return false;
-		std::vector<BlockImpl>& out = s.Levels[level];
-		out.clear();
+		           || vx_level_ranges(ctx, level, ranges.data()) != VX_OK)) return fail();
+		std::vector<BlockImpl>& out = built[level];
 		out.resize(nb);
 		for (uint32_t k = 0; k < nb; ++k) {
 			const vx_block_info& in = infos[k];
@@ -279,6 +281,7 @@ bool FetchSurface(vx_ctx* ctx, unsigned levels, SurfaceImpl& s)
 			}
 		}
 	}
+	s.Levels.swap(built);
 	return true;
 }
 
