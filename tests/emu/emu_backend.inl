@@ -6,6 +6,7 @@ struct ExecParamsView; // ExecParams is defined by vx_host.inl; stages are templ
 struct Backend {
 	std::string lastError;
 	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
+	u32 upperItemsHint = 0; // (HIP backend: sizes the launch of the levels >= 1)
 
 	bool init(int, std::string&) { return true; }
 	bool wants_pyramid() const { return false; }

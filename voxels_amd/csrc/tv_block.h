@@ -26,6 +26,15 @@ template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v;
 #define TV_POPC(x) __builtin_popcount(x)
 #endif
 
+// A load of data that another workgroup of the SAME launch may have written (k_upper: material caches, published with
+// write-through stores): past the CU's L1, which no other CU's store ever refreshes - an agent-scope relaxed atomic load
+// is an `sc1` load on gfx950.  A plain load elsewhere (the CPU emulation; data of earlier launches).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TV_LOAD_THROUGH(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define TV_LOAD_THROUGH(p) (*(p))
+#endif
+
 namespace tv {
 
 enum { MAX_LEVELS = 8, BLOCK_CELLS = 4096, SAMPLES = 17 * 17 * 17, PLANE = 33 * 33 };
@@ -72,6 +81,9 @@ struct LevelDesc {
 	u16* ntCount;       // [cap] number of non-trivial cells of the block (picks the LDS capacity class)
 	BlockRecord* records; // [cap]
 	ListedBlock* listed;  // [cap] the level's block list (see ListedBlock)
+	unsigned long long* matDone; // [cap] levels >= 1, full runs of the GPU backend: Globals::epoch << 32 | non-trivial cells once the block's
+	                      //       material cache, bitmap and cell count are in memory (the dependency flags of k_upper: one 8-byte word per block,
+	                      //       written with one store, polled by whoever needs the block - its parent's vote, its own regular and transition cells)
 #if defined(VX_CASE_DUMP)
 	// test builds only (libvoxels_hip_casedump.so): the case code of every cell the passes looked up in Lengyel's tables,
 	// for tests/test_case_codes.py (case codes are not part of the public result)
@@ -153,6 +165,12 @@ struct Globals {
 	// coordinate and cell count - one dependent round trip less at the head of every block.
 	struct FlatItem* flatItems;
 	const u32* slotCounts;            // [MAX_LEVELS] active blocks per level (LevelDesc::nActive of all levels, contiguous)
+	// full runs of the GPU backend: the levels >= 1 as ONE launch (k_upper) whose work items - material blocks of the levels
+	// 1, 2, ... in that order, then their regular and transition blocks - are dequeued in order and wait for what they
+	// depend on through LevelDesc::matDone
+	u32 epoch;                        // this run's tag in matDone (never 0)
+	u32* upperHead;                   // queue head (zeroed with the run's counters)
+	u32* giveUp;                      // set when a dependency wait ran out of patience (a bug, never data-dependent): the host fails the run
 };
 
 // BF_Empty (VoxelGrid.cpp:455-476 / CompressBlock) means: every sample of the block is non-zero and has the sign of the
@@ -1119,7 +1137,7 @@ TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const
 		st.valid[k] = (u16)tr_slot_valid(T, v, code);
 		int local[3];
 		tr_low_local(face_geom(f), row, col, local);
-		st.cellMat[k] = L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])];
+		st.cellMat[k] = TV_LOAD_THROUGH(&L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])]);
 	}
 }
 

@@ -97,7 +97,7 @@ TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16*
 	const int a0 = smp.dist(txp + yz0), a1 = smp.dist(txm + yz0), a2 = smp.dist(xy0 + tzp), a3 = smp.dist(xy0 + tzm), a4 = smp.dist(xz0 + typ), a5 = smp.dist(xz0 + tym);
 	const int b0 = smp.dist(tx1p + yz1), b1 = smp.dist(tx1m + yz1), b2 = smp.dist(xy1 + tz1p), b3 = smp.dist(xy1 + tz1m), b4 = smp.dist(xz1 + ty1p), b5 = smp.dist(xz1 + ty1m);
 	const u32 M0 = smp.mat(tx0 + yz0, x0, y0, z0), M1 = smp.mat(tx1 + yz1, x0 + ax, y0 + ay, z0 + az);
-	const u32 cellMat = blockCache[c]; // (requested with the fetches above)
+	const u32 cellMat = TV_LOAD_THROUGH(&blockCache[c]); // (requested with the fetches above; past the L1: another workgroup of the launch wrote it)
 	const bool interior = p0 * p1 < 0; // samples of strictly opposite sign: 0 < t < 256, vertex strictly inside its edge
 	const int t = (p0 != p1) ? edge_t(p0, p1) : 0, u = 256 - t; // (:1671-1678)
 	const u32 uu = (u32)u & 0x1FFu;

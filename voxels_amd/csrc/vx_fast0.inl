@@ -12,10 +12,10 @@ namespace {
 constexpr u32 F0_TAB_FIXED = TAB_F0_BYTES - TAB_F0_CASE;   // case rows | triangle rows | edge infos | direction masks
 constexpr u32 F0_TAB_LDS = F0_TAB_FIXED + 2048;            // + the per-case vertex rows widened to 8 bytes
 
-__device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image)
+__device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image, u32 tid)
 {
-	copy16(lds, image + TAB_F0_CASE, F0_TAB_FIXED);
-	for (u32 i = threadIdx.x; i < 256; i += WG) {
+	copy16(lds, image + TAB_F0_CASE, F0_TAB_FIXED, tid);
+	for (u32 i = tid; i < 256; i += WG) {
 		const u8* src = image + TAB_REG_VERT + i * 6;
 		unsigned long long row = 0;
 #pragma unroll
@@ -24,6 +24,7 @@ __device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image)
 	}
 	return f0_tables_from_image(lds - TAB_F0_CASE, (const unsigned long long*)(lds + F0_TAB_FIXED));
 }
+__device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image) { return f0_stage_tables(lds, image, threadIdx.x); }
 
 // inclusive scan over the wave with DPP row shifts and row broadcasts (gfx9): no LDS traffic, six dependent adds
 __device__ __forceinline__ u32 wave_inclusive_scan_dpp(u32 v)

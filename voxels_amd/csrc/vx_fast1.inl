@@ -2,8 +2,9 @@
 // blocks without a zero lattice sample (tv_fast1.h has the per-lane logic), written for gfx950.  Included by vx_hip.hip
 // behind vx_fast0.inl, whose table staging, list building and scans it shares.
 //
-// One workgroup per item of the run's flat list of active blocks (Globals::flatItems: level, slot, coordinate and cell
-// count in one load) at a time: 17^3 lattice samples (17 contiguous bytes per row of the level's lattice copy) + the
+// f1_block is one block's work; k_regular1_fast walks the run's flat list of active blocks (Globals::flatItems: level, slot,
+// coordinate and cell count in one load) with it - the capacity classes of dense surfaces - and k_upper (vx_upper.inl)
+// calls it for the first class inside the one launch of the levels >= 1.  One workgroup per block at a time: 17^3 lattice samples (17 contiguous bytes per row of the level's lattice copy) + the
 // material ids of the block's cache + bitmap into LDS (27 KB in all; nothing is prefetched: the workgroups beside it hide
 // the latency of the voxel fetches around the vertices - and every KB held here is one the level-0 pass on the other
 // stream cannot use) | compact cell list | table-driven cells | bases + reservations +
@@ -39,12 +40,215 @@ struct BrickSamplerT {
 };
 typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller than 4 GiB
 
+// One block of a level 1..3 (CAP = LDS capacity class; `lo`: blocks with at most that many non-trivial cells belong to a lower
+// class).  GATED (k_upper): bitmap, cache block and cell count come from the material work of another workgroup of the same
+// launch; the lattice samples, which do not, are requested before the wait.  Otherwise (k_regular1_fast) `ntc` and `coord`
+// come from the run's flat list.
+template <int CAP, bool GATED>
+__device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables& T, const F1BrickSampler& smp, Fast1State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
+                                         u32 level, u32 slot, u32 coord, u32 ntc, u32 lo, const int tid)
+{
+	typedef R0<CAP> K;
+	const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
+	const LevelDesc& L = p.levels[level];
+	if (!GATED) {
+		if (ntc > (u32)CAP || (lo && ntc <= lo)) return;    // another capacity class owns those (the first class, lo == 0, also owns the empty blocks)
+		if (ntc == 0) {                                     // (uniform) a surface-bearing block without a non-trivial coarse cell
+			if (tid == 0) reg_write_empty_record(L, slot);
+			return;
+		}
+	}
+	u32 bx, by, bz;
+	block_coords(coord, L.cnt, bx, by, bz);
+	__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
+	if (tid == 0) st.suspect = 0;
+	PyramidRow rows[2];
+	{
+		const PyramidLevel& P = p.G.pyr[level];
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int r = min(tid + q * WG, 288), k = r / 17, j = r - k * 17;
+			rows[q] = pyramid_row17(P, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
+		}
+	}
+	if (GATED) {
+		if (tid == 0) st.zero = wait_done(L.matDone + slot, p.G.epoch, p.G.giveUp);
+		acquire_and_meet(tid < 64);
+		ntc = r0_uniform(st.zero);
+		if (ntc > (u32)CAP || (lo && ntc <= lo)) return;
+		if (ntc == 0) {
+			if (tid == 0) reg_write_empty_record(L, slot);
+			return;
+		}
+	}
+
+	// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
+	{
+		u32 zero = 0;
+		// (bitmap and cache block: written by the material work - in k_upper by another workgroup of the same launch, hence past the L1)
+		if (tid < 128) st.ntBits[tid] = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + tid]);
+		if (tid < 16) st.classCount[tid] = 0;
+		const u16* csrc = L.cache + (size_t)slot * BLOCK_CELLS;
+		const uint4 c0 = load16_through(csrc, (u32)tid * 16u), c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
+		// (the ids = the low bytes of the 16-bit entries: lane tid holds the entries [8 tid, 8 tid + 8) and [8 (tid + 256), ...))
+		((uint2*)st.cacheId)[tid] = make_uint2(__builtin_amdgcn_perm(c0.y, c0.x, 0x06040200u), __builtin_amdgcn_perm(c0.w, c0.z, 0x06040200u));
+		((uint2*)st.cacheId)[tid + WG] = make_uint2(__builtin_amdgcn_perm(c1.y, c1.x, 0x06040200u), __builtin_amdgcn_perm(c1.w, c1.z, 0x06040200u));
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int r = tid + q * WG;
+			if (r < 289) {
+				const int k = r / 17, j = r - k * 17;
+				u32* dst = (u32*)(st.samp + k * F1_SPLANE + j * F1_SROW);
+				dst[0] = rows[q].lo.x; dst[1] = rows[q].lo.y; dst[2] = rows[q].lo.z; dst[3] = rows[q].lo.w; dst[4] = rows[q].far;
+				zero |= f0_has_zero_byte(rows[q].lo.x) | f0_has_zero_byte(rows[q].lo.y) | f0_has_zero_byte(rows[q].lo.z) | f0_has_zero_byte(rows[q].lo.w) | ((rows[q].far & 0xFFu) == 0u ? 1u : 0u);
+			}
+		}
+		if (__ballot(zero != 0) && lane == 0) zeroFlag[parity] = 1;
+		if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
+	}
+	__syncthreads();
+	const bool clean = r0_uniform(zeroFlag[parity]) == 0;
+	parity ^= 1u;
+	if (!clean) {
+		if (tid == 0) p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
+		return;
+	}
+
+	// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
+	{
+		const u32 w0 = st.ntBits[lane], w1 = st.ntBits[lane + 64];
+		const u32 c0 = (u32)__popc(w0), c1 = (u32)__popc(w1);
+		const u32 i0 = wave_inclusive_scan_dpp(c0);
+		const u32 half = (u32)__shfl((int)i0, 63, 64);
+		const u32 i1 = wave_inclusive_scan_dpp(c1) + half;
+		const u32 e0 = i0 - c0, e1 = i1 - c1;
+		if (wave == 0) {
+			st.wordPrefix[lane] = (u16)e0; st.wordPrefix[lane + 64] = (u16)e1;
+			if (lane == 63) st.wordPrefix[128] = (u16)i1;
+		}
+		const int src = (tid >> 1) & 63;
+		const u32 wLo = (u32)__shfl((int)w0, src, 64), wHi = (u32)__shfl((int)w1, src, 64);
+		const u32 eLo = (u32)__shfl((int)e0, src, 64), eHi = (u32)__shfl((int)e1, src, 64);
+		const u32 word = (wave >= 2) ? wHi : wLo;
+		u32 kk = (wave >= 2) ? eHi : eLo;
+		u32 bits = word & 0xFFFFu;
+		if (tid & 1) { kk += (u32)__popc(bits); bits = word >> 16; }
+		while (bits) {
+			const u32 x = (u32)__builtin_ctz(bits);
+			bits &= bits - 1;
+			st.cellAN[kk++][0] = (u32)(tid * 16) + x;
+		}
+	}
+	__syncthreads();
+
+	// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
+	const u32 nt = r0_uniform(st.wordPrefix[128]);
+	const u32 Q = ((nt + WG - 1) / WG) * 64u;
+	const u32 kBeg = r0_uniform(min(wave * Q, nt)), kEnd = r0_uniform(min(wave * Q + Q, nt));
+	{
+		u32 carry = 0;
+		for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
+			const u32 k = k0 + lane;
+			u32 cnt = 0;
+			if (k < kEnd) {
+				cnt = fx_cell<F1Layout>(st, T, k, st.classCount);
+#if defined(VX_CASE_DUMP)
+				L.caseDump[(size_t)slot * BLOCK_CELLS + (st.cellAN[k][0] & 0xFFFu)] = (u8)((st.cellAN[k][0] >> 12) & 0xFFu);
+#endif
+			}
+			const u32 incl = wave_inclusive_scan_dpp(cnt);
+			if (k < kEnd) st.cellC[k] = carry + incl - cnt;
+			carry += (u32)__shfl((int)incl, 63, 64);
+		}
+		if (lane == 0) st.waveTot[wave] = carry;
+	}
+	__syncthreads();
+	{
+		u32 waveBase = 0, tot = 0;
+#pragma unroll
+		for (u32 w = 0; w < (u32)(WG / 64); ++w) {
+			const u32 s = st.waveTot[w];
+			if (w < wave) waveBase += s;
+			tot += s;
+		}
+		if (tid == WG - 1) {
+			const u32 vTotal = tot & 0xFFFFu, tTotal = tot >> 16;
+			st.vTotal = vTotal; st.tTotal = tTotal;
+			reserve_both(p.P.cursors, vTotal, tTotal * 3u, st.vOff, st.iOff);
+		}
+		for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
+			const u32 k = k0 + lane;
+			if (k < kEnd) {
+				const u32 base = st.cellC[k] + waveBase;
+				st.cellC[k] = base;
+				f0_describe(st, T, k, base, 0u, 0u);
+			}
+		}
+	}
+	__syncthreads();
+
+	const u32 vTotalU = r0_uniform(st.vTotal), tTotalU = r0_uniform(st.tTotal);
+	const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
+	const int ox = (int)(bx * 16 * L.mult), oy = (int)(by * 16 * L.mult), oz = (int)(bz * 16 * L.mult);
+	if (room) {
+		u32 notInterior = 0;
+		for (u32 chunk = 0; chunk == 0 || chunk * F1_VDESC < vTotalU || chunk * F1_TDESC < tTotalU; ++chunk) {
+			const u32 cv = chunk * F1_VDESC, ct = chunk * F1_TDESC;
+			if (chunk) {
+				__syncthreads();
+				for (u32 k = (u32)tid; k < nt; k += WG) f0_describe(st, T, k, st.cellC[k], cv, ct);
+				__syncthreads();
+			}
+			const u32 vEnd = cv < vTotalU ? min(vTotalU - cv, (u32)F1_VDESC) : 0u;
+			const u32 tEnd = ct < tTotalU ? min(tTotalU - ct, (u32)F1_TDESC) : 0u;
+			PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
+			u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
+			for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
+				const u32 j = base + (u32)tid;
+				if (j < vEnd) {
+					const u32 desc = st.vdesc[j];
+					const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
+					if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
+				}
+				if (j < tEnd) {
+					u32 ids[3];
+					f0_triangle(st, T, j, ids);
+					u32* o3 = iOut + j * 3u;
+					TV_STREAM_STORE(&o3[0], ids[0]); TV_STREAM_STORE(&o3[1], ids[1]); TV_STREAM_STORE(&o3[2], ids[2]);
+				}
+			}
+		}
+		if (__ballot(notInterior != 0) && lane == 0) st.suspect = 1;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		if (st.suspect) {
+			// a chain ended on a voxel: the general pass (degenerate-triangle filter) redoes the block; the ranges reserved
+			// above stay unused
+			st.suspect = 0;
+			p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
+			atomicAdd(&p.G.slowCount[2], st.vTotal); atomicAdd(&p.G.slowCount[3], st.tTotal * 3u); // dead pool ranges (reported, vx_exec_info)
+		} else {
+			BlockRecord& r = L.records[slot];
+			r.coordId = coord;
+			r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.tTotal * 3u : 0;
+			count_listed_block(L, r.coordId, r.vCount);
+			if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
+			r.degenerate = 0;
+			r.ntCells = nt;
+			r.pad = 0;
+			if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
+			wgStats[0] += nt;
+			for (int i = 0; i < 16; ++i) wgStats[4 + i] += st.classCount[i];
+		}
+	}
+}
+
 template <int CAP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_regular1_fast(ExecParamsDev p, u32 levelEnd, u32 lo)
 {
 	if (lo && *p.G.largeBlocks == 0) return; // nothing for the capacity classes above the first (uniform over the grid)
 	typedef Fast1State<CAP> ST;
-	typedef R0<CAP> K;
 	u8* tab = smem;
 	ST& st = *(ST*)(smem + F0_TAB_LDS);
 	__shared__ u32 wgStats[20];
@@ -53,7 +257,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	const int tid = (int)threadIdx.x;
 	if (tid < 20) wgStats[tid] = 0;
 	if (tid < 2) zeroFlag[tid] = 0;
-	if (tid == 0) st.suspect = 0;
 	const F0Tables T = f0_stage_tables(tab, p.tables); // visible after the first barrier of the item loop
 	// the work items are the first entries of the run's list of active blocks of the levels >= 1 (Globals::flatItems, in
 	// level order): those of the levels below levelEnd.  Counts and the item's entry come in one round trip.
@@ -63,191 +266,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
 	const GridView& g = p.G.grid;
 	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
-	const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
 	u32 parity = 0;
 
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
 		const FlatItem fi = p.G.flatItems[item];
-		const u32 level = r0_uniform(fi.where >> 24), slot = r0_uniform(fi.where & 0xFFFFFFu);
-		const LevelDesc& L = p.levels[level];
-		const u32 ntc = r0_uniform(fi.ntCells);
-		if (ntc > (u32)CAP || (lo && ntc <= lo)) continue;   // another capacity class owns those (the first class, lo == 0, also owns the empty blocks)
-		const u32 coord = r0_uniform(fi.coordId);
-		if (ntc == 0) {                                     // (uniform) a surface-bearing block without a non-trivial coarse cell
-			if (tid == 0) reg_write_empty_record(L, slot);
-			continue;
-		}
-		u32 bx, by, bz;
-		block_coords(coord, L.cnt, bx, by, bz);
-		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
-
-		// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
-		{
-			u32 zero = 0;
-			if (tid < 128) st.ntBits[tid] = L.ntBits[(size_t)slot * 128 + tid];
-			if (tid < 16) st.classCount[tid] = 0;
-			const uint4* csrc = (const uint4*)(L.cache + (size_t)slot * BLOCK_CELLS);
-			const uint4 c0 = csrc[tid], c1 = csrc[tid + WG];
-			const PyramidLevel& P = p.G.pyr[level];
-			PyramidRow rows[2];
-#pragma unroll
-			for (int q = 0; q < 2; ++q) {
-				const int r = min(tid + q * WG, 288), k = r / 17, j = r - k * 17;
-				rows[q] = pyramid_row17(P, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
-			}
-			// (the ids = the low bytes of the 16-bit entries: lane tid holds the entries [8 tid, 8 tid + 8) and [8 (tid + 256), ...))
-			((uint2*)st.cacheId)[tid] = make_uint2(__builtin_amdgcn_perm(c0.y, c0.x, 0x06040200u), __builtin_amdgcn_perm(c0.w, c0.z, 0x06040200u));
-			((uint2*)st.cacheId)[tid + WG] = make_uint2(__builtin_amdgcn_perm(c1.y, c1.x, 0x06040200u), __builtin_amdgcn_perm(c1.w, c1.z, 0x06040200u));
-#pragma unroll
-			for (int q = 0; q < 2; ++q) {
-				const int r = tid + q * WG;
-				if (r < 289) {
-					const int k = r / 17, j = r - k * 17;
-					u32* dst = (u32*)(st.samp + k * F1_SPLANE + j * F1_SROW);
-					dst[0] = rows[q].lo.x; dst[1] = rows[q].lo.y; dst[2] = rows[q].lo.z; dst[3] = rows[q].lo.w; dst[4] = rows[q].far;
-					zero |= f0_has_zero_byte(rows[q].lo.x) | f0_has_zero_byte(rows[q].lo.y) | f0_has_zero_byte(rows[q].lo.z) | f0_has_zero_byte(rows[q].lo.w) | ((rows[q].far & 0xFFu) == 0u ? 1u : 0u);
-				}
-			}
-			if (__ballot(zero != 0) && lane == 0) zeroFlag[parity] = 1;
-			if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
-		}
-		__syncthreads();
-		const bool clean = r0_uniform(zeroFlag[parity]) == 0;
-		parity ^= 1u;
-		if (!clean) {
-			if (tid == 0) p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
-			continue;
-		}
-
-		// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
-		{
-			const u32 w0 = st.ntBits[lane], w1 = st.ntBits[lane + 64];
-			const u32 c0 = (u32)__popc(w0), c1 = (u32)__popc(w1);
-			const u32 i0 = wave_inclusive_scan_dpp(c0);
-			const u32 half = (u32)__shfl((int)i0, 63, 64);
-			const u32 i1 = wave_inclusive_scan_dpp(c1) + half;
-			const u32 e0 = i0 - c0, e1 = i1 - c1;
-			if (wave == 0) {
-				st.wordPrefix[lane] = (u16)e0; st.wordPrefix[lane + 64] = (u16)e1;
-				if (lane == 63) st.wordPrefix[128] = (u16)i1;
-			}
-			const int src = (tid >> 1) & 63;
-			const u32 wLo = (u32)__shfl((int)w0, src, 64), wHi = (u32)__shfl((int)w1, src, 64);
-			const u32 eLo = (u32)__shfl((int)e0, src, 64), eHi = (u32)__shfl((int)e1, src, 64);
-			const u32 word = (wave >= 2) ? wHi : wLo;
-			u32 kk = (wave >= 2) ? eHi : eLo;
-			u32 bits = word & 0xFFFFu;
-			if (tid & 1) { kk += (u32)__popc(bits); bits = word >> 16; }
-			while (bits) {
-				const u32 x = (u32)__builtin_ctz(bits);
-				bits &= bits - 1;
-				st.cellAN[kk++][0] = (u32)(tid * 16) + x;
-			}
-		}
-		__syncthreads();
-
-		// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
-		const u32 nt = r0_uniform(st.wordPrefix[128]);
-		const u32 Q = ((nt + WG - 1) / WG) * 64u;
-		const u32 kBeg = r0_uniform(min(wave * Q, nt)), kEnd = r0_uniform(min(wave * Q + Q, nt));
-		{
-			u32 carry = 0;
-			for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
-				const u32 k = k0 + lane;
-				u32 cnt = 0;
-				if (k < kEnd) {
-					cnt = fx_cell<F1Layout>(st, T, k, st.classCount);
-#if defined(VX_CASE_DUMP)
-					L.caseDump[(size_t)slot * BLOCK_CELLS + (st.cellAN[k][0] & 0xFFFu)] = (u8)((st.cellAN[k][0] >> 12) & 0xFFu);
-#endif
-				}
-				const u32 incl = wave_inclusive_scan_dpp(cnt);
-				if (k < kEnd) st.cellC[k] = carry + incl - cnt;
-				carry += (u32)__shfl((int)incl, 63, 64);
-			}
-			if (lane == 0) st.waveTot[wave] = carry;
-		}
-		__syncthreads();
-		{
-			u32 waveBase = 0, tot = 0;
-#pragma unroll
-			for (u32 w = 0; w < (u32)(WG / 64); ++w) {
-				const u32 s = st.waveTot[w];
-				if (w < wave) waveBase += s;
-				tot += s;
-			}
-			if (tid == WG - 1) {
-				const u32 vTotal = tot & 0xFFFFu, tTotal = tot >> 16;
-				st.vTotal = vTotal; st.tTotal = tTotal;
-				reserve_both(p.P.cursors, vTotal, tTotal * 3u, st.vOff, st.iOff);
-			}
-			for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
-				const u32 k = k0 + lane;
-				if (k < kEnd) {
-					const u32 base = st.cellC[k] + waveBase;
-					st.cellC[k] = base;
-					f0_describe(st, T, k, base, 0u, 0u);
-				}
-			}
-		}
-		__syncthreads();
-
-		const u32 vTotalU = r0_uniform(st.vTotal), tTotalU = r0_uniform(st.tTotal);
-		const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
-		const int ox = (int)(bx * 16 * L.mult), oy = (int)(by * 16 * L.mult), oz = (int)(bz * 16 * L.mult);
-		if (room) {
-			u32 notInterior = 0;
-			for (u32 chunk = 0; chunk == 0 || chunk * F1_VDESC < vTotalU || chunk * F1_TDESC < tTotalU; ++chunk) {
-				const u32 cv = chunk * F1_VDESC, ct = chunk * F1_TDESC;
-				if (chunk) {
-					__syncthreads();
-					for (u32 k = (u32)tid; k < nt; k += WG) f0_describe(st, T, k, st.cellC[k], cv, ct);
-					__syncthreads();
-				}
-				const u32 vEnd = cv < vTotalU ? min(vTotalU - cv, (u32)F1_VDESC) : 0u;
-				const u32 tEnd = ct < tTotalU ? min(tTotalU - ct, (u32)F1_TDESC) : 0u;
-				PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
-				u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
-				for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
-					const u32 j = base + (u32)tid;
-					if (j < vEnd) {
-						const u32 desc = st.vdesc[j];
-						const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
-						if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
-					}
-					if (j < tEnd) {
-						u32 ids[3];
-						f0_triangle(st, T, j, ids);
-						u32* o3 = iOut + j * 3u;
-						TV_STREAM_STORE(&o3[0], ids[0]); TV_STREAM_STORE(&o3[1], ids[1]); TV_STREAM_STORE(&o3[2], ids[2]);
-					}
-				}
-			}
-			if (__ballot(notInterior != 0) && lane == 0) st.suspect = 1;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			if (st.suspect) {
-				// a chain ended on a voxel: the general pass (degenerate-triangle filter) redoes the block; the ranges reserved
-				// above stay unused
-				st.suspect = 0;
-				p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
-			} else {
-				BlockRecord& r = L.records[slot];
-				r.coordId = coord;
-				r.vOff = st.vOff; r.vCount = room ? st.vTotal : 0; r.iOff = st.iOff; r.iCount = room ? st.tTotal * 3u : 0;
-				count_listed_block(L, r.coordId, r.vCount);
-				if (!L.hasTransitions) for (int f = 0; f < 6; ++f) { r.tvOff[f] = 0; r.tvCount[f] = 0; r.tiOff[f] = 0; r.tiCount[f] = 0; }
-				r.degenerate = 0;
-				r.ntCells = nt;
-				r.pad = 0;
-				if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
-				wgStats[0] += nt;
-				for (int i = 0; i < 16; ++i) wgStats[4 + i] += st.classCount[i];
-			}
-		}
+		f1_block<CAP, false>(p, T, smp, st, wgStats, zeroFlag, parity, r0_uniform(fi.where >> 24), r0_uniform(fi.where & 0xFFFFFFu), r0_uniform(fi.coordId), r0_uniform(fi.ntCells), lo, tid);
 	}
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);

@@ -112,6 +112,74 @@ __device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indice
 #endif
 }
 
+// ---- dependencies between workgroups of ONE launch (k_upper): LevelDesc::matDone ----------------------------------------
+// Producer: every wave drains its stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back: the eight
+// XCDs' L2s are not coherent with each other) and stores the 8-byte word epoch << 32 | payload.  Consumer: ONE wave polls the
+// word (relaxed, agent scope, s_sleep between polls), then ONE agent-scope acquire drops the stale lines of its CU's L1 /
+// its XCD's L2, the workgroup meets, and everybody reads with plain loads.  Results do not depend on dispatch order,
+// timing or placement; every wait is bounded (Globals::giveUp fails the run instead of hanging the device).
+__device__ __forceinline__ void publish_done(unsigned long long* flag, u32 epoch, u32 payload)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (restates the wait behind the write-back where the compiler cannot drop it)
+		__hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+// The write-through form of publishing (payload stored with sc1: the bytes leave the XCD's L2 at once, nothing has to be
+// written back before the flag): a release fence writes back EVERY dirty line of the XCD's L2 - beside a level-0 pass
+// that dirties hundreds of MB per run, thousands of them per run cost more than the launches they replace.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_through(void* uniformBase, u32 byteOffset, uint4 v)
+{
+	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(uniformBase, 0, 0x7FFFFFFF, 0x00020000);
+	v4u32 x = { v.x, v.y, v.z, v.w };
+	__builtin_amdgcn_raw_buffer_store_b128(x, rsrc, (int)byteOffset, 0, /* aux: sc1 */ 16);
+}
+__device__ __forceinline__ void publish_done_through(unsigned long long* flag, u32 epoch, u32 payload)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
+	__syncthreads();
+	if (threadIdx.x == 0) __hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+enum { WAIT_SPINS = 1u << 22 }; // x ~0.5 us per poll: seconds, against runs of milliseconds
+
+// one lane: poll until the word carries this run's tag; returns its payload (0 after giving up)
+__device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epoch, u32* giveUp)
+{
+	for (u32 spins = 0;; ++spins) {
+		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((u32)(v >> 32) == epoch) return (u32)v;
+		if (spins > (u32)WAIT_SPINS) { atomicOr(giveUp, 1u); return 0u; }
+		__builtin_amdgcn_s_sleep(4);
+	}
+}
+
+// behind the polls of ONE wave (the others wait at the barrier).  What the producers published left through write-through
+// stores and is read through TV_LOAD_THROUGH / load16_through (past the L1), so no acquire - an invalidation of the whole
+// L1 of the CU, also under the other workgroups running there - is needed; VX_UP_RELEASE_FENCE builds (plain stores + release
+// fence on the producer side, A/B) pair it with the acquire.
+__device__ __forceinline__ void acquire_and_meet(bool polled)
+{
+#if defined(VX_UP_RELEASE_FENCE) || defined(VX_UP_ACQUIRE)
+	if (polled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+	(void)polled;
+#endif
+	__syncthreads();
+}
+
+__device__ __forceinline__ uint4 load16_through(const void* uniformBase, u32 byteOffset)
+{
+	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniformBase), 0, 0x7FFFFFFF, 0x00020000);
+	const v4u32 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byteOffset, 0, /* aux: sc1 */ 16);
+	return make_uint4(x.x, x.y, x.z, x.w);
+}
+
 __device__ __forceinline__ void stage_tables(u8* dst, const u8* src)
 {
 	const uint4* s = (const uint4*)src;
@@ -979,250 +1047,254 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 	return bestId | ((avg & 0xFFu) << 8);
 }
 
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_material(ExecParamsDev p, u32 level)
+// One block of one level >= 1.  GATED (k_upper): the children's caches come from other workgroups of the same launch - waited
+// for right in front of the vote, the only phase that reads them - and the block's own completion is published.
+template <bool GATED>
+__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid)
 {
-	__shared__ MatLds st;
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
 	const GridView& g = p.G.grid;
-	const u32 nItems = p.G.dirty ? p.G.workCount[level] : *L.nActive;
-	const int tid = threadIdx.x;
 	const int n = g.n;
 	const int mult = (int)L.mult;
 	constexpr int PER = (SAMPLES + WG - 1) / WG; // 20 samples per lane
 	constexpr int MAT_BATCH = 10;                 // of which this many are in flight together
-#if defined(VX_MAT_PROFILE)
-	u32 prof[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	unsigned long long tick = __builtin_readcyclecounter();
-#define MAT_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
+#if defined(VX_UP_RELEASE_FENCE)
+	constexpr bool THROUGH = false;               // (A/B: publish with plain stores + an agent-scope release fence)
 #else
-#define MAT_TICK(i) do { } while (0)
+	constexpr bool THROUGH = GATED;               // what other workgroups of the launch wait for leaves through write-through stores
 #endif
-	MAT_TICK(0);
-	for (u32 it = blockIdx.x; it < nItems; it += gridDim.x) {
-		const u32 slot = p.G.dirty ? p.G.workItems[level][it] : it;
-		u32 bx, by, bz;
-		block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
-		const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
-		u16* cacheOut = L.cache + (size_t)slot * BLOCK_CELLS;
-		__syncthreads(); // the previous block of this workgroup is done with the LDS state
-		MAT_TICK(1);
+	u32 bx, by, bz;
+	block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
+	const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
+	u16* cacheOut = L.cache + (size_t)slot * BLOCK_CELLS;
+	__syncthreads(); // the previous block of this workgroup is done with the LDS state
 
-		// ---- requests: child slots, old cache contents (incremental runs), samples ----------------------
-		int cs = -1;
-		if (tid < 8) {
-			const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
-			if (cx < C.cnt && cy < C.cnt && cz < C.cnt) cs = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
+	// ---- requests: child slots, old cache contents (incremental runs), samples ----------------------
+	int cs = -1;
+	if (tid < 8) {
+		const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
+		if (cx < C.cnt && cy < C.cnt && cz < C.cnt) cs = C.slotOf[block_coord_id(cx, cy, cz, C.cnt)];
+	}
+	uint4 old0, old1;
+	if (!defineAll) { old0 = ((const uint4*)cacheOut)[tid]; old1 = ((const uint4*)cacheOut)[tid + WG]; }
+	const int x0 = (int)(bx * 16) * mult, y0 = (int)(by * 16) * mult, z0 = (int)(bz * 16) * mult;
+	const i8* base = g.dist + dist_offset(g, x0, y0, z0); // uniform; lanes add 32-bit offsets
+	const int pitch = g.pitchY;
+	const PyramidLevel& pyr = p.G.pyr[level < PYRAMID_LEVELS ? level : 0];
+	const bool lattice = level < PYRAMID_LEVELS && pyr.data != nullptr;
+	for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
+	if (tid < 8) st.childSlot[tid] = cs;
+	if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
+	if (defineAll) {
+		const u32 e2 = (u32)EMPTY_MATINFO | ((u32)EMPTY_MATINFO << 16);
+		old0 = make_uint4(e2, e2, e2, e2); old1 = old0;
+	}
+	((uint4*)st.out)[tid] = old0; ((uint4*)st.out)[tid + WG] = old1;
+	__syncthreads();
+	if (lattice) {
+		// the level's lattice copy (complete: it is kept with the grid's mirrors): one 16-byte load + one byte per sample row
+		for (int r = tid; r < 289; r += WG) {
+			const int k = r / 17, j = r - k * 17;
+			const PyramidRow row = pyramid_row17(pyr, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
+			st.rowMask[r] = sign_nibble(row.lo.x) | (sign_nibble(row.lo.y) << 4) | (sign_nibble(row.lo.z) << 8) | (sign_nibble(row.lo.w) << 12) | (((row.far >> 7) & 1u) << 16);
 		}
-		uint4 old0, old1;
-		if (!defineAll) { old0 = ((const uint4*)cacheOut)[tid]; old1 = ((const uint4*)cacheOut)[tid + WG]; }
-		const int x0 = (int)(bx * 16) * mult, y0 = (int)(by * 16) * mult, z0 = (int)(bz * 16) * mult;
-		const i8* base = g.dist + dist_offset(g, x0, y0, z0); // uniform; lanes add 32-bit offsets
-		const int pitch = g.pitchY;
-		const PyramidLevel& pyr = p.G.pyr[level < PYRAMID_LEVELS ? level : 0];
-		const bool lattice = level < PYRAMID_LEVELS && pyr.data != nullptr;
-		for (int r = tid; r < 292; r += WG) st.rowMask[r] = 0;
-		if (tid < 8) st.childSlot[tid] = cs;
-		if (tid == 0) { st.voteCount = 0; st.ntTotal = 0; }
-		if (defineAll) {
-			const u32 e2 = (u32)EMPTY_MATINFO | ((u32)EMPTY_MATINFO << 16);
-			old0 = make_uint4(e2, e2, e2, e2); old1 = old0;
-		}
-		((uint4*)st.out)[tid] = old0; ((uint4*)st.out)[tid + WG] = old1;
-		__syncthreads();
-		MAT_TICK(2);
-		if (lattice) {
-			// the level's lattice copy (complete: it is kept with the grid's mirrors): one 16-byte load + one byte per sample row
-			for (int r = tid; r < 289; r += WG) {
-				const int k = r / 17, j = r - k * 17;
-				const PyramidRow row = pyramid_row17(pyr, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
-				st.rowMask[r] = sign_nibble(row.lo.x) | (sign_nibble(row.lo.y) << 4) | (sign_nibble(row.lo.z) << 8) | (sign_nibble(row.lo.w) << 12) | (((row.far >> 7) & 1u) << 16);
-			}
-		} else
+	} else
 #pragma unroll 1
-		for (int q0 = 0; q0 < PER; q0 += MAT_BATCH) {
-			i8 v[MAT_BATCH];
+	for (int q0 = 0; q0 < PER; q0 += MAT_BATCH) {
+		i8 v[MAT_BATCH];
 #pragma unroll
-			for (int q = 0; q < MAT_BATCH; ++q) {
-				const int sIdx = tid + (q0 + q) * WG;
-				if (sIdx < SAMPLES) {
-					const int i = sIdx % 17, j = (sIdx / 17) % 17, k = sIdx / 289;
-					const int dx = min(x0 + i * mult, n - 1) - x0, dy = min(y0 + j * mult, n - 1) - y0, dz = min(z0 + k * mult, n - 1) - z0;
-					v[q] = base[(u32)((dz * pitch + dy) * n + dx)];
-				}
-			}
-#pragma unroll
-			for (int q = 0; q < MAT_BATCH; ++q) {
-				const int sIdx = tid + (q0 + q) * WG;
-				if (sIdx < SAMPLES) atomicOr(&st.rowMask[sIdx / 17], (((u32)(v[q] >> 7)) & 1u) << (sIdx % 17));
+		for (int q = 0; q < MAT_BATCH; ++q) {
+			const int sIdx = tid + (q0 + q) * WG;
+			if (sIdx < SAMPLES) {
+				const int i = sIdx % 17, j = (sIdx / 17) % 17, k = sIdx / 289;
+				const int dx = min(x0 + i * mult, n - 1) - x0, dy = min(y0 + j * mult, n - 1) - y0, dz = min(z0 + k * mult, n - 1) - z0;
+				v[q] = base[(u32)((dz * pitch + dy) * n + dx)];
 			}
 		}
-		// ---- child bitmaps (level 1) requested while the rows are classified -----------------------------
-		u32 cb4[4] = { 0, 0, 0, 0 };
-		if (level == 1) {
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const int w = tid + q * WG;
-				const int c = st.childSlot[w >> 7];
-				if (c >= 0) cb4[q] = C.consBits[(size_t)c * 128 + (w & 127)];
-			}
+		for (int q = 0; q < MAT_BATCH; ++q) {
+			const int sIdx = tid + (q0 + q) * WG;
+			if (sIdx < SAMPLES) atomicOr(&st.rowMask[sIdx / 17], (((u32)(v[q] >> 7)) & 1u) << (sIdx % 17));
 		}
-		__syncthreads();
-		MAT_TICK(3);
-		const int y = tid & 15, z = tid >> 4;
-		u32 nt;
-		{
-			const u32 a = st.rowMask[z * 17 + y], b2 = st.rowMask[z * 17 + y + 1], c = st.rowMask[(z + 1) * 17 + y], d = st.rowMask[(z + 1) * 17 + y + 1];
-			const u32 A = a & b2 & c & d, O = a | b2 | c | d;
-			nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
-			st.ntRow[tid] = (u16)nt;
-			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
-			if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
-		}
-		if (level == 1) {
+	}
+	// ---- child bitmaps (level 1) requested while the rows are classified -----------------------------
+	u32 cb4[4] = { 0, 0, 0, 0 };
+	if (level == 1) {
 #pragma unroll
-			for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
+		for (int q = 0; q < 4; ++q) {
+			const int w = tid + q * WG;
+			const int c = st.childSlot[w >> 7];
+			if (c >= 0) cb4[q] = C.consBits[(size_t)c * 128 + (w & 127)];
 		}
-		__syncthreads();
-		MAT_TICK(4);
-		// ---- selection: cells that need an entry (non-trivial, or visited by the transition pass) and have
-		//      any child entry to vote on.  All eight children of a cell live in one child block. -----------
-		{
-			u32 want = nt;
-			if (L.hasTransitions) {
-				const bool wholeRow = (z == 0 && bz > 0) || (y == 0 && by > 0) || (z == 15 && bz + 1 < L.cnt) || (y == 15 && by + 1 < L.cnt);
-				if (wholeRow) want = 0xFFFFu;
-				else { if (bx > 0) want |= 1u; if (bx + 1 < L.cnt) want |= 0x8000u; }
-			}
-			const u32 cbLo = (u32)(((y >> 3) << 1) | ((z >> 3) << 2));
-			u32 have = 0;
+	}
+	__syncthreads();
+	const int y = tid & 15, z = tid >> 4;
+	u32 nt;
+	{
+		const u32 a = st.rowMask[z * 17 + y], b2 = st.rowMask[z * 17 + y + 1], c = st.rowMask[(z + 1) * 17 + y], d = st.rowMask[(z + 1) * 17 + y + 1];
+		const u32 A = a & b2 & c & d, O = a | b2 | c | d;
+		nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+		st.ntRow[tid] = (u16)nt;
+		if (!THROUGH) ((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
+		if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
+	}
+	if (level == 1) {
 #pragma unroll
-			for (u32 h = 0; h < 2; ++h) {
-				const u32 cb = cbLo | h;
-				if (st.childSlot[cb] < 0) continue;
-				u32 r = 0xFFFFu;
-				if (level == 1) {
-					r = 0;
-#pragma unroll
-					for (int dd = 0; dd < 4; ++dd) {
-						const u32 row = (u32)((((2 * z + (dd >> 1)) & 15) << 4) | ((2 * y + (dd & 1)) & 15));
-						r |= (st.childBits[cb][row >> 1] >> ((row & 1u) * 16u)) & 0xFFFFu;
-					}
-					r |= r >> 1;                       // child pair (2x', 2x'+1) -> even bit
-					r &= 0x5555u; r = (r | (r >> 1)) & 0x3333u; r = (r | (r >> 2)) & 0x0F0Fu; r = (r | (r >> 4)) & 0x00FFu;
-				} else {
-					r = 0xFFu;
-				}
-				have |= (r & 0xFFu) << (8u * h);
-			}
-			u32 cand = want & have;
-			if (cand) {
-				u32 pos = atomicAdd(&st.voteCount, (u32)__popc(cand));
-				const u32 rowBase = (u32)tid << 4;
-				while (cand) {
-					const u32 x = (u32)__builtin_ctz(cand);
-					cand &= cand - 1;
-					st.voteList[pos++] = (u16)(rowBase | x);
-				}
-			}
-			if (tid == 0) {
-				const u32 cnt = st.ntTotal;
-				L.ntCount[slot] = (u16)cnt;
-				if (cnt > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
-				if (!p.G.dirty) { // (the slot counts of all levels are final since k_hierarchy)
-					u32 before = 0;
-					for (u32 l = 1; l < level; ++l) before += p.G.slotCounts[l];
-					FlatItem e;
-					e.where = (level << 24) | slot; e.coordId = L.slotCoord[slot]; e.ntCells = cnt; e.pad = 0;
-					p.G.flatItems[before + slot] = e;
-				}
-			}
+		for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
+	}
+	__syncthreads();
+	if (THROUGH && tid < 32) store16_through(L.ntBits + (size_t)slot * 128, (u32)tid * 16u, ((const uint4*)st.ntRow)[tid]); // the bitmap, 16 bytes per lane
+	// ---- selection: cells that need an entry (non-trivial, or visited by the transition pass) and have
+	//      any child entry to vote on.  All eight children of a cell live in one child block. -----------
+	{
+		u32 want = nt;
+		if (L.hasTransitions) {
+			const bool wholeRow = (z == 0 && bz > 0) || (y == 0 && by > 0) || (z == 15 && bz + 1 < L.cnt) || (y == 15 && by + 1 < L.cnt);
+			if (wholeRow) want = 0xFFFFu;
+			else { if (bx > 0) want |= 1u; if (bx + 1 < L.cnt) want |= 0x8000u; }
 		}
-		__syncthreads();
-		MAT_TICK(5);
-		// ---- vote.  A lane takes VB cells per trip and requests ALL their child entries before it looks at any: children
-		//      that are neighbours along x come in one load (two u16 entries / two material bytes), and no load is
-		//      conditional (a load with a default value is waited for on the spot) — the children of a cell are always
-		//      inside the grid; entries the consistency bits rule out are masked after the fact. ----------------------------
-		{
-			const int nVote = (int)st.voteCount;
-			// the children's materials come from the brick mirrors: the 2 x 2 x 2 child blocks are 8 consecutive-in-x pairs of
-			// 4 KB bricks, a cell's 8 children sit in 2 lines per field (4 in the dense fields)
-			const size_t childOrigin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
-			const u8* matBase = g.bMat + childOrigin;
-			const u8* blendBase = g.bBlend + childOrigin;
-			const u32 brickRow = (u32)(g.n >> 4) * BRICK_BYTES, brickPlane = (u32)g.bRowsY * brickRow; // next child block along y / z
+		const u32 cbLo = (u32)(((y >> 3) << 1) | ((z >> 3) << 2));
+		u32 have = 0;
+#pragma unroll
+		for (u32 h = 0; h < 2; ++h) {
+			const u32 cb = cbLo | h;
+			if (st.childSlot[cb] < 0) continue;
+			u32 r = 0xFFFFu;
 			if (level == 1) {
-				constexpr int VB = 2;
-				for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
-					u32 mat2[VB][4], bl2[VB][4];
+				r = 0;
 #pragma unroll
-					for (int v = 0; v < VB; ++v) {
-						const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
-						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+				for (int dd = 0; dd < 4; ++dd) {
+					const u32 row = (u32)((((2 * z + (dd >> 1)) & 15) << 4) | ((2 * y + (dd & 1)) & 15));
+					r |= (st.childBits[cb][row >> 1] >> ((row & 1u) * 16u)) & 0xFFFFu;
+				}
+				r |= r >> 1;                       // child pair (2x', 2x'+1) -> even bit
+				r &= 0x5555u; r = (r | (r >> 1)) & 0x3333u; r = (r | (r >> 2)) & 0x0F0Fu; r = (r | (r >> 4)) & 0x00FFu;
+			} else {
+				r = 0xFFu;
+			}
+			have |= (r & 0xFFu) << (8u * h);
+		}
+		u32 cand = want & have;
+		if (cand) {
+			u32 pos = atomicAdd(&st.voteCount, (u32)__popc(cand));
+			const u32 rowBase = (u32)tid << 4;
+			while (cand) {
+				const u32 x = (u32)__builtin_ctz(cand);
+				cand &= cand - 1;
+				st.voteList[pos++] = (u16)(rowBase | x);
+			}
+		}
+		if (tid == 0) {
+			const u32 cnt = st.ntTotal;
+			L.ntCount[slot] = (u16)cnt;
+			if (cnt > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
+			if (!p.G.dirty) { // (the slot counts of all levels are final since k_hierarchy)
+				u32 before = 0;
+				for (u32 l = 1; l < level; ++l) before += p.G.slotCounts[l];
+				FlatItem e;
+				e.where = (level << 24) | slot; e.coordId = L.slotCoord[slot]; e.ntCells = cnt; e.pad = 0;
+				p.G.flatItems[before + slot] = e;
+			}
+		}
+	}
+	__syncthreads();
+	if (GATED && level >= 2u) {
+		// the children's cache blocks are written by other workgroups of this launch (the level below comes first in the queue)
+		if (tid < 8) { const int c = st.childSlot[tid]; if (c >= 0) (void)wait_done(C.matDone + c, p.G.epoch, p.G.giveUp); }
+		acquire_and_meet(tid < 64);
+	}
+	// ---- vote.  A lane takes VB cells per trip and requests ALL their child entries before it looks at any: children
+	//      that are neighbours along x come in one load (two u16 entries / two material bytes), and no load is
+	//      conditional (a load with a default value is waited for on the spot) — the children of a cell are always
+	//      inside the grid; entries the consistency bits rule out are masked after the fact. ----------------------------
+	{
+		const int nVote = (int)st.voteCount;
+		// the children's materials come from the brick mirrors: the 2 x 2 x 2 child blocks are 8 consecutive-in-x pairs of
+		// 4 KB bricks, a cell's 8 children sit in 2 lines per field (4 in the dense fields)
+		const size_t childOrigin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
+		const u8* matBase = g.bMat + childOrigin;
+		const u8* blendBase = g.bBlend + childOrigin;
+		const u32 brickRow = (u32)(g.n >> 4) * BRICK_BYTES, brickPlane = (u32)g.bRowsY * brickRow; // next child block along y / z
+		if (level == 1) {
+			constexpr int VB = 2;
+			for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
+				u32 mat2[VB][4], bl2[VB][4];
 #pragma unroll
-						for (int q = 0; q < 4; ++q) {
-							const u32 cx = 2u * (u32)lx, cy = 2u * (u32)ly + (u32)(q & 1), cz = 2u * (u32)lz + (u32)(q >> 1);
-							const u32 off = (cz >> 4) * brickPlane + (cy >> 4) * brickRow + (cx >> 4) * BRICK_BYTES + brick_local(cx & 15u, cy & 15u, cz & 15u);
-							mat2[v][q] = *(const u16*)(matBase + off);
-							bl2[v][q] = *(const u16*)(blendBase + off);
-						}
-					}
+				for (int v = 0; v < VB; ++v) {
+					const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
+					const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
 #pragma unroll
-					for (int v = 0; v < VB; ++v) {
-						if (k0 + v * WG >= nVote) continue;
-						const u32 c = st.voteList[k0 + v * WG];
-						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
-						const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
-						u32 e[8];
-#pragma unroll
-						for (int i = 0; i < 8; ++i) {
-							const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
-							const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
-							const u32 sh = (u32)(i & 1) * 8u;
-							const u32 entry = ((mat2[v][i >> 1] >> sh) & 0xFFu) | (((bl2[v][i >> 1] >> sh) & 0xFFu) << 8);
-							e[i] = ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) ? entry : (u32)EMPTY_MATINFO;
-						}
-						const u32 entry = vote8(e);
-						if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
+					for (int q = 0; q < 4; ++q) {
+						const u32 cx = 2u * (u32)lx, cy = 2u * (u32)ly + (u32)(q & 1), cz = 2u * (u32)lz + (u32)(q >> 1);
+						const u32 off = (cz >> 4) * brickPlane + (cy >> 4) * brickRow + (cx >> 4) * BRICK_BYTES + brick_local(cx & 15u, cy & 15u, cz & 15u);
+						mat2[v][q] = *(const u16*)(matBase + off);
+						bl2[v][q] = *(const u16*)(blendBase + off);
 					}
 				}
-			} else {
-				constexpr int VB = 4;
-				for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
-					u32 pair[VB][4];
 #pragma unroll
-					for (int v = 0; v < VB; ++v) {
-						const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
-						const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
-						const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
-						const u16* child = C.cache + (size_t)st.childSlot[cb] * BLOCK_CELLS;
+				for (int v = 0; v < VB; ++v) {
+					if (k0 + v * WG >= nVote) continue;
+					const u32 c = st.voteList[k0 + v * WG];
+					const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+					const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
+					u32 e[8];
 #pragma unroll
-						for (int q = 0; q < 4; ++q)
-							pair[v][q] = *(const u32*)(child + ((((2 * lz + (q >> 1)) & 15) << 8) | (((2 * ly + (q & 1)) & 15) << 4) | ((2 * lx) & 15)));
+					for (int i = 0; i < 8; ++i) {
+						const int cxx = 2 * lx + (i & 1), cyy = 2 * ly + ((i >> 1) & 1), czz = 2 * lz + (i >> 2);
+						const u32 local = (u32)(((czz & 15) << 8) | ((cyy & 15) << 4) | (cxx & 15));
+						const u32 sh = (u32)(i & 1) * 8u;
+						const u32 entry = ((mat2[v][i >> 1] >> sh) & 0xFFu) | (((bl2[v][i >> 1] >> sh) & 0xFFu) << 8);
+						e[i] = ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) ? entry : (u32)EMPTY_MATINFO;
 					}
+					const u32 entry = vote8(e);
+					if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
+				}
+			}
+		} else {
+			constexpr int VB = 4;
+			for (int k0 = tid; k0 < nVote; k0 += WG * VB) {
+				u32 pair[VB][4];
 #pragma unroll
-					for (int v = 0; v < VB; ++v) {
-						if (k0 + v * WG >= nVote) continue;
-						const u32 c = st.voteList[k0 + v * WG];
-						u32 e[8];
+				for (int v = 0; v < VB; ++v) {
+					const u32 c = st.voteList[min(k0 + v * WG, nVote - 1)];
+					const int lx = (int)(c & 15), ly = (int)((c >> 4) & 15), lz = (int)(c >> 8);
+					const u32 cb = (u32)((lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2));
+					const u16* child = C.cache + (size_t)st.childSlot[cb] * BLOCK_CELLS;
 #pragma unroll
-						for (int i = 0; i < 8; ++i) e[i] = (pair[v][i >> 1] >> ((u32)(i & 1) * 16u)) & 0xFFFFu;
-						const u32 entry = vote8(e);
-						if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
-					}
+					for (int q = 0; q < 4; ++q)
+						pair[v][q] = TV_LOAD_THROUGH((const u32*)(child + ((((2 * lz + (q >> 1)) & 15) << 8) | (((2 * ly + (q & 1)) & 15) << 4) | ((2 * lx) & 15))));
+				}
+#pragma unroll
+				for (int v = 0; v < VB; ++v) {
+					if (k0 + v * WG >= nVote) continue;
+					const u32 c = st.voteList[k0 + v * WG];
+					u32 e[8];
+#pragma unroll
+					for (int i = 0; i < 8; ++i) e[i] = (pair[v][i >> 1] >> ((u32)(i & 1) * 16u)) & 0xFFFFu;
+					const u32 entry = vote8(e);
+					if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
 				}
 			}
 		}
-		__syncthreads();
-		MAT_TICK(6);
+	}
+	__syncthreads();
+	if (THROUGH) {
+		store16_through(cacheOut, (u32)tid * 16u, ((const uint4*)st.out)[tid]);
+		store16_through(cacheOut, (u32)(tid + WG) * 16u, ((const uint4*)st.out)[tid + WG]);
+		publish_done_through(L.matDone + slot, p.G.epoch, st.ntTotal);
+	} else {
 		((uint4*)cacheOut)[tid] = ((const uint4*)st.out)[tid];
 		((uint4*)cacheOut)[tid + WG] = ((const uint4*)st.out)[tid + WG];
+		if (GATED) publish_done(L.matDone + slot, p.G.epoch, st.ntTotal);
 	}
-#if defined(VX_MAT_PROFILE)
-	MAT_TICK(9);
-	if (tid == 0 && level == VX_MAT_PROFILE) for (int i = 0; i < 10; ++i) atomicAdd(&p.G.largeBlocks[4 + i], prof[i] >> 4);
-#endif
+}
+
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6))) void k_material(ExecParamsDev p, u32 level)
+{
+	__shared__ MatLds st;
+	const u32 nItems = p.G.dirty ? p.G.workCount[level] : *p.levels[level].nActive;
+	for (u32 it = blockIdx.x; it < nItems; it += gridDim.x) mat_block<false>(p, level, p.G.dirty ? p.G.workItems[level][it] : it, st, (int)threadIdx.x);
 }
 
 
@@ -1251,12 +1323,15 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 constexpr u32 REG_TAB_LDS = 512 + 1600 + 256;           // regClass + regCell | edge words + regVert rows | regOwn
 constexpr u32 TR_TAB_LDS = 2832 + 3072 + 1024;          // trClass + trCorner + trCell + edge words | trVert rows | trOwn
 
-__device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes)
+// (`tid`: the lane's index; a caller inside a loop hands in an opaque copy so that the lane's addresses are not hoisted out of
+// the loop and kept in registers through everything else)
+__device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes, u32 tid)
 {
 	const uint4* s = (const uint4*)src;
 	uint4* d = (uint4*)dst;
-	for (u32 i = threadIdx.x; i < bytes / 16; i += WG) d[i] = s[i];
+	for (u32 i = tid; i < bytes / 16; i += WG) d[i] = s[i];
 }
+__device__ __forceinline__ void copy16(u8* dst, const u8* src, u32 bytes) { copy16(dst, src, bytes, threadIdx.x); }
 
 __device__ __forceinline__ Tables stage_regular_tables(u8* lds, const u8* image)
 {
@@ -1269,11 +1344,11 @@ __device__ __forceinline__ Tables stage_regular_tables(u8* lds, const u8* image)
 	return T;
 }
 
-__device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* image)
+__device__ __forceinline__ Tables stage_transition_tables(u8* lds, const u8* image, u32 tid)
 {
-	copy16(lds, image + TAB_TR_CLASS, 2832);       // class, corner, cell tables + both edge word tables
-	copy16(lds + 2832, image + TAB_TR_VERT, 3072);
-	copy16(lds + 5904, image + TAB_TR_OWN, 1024);
+	copy16(lds, image + TAB_TR_CLASS, 2832, tid);       // class, corner, cell tables + both edge word tables
+	copy16(lds + 2832, image + TAB_TR_VERT, 3072, tid);
+	copy16(lds + 5904, image + TAB_TR_OWN, 1024, tid);
 	Tables T;
 	T.regClassP = nullptr; T.regCellP = nullptr; T.regVertP = nullptr; T.regEdgeP = nullptr; T.regOwnP = nullptr;
 	T.trClassP = lds; T.trCornerP = lds + 512; T.trCellP = lds + 528; T.trEdgeP = (const u16*)(lds + 2768 + 32); T.trVertP = lds + 2832; T.trOwnP = (const u16*)(lds + 5904);
@@ -1569,6 +1644,149 @@ __device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1
 #endif
 // WIDE: a brick mirror of 4 GiB or more (grids beyond 1024^3): 64-bit voxel offsets around the vertices
 // (three waves per SIMD there: the 64-bit address terms do not fit the 128 registers of four)
+// One block of a level with transition cells.  GATED (k_upper): the block's material cache comes from another workgroup of the
+// same launch and is waited for where it is first read (planes, sign summaries, cell classification and scans need none of it).
+template <bool WIDE, bool GATED>
+__device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, u32 coordId, TrState& st, const Tables& T, u32* scanScratch, u32* quietFaces, u32& quietParity,
+                                         const BrickSamplerT<typename std::conditional<WIDE, size_t, u32>::type>& smp, int tid)
+{
+	bool matReady = false;
+	const LevelDesc& L = p.levels[b.level];
+	b.mult = L.mult;
+	block_coords(__builtin_amdgcn_readfirstlane(coordId), L.cnt, b.bx, b.by, b.bz);
+	
+
+	{
+		u32 on = 0;
+		const u32 bc[3] = { b.bx, b.by, b.bz };
+		for (int f = 0; f < 6; ++f) {
+			const FaceGeom fg = face_geom(f);
+			if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
+		}
+		// the planes are requested before the sign summaries below are looked at: both arrive in one round trip, and what
+		// the summaries say only decides which planes are stored
+		// (32-bit offsets: a lattice copy is at most an eighth of the grid; the grid's own mirror - level-1 planes - only
+		// qualifies while it is smaller than 4 GiB)
+		TrLatticeT<u32> lat;
+		uint4 rowLo = { 0, 0, 0, 0 }, rowHi = { 0, 0, 0, 0 };
+		i8 rowFar = 0, xFace[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		const bool haveLattice = !(WIDE && b.level == 1u) && tr_lattice_of(p.G, b.level, lat); // (uniform)
+		if (haveLattice) tr_planes_request(lat, b, tid, rowLo, rowHi, rowFar, xFace);
+		
+		// A boundary plane whose samples all have one sign holds no transition cell.  The sign summaries of the level-0
+		// blocks (MirrorState::blockSign: "every voxel of the block's plane x = 0 / y = 0 / z = 0 is >= 0 / < 0") decide
+		// that without reading the plane: the face covers (mult + 1)^2 of those block planes, its far edge included.
+		// Faces found quiet are treated like faces without a neighbour block: not staged, no cells.
+		if (p.G.blockSign && b.mult <= 8u) {
+			const u32 cnt0 = p.levels[0].cnt, m1 = b.mult + 1u; // m1 <= 9: lane -> (du, dv) = (lane & 15, lane >> 4 + 4 * pass)
+			u32 quiet = 0;
+#pragma unroll
+			for (int f = 0; f < 6; ++f) { // (unrolled: the face's axes are compile-time constants)
+				if ((f & 3) != (tid >> 6) || !((on >> f) & 1u)) continue; // one wave per face; uniform per wave
+				const FaceGeom fg = face_geom(f);
+				const u32 field = fg.axis == 0 ? 1u : (fg.axis == 1 ? 2u : 4u);
+				const u32 du = (u32)tid & 15u;
+				const u32 qa = (fg.positive ? bc[fg.axis] + 1u : bc[fg.axis]) * b.mult;
+				const u32 qu = min(bc[fg.ua] * b.mult + du, cnt0 - 1u);
+				u32 sg[3];
+#pragma unroll
+				for (u32 pass = 0; pass < 3; ++pass) { // all (at most three) summaries of a lane are requested together
+					const u32 dv = (((u32)tid >> 4) & 3u) + 4u * pass;
+					const u32 qv = min(bc[fg.va] * b.mult + dv, cnt0 - 1u);
+					int q[3];
+					face_scatter(fg, (int)qu, (int)qv, (int)qa, q);
+					const u32 id = block_coord_id((u32)q[0], (u32)q[1], (u32)q[2], cnt0);
+					const u32 word = p.G.blockSign[id]; // (the coordinates are clamped: every lane reads a valid entry)
+					sg[pass] = (du < m1 && dv < m1) ? (word >> (2u * field)) & 3u : 3u; // 3: outside the face
+				}
+				u32 seen = 0; // bit 0: a plane of samples >= 0, bit 1: a plane of samples < 0, bit 2: a mixed or unknown plane
+#pragma unroll
+				for (u32 pass = 0; pass < 3; ++pass) seen |= sg[pass] == 1u ? 1u : (sg[pass] == 2u ? 2u : (sg[pass] == 3u ? 0u : 4u));
+				const bool pos = __ballot((seen & 1u) != 0) != 0, neg = __ballot((seen & 2u) != 0) != 0, mixed = __ballot((seen & 4u) != 0) != 0;
+				if (!mixed && !(pos && neg)) quiet |= 1u << f;
+			}
+			if ((tid & 63) == 0 && quiet) atomicOr(&quietFaces[quietParity], quiet);
+		}
+		__syncthreads();
+		on &= ~quietFaces[quietParity];
+		if (tid == 0) quietFaces[quietParity ^ 1u] = 0; // the other word is next written behind this barrier and read behind the next item's
+		quietParity ^= 1u;
+		if (tid == 0) st.faceOn = on;
+		for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
+		if (haveLattice) {
+			tr_planes_store(rowLo, rowHi, rowFar, xFace, lat.xp != nullptr, on, tid, st);
+		} else {
+			// no resident lattice for these planes: sample by sample from the grid's mirror; 33 x 33 samples per face, three
+			// faces (15 loads per lane) in flight together (a face that is off - uniform over the workgroup - is neither
+			// requested nor stored: nothing reads its plane)
+			i8 v[3][5];
+			if (on & 1u) tr_face_request<0>(p.G.grid, b, on, tid, v[0]);
+			if (on & 2u) tr_face_request<1>(p.G.grid, b, on, tid, v[1]);
+			if (on & 4u) tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
+			if (on & 1u) tr_face_store(st.plane[0], tid, v[0], true);
+			if (on & 2u) tr_face_store(st.plane[1], tid, v[1], true);
+			if (on & 4u) tr_face_store(st.plane[2], tid, v[2], true);
+			if (on & 8u) tr_face_request<3>(p.G.grid, b, on, tid, v[0]);
+			if (on & 16u) tr_face_request<4>(p.G.grid, b, on, tid, v[1]);
+			if (on & 32u) tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
+			if (on & 8u) tr_face_store(st.plane[3], tid, v[0], true);
+			if (on & 16u) tr_face_store(st.plane[4], tid, v[1], true);
+			if (on & 32u) tr_face_store(st.plane[5], tid, v[2], true);
+		}
+	}
+	__syncthreads();
+	tr_phase_classify(st, tid, WG);
+	__syncthreads();
+	for (int f0 = 0; f0 < 6;) {
+		const int f1 = tr_batch_end(st, f0); // uniform
+		__syncthreads();
+		tr_phase_batch_bits(st, f0, f1, tid, WG);
+		if (tid == 0) { st.vTotal = st.iTotal = st.vOff = st.iOff = 0; }
+		__syncthreads();
+		{
+			const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
+			if (tid == 0) st.wordPrefix[48] = (u16)nt;
+		}
+		__syncthreads();
+		if (st.wordPrefix[48] != 0) {
+			if (GATED && !matReady) {
+				// the block's material cache (tr_phase_list reads the cells behind the faces) comes from another workgroup of this launch
+				if (tid == 0) (void)wait_done(L.matDone + b.slot, p.G.epoch, p.G.giveUp);
+				acquire_and_meet(tid < 64);
+				matReady = true;
+			}
+			tr_phase_list(st, T, L, b, tid, WG);
+			__syncthreads();
+			tr_phase_count(st, T, tid, WG);
+			__syncthreads();
+			{
+				const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
+				const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
+				if (tid == 0) {
+					st.vTotal = vt; st.iTotal = it2;
+					reserve_both(p.P.cursors, vt, it2, st.vOff, st.iOff);
+				}
+			}
+			__syncthreads();
+			for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
+				if (chunk) __syncthreads();
+				tr_phase_describe(st, chunk, tid, WG);
+				__syncthreads();
+				tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
+			}
+			for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
+				__syncthreads();
+				tr_phase_stage_indices(st, T, chunk, tid, WG);
+				__syncthreads();
+				tr_phase_flush_indices(st, T, p.P, chunk, tid, WG);
+			}
+		}
+		tr_phase_record(st, L, b, p.P, f0, f1, tid);
+		f0 = f1;
+	}
+	__syncthreads();
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : VX_TR_WAVES))) void k_transition(ExecParamsDev p, u32 levels)
 {
@@ -1580,7 +1798,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : V
 	u32 quietParity = 0;
 
 	// (requested first: the copy is in flight while thread 0 fetches the level counts)
-	const Tables T = stage_transition_tables(tab, p.tables); // visible after the first barrier of the item loop
+	const Tables T = stage_transition_tables(tab, p.tables, threadIdx.x); // visible after the first barrier of the item loop
 	if (threadIdx.x < 2) quietFaces[threadIdx.x] = 0;
 	// Full runs: the work items are the leading entries of the run's list of active blocks of the levels >= 1
 	// (Globals::flatItems, level order) - the levels with transition cells are 1 .. refLevels - 2.  Incremental runs walk
@@ -1606,13 +1824,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : V
 	const GridView& gv = p.G.grid;
 	const BrickSamplerT<typename std::conditional<WIDE, size_t, u32>::type> smp = { gv.bDist, gv.bMat, gv.bBlend, gv.n - 1, (u32)gv.n >> 4, (u32)gv.bRowsY, gv.bYb0, gv.bZb0 };
 
-#if defined(VX_TR_PROFILE)
-	u32 prof[24] = { 0 };
-	unsigned long long tick = __builtin_readcyclecounter();
-#define TR_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += (u32)(now_ - tick); tick = now_; } while (0)
-#else
-#define TR_TICK(i) do { } while (0)
-#endif
 	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
@@ -1635,140 +1846,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : V
 			coordId = fi.coordId;
 		}
 		b.level = __builtin_amdgcn_readfirstlane(b.level); b.slot = __builtin_amdgcn_readfirstlane(b.slot);
-		const LevelDesc& L = p.levels[b.level];
-		b.mult = L.mult;
-		block_coords(__builtin_amdgcn_readfirstlane(coordId), L.cnt, b.bx, b.by, b.bz);
-		TR_TICK(0);
-
-		{
-			u32 on = 0;
-			const u32 bc[3] = { b.bx, b.by, b.bz };
-			for (int f = 0; f < 6; ++f) {
-				const FaceGeom fg = face_geom(f);
-				if (fg.positive ? (bc[fg.axis] + 1 < L.cnt) : (bc[fg.axis] > 0)) on |= 1u << f;
-			}
-			// the planes are requested before the sign summaries below are looked at: both arrive in one round trip, and what
-			// the summaries say only decides which planes are stored
-			// (32-bit offsets: a lattice copy is at most an eighth of the grid; the grid's own mirror - level-1 planes - only
-			// qualifies while it is smaller than 4 GiB)
-			TrLatticeT<u32> lat;
-			uint4 rowLo = { 0, 0, 0, 0 }, rowHi = { 0, 0, 0, 0 };
-			i8 rowFar = 0, xFace[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-			const bool haveLattice = !(WIDE && b.level == 1u) && tr_lattice_of(p.G, b.level, lat); // (uniform)
-			if (haveLattice) tr_planes_request(lat, b, tid, rowLo, rowHi, rowFar, xFace);
-			TR_TICK(1);
-			// A boundary plane whose samples all have one sign holds no transition cell.  The sign summaries of the level-0
-			// blocks (MirrorState::blockSign: "every voxel of the block's plane x = 0 / y = 0 / z = 0 is >= 0 / < 0") decide
-			// that without reading the plane: the face covers (mult + 1)^2 of those block planes, its far edge included.
-			// Faces found quiet are treated like faces without a neighbour block: not staged, no cells.
-			if (p.G.blockSign && b.mult <= 8u) {
-				const u32 cnt0 = p.levels[0].cnt, m1 = b.mult + 1u; // m1 <= 9: lane -> (du, dv) = (lane & 15, lane >> 4 + 4 * pass)
-				u32 quiet = 0;
-#pragma unroll
-				for (int f = 0; f < 6; ++f) { // (unrolled: the face's axes are compile-time constants)
-					if ((f & 3) != (tid >> 6) || !((on >> f) & 1u)) continue; // one wave per face; uniform per wave
-					const FaceGeom fg = face_geom(f);
-					const u32 field = fg.axis == 0 ? 1u : (fg.axis == 1 ? 2u : 4u);
-					const u32 du = (u32)tid & 15u;
-					const u32 qa = (fg.positive ? bc[fg.axis] + 1u : bc[fg.axis]) * b.mult;
-					const u32 qu = min(bc[fg.ua] * b.mult + du, cnt0 - 1u);
-					u32 sg[3];
-#pragma unroll
-					for (u32 pass = 0; pass < 3; ++pass) { // all (at most three) summaries of a lane are requested together
-						const u32 dv = (((u32)tid >> 4) & 3u) + 4u * pass;
-						const u32 qv = min(bc[fg.va] * b.mult + dv, cnt0 - 1u);
-						int q[3];
-						face_scatter(fg, (int)qu, (int)qv, (int)qa, q);
-						const u32 id = block_coord_id((u32)q[0], (u32)q[1], (u32)q[2], cnt0);
-						const u32 word = p.G.blockSign[id]; // (the coordinates are clamped: every lane reads a valid entry)
-						sg[pass] = (du < m1 && dv < m1) ? (word >> (2u * field)) & 3u : 3u; // 3: outside the face
-					}
-					u32 seen = 0; // bit 0: a plane of samples >= 0, bit 1: a plane of samples < 0, bit 2: a mixed or unknown plane
-#pragma unroll
-					for (u32 pass = 0; pass < 3; ++pass) seen |= sg[pass] == 1u ? 1u : (sg[pass] == 2u ? 2u : (sg[pass] == 3u ? 0u : 4u));
-					const bool pos = __ballot((seen & 1u) != 0) != 0, neg = __ballot((seen & 2u) != 0) != 0, mixed = __ballot((seen & 4u) != 0) != 0;
-					if (!mixed && !(pos && neg)) quiet |= 1u << f;
-				}
-				if ((tid & 63) == 0 && quiet) atomicOr(&quietFaces[quietParity], quiet);
-			}
-			__syncthreads(); TR_TICK(2);
-			on &= ~quietFaces[quietParity];
-			if (tid == 0) quietFaces[quietParity ^ 1u] = 0; // the other word is next written behind this barrier and read behind the next item's
-			quietParity ^= 1u;
-			if (tid == 0) st.faceOn = on;
-			for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
-			if (haveLattice) {
-				tr_planes_store(rowLo, rowHi, rowFar, xFace, lat.xp != nullptr, on, tid, st);
-			} else {
-				// no resident lattice for these planes: sample by sample from the grid's mirror; 33 x 33 samples per face, three
-				// faces (15 loads per lane) in flight together (a face that is off - uniform over the workgroup - is neither
-				// requested nor stored: nothing reads its plane)
-				i8 v[3][5];
-				if (on & 1u) tr_face_request<0>(p.G.grid, b, on, tid, v[0]);
-				if (on & 2u) tr_face_request<1>(p.G.grid, b, on, tid, v[1]);
-				if (on & 4u) tr_face_request<2>(p.G.grid, b, on, tid, v[2]);
-				if (on & 1u) tr_face_store(st.plane[0], tid, v[0], true);
-				if (on & 2u) tr_face_store(st.plane[1], tid, v[1], true);
-				if (on & 4u) tr_face_store(st.plane[2], tid, v[2], true);
-				if (on & 8u) tr_face_request<3>(p.G.grid, b, on, tid, v[0]);
-				if (on & 16u) tr_face_request<4>(p.G.grid, b, on, tid, v[1]);
-				if (on & 32u) tr_face_request<5>(p.G.grid, b, on, tid, v[2]);
-				if (on & 8u) tr_face_store(st.plane[3], tid, v[0], true);
-				if (on & 16u) tr_face_store(st.plane[4], tid, v[1], true);
-				if (on & 32u) tr_face_store(st.plane[5], tid, v[2], true);
-			}
-		}
-		__syncthreads(); TR_TICK(3);
-		tr_phase_classify(st, tid, WG);
-		__syncthreads(); TR_TICK(4);
-		for (int f0 = 0; f0 < 6;) {
-			const int f1 = tr_batch_end(st, f0); // uniform
-			__syncthreads(); TR_TICK(5);
-			tr_phase_batch_bits(st, f0, f1, tid, WG);
-			if (tid == 0) { st.vTotal = st.iTotal = st.vOff = st.iOff = 0; }
-			__syncthreads(); TR_TICK(6);
-			{
-				const u32 nt = block_exclusive_scan_u16(st.wordPrefix, 48, scanScratch);
-				if (tid == 0) st.wordPrefix[48] = (u16)nt;
-			}
-			__syncthreads(); TR_TICK(7);
-			if (st.wordPrefix[48] != 0) {
-				tr_phase_list(st, T, L, b, tid, WG);
-				__syncthreads(); TR_TICK(8);
-				tr_phase_count(st, T, tid, WG);
-				__syncthreads(); TR_TICK(9);
-				{
-					const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
-					const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
-					if (tid == 0) {
-						st.vTotal = vt; st.iTotal = it2;
-						reserve_both(p.P.cursors, vt, it2, st.vOff, st.iOff);
-					}
-				}
-				__syncthreads(); TR_TICK(10);
-				for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
-					if (chunk) __syncthreads(); TR_TICK(11);
-					tr_phase_describe(st, chunk, tid, WG);
-					__syncthreads(); TR_TICK(12);
-					tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
-				}
-				for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
-					__syncthreads(); TR_TICK(13);
-					tr_phase_stage_indices(st, T, chunk, tid, WG);
-					__syncthreads(); TR_TICK(14);
-					tr_phase_flush_indices(st, T, p.P, chunk, tid, WG);
-				}
-			}
-			tr_phase_record(st, L, b, p.P, f0, f1, tid);
-			f0 = f1;
-		}
-		__syncthreads(); TR_TICK(15);
+		tr_block<WIDE, false>(p, b, coordId, st, T, scanScratch, quietFaces, quietParity, smp, tid);
 	}
-#if defined(VX_TR_PROFILE)
-	if (tid0 == 0) for (int i = 0; i < 24; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[16 + i], prof[i] >> 6); // header words 192..215
-#endif
 }
 
+
+} // namespace
+
+#include "vx_upper.inl"
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------------
 // incremental (Modification) runs: classify only the dirty level-0 blocks, list the slots to rebuild
@@ -2071,7 +2158,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, upPersistent = 1, level0First = 0; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2097,6 +2184,10 @@ struct Backend {
 		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
 		tune.foldBlocks = env_u32("VX_FOLD_BLOCKS", 65536); // level-0 blocks up to which k_classify also activates the ancestors
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
+		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_upper replaces (A/B measurements)
+		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5));
+		tune.upPersistent = env_u32("VX_UP_PERSISTENT", 1);
+		tune.level0First = env_u32("VX_LEVEL0_FIRST", 0);
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -2139,7 +2230,8 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
-		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")
+		    || !check(hipFuncSetAttribute((const void*)k_upper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + UP_STATE_LDS)), "hipFuncSetAttribute(k_upper)")) {
 			err = lastError;
 			return false;
 		}
@@ -2501,12 +2593,12 @@ struct Backend {
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
 				// (as on level 0: the upper classes beside the first one when the run is overlapped, i.e. when this is the main
 				// stream of run_overlapped_tail - on side stream B, behind the transition pass)
-				const bool spread = largeClass && overlappedTail && on == stream;
+				const bool spread = largeClass && overlappedTail && on == stream && !upperDone;
 				hipStream_t sideD = sideB;
 				hipStream_t upper = spread ? sideD : on;
 				const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
 				if (spread) { (void)hipStreamWaitEvent(sideD, evMaterial, 0); spreadD = true; }
-				hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
+				if (!upperDone) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
 				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), upper, dev(p), fastEnd, (u32)REG_CAP_SMALL);
 				if (spread) {
 					(void)hipEventRecord(evMidD, sideD);
@@ -2531,6 +2623,34 @@ struct Backend {
 	template <typename P>
 	void run_regular(const P& p, u32 levels) { launch_regular(p, 0, levels, stream); }
 
+	// The levels >= 1 of a full run as ONE launch (vx_upper.inl) - where the table-driven regular pass and the 32-bit-offset
+	// transition pass apply (lattice copies resident, mirrors below 4 GiB); otherwise the chain of launches it replaces.
+	u32 upperItemsHint = 0; // queue items of the previous full run of this context (0 = unknown)
+	bool upperDone = false; // inside run_overlapped_tail: k_upper did the first capacity class of the levels 1 .. fastEnd - 1
+	template <typename P>
+	bool upper_applies(const P& p, u32 levels) const
+	{
+		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
+		return tune.upper && tune.fast1 && !tune.forceWide && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+	}
+	template <typename P>
+	void run_upper(const P& p, u32 levels)
+	{
+		UpperPlan plan;
+		plan.levels = levels;
+		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
+		plan.persistent = tune.upPersistent;
+		unsigned long long items = 0; // at most: one material item per block, one regular, one transition
+		for (u32 l = 1; l < levels; ++l) items += (unsigned long long)p.levels[l].cap * (1u + (l < plan.fastEnd ? 1u : 0u) + (p.levels[l].hasTransitions ? 1u : 0u));
+		if (!items) return;
+		// persistent workgroups, at most as many as the previous run had items (the host's hint; any number is correct - a
+		// workgroup that finds the queue empty leaves - but every workgroup costs a dequeue)
+		u32 grid = (u32)std::min<unsigned long long>(items, (unsigned long long)cus * tune.upWgsPerCu);
+		if (upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
+		launch_with_event(k_upper, dim3(grid), UP_TAB_LDS + UP_STATE_LDS, dev(p), plan);
+		check(hipGetLastError(), "k_upper launch");
+	}
+
 	// Overlapped tail of a full run (after classify + hierarchy on the main stream):
 	//   side stream A : regular cells of level 0 (independent of the material caches)
 	//   main stream   : material chain L1..Lmax, then regular cells of levels >= 1
@@ -2542,29 +2662,58 @@ struct Backend {
 		// (the classify launch carried the event that releases the level-0 regular pass on side stream A)
 		overlappedTail = true;
 		spreadC = spreadD = false;
+		bool usedSideB = false;
 		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		launch_regular(p, 0, 1, sideA);
-		// the last material launch carries the event that releases the transition pass on side stream B
-		u32 lastMat = 0;
-		for (u32 L = 1; L < levels; ++L) if (p.levels[L].cap) lastMat = L;
-		for (u32 L = 1; L < levels; ++L) { if (L == lastMat) doneEvent = evMaterial; run_material(p, L); }
-		if (!lastMat) (void)hipEventRecord(evMaterial, stream);
-		(void)hipStreamWaitEvent(sideB, evMaterial, 0);
-		{
+		if (tune.level0First && upper_applies(p, levels)) {
+			// (experiment) the level-0 pass on the main stream - it starts at once - and the levels >= 1 on side stream A behind
+			// the classification's event
+			launch_regular(p, 0, 1, stream);
 			hipStream_t keep = stream;
-			stream = sideB;
-			run_transition(p, levels);
+			stream = sideA;
+			run_upper(p, levels);
+			upperDone = true;
+			launch_regular(p, 1, levels, stream);
+			upperDone = false;
+			overlappedTail = false;
 			stream = keep;
+			(void)hipEventRecord(evMain, stream);
+			(void)hipStreamWaitEvent(sideA, evMain, 0);
+			mainKeep = stream;
+			stream = sideA;
+			return;
 		}
-		(void)hipEventRecord(evSideB, sideB);
+		launch_regular(p, 0, 1, sideA);
+		if (upper_applies(p, levels)) {
+			// the levels >= 1 as one launch: material blocks, regular blocks of the first capacity class and transition blocks
+			// wait for each other through device-side flags (vx_upper.inl); what is left for launch_regular below - the upper
+			// capacity classes, what the table-driven pass hands on, levels beyond the lattice copies - follows on this stream
+			run_upper(p, levels);
+			upperDone = true;
+		} else {
+			// the last material launch carries the event that releases the transition pass on side stream B
+			u32 lastMat = 0;
+			for (u32 L = 1; L < levels; ++L) if (p.levels[L].cap) lastMat = L;
+			for (u32 L = 1; L < levels; ++L) { if (L == lastMat) doneEvent = evMaterial; run_material(p, L); }
+			if (!lastMat) (void)hipEventRecord(evMaterial, stream);
+			(void)hipStreamWaitEvent(sideB, evMaterial, 0);
+			{
+				hipStream_t keep = stream;
+				stream = sideB;
+				run_transition(p, levels);
+				stream = keep;
+			}
+			(void)hipEventRecord(evSideB, sideB);
+			usedSideB = true;
+		}
 		if (levels > 1) launch_regular(p, 1, levels, stream);
+		upperDone = false;
 		// What follows the three branches (block lists, header read-back) runs on side stream A: on large grids the level-0
 		// pass there is the last to finish, and a stream that waits for events which have already fired loses nothing,
 		// whereas the main stream would start ~15 us after the event it waits for (1024^3: 0.53 -> 0.51 ms).
 		overlappedTail = false;
 		(void)hipEventRecord(evMain, stream);
 		(void)hipStreamWaitEvent(sideA, evMain, 0);
-		(void)hipStreamWaitEvent(sideA, evSideB, 0);
+		if (usedSideB) (void)hipStreamWaitEvent(sideA, evSideB, 0);
 		if (spreadC) (void)hipStreamWaitEvent(sideA, evSideC, 0);
 		if (spreadD) (void)hipStreamWaitEvent(sideA, evSideD, 0);
 		mainKeep = stream;

@@ -44,7 +44,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 256, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 320, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -106,6 +106,7 @@ struct vx_ctx {
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
 	size_t hRecCap = 0;
 	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
+	u32 runEpoch = 0;           // tag of the current full run in LevelDesc::matDone (Globals::epoch)
 	bool hostTiming = false;    // VX_HOST_TIMING (read once at context creation): print where a vx_polygonize call spends host time
 };
 
@@ -263,6 +264,10 @@ bool ensure_level_tables(vx_ctx* c)
 		d.ntCount = (u16*)alloc(cap * 2);
 		d.records = (BlockRecord*)alloc(cap * sizeof(BlockRecord));
 		d.listed = (ListedBlock*)alloc(cap * sizeof(ListedBlock));
+		if (L) {
+			d.matDone = (unsigned long long*)alloc(cap * 8);
+			if (!d.matDone || !c->be.fill(d.matDone, 0, cap * 8)) return false; // (no run's tag is 0)
+		}
 #if defined(VX_CASE_DUMP)
 		d.caseDump = (u8*)alloc(cap * BLOCK_CELLS);
 		d.trCaseDump = (u16*)alloc(cap * TR_CELLS * 2);
@@ -356,6 +361,9 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.slowCount = (u32*)c->dHeader + HDR_SLOW;
 	p.G.flatItems = (FlatItem*)c->dFlatItems;
 	p.G.slotCounts = (const u32*)c->dHeader;
+	p.G.epoch = c->runEpoch;
+	p.G.upperHead = (u32*)c->dHeader + HDR_UPPER;
+	p.G.giveUp = (u32*)c->dHeader + HDR_GIVEUP;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	for (u32 L = 0; L < XPLANE_LEVELS; ++L) p.G.xp[L] = c->xp[L];
 	p.G.levels = levels;
@@ -1226,6 +1234,11 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	const auto t0 = tNow();
 	auto t1 = t0, t2 = t0, t3 = t0;
 	for (;;) {
+		// every attempt gets a tag of its own for the dependency flags of the upper pass; on wrap-around the flags start over
+		if (++c->runEpoch == 0) {
+			for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) if (c->lv[L].matDone && !c->be.fill(c->lv[L].matDone, 0, (size_t)c->lv[L].cap * 8)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: flag reset failed");
+			c->runEpoch = 1;
+		}
 		ExecParams p;
 		fill_params(c, p, levels);
 		c->be.begin_timing();
@@ -1274,12 +1287,20 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		}
 		t3 = tNow();
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
+		if (c->hdr[HDR_GIVEUP]) return fail(c, VX_ERR_DEVICE, "vx_polygonize: a dependency wait inside the upper pass timed out (internal error)");
 		if (c->hdr[HDR_LARGE] && !c->be.largeClass) { c->be.largeClass = true; continue; } // blocks of the large class showed up: once more, with it
 		if (!overflow) break;
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
 	}
 	c->largeHint = c->hdr[HDR_LARGE] != 0;
+	{
+		// what the next run of this context can expect on the levels >= 1 (sizes the launch of k_upper): a material item per
+		// active block, a regular one on the levels with a lattice copy, a transition one on the levels with transition cells
+		u32 items = 0;
+		for (u32 L = 1; L < levels; ++L) items += c->hdr[L] * (1u + (L < (u32)PYRAMID_LEVELS ? 1u : 0u) + (c->lv[L].hasTransitions ? 1u : 0u));
+		c->be.upperItemsHint = items ? items : 1u;
+	}
 	c->levelsRun = levels;
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->poolLineage = next_lineage(); // the pools were rewritten
@@ -1295,21 +1316,6 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
-#if defined(VX_TR_PROFILE)
-	{
-		unsigned long long sum = 0;
-		for (int i = 0; i < 24; ++i) sum += c->hdr[HDR_LARGE + 16 + i];
-		for (int i = 0; i < 24; ++i) if (c->hdr[HDR_LARGE + 16 + i]) fprintf(stderr, "[transition profile] tick %2d %10u x64 cycles  %5.1f %%\n", i, c->hdr[HDR_LARGE + 16 + i], 100.0 * c->hdr[HDR_LARGE + 16 + i] / (double)(sum ? sum : 1));
-	}
-#endif
-#if defined(VX_MAT_PROFILE)
-	{
-		static const char* names[10] = { "prologue", "stores + next coords + barrier", "requests + init + barrier", "samples + barrier", "classify + barrier", "select + barrier", "vote + barrier", "-", "-", "tail" };
-		unsigned long long sum = 0;
-		for (int i = 0; i < 10; ++i) sum += c->hdr[HDR_LARGE + 4 + i];
-		for (int i = 0; i < 10; ++i) fprintf(stderr, "[material profile, level %d] %-32s %10u x16 cycles  %5.1f %%\n", VX_MAT_PROFILE, names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
-	}
-#endif
 #if defined(VX_REG_PROFILE)
 	{
 		static const char* names[16] = { "next item", "top barrier", "begin+stage+barrier", "prefix scan", "list+barrier", "cells+barrier", "count+barrier", "vertex scan+reserve", "describe+barrier", "emit vertices", "barrier", "keep+barrier", "index scan+reserve", "stage indices+barrier", "flush indices", "record" };
