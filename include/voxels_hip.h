@@ -255,6 +255,9 @@ int vx_selftest(vx_ctx* ctx, uint32_t results[16]);
  * ms[0..7] = reset + block classes, classify, hierarchy, material (all levels), regular cells of level 0, of the levels >= 1,
  * transition cells, block lists of the LAST run. */
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
+/* Diagnostics: the first `count` 32-bit words of the run's device header (queue heads, counters), copied on a stream of
+ * its own so that it also works - from another host thread - while a run is in flight. */
+int vx_debug_header(vx_ctx* ctx, uint32_t* out, uint32_t count);
 int vx_stage_times(vx_ctx* ctx, float ms[8]);
 
 /* name of the code object actually running the kernels ("hip:gfx950") — lets callers assert the native path */

@@ -20,7 +20,7 @@ def _newer(target, sources):
 def build_hip(force=False, verbose=True):
     """hipcc --offload-arch=gfx950 ... -o voxels_amd/csrc/libvoxels_hip.so (cross-compiles without a GPU)."""
     out = os.path.join(CSRC, "libvoxels_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_fast0.inl", "vx_fast1.inl", "vx_upper.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_fast0.h", "tv_fast1.h", "tv_tables.inc")]
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_fast0.inl", "vx_fast1.inl", "vx_main.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_fast0.h", "tv_fast1.h", "tv_tables.inc")]
     srcs.append(os.path.join(ROOT, "include", "voxels_hip.h"))
     if not force and not _newer(out, srcs):
         return out
@@ -68,7 +68,7 @@ def kernel_resources(remarks):
 def build_hip_casedump(force=False):
     """Test build of the HIP library that also records the case codes it looks up (tests/test_case_codes.py)."""
     out = os.path.join(CSRC, "libvoxels_hip_casedump.so")
-    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_fast0.inl", "vx_fast1.inl", "vx_upper.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_fast0.h", "tv_fast1.h", "tv_tables.inc")]
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_fast0.inl", "vx_fast1.inl", "vx_main.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_fast0.h", "tv_fast1.h", "tv_tables.inc")]
     if not force and not _newer(out, srcs):
         return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

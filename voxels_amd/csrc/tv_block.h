@@ -26,7 +26,7 @@ template <typename T> inline T host_atomic_or(T* p, T v) { T o = *p; *p = o | v;
 #define TV_POPC(x) __builtin_popcount(x)
 #endif
 
-// A load of data that another workgroup of the SAME launch may have written (k_upper: material caches, published with
+// A load of data that another workgroup of the SAME launch may have written (k_main: material caches, published with
 // write-through stores): past the CU's L1, which no other CU's store ever refreshes - an agent-scope relaxed atomic load
 // is an `sc1` load on gfx950.  A plain load elsewhere (the CPU emulation; data of earlier launches).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -82,7 +82,7 @@ struct LevelDesc {
 	BlockRecord* records; // [cap]
 	ListedBlock* listed;  // [cap] the level's block list (see ListedBlock)
 	unsigned long long* matDone; // [cap] levels >= 1, full runs of the GPU backend: Globals::epoch << 32 | non-trivial cells once the block's
-	                      //       material cache, bitmap and cell count are in memory (the dependency flags of k_upper: one 8-byte word per block,
+	                      //       material cache, bitmap and cell count are in memory (the dependency flags of k_main: one 8-byte word per block,
 	                      //       written with one store, polled by whoever needs the block - its parent's vote, its own regular and transition cells)
 #if defined(VX_CASE_DUMP)
 	// test builds only (libvoxels_hip_casedump.so): the case code of every cell the passes looked up in Lengyel's tables,
@@ -165,11 +165,12 @@ struct Globals {
 	// coordinate and cell count - one dependent round trip less at the head of every block.
 	struct FlatItem* flatItems;
 	const u32* slotCounts;            // [MAX_LEVELS] active blocks per level (LevelDesc::nActive of all levels, contiguous)
-	// full runs of the GPU backend: the levels >= 1 as ONE launch (k_upper) whose work items - material blocks of the levels
+	// full runs of the GPU backend: everything behind the classification is ONE launch (k_main) whose upper work items - material blocks of the levels
 	// 1, 2, ... in that order, then their regular and transition blocks - are dequeued in order and wait for what they
 	// depend on through LevelDesc::matDone
 	u32 epoch;                        // this run's tag in matDone (never 0)
 	u32* upperHead;                   // queue head (zeroed with the run's counters)
+	u32* level0Head;                  // head of the queue of level-0 slots of the same launch
 	u32* giveUp;                      // set when a dependency wait ran out of patience (a bug, never data-dependent): the host fails the run
 };
 

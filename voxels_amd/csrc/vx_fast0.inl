@@ -157,38 +157,53 @@ __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Bl
 	return zero;
 }
 
-template <int CAP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p, u32 lo)
+// The work list of a walk over level-0 slots: items first, first + stride, ... below `limit`.  REMAP (k_regular0_fast: static
+// striding over all slots): item numbers go through xcd_item and `limit` is the padded slot count; otherwise (k_main: a batch
+// of consecutive slots taken from the queue) an item is its slot.
+template <bool REMAP>
+__device__ __forceinline__ R0Candidate f0_peek(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 limit, u32 it)
 {
-	if (lo && *p.G.largeBlocks == 0) return; // nothing for the capacity classes above the first (uniform over the grid)
-	static_assert(F0_MROW == R0_MROW, "the prefetch of vx_regular0.inl stages 20-byte material rows");
-	typedef Fast0State<CAP> ST;
+	R0Candidate c;
+	u32 item = REMAP ? xcd_item(it) : it;
+	c.valid = (it < limit && item < total) ? 1u : 0u;
+	if (!c.valid) item = 0;
+	c.slot = item;
+	c.ntc = L.ntCount[c.slot];
+	c.skip = L.skip[c.slot];
+	c.coord = L.slotCoord[c.slot];
+	return c;
+}
+
+template <int CAP, bool REMAP>
+__device__ __forceinline__ bool f0_next(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32 stride, u32 limit, u32& it, R0Candidate c, R0Block& b)
+{
+	for (;;) {
+		if (r0_accept<CAP>(L, lo, c, b)) return true;
+		it += stride;
+		if (it >= limit) return false;
+		c = f0_peek<REMAP>(p, L, total, limit, it);
+	}
+}
+
+// The blocks of one walk, software-pipelined: `cur` has its inputs requested, `nxt` is accepted and gets them requested while
+// `cur` writes its output.  Leaves the LDS state free behind a barrier-less tail (callers meet before they reuse it).
+template <int CAP, bool REMAP>
+__device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& T, Fast0State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
+                                        u32 total, u32 lo, u32 first, u32 stride, u32 limit, const int tid)
+{
 	typedef R0<CAP> K;
-	u8* tab = smem;
-	ST& st = *(ST*)(smem + F0_TAB_LDS);
-	__shared__ u32 wgStats[20];  // statistics of every block this workgroup handles, flushed once at the end
-	__shared__ u32 zeroFlag[2];  // "a lane met a zero sample", by parity of the workgroup's block counter
-
 	const LevelDesc& L = p.levels[0];
-	const u32 total = r0_uniform(*L.nActive);
-	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
-	const int tid = (int)threadIdx.x;
-	if (tid < 20) wgStats[tid] = 0;
-	if (tid < 2) zeroFlag[tid] = 0;
-	const F0Tables T = f0_stage_tables(tab, p.tables);
 	const GridView& g = p.G.grid;
-
-	u32 it = blockIdx.x;
+	u32 it = first;
 	R0Block cur, nxt;
 	F0Prefetch pf;
 	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
-	bool have = r0_next_item<CAP, 0>(p, L, total, lo, it, r0_peek<0>(p, L, total, it), cur);
+	bool have = f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), cur);
 	if (have) f0_request(g, L, cur, pf);
-	it += gridDim.x;
-	bool haveNext = have && r0_next_item<CAP, 0>(p, L, total, lo, it, r0_peek<0>(p, L, total, it), nxt);
-	u32 parity = 0;
+	it += stride;
+	bool haveNext = have && f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), nxt);
 	while (have) {
-		const u32 candIt = it + gridDim.x;
+		const u32 candIt = it + stride;
 		R0Candidate cand;
 		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
 		{
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 					PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
 					u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
-						if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); requested = true; }
+						if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
 						if (j < vEnd) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
@@ -329,12 +344,35 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			// a zero sample: the general pass takes the block
 			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;
 		}
-		if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = r0_peek<0>(p, L, total, candIt); }
+		if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); }
 		cur = nxt;
 		have = haveNext;
 		it = candIt;
-		haveNext = have && r0_next_item<CAP, 0>(p, L, total, lo, it, cand, nxt);
+		haveNext = have && f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, cand, nxt);
 	}
+}
+
+template <int CAP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0_fast(ExecParamsDev p, u32 lo)
+{
+	if (lo && *p.G.largeBlocks == 0) return; // nothing for the capacity classes above the first (uniform over the grid)
+	static_assert(F0_MROW == R0_MROW, "the prefetch of vx_regular0.inl stages 20-byte material rows");
+	typedef Fast0State<CAP> ST;
+	u8* tab = smem;
+	ST& st = *(ST*)(smem + F0_TAB_LDS);
+	__shared__ u32 wgStats[20];  // statistics of every block this workgroup handles, flushed once at the end
+	__shared__ u32 zeroFlag[2];  // "a lane met a zero sample", by parity of the workgroup's block counter
+
+	const LevelDesc& L = p.levels[0];
+	const u32 total = r0_uniform(*L.nActive);
+	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	const int tid = (int)threadIdx.x;
+	if (tid < 20) wgStats[tid] = 0;
+	if (tid < 2) zeroFlag[tid] = 0;
+	const F0Tables T = f0_stage_tables(tab, p.tables);
+
+	u32 parity = 0;
+	f0_walk<CAP, true>(p, T, st, wgStats, zeroFlag, parity, total, lo, blockIdx.x, gridDim.x, (total + 63u) & ~63u, tid);
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
 }

@@ -3,7 +3,7 @@
 // behind vx_fast0.inl, whose table staging, list building and scans it shares.
 //
 // f1_block is one block's work; k_regular1_fast walks the run's flat list of active blocks (Globals::flatItems: level, slot,
-// coordinate and cell count in one load) with it - the capacity classes of dense surfaces - and k_upper (vx_upper.inl)
+// coordinate and cell count in one load) with it - the capacity classes of dense surfaces - and k_main (vx_main.inl)
 // calls it for the first class inside the one launch of the levels >= 1.  One workgroup per block at a time: 17^3 lattice samples (17 contiguous bytes per row of the level's lattice copy) + the
 // material ids of the block's cache + bitmap into LDS (27 KB in all; nothing is prefetched: the workgroups beside it hide
 // the latency of the voxel fetches around the vertices - and every KB held here is one the level-0 pass on the other
@@ -41,7 +41,7 @@ struct BrickSamplerT {
 typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller than 4 GiB
 
 // One block of a level 1..3 (CAP = LDS capacity class; `lo`: blocks with at most that many non-trivial cells belong to a lower
-// class).  GATED (k_upper): bitmap, cache block and cell count come from the material work of another workgroup of the same
+// class).  GATED (k_main): bitmap, cache block and cell count come from the material work of another workgroup of the same
 // launch; the lattice samples, which do not, are requested before the wait.  Otherwise (k_regular1_fast) `ntc` and `coord`
 // come from the run's flat list.
 template <int CAP, bool GATED>
@@ -85,7 +85,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
 	{
 		u32 zero = 0;
-		// (bitmap and cache block: written by the material work - in k_upper by another workgroup of the same launch, hence past the L1)
+		// (bitmap and cache block: written by the material work - in k_main by another workgroup of the same launch, hence past the L1)
 		if (tid < 128) st.ntBits[tid] = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + tid]);
 		if (tid < 16) st.classCount[tid] = 0;
 		const u16* csrc = L.cache + (size_t)slot * BLOCK_CELLS;

@@ -112,7 +112,7 @@ __device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indice
 #endif
 }
 
-// ---- dependencies between workgroups of ONE launch (k_upper): LevelDesc::matDone ----------------------------------------
+// ---- dependencies between workgroups of ONE launch (k_main): LevelDesc::matDone ----------------------------------------
 // Producer: every wave drains its stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back: the eight
 // XCDs' L2s are not coherent with each other) and stores the 8-byte word epoch << 32 | payload.  Consumer: ONE wave polls the
 // word (relaxed, agent scope, s_sleep between polls), then ONE agent-scope acquire drops the stale lines of its CU's L1 /
@@ -146,15 +146,16 @@ __device__ __forceinline__ void publish_done_through(unsigned long long* flag, u
 	if (threadIdx.x == 0) __hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-enum { WAIT_SPINS = 1u << 22 }; // x ~0.5 us per poll: seconds, against runs of milliseconds
+enum { WAIT_SPINS = 1u << 17 }; // x ~1 us per poll: a tenth of a second, against runs of a millisecond
 
-// one lane: poll until the word carries this run's tag; returns its payload (0 after giving up)
+// one lane: poll until the word carries this run's tag; returns its payload (0 after giving up).  Once one wait has given
+// up every other one does so at its next look (the run is lost; it must end, not hang the device).
 __device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epoch, u32* giveUp)
 {
 	for (u32 spins = 0;; ++spins) {
 		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if ((u32)(v >> 32) == epoch) return (u32)v;
-		if (spins > (u32)WAIT_SPINS) { atomicOr(giveUp, 1u); return 0u; }
+		if (spins > (u32)WAIT_SPINS || ((spins & 255u) == 255u && __hip_atomic_load(giveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { atomicOr(giveUp, 1u); return 0u; }
 		__builtin_amdgcn_s_sleep(4);
 	}
 }
@@ -1047,7 +1048,7 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 	return bestId | ((avg & 0xFFu) << 8);
 }
 
-// One block of one level >= 1.  GATED (k_upper): the children's caches come from other workgroups of the same launch - waited
+// One block of one level >= 1.  GATED (k_main): the children's caches come from other workgroups of the same launch - waited
 // for right in front of the vote, the only phase that reads them - and the block's own completion is published.
 template <bool GATED>
 __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid)
@@ -1644,7 +1645,7 @@ __device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1
 #endif
 // WIDE: a brick mirror of 4 GiB or more (grids beyond 1024^3): 64-bit voxel offsets around the vertices
 // (three waves per SIMD there: the 64-bit address terms do not fit the 128 registers of four)
-// One block of a level with transition cells.  GATED (k_upper): the block's material cache comes from another workgroup of the
+// One block of a level with transition cells.  GATED (k_main): the block's material cache comes from another workgroup of the
 // same launch and is waited for where it is first read (planes, sign summaries, cell classification and scans need none of it).
 template <bool WIDE, bool GATED>
 __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, u32 coordId, TrState& st, const Tables& T, u32* scanScratch, u32* quietFaces, u32& quietParity,
@@ -1853,7 +1854,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WIDE ? 3 : V
 
 } // namespace
 
-#include "vx_upper.inl"
+#include "vx_main.inl"
 
 namespace {
 
@@ -2158,7 +2159,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, upPersistent = 1, level0First = 0; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2184,10 +2185,13 @@ struct Backend {
 		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
 		tune.foldBlocks = env_u32("VX_FOLD_BLOCKS", 65536); // level-0 blocks up to which k_classify also activates the ancestors
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
-		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_upper replaces (A/B measurements)
-		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5));
-		tune.upPersistent = env_u32("VX_UP_PERSISTENT", 1);
-		tune.level0First = env_u32("VX_LEVEL0_FIRST", 0);
+		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_main replaces (A/B measurements)
+		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5)); // k_main without the level-0 queue (VX_MAIN_LEVEL0=0)
+		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
+		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
+		tune.mainBatch = std::max<u32>(1, env_u32("VX_MAIN_BATCH", 2));
+		tune.mainUpperNum = env_u32("VX_MAIN_UPPER_NUM", 1);
+		tune.mainUpperDen = std::max<u32>(1, env_u32("VX_MAIN_UPPER_DEN", 4));
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -2231,7 +2235,7 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")
-		    || !check(hipFuncSetAttribute((const void*)k_upper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + UP_STATE_LDS)), "hipFuncSetAttribute(k_upper)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main)")) {
 			err = lastError;
 			return false;
 		}
@@ -2291,6 +2295,13 @@ struct Backend {
 	void sync() { (void)hipStreamSynchronize(stream); }
 	bool sync_ok() { return check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 	bool d2h_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)"); }
+	// a copy that does not queue behind the context's streams (diagnostics while a run is in flight)
+	bool d2h_side(void* d, const void* s, size_t bytes)
+	{
+		(void)hipSetDevice(device);
+		if (!copyStream[0] && hipStreamCreateWithFlags(&copyStream[0], hipStreamNonBlocking) != hipSuccess) return false;
+		return hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, copyStream[0]) == hipSuccess && hipStreamSynchronize(copyStream[0]) == hipSuccess;
+	}
 	void* alloc_pinned(size_t bytes)
 	{
 		void* p = nullptr;
@@ -2476,7 +2487,7 @@ struct Backend {
 			if (!rowGroup) rowGroup = 1;
 		}
 		stage_mark(1); // stage times: [0] = reset + block classes, [1] = k_classify alone
-		if (carryClassified) doneEvent = evClassified;
+		if (carryClassified && (!single_stream(p, p.G.levels) || largeClass)) doneEvent = evClassified; // (a single-stream run forks only for the upper capacity classes of dense surfaces)
 		launch_with_event(k_classify, dim3(grid), 0u, dev(p), rowGroup, classify_activates_ancestors(p) ? 1u : 0u);
 		check(hipGetLastError(), "k_classify launch");
 	}
@@ -2519,6 +2530,7 @@ struct Backend {
 	template <typename P>
 	void run_hierarchy(const P& p, u32 levels, bool carryClassified = false)
 	{
+		if (carryClassified && single_stream(p, levels) && !largeClass) carryClassified = false;
 		if (levels < 2) { if (carryClassified) (void)hipEventRecord(evClassified, stream); return; }
 		const u32 grid = (p.levels[0].cap + WG - 1) / WG;
 		if (carryClassified) doneEvent = evClassified;
@@ -2556,10 +2568,10 @@ struct Backend {
 				// classification): with three or one workgroup per CU they run long and leave room, so they belong beside the
 				// first class, not behind it (second bench workload: 3.84 -> 3.69 ms).  What the two table-driven classes hand
 				// on is only complete when both are done.
-				const bool spread = largeClass && on == sideA;
+				const bool spread = largeClass && (on == sideA || (level0Done && overlappedTail));
 				hipStream_t upper = spread ? sideC : on;
 				if (spread) { (void)hipStreamWaitEvent(sideC, evClassified, 0); spreadC = true; }
-				hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p), 0u);
+				if (!level0Done) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_MID>), dim3(std::min<u32>(cap, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>), upper, dev(p), (u32)REG_CAP_SMALL);
 				if (spread) {
 					(void)hipEventRecord(evMidC, sideC);
@@ -2623,32 +2635,39 @@ struct Backend {
 	template <typename P>
 	void run_regular(const P& p, u32 levels) { launch_regular(p, 0, levels, stream); }
 
-	// The levels >= 1 of a full run as ONE launch (vx_upper.inl) - where the table-driven regular pass and the 32-bit-offset
-	// transition pass apply (lattice copies resident, mirrors below 4 GiB); otherwise the chain of launches it replaces.
-	u32 upperItemsHint = 0; // queue items of the previous full run of this context (0 = unknown)
-	bool upperDone = false; // inside run_overlapped_tail: k_upper did the first capacity class of the levels 1 .. fastEnd - 1
+	// Everything behind the classification as ONE launch (vx_main.inl) - where the table-driven regular pass of the levels >= 1
+	// and the 32-bit-offset transition pass apply (lattice copies resident, mirrors below 4 GiB); otherwise the chain of
+	// launches it replaces.  With the level-0 queue inside (the default) a full run is a single stream without events.
+	u32 upperItemsHint = 0; // upper-queue items of the previous full run of this context (0 = unknown)
+	bool upperDone = false;  // inside run_overlapped_tail: k_main did the first capacity class of the levels 1 .. fastEnd - 1
+	bool level0Done = false; // ... and the first capacity class of level 0
 	template <typename P>
-	bool upper_applies(const P& p, u32 levels) const
+	bool main_applies(const P& p, u32 levels) const
 	{
 		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
 		return tune.upper && tune.fast1 && !tune.forceWide && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	template <typename P>
-	void run_upper(const P& p, u32 levels)
+	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0; }
+	template <typename P>
+	void run_main(const P& p, u32 levels, bool withLevel0)
 	{
-		UpperPlan plan;
+		MainPlan plan;
 		plan.levels = levels;
 		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
-		plan.persistent = tune.upPersistent;
+		plan.level0 = withLevel0 ? 1u : 0u;
+		plan.batch = tune.mainBatch;
+		plan.upperNum = withLevel0 ? tune.mainUpperNum : 1u; plan.upperDen = withLevel0 ? tune.mainUpperDen : 1u;
 		unsigned long long items = 0; // at most: one material item per block, one regular, one transition
 		for (u32 l = 1; l < levels; ++l) items += (unsigned long long)p.levels[l].cap * (1u + (l < plan.fastEnd ? 1u : 0u) + (p.levels[l].hasTransitions ? 1u : 0u));
+		if (withLevel0) items += p.levels[0].cap;
 		if (!items) return;
-		// persistent workgroups, at most as many as the previous run had items (the host's hint; any number is correct - a
-		// workgroup that finds the queue empty leaves - but every workgroup costs a dequeue)
-		u32 grid = (u32)std::min<unsigned long long>(items, (unsigned long long)cus * tune.upWgsPerCu);
-		if (upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
-		launch_with_event(k_upper, dim3(grid), UP_TAB_LDS + UP_STATE_LDS, dev(p), plan);
-		check(hipGetLastError(), "k_upper launch");
+		// persistent workgroups; without the level-0 queue at most as many as the previous run had items (the host's hint; any
+		// number is correct - a workgroup that finds the queues empty leaves - but every workgroup costs a dequeue)
+		u32 grid = (u32)std::min<unsigned long long>(items, (unsigned long long)cus * (withLevel0 ? tune.mainWgsPerCu : tune.upWgsPerCu));
+		if (!withLevel0 && upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
+		launch_with_event(k_main, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
+		check(hipGetLastError(), "k_main launch");
 	}
 
 	// Overlapped tail of a full run (after classify + hierarchy on the main stream):
@@ -2663,31 +2682,25 @@ struct Backend {
 		overlappedTail = true;
 		spreadC = spreadD = false;
 		bool usedSideB = false;
-		(void)hipStreamWaitEvent(sideA, evClassified, 0);
-		if (tune.level0First && upper_applies(p, levels)) {
-			// (experiment) the level-0 pass on the main stream - it starts at once - and the levels >= 1 on side stream A behind
-			// the classification's event
-			launch_regular(p, 0, 1, stream);
-			hipStream_t keep = stream;
-			stream = sideA;
-			run_upper(p, levels);
-			upperDone = true;
-			launch_regular(p, 1, levels, stream);
-			upperDone = false;
+		if (single_stream(p, levels)) {
+			// one launch for the level-0 blocks and the levels >= 1 (vx_main.inl); what the table-driven passes leave - the upper
+			// capacity classes, what they hand on, levels beyond the lattice copies - follows on the same stream, and so do the
+			// block lists and the header read-back: no second stream, no event
+			run_main(p, levels, true);
+			upperDone = level0Done = true;
+			launch_regular(p, 0, levels, stream);
+			upperDone = level0Done = false;
 			overlappedTail = false;
-			stream = keep;
-			(void)hipEventRecord(evMain, stream);
-			(void)hipStreamWaitEvent(sideA, evMain, 0);
-			mainKeep = stream;
-			stream = sideA;
+			if (spreadC) (void)hipStreamWaitEvent(stream, evSideC, 0); // (dense surfaces: the upper capacity classes of level 0 ran beside k_main on a side stream)
 			return;
 		}
+		(void)hipStreamWaitEvent(sideA, evClassified, 0);
 		launch_regular(p, 0, 1, sideA);
-		if (upper_applies(p, levels)) {
+		if (main_applies(p, levels)) {
 			// the levels >= 1 as one launch: material blocks, regular blocks of the first capacity class and transition blocks
-			// wait for each other through device-side flags (vx_upper.inl); what is left for launch_regular below - the upper
+			// wait for each other through device-side flags (vx_main.inl); what is left for launch_regular below - the upper
 			// capacity classes, what the table-driven pass hands on, levels beyond the lattice copies - follows on this stream
-			run_upper(p, levels);
+			run_main(p, levels, false);
 			upperDone = true;
 		} else {
 			// the last material launch carries the event that releases the transition pass on side stream B

@@ -44,7 +44,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 320, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 352, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_L0HEAD = 320, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -364,6 +364,7 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.epoch = c->runEpoch;
 	p.G.upperHead = (u32*)c->dHeader + HDR_UPPER;
 	p.G.giveUp = (u32*)c->dHeader + HDR_GIVEUP;
+	p.G.level0Head = (u32*)c->dHeader + HDR_L0HEAD;
 	for (u32 L = 0; L < PYRAMID_LEVELS; ++L) p.G.pyr[L] = c->pyr[L];
 	for (u32 L = 0; L < XPLANE_LEVELS; ++L) p.G.xp[L] = c->xp[L];
 	p.G.levels = levels;
@@ -1295,7 +1296,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 	}
 	c->largeHint = c->hdr[HDR_LARGE] != 0;
 	{
-		// what the next run of this context can expect on the levels >= 1 (sizes the launch of k_upper): a material item per
+		// what the next run of this context can expect on the levels >= 1 (sizes the launch of k_main): a material item per
 		// active block, a regular one on the levels with a lattice copy, a transition one on the levels with transition cells
 		u32 items = 0;
 		for (u32 L = 1; L < levels; ++L) items += c->hdr[L] * (1u + (L < (u32)PYRAMID_LEVELS ? 1u : 0u) + (c->lv[L].hasTransitions ? 1u : 0u));
@@ -1316,6 +1317,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
+#if defined(VX_MAIN_PROFILE)
+	{
+		static const char* names[8] = { "barrier before dequeue", "dequeue", "level-0 batch", "material block", "regular block (levels >= 1)", "transition block", "exit", "-" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 8; ++i) sum += c->hdr[HDR_LARGE + 4 + i];
+		for (int i = 0; i < 7; ++i) fprintf(stderr, "[main profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_REG_PROFILE)
 	{
 		static const char* names[16] = { "next item", "top barrier", "begin+stage+barrier", "prefix scan", "list+barrier", "cells+barrier", "count+barrier", "vertex scan+reserve", "describe+barrier", "emit vertices", "barrier", "keep+barrier", "index scan+reserve", "stage indices+barrier", "flush indices", "record" };
@@ -1720,6 +1729,12 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 	if (!c) return VX_ERR_INVALID;
 	c->be.stage_enable(enable != 0);
 	return VX_OK;
+}
+
+int vx_debug_header(vx_ctx* c, uint32_t* out, uint32_t count)
+{
+	if (!c || !out || count > (uint32_t)HDR_WORDS) return VX_ERR_INVALID;
+	return c->be.d2h_side(out, c->dHeader, (size_t)count * 4) ? VX_OK : VX_ERR_DEVICE;
 }
 
 int vx_stage_times(vx_ctx* c, float ms[8]) /* reset, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists */
