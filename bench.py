@@ -325,15 +325,53 @@ def main():
     surface_blocks = int(info.active_blocks[0])
     blocks_read = int(info.blocks_read)
     # algorithmic bytes per kernel (SURVEY.md §8(d) shares); k_classify is charged what it has to read: the blocks the
-    # BF_Empty flags do not already prove surface-free (the full n^3 figure is kept beside it, see whole_execute)
+    # BF_Empty flags do not already prove surface-free (the full n^3 figure is kept beside it, see whole_execute).  k_main is
+    # everything behind the classification in one launch: material + blend of the surface blocks of level 0 and every mesh.
+    out_bytes_all = 48 * (int(totals[0]) + int(totals[2])) + 4 * (int(totals[1]) + int(totals[3]))
     alg = {"k_classify": float(4096 * blocks_read),
-           "k_regular0": float(2 * 4096 * surface_blocks + 48 * v0 + 4 * i0),
-           "k_regular": float(48 * (int(totals[0]) - v0) + 4 * (int(totals[1]) - i0)),
-           "k_transition": float(48 * int(totals[2]) + 4 * int(totals[3]))}
-    stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
+           "k_main": float(2 * 4096 * surface_blocks + out_bytes_all)}
+    stage_names = ["reset", "k_classify", "k_hierarchy", "k_main", "k_after_level0", "k_after_upper", "unused", "k_lists"]
     stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
+    single_stream = poly.stage_layout() == 1
+    if not single_stream:  # (a configuration without k_main: the chain of launches, VX_UPPER=0 / VX_MAIN_LEVEL0=0)
+        stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
+        stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
+        alg = {"k_classify": float(4096 * blocks_read),
+               "k_regular0": float(2 * 4096 * surface_blocks + 48 * v0 + 4 * i0),
+               "k_regular": float(48 * (int(totals[0]) - v0) + 4 * (int(totals[1]) - i0)),
+               "k_transition": float(48 * int(totals[2]) + 4 * int(totals[3]))}
     dominant = max(alg.keys(), key=lambda k: stage_ms[k])
     achieved = alg[dominant] / (stage_ms[dominant] * 1e-3) / 1e9
+    # The per-block bodies of k_main also exist as launches of their own (incremental runs, capacity classes): timed one at a
+    # time in a second context (VX_UPPER=0: the chain of launches k_main replaces) they show what each part of k_main costs
+    # alone - the figures earlier rounds reported as k_regular0 / k_regular / k_transition
+    isolated = None
+    if single_stream and world == 1 and not args.serialize:
+        try:
+            os.environ["VX_UPPER"] = "0"
+            iso = Polygonizer(device=local_rank)
+            del os.environ["VX_UPPER"]
+            iso.set_materials(synth.default_lut())
+            iso.create_terrain(n, seed)
+            iso.set_stage_timing(True)
+            ist = np.zeros(8, np.float64)
+            for _ in range(2):
+                iso.execute(levels)
+            for _ in range(reps):
+                iso.execute(levels)
+                ist += iso.stage_times()
+            ist /= reps
+            iso.close()
+            inames = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
+            ialg = {"k_regular0": float(2 * 4096 * surface_blocks + 48 * v0 + 4 * i0),
+                    "k_regular": float(48 * (int(totals[0]) - v0) + 4 * (int(totals[1]) - i0)),
+                    "k_transition": float(48 * int(totals[2]) + 4 * int(totals[3])), "k_material": 0.0}
+            isolated = {k: {"ms": round(float(v), 4), "algorithmic_bytes": ialg.get(k), "frac": (round(ialg[k] / (float(v) * 1e-3) / 8e12, 5) if ialg.get(k) and v > 0 else None)}
+                        for k, v in zip(inames, ist) if k in ialg}
+        except Exception as e:  # noqa: BLE001
+            isolated = {"error": str(e)[-200:]}
+        finally:
+            os.environ.pop("VX_UPPER", None)
     # HBM bytes per launch from rocprofv3 PMC passes of this same command, when a summary was committed
     traffic = None
     traffic_all = None
@@ -349,7 +387,8 @@ def main():
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": stage_ms[dominant],
-                "per_kernel": {k: {"ms": stage_ms[k], "algorithmic_bytes": alg[k], "frac": round(alg[k] / (stage_ms[k] * 1e-3) / 8e12, 5) if stage_ms[k] > 0 else None} for k in alg}}
+                "per_kernel": {k: {"ms": stage_ms[k], "algorithmic_bytes": alg[k], "frac": round(alg[k] / (stage_ms[k] * 1e-3) / 8e12, 5) if stage_ms[k] > 0 else None} for k in alg},
+                "parts_of_k_main_as_launches_of_their_own": isolated}
     outputs = 48 * (int(totals[0]) + int(totals[2])) + 4 * (int(totals[1]) + int(totals[3]))
     bytes_nominal = int(info.algorithmic_bytes)                               # §8(d): n^3 + 2*4096*surface blocks + outputs
     bytes_needed = 4096 * blocks_read + 2 * 4096 * surface_blocks + outputs  # with only the blocks that have to be read

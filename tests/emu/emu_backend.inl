@@ -150,6 +150,8 @@ struct Backend {
 	}
 	bool stage_timing_on() const { return true; } // the emulation always runs the serial order
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
+	template <typename P> bool single_stream(const P&, u32) const { return false; } // (HIP backend: one launch behind the classification)
+	template <typename P> void run_main_staged(const P&, u32) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
 	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange

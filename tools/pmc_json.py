@@ -5,7 +5,7 @@ import json
 import re
 import sys
 
-CLASSES = {"k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular0": "k_regular0",
+CLASSES = {"k_main": "k_main", "k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular0": "k_regular0",
            "k_regular": "k_regular", "k_run_head": "k_classify", "k_run_reset": "k_classify", "k_block_class": "k_classify", "k_list": "k_lists"}
 
 

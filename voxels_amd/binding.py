@@ -129,6 +129,7 @@ class HipLibrary:
         lib.vx_host_meshes_trim.restype = None
         lib.vx_stats.argtypes = [vp, vp]
         lib.vx_selftest.argtypes = [vp, vp]
+        lib.vx_stage_layout.argtypes = [vp, C.POINTER(C.c_int)]
         lib.vx_set_stage_timing.argtypes = [vp, C.c_int]
         lib.vx_stage_times.argtypes = [vp, vp]
         self.lib = lib
@@ -386,6 +387,12 @@ class Polygonizer:
     def set_stage_timing(self, enable):
         self._check(self._lib.vx_set_stage_timing(self._h, int(bool(enable))), "vx_set_stage_timing")
 
+
+    def stage_layout(self):
+        """vx_stage_layout: 1 if the last run with stage timing used the single-stream form (k_main), else 0"""
+        v = C.c_int(0)
+        self._check(self._lib.vx_stage_layout(self._h, C.byref(v)), "vx_stage_layout")
+        return v.value
 
     def stage_times(self):
         """ms of (reset, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists) of the last run."""

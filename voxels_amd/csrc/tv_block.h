@@ -1042,6 +1042,8 @@ struct TrState {
 	u16 ibase[TR_CAP];        // compact: exclusive scan of index counts (flat over the batch's faces)
 	u16 newMask[TR_CAP];      // compact: table vertices this cell creates
 	u16 vdesc[VDESC_CAP];     // one chunk of new-vertex descriptors: compact cell | table vertex << 11
+	u16 faceMat[TR_CELLS];    // GPU passes: the material entries of the low-res cells behind ALL transition cells, requested with the planes
+	                          // (one round trip less in front of the list phase) when the block's material cache is known to be complete
 	u32 faceOn;               // bit f = face has a neighbour block
 	u32 vOff, iOff, vTotal, iTotal;
 };
@@ -1120,7 +1122,8 @@ TV_HD void tr_low_local(const FaceGeom& fg, int row, int col, int local[3])
 	face_scatter(fg, col, row, fg.positive ? 15 : 0, local);
 }
 
-TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth)
+// preMat: TrState::faceMat filled by the caller (per transition cell), or nullptr: the entries are fetched here
+TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth, const u16* preMat = nullptr)
 {
 	for (int c = tid; c < TR_CELLS; c += nth) {
 		if (!bit_get(st.ntBits, (u32)c)) continue;
@@ -1138,7 +1141,7 @@ TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const
 		st.valid[k] = (u16)tr_slot_valid(T, v, code);
 		int local[3];
 		tr_low_local(face_geom(f), row, col, local);
-		st.cellMat[k] = TV_LOAD_THROUGH(&L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])]);
+		st.cellMat[k] = preMat ? preMat[c] : TV_LOAD_THROUGH(&L.cache[(size_t)b.slot * BLOCK_CELLS + (u32)((local[2] << 8) | (local[1] << 4) | local[0])]);
 	}
 }
 

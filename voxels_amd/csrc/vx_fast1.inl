@@ -46,7 +46,7 @@ typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller th
 // come from the run's flat list.
 template <int CAP, bool GATED>
 __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables& T, const F1BrickSampler& smp, Fast1State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
-                                         u32 level, u32 slot, u32 coord, u32 ntc, u32 lo, const int tid)
+                                         u32 level, u32 slot, u32 coord, u32 ntc, u32 lo, const int tid, const bool matKnown = false)
 {
 	typedef R0<CAP> K;
 	const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
@@ -71,25 +71,38 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 			rows[q] = pyramid_row17(P, (int)(bx * 16), (int)(by * 16) + j, (int)(bz * 16) + k);
 		}
 	}
-	if (GATED) {
+	// (bitmap and cache block: written by the material work - in k_main by another workgroup of the same launch, hence past the L1)
+	const u16* csrc = L.cache + (size_t)slot * BLOCK_CELLS;
+	u32 bitsWord = 0;
+	uint4 c0, c1;
+	const bool early = GATED && matKnown; // every material block of the launch is published: bitmap, cache block and cell count are requested with the samples
+	if (early) {
+		const u32 flagLow = (u32)TV_LOAD_THROUGH(L.matDone + slot);
+		bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
+		c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
+		ntc = r0_uniform(flagLow);
+	} else if (GATED) {
 		if (tid == 0) st.zero = wait_done(L.matDone + slot, p.G.epoch, p.G.giveUp);
 		acquire_and_meet(tid < 64);
 		ntc = r0_uniform(st.zero);
+	}
+	if (GATED) {
 		if (ntc > (u32)CAP || (lo && ntc <= lo)) return;
 		if (ntc == 0) {
 			if (tid == 0) reg_write_empty_record(L, slot);
 			return;
 		}
 	}
+	if (!early) {
+		bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
+		c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
+	}
 
 	// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
 	{
 		u32 zero = 0;
-		// (bitmap and cache block: written by the material work - in k_main by another workgroup of the same launch, hence past the L1)
-		if (tid < 128) st.ntBits[tid] = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + tid]);
+		if (tid < 128) st.ntBits[tid] = bitsWord;
 		if (tid < 16) st.classCount[tid] = 0;
-		const u16* csrc = L.cache + (size_t)slot * BLOCK_CELLS;
-		const uint4 c0 = load16_through(csrc, (u32)tid * 16u), c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
 		// (the ids = the low bytes of the 16-bit entries: lane tid holds the entries [8 tid, 8 tid + 8) and [8 (tid + 256), ...))
 		((uint2*)st.cacheId)[tid] = make_uint2(__builtin_amdgcn_perm(c0.y, c0.x, 0x06040200u), __builtin_amdgcn_perm(c0.w, c0.z, 0x06040200u));
 		((uint2*)st.cacheId)[tid + WG] = make_uint2(__builtin_amdgcn_perm(c1.y, c1.x, 0x06040200u), __builtin_amdgcn_perm(c1.w, c1.z, 0x06040200u));

@@ -113,25 +113,13 @@ __device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indice
 }
 
 // ---- dependencies between workgroups of ONE launch (k_main): LevelDesc::matDone ----------------------------------------
-// Producer: every wave drains its stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back: the eight
-// XCDs' L2s are not coherent with each other) and stores the 8-byte word epoch << 32 | payload.  Consumer: ONE wave polls the
-// word (relaxed, agent scope, s_sleep between polls), then ONE agent-scope acquire drops the stale lines of its CU's L1 /
-// its XCD's L2, the workgroup meets, and everybody reads with plain loads.  Results do not depend on dispatch order,
-// timing or placement; every wait is bounded (Globals::giveUp fails the run instead of hanging the device).
-__device__ __forceinline__ void publish_done(unsigned long long* flag, u32 epoch, u32 payload)
-{
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (restates the wait behind the write-back where the compiler cannot drop it)
-		__hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-
-// The write-through form of publishing (payload stored with sc1: the bytes leave the XCD's L2 at once, nothing has to be
-// written back before the flag): a release fence writes back EVERY dirty line of the XCD's L2 - beside a level-0 pass
-// that dirties hundreds of MB per run, thousands of them per run cost more than the launches they replace.
+// Producer: the payload leaves through write-through (sc1) stores, every storing wave drains them, the workgroup meets and
+// ONE lane stores the 8-byte word epoch << 32 | payload.  Consumer: ONE lane polls the word (relaxed, agent scope, s_sleep
+// between polls), the workgroup meets, and the payload is read with write-through loads (TV_LOAD_THROUGH / load16_through:
+// past the CU's L1, which no other CU's store refreshes).  Results do not depend on dispatch order, timing or placement;
+// every wait is bounded (Globals::giveUp fails the run instead of hanging the device).
+// (Why not plain stores + an agent-scope release fence: the fence writes back EVERY dirty line of the XCD's L2 - beside
+// level-0 blocks that dirty hundreds of MB per run, thousands of fences per run cost more than the launches they replace.)
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_through(void* uniformBase, u32 byteOffset, uint4 v)
 {
@@ -162,15 +150,11 @@ __device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epo
 
 // behind the polls of ONE wave (the others wait at the barrier).  What the producers published left through write-through
 // stores and is read through TV_LOAD_THROUGH / load16_through (past the L1), so no acquire - an invalidation of the whole
-// L1 of the CU, also under the other workgroups running there - is needed; VX_UP_RELEASE_FENCE builds (plain stores + release
-// fence on the producer side, A/B) pair it with the acquire.
+// L1 of the CU, also under the other workgroups running there - is needed (measured: plain stores + release fence + acquire
+// 0.553 ms per step at 1024^3, write-through stores + acquire 0.461, write-through stores and loads 0.445).
 __device__ __forceinline__ void acquire_and_meet(bool polled)
 {
-#if defined(VX_UP_RELEASE_FENCE) || defined(VX_UP_ACQUIRE)
-	if (polled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
 	(void)polled;
-#endif
 	__syncthreads();
 }
 
@@ -1060,11 +1044,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	const int mult = (int)L.mult;
 	constexpr int PER = (SAMPLES + WG - 1) / WG; // 20 samples per lane
 	constexpr int MAT_BATCH = 10;                 // of which this many are in flight together
-#if defined(VX_UP_RELEASE_FENCE)
-	constexpr bool THROUGH = false;               // (A/B: publish with plain stores + an agent-scope release fence)
-#else
 	constexpr bool THROUGH = GATED;               // what other workgroups of the launch wait for leaves through write-through stores
-#endif
 	u32 bx, by, bz;
 	block_coords(L.slotCoord[slot], L.cnt, bx, by, bz);
 	const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
@@ -1287,7 +1267,6 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	} else {
 		((uint4*)cacheOut)[tid] = ((const uint4*)st.out)[tid];
 		((uint4*)cacheOut)[tid + WG] = ((const uint4*)st.out)[tid + WG];
-		if (GATED) publish_done(L.matDone + slot, p.G.epoch, st.ntTotal);
 	}
 }
 
@@ -1649,9 +1628,21 @@ __device__ __forceinline__ void tr_planes_store(const uint4& r0, const uint4& r1
 // same launch and is waited for where it is first read (planes, sign summaries, cell classification and scans need none of it).
 template <bool WIDE, bool GATED>
 __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, u32 coordId, TrState& st, const Tables& T, u32* scanScratch, u32* quietFaces, u32& quietParity,
-                                         const BrickSamplerT<typename std::conditional<WIDE, size_t, u32>::type>& smp, int tid)
+                                         const BrickSamplerT<typename std::conditional<WIDE, size_t, u32>::type>& smp, int tid, const bool matKnown = true)
 {
-	bool matReady = false;
+	// matKnown: the block's material cache is known to be complete (the stand-alone pass: earlier launches wrote it): its entries
+	// behind the transition cells are then requested with the planes.  (Inside k_main that would need a launch-wide "all
+	// material blocks published" counter: measured, the counter's hot line cost the material blocks more than the round trip
+	// saved here.)
+	bool matReady = !GATED || matKnown;
+	const bool preMat = matReady;
+#if defined(VX_TR_PROFILE)
+	// tools builds: where a transition block's time goes (cycles / 64 as thread 0 sees them; header words 192..)
+	unsigned long long trTick = __builtin_readcyclecounter();
+#define TRB_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&p.G.largeBlocks[16 + (i)], (u32)((now_ - trTick) >> 6)); trTick = now_; } while (0)
+#else
+#define TRB_TICK(i) do { } while (0)
+#endif
 	const LevelDesc& L = p.levels[b.level];
 	b.mult = L.mult;
 	block_coords(__builtin_amdgcn_readfirstlane(coordId), L.cnt, b.bx, b.by, b.bz);
@@ -1673,6 +1664,18 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 		i8 rowFar = 0, xFace[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 		const bool haveLattice = !(WIDE && b.level == 1u) && tr_lattice_of(p.G, b.level, lat); // (uniform)
 		if (haveLattice) tr_planes_request(lat, b, tid, rowLo, rowHi, rowFar, xFace);
+		// the material entries of the low-res cells behind the 6 x 256 transition cells (lane t: cell t of every face)
+		u16 fm[6] = { 0, 0, 0, 0, 0, 0 };
+		if (preMat) { // (uniform)
+			const u16* cache = L.cache + (size_t)b.slot * BLOCK_CELLS;
+#pragma unroll
+			for (int f = 0; f < 6; ++f) {
+				int local[3];
+				tr_low_local(face_geom(f), tid >> 4, tid & 15, local);
+				fm[f] = TV_LOAD_THROUGH(&cache[(u32)((local[2] << 8) | (local[1] << 4) | local[0])]);
+			}
+		}
+		TRB_TICK(0);
 		
 		// A boundary plane whose samples all have one sign holds no transition cell.  The sign summaries of the level-0
 		// blocks (MirrorState::blockSign: "every voxel of the block's plane x = 0 / y = 0 / z = 0 is >= 0 / < 0") decide
@@ -1709,11 +1712,16 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 			if ((tid & 63) == 0 && quiet) atomicOr(&quietFaces[quietParity], quiet);
 		}
 		__syncthreads();
+		TRB_TICK(1);
 		on &= ~quietFaces[quietParity];
 		if (tid == 0) quietFaces[quietParity ^ 1u] = 0; // the other word is next written behind this barrier and read behind the next item's
 		quietParity ^= 1u;
 		if (tid == 0) st.faceOn = on;
 		for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0;
+		if (preMat) {
+#pragma unroll
+			for (int f = 0; f < 6; ++f) st.faceMat[f * 256 + tid] = fm[f];
+		}
 		if (haveLattice) {
 			tr_planes_store(rowLo, rowHi, rowFar, xFace, lat.xp != nullptr, on, tid, st);
 		} else {
@@ -1736,8 +1744,10 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 		}
 	}
 	__syncthreads();
+	TRB_TICK(2);
 	tr_phase_classify(st, tid, WG);
 	__syncthreads();
+	TRB_TICK(3);
 	for (int f0 = 0; f0 < 6;) {
 		const int f1 = tr_batch_end(st, f0); // uniform
 		__syncthreads();
@@ -1749,6 +1759,7 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 			if (tid == 0) st.wordPrefix[48] = (u16)nt;
 		}
 		__syncthreads();
+		TRB_TICK(4);
 		if (st.wordPrefix[48] != 0) {
 			if (GATED && !matReady) {
 				// the block's material cache (tr_phase_list reads the cells behind the faces) comes from another workgroup of this launch
@@ -1756,25 +1767,37 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 				acquire_and_meet(tid < 64);
 				matReady = true;
 			}
-			tr_phase_list(st, T, L, b, tid, WG);
+			TRB_TICK(5);
+			tr_phase_list(st, T, L, b, tid, WG, preMat ? st.faceMat : nullptr);
 			__syncthreads();
+			TRB_TICK(6);
 			tr_phase_count(st, T, tid, WG);
 			__syncthreads();
+			TRB_TICK(7);
 			{
+				// the reservation is requested here and first looked at behind the descriptors of the first chunk (which need
+				// none of it): one round trip off the block's chain
 				const u32 vt = block_exclusive_scan_u16(st.vbase, st.wordPrefix[48], scanScratch);
 				const u32 it2 = block_exclusive_scan_u16(st.ibase, st.wordPrefix[48], scanScratch);
+				u32 resV = 0, resI = 0;
 				if (tid == 0) {
 					st.vTotal = vt; st.iTotal = it2;
-					reserve_both(p.P.cursors, vt, it2, st.vOff, st.iOff);
+					reserve_both(p.P.cursors, vt, it2, resV, resI);
 				}
+				tr_phase_describe(st, 0, tid, WG);
+				if (tid == 0) { st.vOff = resV; st.iOff = resI; }
 			}
 			__syncthreads();
+			TRB_TICK(8);
 			for (u32 chunk = 0; chunk == 0 || chunk < st.vTotal; chunk += VDESC_CAP) {
-				if (chunk) __syncthreads();
-				tr_phase_describe(st, chunk, tid, WG);
-				__syncthreads();
+				if (chunk) {
+					__syncthreads();
+					tr_phase_describe(st, chunk, tid, WG);
+					__syncthreads();
+				}
 				tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
 			}
+			TRB_TICK(9);
 			for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
 				__syncthreads();
 				tr_phase_stage_indices(st, T, chunk, tid, WG);
@@ -1782,6 +1805,7 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 				tr_phase_flush_indices(st, T, p.P, chunk, tid, WG);
 			}
 		}
+		TRB_TICK(10);
 		tr_phase_record(st, L, b, p.P, f0, f1, tid);
 		f0 = f1;
 	}
@@ -2668,6 +2692,20 @@ struct Backend {
 		if (!withLevel0 && upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
 		launch_with_event(k_main, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
 		check(hipGetLastError(), "k_main launch");
+	}
+
+	// the same as the single-stream branch of run_overlapped_tail with stage marks in between (vx_set_stage_timing)
+	template <typename P>
+	void run_main_staged(const P& p, u32 levels)
+	{
+		spreadC = spreadD = false;
+		run_main(p, levels, true);
+		stage_mark(4);
+		upperDone = level0Done = true;
+		launch_regular(p, 0, levels, stream); // (records stage event 8 between its level-0 part and the rest)
+		upperDone = level0Done = false;
+		stage_mark(5);
+		stage_mark(6);
 	}
 
 	// Overlapped tail of a full run (after classify + hierarchy on the main stream):

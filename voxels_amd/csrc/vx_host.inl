@@ -106,6 +106,7 @@ struct vx_ctx {
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
 	size_t hRecCap = 0;
 	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
+	bool stagedMain = false;    // the last run with stage timing used the single-stream form (vx_stage_layout)
 	u32 runEpoch = 0;           // tag of the current full run in LevelDesc::matDone (Globals::epoch)
 	bool hostTiming = false;    // VX_HOST_TIMING (read once at context creation): print where a vx_polygonize call spends host time
 };
@@ -441,6 +442,14 @@ void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 	}
 	if (!ancestorsDone) c->be.run_hierarchy(p, levels, false);
 	c->be.stage_mark(3);
+	c->stagedMain = false;
+	if (c->be.single_stream(p, levels)) {
+		// stage timing of the product path: [3] = k_main, [4] / [5] = what follows it for level 0 / for the levels >= 1 (what the
+		// table-driven passes hand on, the upper capacity classes, levels beyond the lattice copies), [6] = nothing
+		c->be.run_main_staged(p, levels);
+		c->stagedMain = true;
+		return;
+	}
 	for (u32 L = 1; L < levels; ++L) c->be.run_material(p, L);
 	c->be.stage_mark(4);
 	c->be.run_regular(p, levels);
@@ -1325,6 +1334,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		for (int i = 0; i < 7; ++i) fprintf(stderr, "[main profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
 	}
 #endif
+#if defined(VX_TR_PROFILE)
+	{
+		static const char* names[11] = { "requests issued", "sign summaries + barrier", "planes to LDS + barrier", "classification + barrier", "batch bits + scan", "material wait", "list + barrier", "count + barrier", "scans + reservation", "describe + vertices", "indices" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 11; ++i) sum += c->hdr[HDR_LARGE + 16 + i];
+		for (int i = 0; i < 11; ++i) fprintf(stderr, "[transition profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 16 + i], 100.0 * c->hdr[HDR_LARGE + 16 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_REG_PROFILE)
 	{
 		static const char* names[16] = { "next item", "top barrier", "begin+stage+barrier", "prefix scan", "list+barrier", "cells+barrier", "count+barrier", "vertex scan+reserve", "describe+barrier", "emit vertices", "barrier", "keep+barrier", "index scan+reserve", "stage indices+barrier", "flush indices", "record" };
@@ -1728,6 +1745,13 @@ int vx_set_stage_timing(vx_ctx* c, int enable)
 	VX_ENTER(c);
 	if (!c) return VX_ERR_INVALID;
 	c->be.stage_enable(enable != 0);
+	return VX_OK;
+}
+
+int vx_stage_layout(vx_ctx* c, int* layout)
+{
+	if (!c || !layout) return VX_ERR_INVALID;
+	*layout = c->stagedMain ? 1 : 0;
 	return VX_OK;
 }
 

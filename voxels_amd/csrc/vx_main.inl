@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			if (tabKind != 2u) { TT = stage_transition_tables(tab, p.tables, (u32)tid); tabKind = 2u; }
 			RegBlockCtx b;
 			b.level = level; b.slot = slot;
-			tr_block<false, true>(p, b, coord, *(TrState*)state, TT, scanScratch, quietFaces, quietParity, smp, tid);
+			tr_block<false, true>(p, b, coord, *(TrState*)state, TT, scanScratch, quietFaces, quietParity, smp, tid, false);
 			MAIN_TICK(5);
 		}
 	}
