@@ -30,6 +30,7 @@ struct Backend {
 	bool sync_ok() { return true; }
 	bool d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool d2h_side(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	bool h2d_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void* alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
 	void free_pinned(void* p) { ::free(p); }
 	static void release_pinned(void* p) { ::free(p); }

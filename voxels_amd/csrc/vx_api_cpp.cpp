@@ -321,18 +321,29 @@ struct DeviceState
 	// mirror the host grid into HBM: whole grid the first time, edited blocks afterwards
 	bool SyncGrid(VoxelGrid& g)
 	{
+		static const bool trace = getenv("VOXELS_TRACE") != nullptr;
+		auto t0 = std::chrono::steady_clock::now();
+		auto lap = [&](const char* what) {
+			if (!trace) return;
+			const auto t1 = std::chrono::steady_clock::now();
+			fprintf(stderr, "[Voxels]   %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+			t0 = t1;
+		};
 		std::vector<uint8_t> flags;
-		g.EmptyFlags(flags);
 		if (ResidentGridUid != g.Uid()) {
 			// a grid that came from Grid::Load and was not edited since travels as its (much smaller) file and is
-			// expanded on the device; anything else as dense fields
+			// expanded on the device (its BF_Empty flags are in the file); anything else as dense fields
 			const std::vector<char>* file = g.PristineFile();
+			if (!file) g.EmptyFlags(flags);
 			const int rc = file ? vx_grid_upload_packed(Ctx, file->data(), file->size())
 			                    : vx_grid_upload(Ctx, g.Size(), g.Distances(), g.Materials(), g.Blends(), flags.data());
+			lap(file ? "packed file to device" : "dense fields to device");
 			if (rc != VX_OK) return false;
-			g.DropFile();
+			// (the grid keeps its file copy - a thirtieth of the dense fields: handing 87 MB back to the system inside Execute
+			// cost 7.6 ms, more than bringing the grid to the device)
 			ResidentGridUid = g.Uid();
 		} else if (ResidentGeneration != g.Generation()) {
+			g.EmptyFlags(flags);
 			std::vector<uint32_t> ids;
 			g.DirtySince(ResidentGeneration, ids); // per-consumer: another mirror of the same grid is not affected
 			std::vector<int8_t> d(ids.size() * 4096);

@@ -940,20 +940,33 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 			if (blockCnt[tid] > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u);
 			blockSkipped[tid] = skipped ? 1u : 0u;
 			blockSlot[tid] = (int)slot;
-			// Small block ranges (128^3 grids, the slabs of an 8-rank run): the block's ancestors become active on the levels
-			// 1 .. levels-1 right here (whoever marks an ancestor first gives it its slot and goes on upwards) - one launch and
-			// its hand-over less on a run's critical path (128^3: kernels done after 147 us instead of 173).  With many active
-			// blocks the chains of dependent atomics at the tail of the workgroups cost more than that (1024^3: +21 us on
-			// k_classify against 9 us for k_hierarchy, where every block has a lane of its own).
-			for (u32 l = 1; activateAncestors && l < p.G.levels; ++l) {
-				const LevelDesc& A = p.levels[l];
-				const u32 px = bx >> l, py = by >> l, pz = bz >> l;
-				if (px >= A.cnt || py >= A.cnt || pz >= A.cnt) break;
-				const u32 aid = block_coord_id(px, py, pz, A.cnt);
-				if (atomicCAS(&A.slotOf[aid], -1, -2) != -1) break; // somebody else owns this ancestor chain
-				const u32 aslot = atomicAdd(A.nActive, 1u);
-				A.slotCoord[aslot] = aid;
-				A.slotOf[aid] = (int)aslot; // visible to the next kernel
+			// The block's ancestors become active on the levels 1 .. levels-1 right here: whoever marks an ancestor first gives
+			// it its slot.  All levels are tried at once - the claims of the different levels are independent addresses, so the
+			// compare-and-swaps travel together and the slot counters of the levels won follow in a second round trip: two
+			// dependent round trips per block instead of two per level (as a chain that stopped at the first ancestor somebody
+			// else owned this cost k_classify +21 us at 1024^3 and was left to a launch of its own, k_hierarchy, there).
+			if (activateAncestors) {
+				int won[MAX_LEVELS];
+#pragma unroll
+				for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+					won[l] = 0;
+					if (l < p.G.levels) {
+						const LevelDesc& A = p.levels[l];
+						const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+						if (px < A.cnt && py < A.cnt && pz < A.cnt) won[l] = atomicCAS(&A.slotOf[block_coord_id(px, py, pz, A.cnt)], -1, -2) == -1 ? 1 : 0;
+					}
+				}
+				u32 aslot[MAX_LEVELS];
+#pragma unroll
+				for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) if (won[l]) aslot[l] = atomicAdd(p.levels[l].nActive, 1u);
+#pragma unroll
+				for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+					if (!won[l]) continue;
+					const LevelDesc& A = p.levels[l];
+					const u32 aid = block_coord_id(bx >> l, by >> l, bz >> l, A.cnt);
+					A.slotCoord[aslot[l]] = aid;
+					A.slotOf[aid] = (int)aslot[l]; // visible to the next kernel
+				}
 			}
 		}
 	}
@@ -2319,6 +2332,7 @@ struct Backend {
 	void sync() { (void)hipStreamSynchronize(stream); }
 	bool sync_ok() { return check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 	bool d2h_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)"); }
+	bool h2d_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)"); } // (page-locked source)
 	// a copy that does not queue behind the context's streams (diagnostics while a run is in flight)
 	bool d2h_side(void* d, const void* s, size_t bytes)
 	{

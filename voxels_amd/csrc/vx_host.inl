@@ -13,6 +13,7 @@
 #include "tv_fast1.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -104,6 +106,8 @@ struct vx_ctx {
 	void* dScratch = nullptr;  // small reusable device buffer (block id lists of edits)
 	size_t scratchCap = 0;
 	BlockRecord* hRecs = nullptr; // pinned staging for record read-back
+	void *dBlobStage = nullptr, *hBlobStage = nullptr, *dWhereStage = nullptr, *hWhereStage = nullptr; // vx_grid_upload_packed: the file and its block offsets on their way to the device (kept across calls)
+	size_t blobCap = 0, whereCap = 0;
 	size_t hRecCap = 0;
 	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
 	bool stagedMain = false;    // the last run with stage timing used the single-stream form (vx_stage_layout)
@@ -663,6 +667,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
+	c->be.free(c->dBlobStage); c->be.free_pinned(c->hBlobStage); c->be.free(c->dWhereStage); c->be.free_pinned(c->hWhereStage);
 	arena_recycle(c->hostArena);
 	for (void* hb : c->haloBuf) c->be.free(hb);
 	c->be.comm_destroy();
@@ -793,35 +798,92 @@ int vx_grid_upload_packed(vx_ctx* c, const void* blobPtr, uint64_t size)
 	const size_t blocks = (size_t)nb * nb * nb, tot = (size_t)n * n * n;
 	const uint64_t tableEnd = 16 + (uint64_t)blocks * 12;
 	if (size < tableEnd) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: truncated size table");
-	// per block: offset of its record {flags, 3 streams} and the three stream sizes
-	std::vector<uint64_t> where(blocks * 2);
+	// The file travels through a page-locked staging buffer of the context (a copy from pageable memory is staged by the
+	// runtime anyway, by one thread, piece by piece): a few host threads fill it in pieces, and every piece goes on its way to
+	// the device as soon as it and its predecessors are complete, while the calling thread walks the size table (per block:
+	// offset of its record {flags, 3 streams} and the three stream sizes).  Device-side staging is kept across calls as well.
+	// Nothing of the context's grid is touched before the file has been found sound.
+	if (size + 16 > c->blobCap) {
+		c->be.free(c->dBlobStage); c->be.free_pinned(c->hBlobStage);
+		c->blobCap = size + size / 8 + 4096;
+		c->dBlobStage = c->be.alloc(c->blobCap);
+		c->hBlobStage = c->be.alloc_pinned(c->blobCap);
+		if (!c->dBlobStage || !c->hBlobStage) { c->blobCap = 0; return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: staging allocation failed: " + c->be.error()); }
+	}
+	if (blocks * 16 > c->whereCap) {
+		c->be.free(c->dWhereStage); c->be.free_pinned(c->hWhereStage);
+		c->whereCap = blocks * 16;
+		c->dWhereStage = c->be.alloc(c->whereCap);
+		c->hWhereStage = c->be.alloc_pinned(c->whereCap);
+		if (!c->dWhereStage || !c->hWhereStage) { c->whereCap = 0; return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: staging allocation failed: " + c->be.error()); }
+	}
+	const auto tp0 = std::chrono::steady_clock::now();
+	enum { PIECES = 16 };
+	const uint64_t step = ((size + PIECES - 1) / PIECES + 255) & ~uint64_t(255);
+	std::atomic<unsigned> next(0);
+	std::atomic<unsigned char> done[PIECES];
+	for (auto& d : done) d.store(0);
+	auto filler = [&]() {
+		for (;;) {
+			const unsigned k = next.fetch_add(1);
+			if (k >= (unsigned)PIECES) return;
+			const uint64_t at = (uint64_t)k * step;
+			if (at < size) memcpy((u8*)c->hBlobStage + at, blob + at, std::min(step, size - at));
+			done[k].store(1, std::memory_order_release);
+		}
+	};
+	std::thread helpers[3];
+	for (std::thread& t : helpers) t = std::thread(filler);
+	uint64_t* where = (uint64_t*)c->hWhereStage;
 	uint64_t off = tableEnd;
+	bool corrupt = false;
 	for (size_t i = 0; i < blocks; ++i) {
 		const u32 sd = rd32(16 + i * 12), sm = rd32(16 + i * 12 + 4), sb = rd32(16 + i * 12 + 8);
-		if (sd > 4096 || sm > 4096 || sb > 4096 || (sd & 1) || (sm & 1) || (sb & 1)) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: corrupt stream size");
+		if (sd > 4096 || sm > 4096 || sb > 4096 || (sd & 1) || (sm & 1) || (sb & 1)) { corrupt = true; break; }
 		where[i * 2] = off;
 		where[i * 2 + 1] = (uint64_t)sd | ((uint64_t)sm << 16) | ((uint64_t)sb << 32);
 		off += 4 + (uint64_t)sd + sm + sb;
-		if (off > size) return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: truncated block data");
+		if (off > size) { corrupt = true; break; }
+	}
+	if (corrupt) {
+		for (std::thread& t : helpers) t.join();
+		return fail(c, VX_ERR_INVALID, "vx_grid_upload_packed: corrupt or truncated block data");
 	}
 	if (!(c->ownsGrid && c->n == n && c->zBegin == 0 && c->zEnd == n)) {
 		release_grid(c);
 		c->dDist = c->be.alloc(tot); c->dMat = c->be.alloc(tot); c->dBlend = c->be.alloc(tot); c->dFlags = c->be.alloc(blocks);
 		c->ownsGrid = true;
-		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device allocation failed: " + c->be.error()); }
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) {
+			for (std::thread& t : helpers) t.join();
+			release_grid(c);
+			return fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device allocation failed: " + c->be.error());
+		}
 	}
 	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
 	c->yBegin = 0; c->yEnd = n; c->distY0 = 0; c->matY0 = 0; c->distRows = n; c->matRows = n;
 	c->haveSurface = false;
 	c->bricksStale = true;
-	void* dBlob = c->be.alloc(off + 16);
-	void* dWhere = c->be.alloc(where.size() * 8);
-	bool ok = dBlob && dWhere && c->be.h2d(dBlob, blob, off) && c->be.h2d(dWhere, where.data(), where.size() * 8);
+	const auto tp1 = std::chrono::steady_clock::now();
+	bool ok = c->be.h2d_async(c->dWhereStage, c->hWhereStage, blocks * 16);
+	for (unsigned k = 0; k < (unsigned)PIECES; ++k) {
+		if (!done[k].load(std::memory_order_acquire)) filler(); // (lend a hand while there is something to wait for)
+		while (!done[k].load(std::memory_order_acquire)) std::this_thread::yield();
+		const uint64_t at = (uint64_t)k * step;
+		if (ok && at < off) ok = c->be.h2d_async((u8*)c->dBlobStage + at, (const u8*)c->hBlobStage + at, std::min(step, off - at));
+	}
+	for (std::thread& t : helpers) t.join();
+	const auto tp2 = std::chrono::steady_clock::now();
+	if (ok && c->hostTiming) ok = c->be.sync_ok(); // (so that the copies and the decode are timed apart)
+	const auto tp3 = std::chrono::steady_clock::now();
 	if (ok) {
-		c->be.run_decode_grid((const u8*)dBlob, (const uint64_t*)dWhere, n, (i8*)c->dDist, (u8*)c->dMat, (u8*)c->dBlend, (u8*)c->dFlags);
+		c->be.run_decode_grid((const u8*)c->dBlobStage, (const uint64_t*)c->dWhereStage, n, (i8*)c->dDist, (u8*)c->dMat, (u8*)c->dBlend, (u8*)c->dFlags);
 		ok = c->be.sync_ok();
 	}
-	c->be.free(dBlob); c->be.free(dWhere);
+	if (c->hostTiming) {
+		const auto tp4 = std::chrono::steady_clock::now();
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "[vx host] upload_packed: size table + start of staging %.2f ms, rest of staging + copies queued %.2f ms, copies done %.2f ms, decode %.2f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, tp4));
+	}
 	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload_packed: device decode failed: " + c->be.error());
 }
 
