@@ -65,6 +65,8 @@ typedef struct vx_exec_info {
 } vx_exec_info;
 
 /* ---- context ------------------------------------------------------------------------------------------- */
+/* Number of HIP devices this process sees (0 and VX_ERR_DEVICE when there is none). */
+int vx_device_count(int* count);
 int vx_ctx_create(int device_index, vx_ctx** out);
 void vx_ctx_destroy(vx_ctx* ctx);
 const char* vx_last_error(const vx_ctx* ctx);
@@ -113,6 +115,14 @@ int vx_grid_attach(vx_ctx* ctx, uint32_t n, uint32_t z_begin, uint32_t z_end,
 int vx_grid_attach_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end,
                      const void* d_dist, int32_t dist_y0, uint32_t dist_rows,
                      const void* d_mat, const void* d_blend, int32_t mat_y0, uint32_t mat_rows, const void* d_empty_flags);
+/* A slab of rows of a HOST grid onto the device, halo included: the context polygonizes the rows [y_begin, y_end) of every
+ * z-plane of the whole n^3 host grid `dist` / `mat` / `blend` (layout of vx_grid_upload; mat / blend may be NULL) and copies
+ * what that takes - distance rows [y_begin - 1, y_end + 2), material and blend rows [y_begin, y_end + 1), clamped to the grid,
+ * and all BF_Empty flags - into memory of its own (strided copies straight from the host arrays: a host that owns the whole
+ * Voxels::Grid needs no halo exchange between its devices).  Afterwards the context is in the state vx_grid_attach_y leaves
+ * it in.  What a multi-device Polygonizer::Execute calls once per device (voxels_amd/csrc/vx_api_cpp.cpp). */
+int vx_grid_upload_slab_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_end, const int8_t* dist, const uint8_t* mat,
+                          const uint8_t* blend, const uint8_t* empty_flags);
 /* Tell the library that the caller rewrote the resident (attached) fields in place — the zero-copy use of
  * vx_grid_attach*, where the application edits its own device tensors (the reference's Grid::Modify*BlockData on
  * memory the library does not own).  The mirrors are rebuilt by the next polygonization; the emptiness flags stay the

@@ -8,6 +8,7 @@ struct Backend {
 	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
 	u32 upperItemsHint = 0; // (HIP backend: sizes the launch of the levels >= 1)
 
+	static int device_count() { return 1; }
 	bool init(int, std::string&) { return true; }
 	bool wants_pyramid() const { return false; }
 	bool wants_bricks() const { return false; } // the emulation reads the dense fields
@@ -31,6 +32,11 @@ struct Backend {
 	bool d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool d2h_side(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool h2d_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
+	bool h2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height)
+	{
+		for (size_t r = 0; r < height; ++r) memcpy((u8*)d + r * dpitch, (const u8*)s + r * spitch, width);
+		return true;
+	}
 	void* alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
 	void free_pinned(void* p) { ::free(p); }
 	static void release_pinned(void* p) { ::free(p); }

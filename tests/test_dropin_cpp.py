@@ -43,6 +43,29 @@ def test_same_application_same_bytes(tmp_path, n, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,devices,variant", [(64, 2, ""), (64, 4, "B"), (128, 2, ""), (128, 4, ""), (128, 8, "B")])
+def test_same_application_same_bytes_on_several_devices(tmp_path, n, devices, variant):
+    """The same application, unchanged, with VOXELS_DEVICES=N: Polygonizer::Execute cuts the grid into N slabs of rows, one
+    helper context per slab (on a box with one GPU they share it), the finer levels come from the helpers, the levels coarser
+    than a slab and the statistics from the primary context, the Modification continues on the primary.  The dump must still
+    be the reference binary's, byte for byte."""
+    from voxels_amd import build
+    build.build_cpp_api()
+    build.build_dropin_tests()
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/dropin_ref not built (needs /root/reference at build time)")
+    a, b = str(tmp_path / "ours.bin"), str(tmp_path / "ref.bin")
+    extra = [variant] if variant else []
+    subprocess.check_call([OURS, str(n), a] + extra, env=dict(os.environ, VOXELS_DEVICES=str(devices)), timeout=300)
+    subprocess.check_call([REF, str(n), b] + extra, timeout=300)
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert len(da) == len(db), (len(da), len(db))
+    if da != db:
+        first = next(i for i in range(len(da)) if da[i] != db[i])
+        raise AssertionError("dumps differ at byte %d of %d" % (first, len(da)))
+
+
+@pytest.mark.gpu
 def test_device_mirror_tracks_grids_and_edits():
     """a Polygonizer reused on a new grid at a recycled address must upload it; two Polygonizers on one grid
     must both see an edit (tests/cpp/mirror_test.cpp)."""

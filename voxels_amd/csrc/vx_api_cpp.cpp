@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 namespace Voxels
@@ -196,11 +197,22 @@ struct SurfaceImpl : public PolygonSurface
 	float3 Extents;
 	std::vector<std::vector<BlockImpl> > Levels;
 	vx_host_meshes Meshes = { nullptr, nullptr, 0, 0, nullptr }; // owned: released with the surface
+	// a surface made by several devices (VOXELS_DEVICES): one page-locked copy per helper device for the finer levels, plain
+	// arrays for the few blocks of the levels coarser than a slab (from the primary device)
+	std::vector<vx_host_meshes> ShardMeshes;
+	struct CoarseLevel { std::vector<PolygonVertex> V, TV; std::vector<unsigned> I, TI; };
+	std::vector<CoarseLevel> Coarse;
 	PolygonizationStatistics Stats;
 	unsigned GridSize = 0;
 	std::shared_ptr<DeviceState> Device; // the context whose device caches describe this surface: kept alive by the surface, usable by any Polygonizer (Modification)
 
-	~SurfaceImpl() { if (Meshes.arena) vx_host_meshes_release(Meshes.arena); }
+	void ReleaseShardCopies()
+	{
+		for (vx_host_meshes& m : ShardMeshes) if (m.arena) vx_host_meshes_release(m.arena);
+		ShardMeshes.clear();
+		Coarse.clear();
+	}
+	~SurfaceImpl() { if (Meshes.arena) vx_host_meshes_release(Meshes.arena); ReleaseShardCopies(); }
 	float3 GetExtents() const override { return Extents; }
 	unsigned GetLevelsCount() const override { return (unsigned)Levels.size(); }
 	unsigned GetBlocksForLevelCount(unsigned level) const override { return (unsigned)Levels[level].size(); }
@@ -301,11 +313,33 @@ Modification::~Modification() {}
 // here they live in HBM, owned jointly by the Polygonizer that made the surface and by the surface itself).
 struct DeviceState
 {
-	vx_ctx* Ctx = nullptr;
+	vx_ctx* Ctx = nullptr;        // the primary context: the whole grid, every level, the caches a Modification continues from
 	uint64_t ResidentGridUid = 0; // VoxelGrid::Uid of the grid mirrored in HBM (0 = none; never compare addresses: they get reused)
 	uint64_t ResidentGeneration = 0;
+	// Helper contexts, one per further device (VOXELS_DEVICES = N; on a box with fewer devices they share them): each holds a
+	// slab of rows of the grid, polygonizes the levels whose blocks fit the slab and delivers those meshes over its own link
+	// - of a 1024^3 Execute 10 of 18 ms are the meshes on their way to the host.
+	std::vector<vx_ctx*> Helpers;
 
-	~DeviceState() { if (Ctx) vx_ctx_destroy(Ctx); }
+	~DeviceState()
+	{
+		for (vx_ctx* h : Helpers) if (h) vx_ctx_destroy(h);
+		if (Ctx) vx_ctx_destroy(Ctx);
+	}
+
+	// helper contexts for slabs of n / count rows (created on first use, kept); false: the grid is not cut that way
+	bool EnsureHelpers(unsigned n, unsigned count)
+	{
+		if (count < 2 || (n / 16) % count) return false;
+		int devices = 0;
+		if (vx_device_count(&devices) != VX_OK || devices < 1) return false;
+		while (Helpers.size() < count) {
+			vx_ctx* h = nullptr;
+			if (vx_ctx_create((int)(Helpers.size() % (size_t)devices), &h) != VX_OK) return false;
+			Helpers.push_back(h);
+		}
+		return true;
+	}
 
 	static std::shared_ptr<DeviceState> Create()
 	{
@@ -384,6 +418,143 @@ public:
 		for (int i = 0; i < 16; ++i) st.PerCaseCellsCount[i] = s[4 + i];
 	}
 
+	static unsigned RequestedDevices()
+	{
+		const char* e = getenv("VOXELS_DEVICES");
+		const int v = e ? atoi(e) : 1;
+		return v > 1 ? (unsigned)v : 1u;
+	}
+
+	// One helper's share of a full Execute: its slab of the host grid to its device, the levels whose blocks fit the slab,
+	// every mesh into a page-locked copy of its own, and the block tables of those levels.
+	struct HelperResult {
+		bool Ok = false;
+		vx_host_meshes Meshes = { nullptr, nullptr, 0, 0, nullptr };
+		std::vector<std::vector<vx_block_info> > Infos;
+		std::vector<std::vector<vx_block_ranges> > Ranges;
+	};
+	static void RunHelper(vx_ctx* ctx, const VoxelGrid* g, const uint8_t* flags, const uint8_t* lut, const uint8_t* valid, unsigned y0, unsigned y1, unsigned levels, HelperResult* out)
+	{
+		vx_exec_info info;
+		if (vx_grid_upload_slab_y(ctx, g->Size(), y0, y1, g->Distances(), g->Materials(), g->Blends(), flags) != VX_OK) return;
+		if (vx_material_lut(ctx, lut, valid) != VX_OK) return;
+		if (vx_polygonize(ctx, levels, &info) != VX_OK) return;
+		if (vx_host_meshes_acquire(ctx, &out->Meshes) != VX_OK) return;
+		out->Infos.resize(levels); out->Ranges.resize(levels);
+		for (unsigned l = 0; l < levels; ++l) {
+			uint32_t nb = 0;
+			if (vx_level_counts(ctx, l, &nb, nullptr) != VX_OK) return;
+			out->Infos[l].resize(nb); out->Ranges[l].resize(nb);
+			if (nb && (vx_download_level(ctx, l, out->Infos[l].data(), nullptr, nullptr, nullptr, nullptr) != VX_OK || vx_level_ranges(ctx, l, out->Ranges[l].data()) != VX_OK)) return;
+		}
+		out->Ok = true;
+	}
+
+	static void FillBlock(BlockImpl& b, const vx_block_info& in, const vx_block_ranges& r, const PolygonVertex* pv, const unsigned* pi)
+	{
+		b.Id = in.id;
+		b.MinCorner = float3(in.min_corner[0], in.min_corner[1], in.min_corner[2]);
+		b.MaxCorner = float3(in.max_corner[0], in.max_corner[1], in.max_corner[2]);
+		b.Vertices = pv + r.v_off; b.VertexCount = in.n_verts;
+		b.Indices = pi + r.i_off; b.IndexCount = in.n_idx;
+		for (int f = 0; f < 6; ++f) {
+			b.TVertices[f] = pv + r.tv_off[f]; b.TVertexCount[f] = in.n_tverts[f];
+			b.TIndices[f] = pi + r.ti_off[f]; b.TIndexCount[f] = in.n_tidx[f];
+		}
+	}
+
+	// A full Execute on several devices.  The primary context polygonizes the whole grid as always (it keeps the caches a
+	// later Modification continues from, gives the statistics, and the few blocks of the levels coarser than a slab, which read
+	// voxels of every slab); the meshes of the finer levels - nearly all bytes of the result - are produced a second time by
+	// the helpers, each for its slab, and travel to the host over the helpers' own links, side by side.
+	PolygonSurface* ExecuteOnDevices(VoxelGrid* g, const MaterialMap* materials, unsigned devices)
+	{
+		const unsigned n = g->Size(), rows = n / devices;
+		unsigned helperLevels = 1;
+		for (unsigned m = rows / 16; !(m & 1u); m >>= 1) ++helperLevels; // coarsest block that divides the slab (and its origin)
+		unsigned refLevels = 1;
+		for (unsigned v = n / 16; v >>= 1;) ++refLevels;
+		if (helperLevels > refLevels) helperLevels = refLevels;
+		std::vector<uint8_t> flags;
+		g->EmptyFlags(flags);
+		uint8_t lut[256 * 6], valid[256];
+		memset(lut, 0, sizeof(lut));
+		for (int id = 0; id < 256; ++id) { // (MaterialMap::GetMaterial is only ever called from the calling thread)
+			MaterialMap::Material* m = materials ? materials->GetMaterial((unsigned char)id) : nullptr;
+			valid[id] = m ? 1 : 0;
+			if (m) { memcpy(lut + id * 6, m->DiffuseIds0, 3); memcpy(lut + id * 6 + 3, m->DiffuseIds1, 3); }
+		}
+		std::vector<HelperResult> res(devices);
+		std::vector<std::thread> threads;
+		for (unsigned i = 0; i < devices; ++i)
+			threads.emplace_back(&TransVoxelImpl::RunHelper, Device->Helpers[i], (const VoxelGrid*)g, (const uint8_t*)flags.data(), (const uint8_t*)lut, (const uint8_t*)valid, i * rows, (i + 1) * rows, helperLevels, &res[i]);
+		// the primary, on the calling thread
+		vx_ctx* ctx = Device->Ctx;
+		vx_exec_info info;
+		bool ok = Device->SyncGrid(*g) && vx_material_lut(ctx, lut, valid) == VX_OK && vx_polygonize(ctx, 0, &info) == VX_OK;
+		std::unique_ptr<SurfaceImpl> s(new SurfaceImpl);
+		s->GridSize = n;
+		s->Device = Device;
+		s->Extents = float3((float)n, (float)n, (float)n);
+		std::vector<std::vector<vx_block_info> > coarseInfos;
+		if (ok) {
+			s->Levels.resize(info.levels);
+			s->Coarse.resize(info.levels);
+			coarseInfos.resize(info.levels);
+			for (unsigned l = helperLevels; ok && l < info.levels; ++l) {
+				uint32_t nb = 0;
+				uint64_t tot[4] = { 0, 0, 0, 0 };
+				ok = vx_level_counts(ctx, l, &nb, tot) == VX_OK;
+				if (!ok) break;
+				SurfaceImpl::CoarseLevel& c = s->Coarse[l];
+				coarseInfos[l].resize(nb);
+				c.V.resize(tot[0]); c.I.resize(tot[1]); c.TV.resize(tot[2]); c.TI.resize(tot[3]);
+				ok = !nb || vx_download_level(ctx, l, coarseInfos[l].data(), (vx_vertex*)c.V.data(), c.I.data(), (vx_vertex*)c.TV.data(), c.TI.data()) == VX_OK;
+			}
+			FillStats(ctx, s->Stats);
+		}
+		for (std::thread& t : threads) t.join();
+		for (unsigned i = 0; i < devices; ++i) { s->ShardMeshes.push_back(res[i].Meshes); ok = ok && res[i].Ok; } // (the surface owns the copies from here on)
+		if (!ok) { Log(LS_Error, vx_last_error(ctx)); for (vx_ctx* h : Device->Helpers) if (h && *vx_last_error(h)) Log(LS_Error, vx_last_error(h)); return nullptr; }
+		// the finer levels: every helper's blocks, merged by id (ids number the blocks of the whole grid: = GetBlockForLevel order)
+		for (unsigned l = 0; l < helperLevels && l < info.levels; ++l) {
+			struct Ref { unsigned id, helper, k; };
+			std::vector<Ref> order;
+			for (unsigned i = 0; i < devices; ++i) for (unsigned k = 0; k < res[i].Infos[l].size(); ++k) order.push_back({ res[i].Infos[l][k].id, i, k });
+			std::sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.id < b.id; });
+			std::vector<BlockImpl>& out = s->Levels[l];
+			out.resize(order.size());
+			for (size_t q = 0; q < order.size(); ++q) {
+				const Ref& r = order[q];
+				FillBlock(out[q], res[r.helper].Infos[l][r.k], res[r.helper].Ranges[l][r.k], (const PolygonVertex*)res[r.helper].Meshes.verts, res[r.helper].Meshes.indices);
+			}
+		}
+		// the coarser levels: compact arrays in block order (vx_download_level's layout)
+		for (unsigned l = helperLevels; l < info.levels; ++l) {
+			const SurfaceImpl::CoarseLevel& c = s->Coarse[l];
+			std::vector<BlockImpl>& out = s->Levels[l];
+			out.resize(coarseInfos[l].size());
+			size_t ov = 0, oi = 0, otv = 0, oti = 0;
+			for (size_t k = 0; k < out.size(); ++k) {
+				const vx_block_info& in = coarseInfos[l][k];
+				vx_block_ranges r;
+				r.v_off = (uint32_t)ov; r.i_off = (uint32_t)oi;
+				ov += in.n_verts; oi += in.n_idx;
+				BlockImpl& b = out[k];
+				b.Id = in.id;
+				b.MinCorner = float3(in.min_corner[0], in.min_corner[1], in.min_corner[2]);
+				b.MaxCorner = float3(in.max_corner[0], in.max_corner[1], in.max_corner[2]);
+				b.Vertices = c.V.data() + r.v_off; b.VertexCount = in.n_verts;
+				b.Indices = c.I.data() + r.i_off; b.IndexCount = in.n_idx;
+				for (int f = 0; f < 6; ++f) {
+					b.TVertices[f] = c.TV.data() + otv; b.TVertexCount[f] = in.n_tverts[f]; otv += in.n_tverts[f];
+					b.TIndices[f] = c.TI.data() + oti; b.TIndexCount[f] = in.n_tidx[f]; oti += in.n_tidx[f];
+				}
+			}
+		}
+		return s.release();
+	}
+
 	PolygonSurface* Execute(const Grid& grid, const MaterialMap* materials, Modification* modification)
 	{
 		VoxelGrid* g = grid.GetInternalRepresentation();
@@ -402,6 +573,12 @@ public:
 			// Modification needs them): a new full run then gets a context of its own instead of overwriting them.
 			if (!Device || Device.use_count() > 1) Device = DeviceState::Create();
 			if (!Device) return nullptr;
+			const unsigned devices = RequestedDevices();
+			if (devices > 1 && Device->EnsureHelpers(g->Size(), devices)) {
+				PolygonSurface* r = ExecuteOnDevices(g, materials, devices);
+				lap("Execute on several devices");
+				return r;
+			}
 			vx_ctx* ctx = Device->Ctx;
 			if (!Device->SyncGrid(*g) || !Device->SyncMaterials(materials)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 			lap("grid + materials to device");
@@ -445,6 +622,9 @@ public:
 		if (rc != VX_OK) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 		mod->ModifiedBlocks.insert(mod->ModifiedBlocks.end(), ids.begin(), ids.begin() + count);
 		if (!FetchSurface(ctx, std::min<unsigned>(info.levels, (unsigned)s->Levels.size()), *s)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
+		// (a surface made by several devices continues on its primary context, which holds every level and every cache: all views
+		// now point into the primary's copy, the helpers' copies can go)
+		s->ReleaseShardCopies();
 		FillStats(ctx, s->Stats);
 		return s;
 	}

@@ -269,6 +269,20 @@ __global__ __launch_bounds__(WG) void k_decode_grid(const u8* blob, const unsign
 			// raw: 4096 bytes, row t at offset 16 t (the stream itself is not aligned)
 #pragma unroll
 			for (u32 i = 0; i < 16; ++i) if (tid * 16 + i < sz) b[i >> 2] |= (u32)src[tid * 16 + i] << ((i & 3) * 8);
+		} else if ((sz >> 1) <= 16u) {
+			// a handful of runs (the blocks away from the surface: one or two): every lane walks them itself - uniform addresses,
+			// no LDS, no barrier (most blocks of a terrain take this path three times and are bound by their stores)
+			const u32 pairs = sz >> 1, q0 = tid * 16;
+			u32 start = 0, r = 0; // the run covering the row's first voxel, then voxel by voxel from there
+			for (; r < pairs; ++r) { const u32 len = src[2 * r]; if (start + len > q0) break; start += len; }
+			u32 end = r < pairs ? start + (u32)src[2 * r] : 0u;
+#pragma unroll
+			for (u32 i = 0; i < 16; ++i) {
+				const u32 pos = q0 + i;
+				while (r < pairs && pos >= end) { ++r; if (r < pairs) end += (u32)src[2 * r]; }
+				const u32 x = r < pairs ? (u32)src[2 * r + 1] : 0u;
+				b[i >> 2] |= x << ((i & 3) * 8);
+			}
 		} else {
 			const u32 pairs = sz >> 1; // <= 2048
 #pragma unroll
@@ -2207,6 +2221,11 @@ struct Backend {
 		return false;
 	}
 
+	static int device_count()
+	{
+		int count = 0;
+		return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+	}
 	bool init(int device, std::string& err)
 	{
 		int count = 0;
@@ -2322,6 +2341,12 @@ struct Backend {
 	bool h2d(void* d, const void* s, size_t bytes)
 	{
 		return check(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)")
+		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	// `height` pieces of `width` bytes, host -> device, with their own pitches (the rows of a slab out of a whole host grid)
+	bool h2d_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height)
+	{
+		return check(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, stream), "hipMemcpy2DAsync(H2D)")
 		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	bool d2h(void* d, const void* s, size_t bytes)

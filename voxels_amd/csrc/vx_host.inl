@@ -59,6 +59,7 @@ struct vx_ctx {
 	int distY0 = 0, matY0 = 0;           // global y of row 0 of every resident plane
 	u32 distRows = 0, matRows = 0;       // rows per resident plane (n for a whole grid or a z-slab)
 	bool ownsGrid = false;
+	bool ownsSlab = false;               // the attached slab buffers are the context's own (vx_grid_upload_slab_y)
 	void *dDist = nullptr, *dMat = nullptr, *dBlend = nullptr, *dFlags = nullptr;
 	void* dBlockClass = nullptr;                           // per level-0 block scratch of the classify pass
 	void* dFlatItems = nullptr;                            // active blocks of the levels >= 1 in level order (Globals::flatItems)
@@ -142,11 +143,12 @@ void free_level_tables(vx_ctx* c)
 
 void release_grid(vx_ctx* c)
 {
-	if (c->ownsGrid) {
+	if (c->ownsGrid || c->ownsSlab) {
 		c->be.free(c->dDist); c->be.free(c->dMat); c->be.free(c->dBlend); c->be.free(c->dFlags);
 	}
 	c->dDist = c->dMat = c->dBlend = c->dFlags = nullptr;
 	c->ownsGrid = false;
+	c->ownsSlab = false;
 	c->slabAxis = 0;
 	c->bricksStale = true;
 }
@@ -628,6 +630,13 @@ extern "C" {
 
 const char* vx_backend(void) { return VX_BACKEND_NAME; }
 
+int vx_device_count(int* count)
+{
+	if (!count) return VX_ERR_INVALID;
+	*count = Backend::device_count();
+	return *count > 0 ? VX_OK : VX_ERR_DEVICE;
+}
+
 int vx_ctx_create(int device_index, vx_ctx** out)
 {
 	if (!out) return VX_ERR_INVALID;
@@ -983,6 +992,39 @@ int vx_grid_attach_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, co
 	c->bricksStale = true;
 	c->slabAxis = 2;
 	return VX_OK;
+}
+
+int vx_grid_upload_slab_y(vx_ctx* c, uint32_t n, uint32_t y_begin, uint32_t y_end, const int8_t* dist, const uint8_t* mat, const uint8_t* blend, const uint8_t* flags)
+{
+	VX_ENTER(c);
+	if (!c || !dist || !flags || n < 16 || (n & 15) || n > VX_MAX_GRID || y_begin >= y_end || y_end > n || (y_begin & 15) || (y_end & 15))
+		return fail(c, VX_ERR_INVALID, "vx_grid_upload_slab_y: bad arguments (slab bounds must be multiples of 16)");
+	const u32 rows = y_end - y_begin, dRows = rows + 3, mRows = rows + 1;
+	const size_t nb = (size_t)(n / 16) * (n / 16) * (n / 16);
+	const bool reuse = c->ownsSlab && c->slabAxis == 2 && c->n == n && c->yBegin == y_begin && c->yEnd == y_end;
+	if (!reuse) {
+		release_grid(c);
+		c->dDist = c->be.alloc((size_t)n * dRows * n); c->dMat = c->be.alloc((size_t)n * mRows * n); c->dBlend = c->be.alloc((size_t)n * mRows * n); c->dFlags = c->be.alloc(nb);
+		c->ownsSlab = true;
+		if (!c->dDist || !c->dMat || !c->dBlend || !c->dFlags) { release_grid(c); return fail(c, VX_ERR_DEVICE, "vx_grid_upload_slab_y: device allocation failed: " + c->be.error()); }
+	}
+	c->n = n; c->zBegin = 0; c->zEnd = n; c->distZ0 = 0; c->matZ0 = 0;
+	c->yBegin = y_begin; c->yEnd = y_end;
+	c->distY0 = (int)y_begin - 1; c->matY0 = (int)y_begin; c->distRows = dRows; c->matRows = mRows;
+	c->slabAxis = 2;
+	c->haveSurface = false;
+	c->bricksStale = true;
+	// rows [a, b) of every plane: (b - a) * n contiguous bytes per plane, n planes, n * n bytes apart in the host array
+	auto rows_of = [&](void* dDst, u32 dstRows, int dstRow0, const void* src, int a, int b) -> bool {
+		a = std::max(a, 0); b = std::min(b, (int)n);
+		if (!src) return c->be.fill(dDst, 0, (size_t)n * dstRows * n);
+		return c->be.h2d_2d((u8*)dDst + (size_t)(a - dstRow0) * n, (size_t)dstRows * n, (const u8*)src + (size_t)a * n, (size_t)n * n, (size_t)(b - a) * n, n);
+	};
+	bool ok = rows_of(c->dDist, dRows, c->distY0, dist, (int)y_begin - 1, (int)y_end + 2)
+	       && rows_of(c->dMat, mRows, c->matY0, mat, (int)y_begin, (int)y_end + 1)
+	       && rows_of(c->dBlend, mRows, c->matY0, blend, (int)y_begin, (int)y_end + 1)
+	       && c->be.h2d(c->dFlags, flags, nb);
+	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_grid_upload_slab_y: copy failed: " + c->be.error());
 }
 
 int vx_grid_invalidate(vx_ctx* c)
@@ -1677,7 +1719,50 @@ int vx_download_level(vx_ctx* c, uint32_t level, vx_block_info* infos, vx_vertex
 	VX_ENTER(c);
 	if (!c || !c->haveSurface || level >= c->levelsRun) return fail(c, VX_ERR_INVALID, "vx_download_level: no such level");
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
-	if ((verts || idx || tverts || tidx) && !fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
+	if (verts || idx || tverts || tidx) {
+		// A level that is a small part of the pools (the coarse levels; a caller that wants them alone) is gathered on the device
+		// and copied by itself while no host copy of the pools exists; otherwise both pools travel once (fetch_pools) and every
+		// level is served from that copy.
+		uint64_t lv = 0, li = 0;
+		for (const EmittedBlock& e : c->blocks[level]) {
+			lv += e.rec.vCount; li += e.rec.iCount;
+			for (int f = 0; f < 6; ++f) { lv += e.rec.tvCount[f]; li += e.rec.tiCount[f]; }
+		}
+		const bool haveCopy = c->hostArena && c->hostArena->lineage == c->poolLineage && c->hostArena->haveVerts >= c->poolVerts && c->hostArena->haveIdx >= c->poolIdx;
+		if (!haveCopy && (lv + li) * 8 < (uint64_t)c->poolVerts + c->poolIdx) {
+			std::vector<u32> segV, segI; // (source offset, destination offset, count): vertices first, transition vertices behind them; indices likewise
+			u32 nv = 0, ntv = 0, ni = 0, nti = 0;
+			for (const EmittedBlock& e : c->blocks[level]) { nv += e.rec.vCount; ni += e.rec.iCount; }
+			u32 av = 0, atv = nv, ai = 0, ati = ni;
+			for (const EmittedBlock& e : c->blocks[level]) {
+				const BlockRecord& r = e.rec;
+				if (r.vCount) { segV.push_back(r.vOff); segV.push_back(av); segV.push_back(r.vCount); av += r.vCount; }
+				if (r.iCount) { segI.push_back(r.iOff); segI.push_back(ai); segI.push_back(r.iCount); ai += r.iCount; }
+				for (int f = 0; f < 6; ++f) {
+					if (r.tvCount[f]) { segV.push_back(r.tvOff[f]); segV.push_back(atv); segV.push_back(r.tvCount[f]); atv += r.tvCount[f]; ntv += r.tvCount[f]; }
+					if (r.tiCount[f]) { segI.push_back(r.tiOff[f]); segI.push_back(ati); segI.push_back(r.tiCount[f]); ati += r.tiCount[f]; nti += r.tiCount[f]; }
+				}
+			}
+			void* dSeg = c->be.alloc((segV.size() + segI.size() + 4) * 4);
+			void* dV = c->be.alloc((size_t)(nv + ntv) * sizeof(PolyVertex) + 16);
+			void* dI = c->be.alloc((size_t)(ni + nti) * 4 + 16);
+			bool ok = dSeg && dV && dI;
+			if (ok && !segV.empty()) ok = c->be.h2d(dSeg, segV.data(), segV.size() * 4);
+			if (ok && !segI.empty()) ok = c->be.h2d((u32*)dSeg + segV.size(), segI.data(), segI.size() * 4);
+			if (ok) {
+				c->be.run_copy_segments((const u32*)dSeg, (u32)(segV.size() / 3), c->dVerts, dV, (u32)sizeof(PolyVertex));
+				c->be.run_copy_segments((const u32*)dSeg + segV.size(), (u32)(segI.size() / 3), c->dIdx, dI, 4u);
+				if (verts && nv) ok = ok && c->be.d2h(verts, dV, (size_t)nv * sizeof(PolyVertex));
+				if (tverts && ntv) ok = ok && c->be.d2h(tverts, (const PolyVertex*)dV + nv, (size_t)ntv * sizeof(PolyVertex));
+				if (idx && ni) ok = ok && c->be.d2h(idx, dI, (size_t)ni * 4);
+				if (tidx && nti) ok = ok && c->be.d2h(tidx, (const u32*)dI + ni, (size_t)nti * 4);
+				ok = ok && c->be.sync_ok();
+			}
+			c->be.free(dSeg); c->be.free(dV); c->be.free(dI);
+			if (!ok) return fail(c, VX_ERR_DEVICE, "vx_download_level: gathered download failed: " + c->be.error());
+			verts = nullptr; idx = nullptr; tverts = nullptr; tidx = nullptr; // (done; the loop below only fills the block infos)
+		} else if (!fetch_pools(c)) return fail(c, VX_ERR_DEVICE, "vx_download_level: pool download failed: " + c->be.error());
+	}
 	size_t ov = 0, oi = 0, otv = 0, oti = 0, k = 0;
 	for (const EmittedBlock& e : c->blocks[level]) {
 		const BlockRecord& r = e.rec;
