@@ -2708,7 +2708,10 @@ struct Backend {
 	bool main_applies(const P& p, u32 levels) const
 	{
 		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
-		return tune.upper && tune.fast1 && !tune.forceWide && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+		// (dense surfaces - blocks beyond the first capacity class are expected - keep the chain of launches on five streams: the
+		// upper classes run at one to three workgroups per CU for hundreds of microseconds and belong BESIDE the rest; behind
+		// k_main they made the second bench workload 3.9 ms per step against 3.5)
+		return tune.upper && tune.fast1 && !tune.forceWide && !largeClass && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	template <typename P>
 	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0; }
