@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--slab-axis", choices=["y", "z"], default="y", help="axis along which the grid is cut into one slab per GPU (y balances height-field terrains, whose surface sits in a few z-layers)")
     ap.add_argument("--serialize", action="store_true", help="run EVERY launch of this process with the library's streams serialised (one kernel at a time), for per-kernel profiling: the end-to-end figures are skipped")
     ap.add_argument("--no-extra", action="store_true", help="skip the second ('caves') workload reported under config.extra")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the second context that times the parts of k_main as launches of their own (profiling runs: only the product path's kernels in the trace)")
     ap.add_argument("--allow-torch-transport", action="store_true", help="N > 1 only: if the C-ABI RCCL communicator (vx_comm_init) cannot be brought up, move the halo with torch.distributed instead of failing (such a run is no evidence for vx_halo_exchange)")
     ap.add_argument("--halo-every-step", action="store_true", help="N > 1 only: exchange the slab halo inside every timed step (as after an edit) instead of once before the steps")
     return ap.parse_args()
@@ -346,7 +347,7 @@ def main():
     # time in a second context (VX_UPPER=0: the chain of launches k_main replaces) they show what each part of k_main costs
     # alone - the figures earlier rounds reported as k_regular0 / k_regular / k_transition
     isolated = None
-    if single_stream and world == 1 and not args.serialize:
+    if single_stream and world == 1 and not args.serialize and not args.no_isolated:
         try:
             os.environ["VX_UPPER"] = "0"
             iso = Polygonizer(device=local_rank)

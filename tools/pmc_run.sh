@@ -7,6 +7,6 @@ mkdir -p "$out"
 i=0
 for c in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $c --kernel-trace -d "$out/pass$i" -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$out/pass$i.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d "$out/pass$i" -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-isolated > "$out/pass$i.log" 2>&1
   python tools/rocpd_summary.py "$out/pass$i/pmc_results.db" "$out/pass$i.txt" --pmc > /dev/null 2>&1 || echo "summary failed for pass $i"
 done

@@ -815,8 +815,15 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 		if (bx < L.cnt) myClass = p.G.blockClass[block_coord_id(bx, by, bz, L.cnt)];
 		if (__ballot(!(myClass & BC_QUIET)) == 0ull) return; // (every wave holds the 16 classes four times over: uniform over the workgroup)
 	}
+#if defined(VX_CLS_PROFILE)
+	unsigned long long clsTick = __builtin_readcyclecounter();
+#define CLS_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&p.G.largeBlocks[16 + (i)], (u32)((now_ - clsTick) >> 4)); clsTick = now_; } while (0)
+#else
+#define CLS_TICK(i) do { } while (0)
+#endif
 	if (tid < TB) { blockAny[tid] = 0; blockCnt[tid] = 0; blockSlot[tid] = -1; blockCls[tid] = myClass; }
 	__syncthreads();
+	CLS_TICK(0);
 
 	// ---- load from the brick mirror: the TB blocks of a tile are 64 KB of consecutive addresses, lane t takes the 16-byte
 	//      voxel row t (memory order) of every block, so a wave reads 1 KB at a stretch (the dense field would hand out the
@@ -892,6 +899,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 		for (int i = 0; i < 2; ++i) { const int r = tid + i * WG; if (r < 289) halo[r] = (u8)((u32)(xv[i] >> 7) & 1u); }
 	}
 	__syncthreads();
+	CLS_TICK(1);
 
 	// ---- classify the 16*TB cells of one (y,z) row per thread, bit-parallel -----------------------------
 	{
@@ -931,6 +939,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 		}
 	}
 	__syncthreads();
+	CLS_TICK(2);
 
 	// ---- one lane per block: emptiness rule, slot allocation (one reservation per tile) -------------------
 	if (tid < 64) { // the first wave; lanes >= TB only take part in the ballots
@@ -985,6 +994,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 		}
 	}
 	__syncthreads();
+	CLS_TICK(3);
 #pragma unroll
 	for (int j = 0; j < TB; ++j) {
 		const int slot = blockSlot[j];
@@ -994,6 +1004,7 @@ __global__ __launch_bounds__(WG) void k_classify(ExecParamsDev p, u32 rowGroup, 
 			((u16*)(L.consBits + (size_t)slot * 128))[tid] = blockSkipped[j] ? (u16)0 : bits;
 		}
 	}
+	CLS_TICK(4);
 }
 
 // ------------------------------------------------------------------------------------------------------

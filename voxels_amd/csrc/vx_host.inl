@@ -1438,6 +1438,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		for (int i = 0; i < 7; ++i) fprintf(stderr, "[main profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
 	}
 #endif
+#if defined(VX_CLS_PROFILE)
+	{
+		static const char* names[5] = { "class bytes + init", "loads + sign masks", "classification", "slot allocation (+ ancestors)", "bitmap stores" };
+		unsigned long long sum = 0;
+		for (int i = 0; i < 5; ++i) sum += c->hdr[HDR_LARGE + 16 + i];
+		for (int i = 0; i < 5; ++i) fprintf(stderr, "[classify profile] %-30s %10u x16 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 16 + i], 100.0 * c->hdr[HDR_LARGE + 16 + i] / (double)(sum ? sum : 1));
+	}
+#endif
 #if defined(VX_TR_PROFILE)
 	{
 		static const char* names[11] = { "requests issued", "sign summaries + barrier", "planes to LDS + barrier", "classification + barrier", "batch bits + scan", "material wait", "list + barrier", "count + barrier", "scans + reservation", "describe + vertices", "indices" };
