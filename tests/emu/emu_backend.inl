@@ -217,6 +217,7 @@ struct Backend {
 	}
 
 	template <typename P> bool classify_activates_ancestors(const P&) const { return false; }
+	template <typename P> bool ancestors_with_classification(const P&, u32) const { return false; }
 	template <typename P>
 	void run_classify(const P& p, bool)
 	{

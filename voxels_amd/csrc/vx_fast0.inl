@@ -74,13 +74,14 @@ __device__ __forceinline__ int f0_row_part(int r, int lo, int hi, int brickStrid
 	return q * brickStride + (isZ ? (((l >> 1) << 9) | ((l & 1) << 6)) : (((l >> 2) << 7) | ((l & 3) << 4)));
 }
 
+template <bool SELF = false>
 __device__ __forceinline__ void f0_request(const GridView& g, const LevelDesc& L, const R0Block& b, F0Prefetch& pf)
 {
 	const int tid = f0_opaque_tid();
 	const int n = g.n, cnt = (int)L.cnt;
 	// every lane loads (indices clamped into range): a conditional load with a default value makes the compiler wait for
 	// the data right behind the load, and these requests must stay in flight
-	pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
+	if (!SELF) pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
 	const int brickRow = (n >> 4) * BRICK_BYTES, brickPlane = g.bRowsY * brickRow; // next block along y / z
 	const size_t own = brick_base(g, (int)b.bx, (int)b.by, (int)b.bz);
 	const bool firstX = b.bx == 0, lastX = (int)b.bx + 1 == cnt;
@@ -119,13 +120,16 @@ __device__ __forceinline__ void f0_request(const GridView& g, const LevelDesc& L
 
 // registers -> LDS, and: does a staged distance sample equal zero?  (The rows y, z = -1 and 17 are looked at as well: a
 // zero there sends a block to the general pass without need, which costs time, never correctness.)
-template <typename ST>
+// SELF: nobody classified the block; the sign masks of its 19 x 19 sample rows (bit i = sample x = i, 0..16) are left in LDS
+// (on top of the vertex descriptors, which are written two barriers later) for f0_self_bits.
+template <bool SELF = false, typename ST>
 __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Block& b, const F0Prefetch& pf)
 {
 	const int tid = f0_opaque_tid();
 	const bool firstX = b.bx == 0, lastX = b.bx + 1 == L.cnt;
 	u32 zero = 0;
-	if (tid < 128) st.ntBits[tid] = pf.bits;
+	if (!SELF) { if (tid < 128) st.ntBits[tid] = pf.bits; }
+	else if (tid == 0) st.zero = 0; // (the block's count of non-trivial cells is summed up here)
 	{
 		const int jj = tid % 19, group = tid / 19;
 #pragma unroll
@@ -138,6 +142,7 @@ __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Bl
 				u32* dst = (u32*)(st.samp + kk * SPLANE + jj * SROW);       // bytes 0..3: x = -4..-1, 4..19: x = 0..15, 20..23: x = 16..19
 				dst[0] = left; dst[1] = pf.d[q].x; dst[2] = pf.d[q].y; dst[3] = pf.d[q].z; dst[4] = pf.d[q].w; dst[5] = right;
 				zero |= f0_has_zero_byte(pf.d[q].x) | f0_has_zero_byte(pf.d[q].y) | f0_has_zero_byte(pf.d[q].z) | f0_has_zero_byte(pf.d[q].w) | f0_has_zero_byte(right | 0xFFFFFF00u);
+				if (SELF) ((u32*)st.vdesc)[kk * 19 + jj] = sign_nibble(pf.d[q].x) | (sign_nibble(pf.d[q].y) << 4) | (sign_nibble(pf.d[q].z) << 8) | (sign_nibble(pf.d[q].w) << 12) | (((right >> 7) & 1u) << 16);
 			}
 		}
 	}
@@ -157,6 +162,29 @@ __device__ __forceinline__ u32 f0_deposit(ST& st, const LevelDesc& L, const R0Bl
 	return zero;
 }
 
+// The bitmap of a block nobody classified (k_run_head gave it its slot because its samples are not of one sign): lane
+// (y, z) = (tid & 15, tid >> 4) forms the 16 non-trivial bits of its cell row from the sign masks f0_deposit left, exactly
+// as k_classify does (a cell is non-trivial unless its eight corners agree in sign), keeps them for this walk and for the
+// passes behind it (the general pass, incremental runs, the parent's vote) and adds its count to st.zero.
+template <typename ST>
+__device__ __forceinline__ void f0_self_bits(ST& st, const LevelDesc& L, const R0Block& b, const int tid)
+{
+	static_assert(sizeof(st.vdesc) >= 361 * 4, "the row masks lie on top of the vertex descriptors");
+	const u32* rows = (const u32*)st.vdesc;
+	const int y = tid & 15, z = tid >> 4;
+	const int r00 = (z + 1) * 19 + (y + 1);
+	const u32 a = rows[r00], b2 = rows[r00 + 1], c = rows[r00 + 19], d = rows[r00 + 20];
+	const u32 A = a & b2 & c & d, O = a | b2 | c | d;
+	const u32 nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+	((u16*)st.ntBits)[tid] = (u16)nt;
+	((u16*)(L.ntBits + (size_t)b.slot * 128))[tid] = (u16)nt;
+	((u16*)(L.consBits + (size_t)b.slot * 128))[tid] = (u16)nt; // (a block the emptiness rule skips never gets here: f0_accept)
+	u32 cnt = (u32)__popc(nt);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) cnt += (u32)__shfl_xor((int)cnt, o, 64);
+	if ((tid & 63) == 0 && cnt) atomicAdd(&st.zero, cnt);
+}
+
 // The work list of a walk over level-0 slots: items first, first + stride, ... below `limit`.  REMAP (k_regular0_fast: static
 // striding over all slots): item numbers go through xcd_item and `limit` is the padded slot count; otherwise (k_main: a batch
 // of consecutive slots taken from the queue) an item is its slot.
@@ -174,10 +202,17 @@ __device__ __forceinline__ R0Candidate f0_peek(const ExecParamsDev& p, const Lev
 	return c;
 }
 
-template <int CAP, bool REMAP>
+template <int CAP, bool REMAP, bool SELF = false>
 __device__ __forceinline__ bool f0_next(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32 stride, u32 limit, u32& it, R0Candidate c, R0Block& b)
 {
 	for (;;) {
+		if (SELF && r0_uniform(c.valid) && r0_uniform(c.skip)) {
+			// a block the emptiness rule skips (its empty record follows in r0_accept): no cells, nothing for its parent's vote
+			const u32 slot = r0_uniform(c.slot);
+			((u16*)(L.ntBits + (size_t)slot * 128))[threadIdx.x] = 0;
+			((u16*)(L.consBits + (size_t)slot * 128))[threadIdx.x] = 0;
+			if (threadIdx.x == 0) L.ntCount[slot] = 0;
+		}
 		if (r0_accept<CAP>(L, lo, c, b)) return true;
 		it += stride;
 		if (it >= limit) return false;
@@ -187,7 +222,7 @@ __device__ __forceinline__ bool f0_next(const ExecParamsDev& p, const LevelDesc&
 
 // The blocks of one walk, software-pipelined: `cur` has its inputs requested, `nxt` is accepted and gets them requested while
 // `cur` writes its output.  Leaves the LDS state free behind a barrier-less tail (callers meet before they reuse it).
-template <int CAP, bool REMAP>
+template <int CAP, bool REMAP, bool SELF = false>
 __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& T, Fast0State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
                                         u32 total, u32 lo, u32 first, u32 stride, u32 limit, const int tid)
 {
@@ -198,16 +233,16 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 	R0Block cur, nxt;
 	F0Prefetch pf;
 	// as in k_regular0: `cur` has its inputs requested, `nxt` is accepted and gets them requested while `cur` writes its output
-	bool have = f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), cur);
-	if (have) f0_request(g, L, cur, pf);
+	bool have = f0_next<CAP, REMAP, SELF>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), cur);
+	if (have) f0_request<SELF>(g, L, cur, pf);
 	it += stride;
-	bool haveNext = have && f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), nxt);
+	bool haveNext = have && f0_next<CAP, REMAP, SELF>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), nxt);
 	while (have) {
 		const u32 candIt = it + stride;
 		R0Candidate cand;
 		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
 		{
-			const u32 z = f0_deposit(st, L, cur, pf);
+			const u32 z = f0_deposit<SELF>(st, L, cur, pf);
 			if (__ballot(z != 0) && (tid & 63) == 0) zeroFlag[parity] = 1;
 			if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
 		}
@@ -215,7 +250,19 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 		const bool clean = r0_uniform(zeroFlag[parity]) == 0;
 		parity ^= 1u;
 		bool requested = false;
-		if (clean) {
+		bool mine = true; // (SELF: the block turns out to have geometry, and no more cells than this capacity class holds)
+		if (SELF) {
+			f0_self_bits(st, L, cur, tid);
+			__syncthreads();
+			const u32 cells = r0_uniform(st.zero);
+			if (tid == 0) {
+				L.ntCount[cur.slot] = (u16)cells;
+				if (cells == 0) reg_write_empty_record(L, cur.slot);
+				if (cells > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u); // (the host repeats the run with the upper classes)
+			}
+			mine = cells != 0 && cells <= (u32)CAP;
+		}
+		if (mine && clean) {
 			// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
 			{
 				const int lane = tid & 63, wave = tid >> 6;
@@ -312,7 +359,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 					PolyVertex* vOut = p.P.verts + r0_uniform(st.vOff) + cv;
 					u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
-						if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
+						if (!requested) { if (haveNext) f0_request<SELF>(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
 						if (j < vEnd) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
@@ -340,15 +387,15 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
 				wgStats[0] += nt;
 			}
-		} else if (tid == 0) {
+		} else if (mine && tid == 0) {
 			// a zero sample: the general pass takes the block
 			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;
 		}
-		if (!requested) { if (haveNext) f0_request(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); }
+		if (!requested) { if (haveNext) f0_request<SELF>(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); }
 		cur = nxt;
 		have = haveNext;
 		it = candIt;
-		haveNext = have && f0_next<CAP, REMAP>(p, L, total, lo, stride, limit, it, cand, nxt);
+		haveNext = have && f0_next<CAP, REMAP, SELF>(p, L, total, lo, stride, limit, it, cand, nxt);
 	}
 }
 

@@ -74,7 +74,8 @@ __device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
 // in-place exclusive scan of a[0..n) (LDS), all 256 threads must call; returns the total
 __device__ u32 block_exclusive_scan_u16(u16* a, u32 n, u32* scratch)
 {
-	const u32 tid = threadIdx.x;
+	u32 tid = threadIdx.x;
+	asm volatile("" : "+v"(tid)); // (inside a persistent kernel's block loop: the lane's addresses are formed here, not ahead of the loop)
 	const u32 per = (n + WG - 1) / WG;
 	u32 beg = tid * per, end = beg + per;
 	if (beg > n) beg = n;
@@ -622,7 +623,10 @@ struct RebrickRanges { int dz0, dz1, dy0, dy1, mz0, mz1, my0, my1; };
 __device__ __forceinline__ u32 rebrick_row(const GridView& g, const RebrickRanges& r, const MirrorState& X, int bx, int gy, int gz)
 {
 	const size_t dst = brick_base(g, bx, gy >> 4, gz >> 4) + brick_local(0u, (u32)gy & 15u, (u32)gz & 15u);
-	u32 fields = 0xFFFFu;
+	const bool y0 = (gy & 15) == 0, z0 = (gz & 15) == 0;
+	// (a row that is not resident makes the fields it belongs to unknown - those alone: of a slab's halo block layer the
+	// plane y = 0 is resident, and that plane is all the cells of the last owned block layer read of it)
+	u32 fields = 0xFu | (y0 ? 0xF0u : 0u) | (z0 ? 0xF00u : 0u) | (y0 && z0 ? 0xF000u : 0u);
 	if (gz >= r.dz0 && gz < r.dz1 && gy >= r.dy0 && gy < r.dy1) {
 		const uint4 d = *(const uint4*)(g.dist + dist_offset(g, bx * 16, gy, gz));
 		*(uint4*)(const_cast<i8*>(g.bDist) + dst) = d;
@@ -631,7 +635,6 @@ __device__ __forceinline__ u32 rebrick_row(const GridView& g, const RebrickRange
 		const u32 rowAll = (any ? 2u : 0u) | (all != 0x80808080u ? 1u : 0u);
 		const u32 rowX0 = (d.x & 0x80u) ? 2u : 1u;
 		const u32 pair = rowAll | (rowX0 << 2);                   // fields 0 and 1 of this row
-		const bool y0 = (gy & 15) == 0, z0 = (gz & 15) == 0;
 		fields = pair | (y0 ? pair << 4 : 0u) | (z0 ? pair << 8 : 0u) | (y0 && z0 ? pair << 12 : 0u);
 	}
 	if (gz >= r.mz0 && gz < r.mz1 && gy >= r.my0 && gy < r.my1) {
@@ -716,7 +719,20 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 // ---- head of a full run, one launch: the run's counters = 0 and block -> slot maps = -1 (four words per lane), and per
 //      level-0 block what the emptiness flags and the sign summaries already say about it (one block per lane).  The two
 //      halves touch different memory, so one kernel can do both; the statistics of the classes leave as partial sums. ---------
-__global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r)
+// (the reset alone: in front of a k_run_head that hands out slots, which needs the counters and the maps of the levels >= 1
+// in their start state before its first atomic)
+__global__ __launch_bounds__(WG) void k_reset(ExecParamsDev p, ResetRanges r)
+{
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	reset_words(p, r, i);
+	if (i < r.listWgs) r.listCounts[i] = 0;
+}
+
+// allocate: the blocks that are not quiet get their level-0 slots here, and their ancestors the slots of the levels above
+// (what k_classify + k_hierarchy do for a run whose classification is a pass of its own).  Not quiet means: the 17^3 samples
+// the block's cells read are not of one sign, so at least one cell is non-trivial - exactly the blocks k_classify finds
+// active.  Their bitmaps are then the business of whoever polygonizes them (k_main: f0_walk<.., SELF>, mat_block).
+__global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r, u32 allocate)
 {
 	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
@@ -753,6 +769,51 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r)
 	}
 	if (signAll == signAny && signAll != 0u) c |= BC_QUIET | (signAll == 2u ? (u32)BC_NEGATIVE : 0u);
 	if (inRange) p.G.blockClass[id] = (u8)c;
+	if (allocate) {
+		__shared__ u32 waveActive[WG / 64];
+		__shared__ u32 wgBase;
+		const bool active = inRange && !(c & BC_QUIET);
+		const unsigned long long m = __ballot(active);
+		const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+		if (lane == 0) waveActive[wave] = (u32)__popcll(m);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			u32 tot = 0;
+			for (u32 w = 0; w < (u32)(WG / 64); ++w) tot += waveActive[w];
+			wgBase = tot ? atomicAdd(L.nActive, tot) : 0u;
+		}
+		__syncthreads();
+		if (active) {
+			u32 slot = wgBase + (u32)__popcll(m & ((1ull << lane) - 1ull));
+			for (u32 w = 0; w < wave; ++w) slot += waveActive[w];
+			L.slotOf[id] = (int)slot;
+			L.slotCoord[slot] = id;
+			L.skip[slot] = (c & BC_SKIPPED) ? 1 : 0;
+			L.ntCount[slot] = 1; // (not known yet: whoever walks the slot counts its cells; 0 would mean "no geometry")
+			// the ancestors: all levels are tried at once (see k_classify)
+			int won[MAX_LEVELS];
+#pragma unroll
+			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+				won[l] = 0;
+				if (l < p.G.levels) {
+					const LevelDesc& A = p.levels[l];
+					const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+					if (px < A.cnt && py < A.cnt && pz < A.cnt) won[l] = atomicCAS(&A.slotOf[block_coord_id(px, py, pz, A.cnt)], -1, -2) == -1 ? 1 : 0;
+				}
+			}
+			u32 aslot[MAX_LEVELS];
+#pragma unroll
+			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) if (won[l]) aslot[l] = atomicAdd(p.levels[l].nActive, 1u);
+#pragma unroll
+			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+				if (!won[l]) continue;
+				const LevelDesc& A = p.levels[l];
+				const u32 aid = block_coord_id(bx >> l, by >> l, bz >> l, A.cnt);
+				A.slotCoord[aslot[l]] = aid;
+				A.slotOf[aid] = (int)aslot[l]; // visible to the next kernel
+			}
+		}
+	}
 	// Two statistics, as per-workgroup partial sums that travel with the header (no atomics: the header is being zeroed by
 	// this very launch): blocks the classify pass will read - what "every distance sample once" amounts to for this grid
 	// (reported, bench.py) - and the reference's "blocks calculated" on level 0: every block its emptiness rule does not
@@ -1042,6 +1103,7 @@ struct MatLds {
 	u16 ntRow[256];            // non-trivial cells of cell row (y,z) = the block's ntBits
 	u32 childBits[8][128];     // level 1: consistency bitmaps of the 2x2x2 child blocks
 	int childSlot[8];
+	u32 childSkip[8];          // level 1, children without a classification pass: the emptiness rule skips the child
 	u32 voteCount, ntTotal;
 	u16 voteList[BLOCK_CELLS];
 	__attribute__((aligned(16))) u16 out[BLOCK_CELLS];
@@ -1073,7 +1135,10 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 // One block of one level >= 1.  GATED (k_main): the children's caches come from other workgroups of the same launch - waited
 // for right in front of the vote, the only phase that reads them - and the block's own completion is published.
 template <bool GATED>
-__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid)
+// selfChild (level 1): the children's consistency bitmaps are not read but formed here, from the children's own samples -
+// the run has no classification pass (k_run_head<allocate>), and the level-0 blocks that form their bitmaps themselves run
+// beside this block, in no order.
+__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid, const bool selfChild = false)
 {
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
@@ -1139,7 +1204,55 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	}
 	// ---- child bitmaps (level 1) requested while the rows are classified -----------------------------
 	u32 cb4[4] = { 0, 0, 0, 0 };
-	if (level == 1) {
+	if (level == 1 && selfChild) {
+		// The 2 x 2 x 2 children span 33 x 33 sample rows (Y, Z) of 33 samples; a row is two 16-byte pieces of the brick mirror
+		// (x half h = the child column) and the sample behind them.  Sign masks: 16 bits per piece, one byte per far sample,
+		// on top of the vote list (written after the bitmaps are complete).  A piece only some absent child would read is
+		// not resident on a rank that owns a slab of the grid: it is read from a resident address instead and masked.
+		static_assert(sizeof(st.voteList) >= 1089 * 4 + 1092, "row masks of the children on top of the vote list");
+		u16* piece = (u16*)st.voteList;                 // [row * 2 + h]
+		u8* farBit = (u8*)st.voteList + 1089 * 4;       // [row]
+		u32 ex = 0;
+		size_t resident = 0;
+#pragma unroll
+		for (int c = 7; c >= 0; --c) if (st.childSlot[c] >= 0) { ex |= 1u << c; resident = brick_base(g, (int)(bx * 2) + (c & 1), (int)(by * 2) + ((c >> 1) & 1), (int)(bz * 2) + (c >> 2)); }
+		if (tid < 8) st.childSkip[tid] = st.childSlot[tid] >= 0 ? (u32)C.skip[st.childSlot[tid]] : 1u;
+		const auto needed = [&](int Y, int Z, int h) {
+			const u32 sel = ((Y <= 16 ? 0x11u : 0u) | (Y >= 16 ? 0x44u : 0u)) & ((Z <= 16 ? 0x0Fu : 0u) | (Z >= 16 ? 0xF0u : 0u));
+			(void)h; // (the second piece of a row also holds sample 16 of the first child column: x is never partitioned)
+			return (((ex | (ex >> 1)) & 0x55u) & sel) != 0u;
+		};
+		const int X0 = (int)(bx * 32), Y0 = (int)(by * 32), Z0 = (int)(bz * 32);
+#pragma unroll 1
+		for (int batch = 0; batch < 2; ++batch) {
+			uint4 d[5];
+#pragma unroll
+			for (int q = 0; q < 5; ++q) {
+				const int u = min(tid + (batch * 5 + q) * WG, 2177);
+				const int h = u & 1, row = u >> 1, Y = row % 33, Z = row / 33;
+				size_t off = resident;
+				if (needed(Y, Z, h)) off = brick_offset(g, min(X0 + h * 16, n - 16), min(Y0 + Y, n - 1), min(Z0 + Z, n - 1));
+				d[q] = *(const uint4*)(g.bDist + off);
+			}
+#pragma unroll
+			for (int q = 0; q < 5; ++q) {
+				const int u = tid + (batch * 5 + q) * WG;
+				if (u < 2178) piece[u] = (u16)(sign_nibble(d[q].x) | (sign_nibble(d[q].y) << 4) | (sign_nibble(d[q].z) << 8) | (sign_nibble(d[q].w) << 12));
+			}
+		}
+		{
+			i8 f[5];
+#pragma unroll
+			for (int q = 0; q < 5; ++q) {
+				const int row = min(tid + q * WG, 1088), Y = row % 33, Z = row / 33;
+				size_t off = resident;
+				if (needed(Y, Z, 1)) off = brick_offset(g, min(X0 + 32, n - 1), min(Y0 + Y, n - 1), min(Z0 + Z, n - 1));
+				f[q] = g.bDist[off];
+			}
+#pragma unroll
+			for (int q = 0; q < 5; ++q) { const int row = tid + q * WG; if (row < 1089) farBit[row] = (u8)(((u32)(f[q] >> 7)) & 1u); }
+		}
+	} else if (level == 1) {
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const int w = tid + q * WG;
@@ -1158,7 +1271,29 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		if (!THROUGH) ((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
 		if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
 	}
-	if (level == 1) {
+	if (level == 1 && selfChild) {
+		const u32* pair = (const u32*)st.voteList;       // both pieces of a row: bit 16 = the first sample of the second piece
+		const u8* farBit = (const u8*)st.voteList + 1089 * 4;
+		const bool lastHalf = (int)(bx * 32) + 16 >= n; // the grid ends behind the first child column: sample 16 = sample 15
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int c = tid + q * WG;                   // (x half, cell row Y, cell plane Z) of the 32 x 32 x 2 child cell rows
+			const int h = c & 1, Y = (c >> 1) & 31, Z = c >> 6;
+			const int r00 = Z * 33 + Y;
+			u32 m[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int r = r00 + (k & 1) + (k >> 1) * 33;
+				const u32 w = pair[r];
+				m[k] = h ? ((w >> 16) | ((u32)farBit[r] << 16)) : (lastHalf ? ((w & 0xFFFFu) | ((w & 0x8000u) << 1)) : (w & 0x1FFFFu));
+			}
+			const u32 A = m[0] & m[1] & m[2] & m[3], O = m[0] | m[1] | m[2] | m[3];
+			u32 bits = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+			const int cb = h | ((Y >> 4) << 1) | ((Z >> 4) << 2);
+			if (st.childSkip[cb]) bits = 0;                // (absent children count as skipped)
+			((u16*)st.childBits[cb])[((Z & 15) << 4) | (Y & 15)] = (u16)bits;
+		}
+	} else if (level == 1) {
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
 	}
@@ -2221,7 +2356,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2254,6 +2389,7 @@ struct Backend {
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
 		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_main replaces (A/B measurements)
 		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5)); // k_main without the level-0 queue (VX_MAIN_LEVEL0=0)
+		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
 		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
 		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
 		tune.mainBatch = std::max<u32>(1, env_u32("VX_MAIN_BATCH", 2));
@@ -2537,6 +2673,12 @@ struct Backend {
 		const LevelDesc& L = p.levels[0];
 		return (size_t)L.cnt * (L.yb1 - L.yb0) * (L.zb1 - L.zb0) <= (size_t)tune.foldBlocks;
 	}
+	// the runs whose head hands out the slots and whose k_main classifies (see k_run_head): what k_classify's launch and
+	// k_hierarchy's cost is most of a small run
+	template <typename P>
+	bool self_head(const P& p, u32 levels) const { return single_stream(p, levels); }
+	template <typename P>
+	bool ancestors_with_classification(const P& p, u32 levels) const { return self_head(p, levels) || classify_activates_ancestors(p); }
 	// carryClassified: the classify launch carries the event that releases the level-0 regular pass on side stream A
 	template <typename P>
 	void run_classify(const P& p, bool carryClassified)
@@ -2546,12 +2688,27 @@ struct Backend {
 		const u32 rowsY = L.yb1 - L.yb0;
 		const u32 grid = tilesX * rowsY * (L.zb1 - L.zb0);
 		if (!grid) return;
+		if (self_head(p, p.G.levels)) {
+			// no classification pass: k_run_head hands out the slots, k_main's level-0 blocks form their own bitmaps
+			ResetRanges r = pendingReset;
+			pendingReset.header = nullptr;
+			if (r.header) {
+				const u32 lanes = std::max<u32>((r.start[MAX_LEVELS] + 3) / 4, r.listWgs);
+				hipLaunchKernelGGL(k_reset, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r);
+				r.header = nullptr;
+			}
+			headWorkgroups = (L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG;
+			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r, 1u);
+			check(hipGetLastError(), "k_run_head launch");
+			stage_mark(1);
+			return;
+		}
 		{
 			const ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
 			const u32 lanes = std::max<u32>(L.cnt * rowsY * (L.zb1 - L.zb0), r.header ? std::max<u32>((r.start[MAX_LEVELS] + 3) / 4, r.listWgs) : 0u);
 			headWorkgroups = (lanes + WG - 1) / WG;
-			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r);
+			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r, 0u);
 		}
 		const u32 rows = rowsY * (L.zb1 - L.zb0);
 		u32 rowGroup = 0; // 0 = no remap
@@ -2725,7 +2882,7 @@ struct Backend {
 		return tune.upper && tune.fast1 && !tune.forceWide && !largeClass && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	template <typename P>
-	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0; }
+	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0 && tune.selfHead; }
 	template <typename P>
 	void run_main(const P& p, u32 levels, bool withLevel0)
 	{

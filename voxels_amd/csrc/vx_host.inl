@@ -435,7 +435,7 @@ void build_table_image(std::vector<u8>& img)
 void run_pipeline(vx_ctx* c, const ExecParams& p, u32 levels)
 {
 	const bool overlapped = !c->be.stage_timing_on();
-	const bool ancestorsDone = c->be.classify_activates_ancestors(p);
+	const bool ancestorsDone = c->be.ancestors_with_classification(p, levels);
 	c->be.run_classify(p, overlapped && ancestorsDone); // k_run_head, stage_mark(1), k_classify: slot 0 = the head, slot 1 = the classify pass alone
 	c->be.stage_mark(2);
 	// (the HIP backend's classify pass also activates the ancestors of the blocks it finds; the hierarchy pass remains the

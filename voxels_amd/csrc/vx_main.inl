@@ -37,7 +37,8 @@ static_assert((UP_TAB_LDS & 15u) == 0, "the state behind the tables stays 16-byt
 struct MainPlan {
 	u32 levels;     // levels of the run: material items for 1 .. levels - 1
 	u32 fastEnd;    // regular items for the levels 1 .. fastEnd - 1 (the levels with a lattice copy)
-	u32 level0;     // 1: the level-0 queue is part of the launch (its LDS then holds a Fast0State)
+	u32 level0;     // 1: the level-0 queue is part of the launch (its LDS then holds a Fast0State), and no classification pass ran
+	                // (k_run_head<allocate>): level-0 blocks and level-1 material blocks form the bitmaps they need
 	u32 batch;      // level-0 slots per dequeue
 	u32 upperNum, upperDen; // workgroups with blockIdx % upperDen < upperNum prefer the upper queue
 };
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			if (first >= total0) { level0Left = false; continue; }
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (visible after the walk's first barrier)
 			MAIN_TICK(1);
-			f0_walk<REG_CAP_SMALL, false>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
+			f0_walk<REG_CAP_SMALL, false, true>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
 			MAIN_TICK(2);
 			continue;
 		}
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		for (u32 l = 1; l + 1 < MAX_LEVELS; ++l) if (f >= matEnd[l]) { level = l + 1; base = matEnd[l]; }
 		const u32 slot = f - base;
 		if (isMat) {
-			mat_block<true>(p, level, slot, *(MatLds*)state, tid);
+			mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
 			MAIN_TICK(3);
 			continue;
 		}
@@ -141,7 +142,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		}
 	}
 	__syncthreads();
-	if (tid0 < 20 && wgStats[tid0]) atomicAdd(&p.G.stats[tid0], wgStats[tid0]);
+	{
+		int tid = tid0;
+		asm volatile("" : "+v"(tid)); // (the address is formed here, not carried through the kernel)
+		if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+	}
 #if defined(VX_MAIN_PROFILE)
 	MAIN_TICK(6);
 	if (tid0 == 0) for (int i = 0; i < 8; ++i) if (prof[i]) atomicAdd(&p.G.largeBlocks[4 + i], prof[i]);
