@@ -7,6 +7,8 @@ struct Backend {
 	std::string lastError;
 	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
 	u32 upperItemsHint = 0; // (HIP backend: sizes the launch of the levels >= 1)
+	u32* tailDone = nullptr;
+	u32 slowHint[2] = { ~0u, ~0u }; // (HIP backend: sizes the launches of the general passes behind the table-driven ones)
 
 	static int device_count() { return 1; }
 	bool init(int, std::string&) { return true; }
@@ -183,8 +185,9 @@ struct Backend {
 	void comm_destroy() {}
 	bool comm_exchange(int, const void*, size_t, void*, size_t, int, const void*, size_t, void*, size_t) { lastError = "the emulation has no communicator"; return false; }
 	bool copy_from_peer(void* dst, Backend&, const void* src, size_t bytes) { memcpy(dst, src, bytes); return true; }
+	bool lists_publish_header(u32*, const u32*, u32, u32*) { return false; }
 	template <typename P>
-	void run_block_lists(const P& p, const ListPlan& plan, u32 levels)
+	bool run_block_lists(const P& p, const ListPlan& plan, u32 levels)
 	{
 		for (u32 l = 0; l < levels; ++l) {
 			const LevelDesc& L = p.levels[l];
@@ -195,6 +198,7 @@ struct Backend {
 			}
 			plan.totals[l] = n;
 		}
+		return false;
 	}
 	bool stage_ms(float*) { return false; }
 	bool run_selftest(u32* out) { memset(out, 0, 16 * 4); return true; } // the device forms do not exist here

@@ -1524,11 +1524,13 @@ namespace {
 #endif
 // MODE 0: the slots of the levels [levelBegin, levels) (or the work lists of an incremental run); MODE 2: the blocks the
 // fast pass of the levels >= 1 (vx_fast1.inl) handed on (Globals::slowItems[1])
+// (the pass as workgroup `first` of `stride`: a launch of its own - k_regular below - or the second group of workgroups of
+// k_tail; returns whether the workgroup wrote anything)
 template <int CAP, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CAP_SMALL ? 1 : VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
+__device__ __forceinline__ bool regular_pass(const ExecParamsDev& p, u32 levelBegin, u32 levels, u32 lo, const u32 first, const u32 stride)
 {
 	typedef RegStateT<CAP> ST;
-	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
+	if (lo && *p.G.largeBlocks == 0) return false; // nothing for the 4096-cell class (uniform over the grid)
 	u8* tab = smem;
 	ST& st = *(ST*)(smem + REG_TAB_LDS);
 	__shared__ WorkList wl;
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CA
 	}
 	__syncthreads();
 	const u32 total = wl.start[MAX_LEVELS];
-	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	if (first >= ((total + 63u) & ~63u)) return false; // the grid is sized before the block counts are known
 	const Tables T = stage_regular_tables(tab, p.tables); // visible after the first barrier of the item loop
 	const int tid = threadIdx.x;
 #if defined(VX_REG_PROFILE)
@@ -1555,7 +1557,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CA
 #define RG_TICK(i) do { } while (0)
 #endif
 
-	for (u32 it = blockIdx.x; it < ((total + 63u) & ~63u); it += gridDim.x) {
+	for (u32 it = first; it < ((total + 63u) & ~63u); it += stride) {
 		const u32 item = xcd_item(it);
 		if (item >= total) continue;
 		RegBlockCtx b;
@@ -1640,6 +1642,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CA
 #endif
 	__syncthreads();
 	if (threadIdx.x < 20 && wgStats[threadIdx.x]) atomicAdd(&p.G.stats[threadIdx.x], wgStats[threadIdx.x]);
+	return true;
+}
+
+template <int CAP, int MODE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(CAP > REG_CAP_SMALL ? 1 : VX_REG_WAVES))) void k_regular(ExecParamsDev p, u32 levelBegin, u32 levels, u32 lo)
+{
+	(void)regular_pass<CAP, MODE>(p, levelBegin, levels, lo, blockIdx.x, gridDim.x);
 }
 
 // Samples of one boundary plane of a block (tr_phase_load of tv_block.h for a compile-time face): the plane is an
@@ -2105,17 +2114,28 @@ __global__ __launch_bounds__(LIST_WG) void k_list_count(ExecParamsDev p, ListPla
 	if (threadIdx.x == 0) plan.counts[w] = (u32)n;
 }
 
-__global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPlan plan, u32 levels)
+// publish: the workgroup that finishes last copies the run's header (counters, totals, statistics; the block-class partial
+// sums behind it) into page-locked host memory - the host then needs no copy behind the run's last kernel (a blit kernel of
+// its own: ~3.5 us, and ~5.5 us until it starts), only the wait it does anyway.
+struct HeaderPublish {
+	u32* done;         // counter of finished workgroups (a header word: zeroed with the run's counters)
+	u32* host;         // page-locked destination (nullptr: no publication)
+	const u32* dev;    // the header
+	u32 words;
+};
+
+// (workgroup w of listWgs: a launch of its own, or the workgroups of k_tail behind the general passes)
+__device__ __forceinline__ void list_write_pass(const ExecParamsDev& p, const ListPlan& plan, u32 levels, const HeaderPublish& pub, const u32 w, const u32 listWgs, const bool countsThrough)
 {
 	__shared__ u32 waveSum[LIST_WG / 64];
 	__shared__ u32 baseShared;
-	const u32 w = blockIdx.x, l = list_level_of(plan, levels, w), tid = threadIdx.x;
+	const u32 l = list_level_of(plan, levels, w), tid = threadIdx.x;
 	const LevelDesc& L = p.levels[l];
 	const u32 id = (w - plan.wgStart[l]) * LIST_WG + tid;
 	const int slot = listed_block_slot(L, id);
 	// listed blocks of this level in the workgroups before this one
 	u32 before = 0;
-	for (u32 q = plan.wgStart[l] + tid; q < w; q += LIST_WG) before += plan.counts[q];
+	for (u32 q = plan.wgStart[l] + tid; q < w; q += LIST_WG) before += countsThrough ? TV_LOAD_THROUGH(plan.counts + q) : plan.counts[q];
 	for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
 	if ((tid & 63) == 0) waveSum[tid >> 6] = before;
 	__syncthreads();
@@ -2133,8 +2153,66 @@ __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPla
 	if (w + 1 == plan.wgStart[l + 1] && tid == 0) {
 		u32 total = base;
 		for (u32 q = 0; q < LIST_WG / 64; ++q) total += waveSum[q];
-		plan.totals[l] = total;
+		__hip_atomic_store(&plan.totals[l], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (read by the publishing workgroup, possibly on another XCD)
 	}
+	if (pub.host) {
+		if (tid == 0) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the total is on its way out before this workgroup counts as finished
+			baseShared = atomicAdd(pub.done, 1u) + 1u == listWgs ? 1u : 0u;
+		}
+		__syncthreads();
+		if (baseShared) for (u32 i = tid; i < pub.words; i += LIST_WG) pub.host[i] = TV_LOAD_THROUGH(pub.dev + i);
+	}
+}
+
+__global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPlan plan, u32 levels, HeaderPublish pub)
+{
+	list_write_pass(p, plan, levels, pub, blockIdx.x, gridDim.x, false);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_tail: what follows k_main in a single-stream run, as ONE launch (a launch behind k_main costs ~4.5 us on this chip
+// whether it finds work or not - three of them were a tenth of a 128^3 run): the general passes over what the table-driven
+// level-0 blocks and the table-driven blocks of the levels >= 1 handed on (blocks with a zero sample: none, or a handful)
+// as the first workgroups, the block lists as the rest.  The list workgroups need every record: they wait until the
+// general workgroups - which wait for nobody, and are dispatched first - have counted themselves done.  A general
+// workgroup that wrote something makes it visible device-wide first (records and list counts are read by list workgroups
+// on other XCDs; those have not touched the lines before the wait, so their L2 holds no older copy).
+// ------------------------------------------------------------------------------------------------------
+struct TailPlan {
+	u32 wgs0, wgs1, listWgs; // workgroups: general pass of level 0 | of the levels >= 1 | lists
+	u32 levels;
+	u32* slowDone;           // finished general workgroups (a header word: zeroed with the run's counters)
+};
+
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_tail(ExecParamsDev p, ListPlan plan, HeaderPublish pub, TailPlan t)
+{
+	static_assert(LIST_WG == WG, "one workgroup shape for the passes of k_tail");
+	const u32 general = t.wgs0 + t.wgs1;
+	if (blockIdx.x < general) {
+		bool wrote = false;
+#if !defined(VX_TAIL_NO0)
+		if (blockIdx.x < t.wgs0) wrote = regular0_pass<REG_CAP_SMALL, 2>(p, 0u, blockIdx.x, t.wgs0);
+#endif
+#if !defined(VX_TAIL_NO1)
+		if (blockIdx.x >= t.wgs0) wrote = regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, blockIdx.x - t.wgs0, t.wgs1);
+#endif
+		if (wrote) __threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) atomicAdd(t.slowDone, 1u);
+		return;
+	}
+	if (threadIdx.x == 0) {
+		u32 spins = 0;
+		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
+			__builtin_amdgcn_s_sleep(4);
+			if (++spins > (u32)WAIT_SPINS) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
+		}
+	}
+	__syncthreads();
+#if !defined(VX_TAIL_NOL)
+	list_write_pass(p, plan, t.levels, pub, blockIdx.x - general, t.listWgs, true);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2356,7 +2434,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2389,6 +2467,8 @@ struct Backend {
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
 		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_main replaces (A/B measurements)
 		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5)); // k_main without the level-0 queue (VX_MAIN_LEVEL0=0)
+		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
+		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
 		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
 		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
@@ -2810,7 +2890,8 @@ struct Backend {
 					(void)hipEventRecord(evSideC, sideC);
 					(void)hipStreamWaitEvent(on, evMidC, 0);
 				}
-				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(std::min<u32>(gridS, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 0u);
+				tailWgs[0] = slow_grid(std::min<u32>(gridS, (u32)cus * 4), 0);
+				if (!tailPending) hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(tailWgs[0]), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
 					if (!spread) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
@@ -2849,7 +2930,8 @@ struct Backend {
 					(void)hipEventRecord(evSideD, sideD);
 					(void)hipStreamWaitEvent(on, evMidD, 0);
 				}
-				hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
+				tailWgs[1] = slow_grid(std::min<u32>(capFast, (u32)cus * 4), 1);
+				if (!tailPending) hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(tailWgs[1]), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
 					if (!spread) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
@@ -2869,6 +2951,14 @@ struct Backend {
 	// Everything behind the classification as ONE launch (vx_main.inl) - where the table-driven regular pass of the levels >= 1
 	// and the 32-bit-offset transition pass apply (lattice copies resident, mirrors below 4 GiB); otherwise the chain of
 	// launches it replaces.  With the level-0 queue inside (the default) a full run is a single stream without events.
+	// What the table-driven passes handed on in the previous full run of this context (blocks with a zero sample; ~0u =
+	// unknown): the general passes behind them are launched with about that many workgroups - they stride over whatever
+	// they find, and a launch of a thousand workgroups that find nothing costs 4.5 us against 2.
+	bool tailPending = false; // single-stream runs: the general passes behind k_main wait for the list pass and share its launch (k_tail)
+	u32 tailWgs[2] = { 0, 0 };
+	u32* tailDone = nullptr;  // header word for k_tail's counter (set by the host with the header)
+	u32 slowHint[2] = { ~0u, ~0u };
+	u32 slow_grid(u32 full, int which) const { return slowHint[which] == ~0u ? full : std::max<u32>(1u, std::min<u32>(full, std::max<u32>(slowHint[which] + slowHint[which] / 4, 32u))); }
 	u32 upperItemsHint = 0; // upper-queue items of the previous full run of this context (0 = unknown)
 	bool upperDone = false;  // inside run_overlapped_tail: k_main did the first capacity class of the levels 1 .. fastEnd - 1
 	bool level0Done = false; // ... and the first capacity class of level 0
@@ -2936,6 +3026,8 @@ struct Backend {
 			// block lists and the header read-back: no second stream, no event
 			run_main(p, levels, true);
 			upperDone = level0Done = true;
+			tailWgs[0] = tailWgs[1] = 0;
+			tailPending = tune.tail && tailDone && p.levels[0].listCounts;
 			launch_regular(p, 0, levels, stream);
 			upperDone = level0Done = false;
 			overlappedTail = false;
@@ -3057,14 +3149,36 @@ struct Backend {
 	}
 
 	// the result's block lists, written on the device behind the last kernel of a full run
+	// the header's way to the host: with the list pass (see HeaderPublish).  Returns false when the caller has to copy.
+	HeaderPublish publish = {};
+	bool lists_publish_header(u32* hostDst, const u32* devHeader, u32 words, u32* doneCounter)
+	{
+		if (!tune.publishHeader) return false;
+		publish.host = hostDst; publish.dev = devHeader; publish.words = words; publish.done = doneCounter;
+		return true;
+	}
 	template <typename P>
-	void run_block_lists(const P& p, const ListPlan& plan, u32 levels)
+	bool run_block_lists(const P& p, const ListPlan& plan, u32 levels)
 	{
 		const u32 wgs = plan.wgStart[levels];
-		if (!wgs) return;
+		const HeaderPublish pub = publish;
+		publish = HeaderPublish();
+		const bool tail = tailPending;
+		tailPending = false;
+		if (tail) {
+			// (with or without list workgroups: the general passes were left to this launch)
+			TailPlan t;
+			t.wgs0 = tailWgs[0]; t.wgs1 = tailWgs[1]; t.listWgs = wgs; t.levels = levels; t.slowDone = tailDone;
+			const u32 lds = std::max<u32>(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>));
+			if (t.wgs0 + t.wgs1 + wgs) hipLaunchKernelGGL(k_tail, dim3(t.wgs0 + t.wgs1 + wgs), dim3(WG), lds, stream, dev(p), plan, wgs ? pub : HeaderPublish(), t);
+			check(hipGetLastError(), "k_tail launch");
+			return wgs && pub.host != nullptr;
+		}
+		if (!wgs) return false;
 		if (!p.levels[0].listCounts) hipLaunchKernelGGL(k_list_count, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
-		hipLaunchKernelGGL(k_list_write, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels);
+		hipLaunchKernelGGL(k_list_write, dim3(wgs), dim3(LIST_WG), 0, stream, dev(p), plan, levels, pub);
 		check(hipGetLastError(), "k_list launch");
+		return pub.host != nullptr;
 	}
 
 	template <typename P>

@@ -46,7 +46,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 352, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_L0HEAD = 320, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 352, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_PUBLISHED = 289 /* workgroups of the list pass that are done */, HDR_L0HEAD = 320, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
 
 } // namespace
 
@@ -377,8 +377,9 @@ void fill_params(vx_ctx* c, ExecParams& p, u32 levels)
 	p.G.levels = levels;
 	p.G.refLevels = c->refLevels;
 	for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L] = c->lv[L];
-	// listed blocks are counted where their records are written only on small block ranges (k_list_count otherwise)
-	if (!c->be.classify_activates_ancestors(p)) for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L].listCounts = nullptr;
+	// listed blocks are counted where their records are written - on small block ranges, and in every run that is one stream
+	// with k_main (a launch less); k_list_count otherwise
+	if (!c->be.ancestors_with_classification(p, levels)) for (u32 L = 0; L < MAX_LEVELS; ++L) p.levels[L].listCounts = nullptr;
 	p.P.verts = (PolyVertex*)c->dVerts;
 	p.P.idx = (u32*)c->dIdx;
 	p.P.cursors = (u32*)c->dHeader + HDR_CURSORS;
@@ -1357,11 +1358,14 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		fill_params(c, p, levels);
 		c->be.begin_timing();
 		c->be.stage_mark(0);
+		c->be.tailDone = (u32*)c->dHeader + HDR_PUBLISHED + 1; // (k_tail's count of finished general workgroups)
 		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS, (u32*)c->dListCounts, c->listWgs); // header = 0, slot maps = -1, list counts = 0
 #if defined(VX_CASE_DUMP)
 		for (u32 L = 0; L < levels; ++L) { c->be.fill(c->lv[L].caseDump, 0, (size_t)c->lv[L].cap * BLOCK_CELLS); c->be.fill(c->lv[L].trCaseDump, 0, (size_t)c->lv[L].cap * TR_CELLS * 2); }
 #endif
 		run_pipeline(c, p, levels);
+		u32 partials = 0;
+		bool published = false;
 		{
 			ListPlan plan;
 			memset(&plan, 0, sizeof(plan));
@@ -1377,21 +1381,24 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 			}
 			plan.counts = (u32*)c->dListCounts;
 			plan.totals = (u32*)c->dHeader + HDR_LISTS;
-			c->be.run_block_lists(p, plan, levels);
+			// the header reaches the host with the run's last kernel (HeaderPublish) - or as a copy behind it
+			if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned((HDR_WORDS + HDR_PARTIALS) * 4);
+			if (!c->hdrPinned) { c->be.sync(); c->be.end_overlapped(); return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed"); }
+			partials = std::min<u32>(c->be.head_partials(), (u32)HDR_PARTIALS);
+			c->hdrPinned[HDR_PUBLISHED] = 0;
+			published = c->be.lists_publish_header(c->hdrPinned, (const u32*)c->dHeader, HDR_WORDS + partials, (u32*)c->dHeader + HDR_PUBLISHED);
+			published = c->be.run_block_lists(p, plan, levels) && published;
 			c->be.stage_mark(7);
 		}
 		c->be.end_timing_record();
-		// the header travels right behind the kernels: one host wait per run
-		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned((HDR_WORDS + HDR_PARTIALS) * 4);
-		if (!c->hdrPinned) { c->be.sync(); c->be.end_overlapped(); return fail(c, VX_ERR_DEVICE, "vx_polygonize: pinned allocation failed"); }
-		const u32 partials = std::min<u32>(c->be.head_partials(), (u32)HDR_PARTIALS);
-		bool okRun = c->be.d2h_async(c->hdrPinned, c->dHeader, (HDR_WORDS + partials) * 4);
+		bool okRun = published || c->be.d2h_async(c->hdrPinned, c->dHeader, (HDR_WORDS + partials) * 4); // (one host wait per run either way)
 		t1 = tNow();
 		okRun = okRun && c->be.sync_ok();
 		c->be.end_overlapped(); // (the tail of an overlapped run was queued on a side stream)
 		t2 = tNow();
 		if (!okRun) return fail(c, VX_ERR_DEVICE, "vx_polygonize: device run failed: " + c->be.error());
 		ms = c->be.elapsed_ms();
+		if (published && c->hdrPinned[HDR_PUBLISHED] == 0) return fail(c, VX_ERR_DEVICE, "vx_polygonize: the run's header did not arrive (internal error)");
 		memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
 		if (partials) { // the block-class statistics arrive as per-workgroup partial sums behind the header (k_run_head)
 			u32 readers = 0, calculated = 0;
@@ -1414,6 +1421,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		u32 items = 0;
 		for (u32 L = 1; L < levels; ++L) items += c->hdr[L] * (1u + (L < (u32)PYRAMID_LEVELS ? 1u : 0u) + (c->lv[L].hasTransitions ? 1u : 0u));
 		c->be.upperItemsHint = items ? items : 1u;
+		c->be.slowHint[0] = c->hdr[HDR_SLOW]; c->be.slowHint[1] = c->hdr[HDR_SLOW + 1];
 	}
 	c->levelsRun = levels;
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];

@@ -484,14 +484,14 @@ __device__ __forceinline__ bool r0_accept(const LevelDesc& L, u32 lo, const R0Ca
 	return true;
 }
 
-// next accepted item at or after `it` (stride gridDim.x), starting with an already requested candidate for `it`
+// next accepted item at or after `it` (stride: the workgroups of the pass), starting with an already requested candidate for `it`
 template <int CAP, int MODE>
-__device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32& it, R0Candidate c, R0Block& b)
+__device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const LevelDesc& L, u32 total, u32 lo, u32 stride, u32& it, R0Candidate c, R0Block& b)
 {
 	const u32 padded = (total + 63u) & ~63u;
 	for (;;) {
 		if (r0_accept<CAP>(L, lo, c, b)) return true;
-		it += gridDim.x;
+		it += stride;
 		if (it >= padded) return false;
 		c = r0_peek<MODE>(p, L, total, it);
 	}
@@ -505,8 +505,10 @@ __device__ __forceinline__ bool r0_next_item(const ExecParamsDev& p, const Level
 #define R0_TICK(i) do { } while (0)
 #endif
 
+// The pass as workgroup `first` of `stride` (a launch of its own: k_regular0 below; the slots the table-driven pass handed
+// on are also walked by the first workgroups of k_tail).  Returns whether the workgroup wrote anything.
 template <int CAP, int MODE>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0(ExecParamsDev p, u32 lo)
+__device__ __forceinline__ bool regular0_pass(const ExecParamsDev& p, u32 lo, const u32 first, const u32 stride)
 {
 #if defined(VX_R0_PROFILE)
 	u32 prof[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -514,33 +516,34 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #endif
 	typedef Reg0State<CAP> ST;
 	typedef R0<CAP> K;
-	if (lo && *p.G.largeBlocks == 0) return; // nothing for the 4096-cell class (uniform over the grid)
+	if (lo && *p.G.largeBlocks == 0) return false; // nothing for the 4096-cell class (uniform over the grid)
 	u8* tab = smem;
 	ST& st = *(ST*)(smem + R0_TAB_LDS);
 	__shared__ u32 wgStats[20]; // statistics of every block this workgroup handles, flushed once at the end
 
 	const LevelDesc& L = p.levels[0];
 	const u32 total = r0_uniform(MODE == 1 ? p.G.workCount[0] : (MODE == 2 ? *p.G.slowCount : *L.nActive));
-	if (blockIdx.x >= ((total + 63u) & ~63u)) return; // the grid is sized before the block counts are known
+	if (first >= ((total + 63u) & ~63u)) return false; // the grid is sized before the block counts are known
 	const int tid = (int)threadIdx.x;
 	if (tid < 20) wgStats[tid] = 0;
 	const R0Tables RT = r0_stage_tables(tab, p.tables);
 	const Tables T = r0_portable_tables(tab, p.tables + TAB_REG_VERT); // the 6-byte rows stay in global memory (rare paths)
 	const GridView& g = p.G.grid;
 
-	u32 it = blockIdx.x;
+	u32 it = first;
 	R0Block cur, nxt;
 	R0Prefetch pf;
 	// Two blocks are known ahead: `cur` (inputs requested, being processed) and `nxt` (accepted; inputs requested while
 	// `cur` writes its output).  The work list entry behind `nxt` is requested together with nxt's inputs and looked at
 	// when the iteration ends — all requests of an iteration sit in ONE place (see the output loop below).
-	bool have = r0_next_item<CAP, MODE>(p, L, total, lo, it, r0_peek<MODE>(p, L, total, it), cur);
+	bool have = r0_next_item<CAP, MODE>(p, L, total, lo, stride, it, r0_peek<MODE>(p, L, total, it), cur);
+	const bool wrote = true; // (records of blocks without geometry count as well)
 	if (have) K::request(g, L, cur, pf);
-	it += gridDim.x;
-	bool haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, it, r0_peek<MODE>(p, L, total, it), nxt);
+	it += stride;
+	bool haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, stride, it, r0_peek<MODE>(p, L, total, it), nxt);
 	while (have) {
-		const u32 candIt = it + gridDim.x;
-		R0Candidate cand;
+		const u32 candIt = it + stride;
+		R0Candidate cand = { 0u, 0u, 0u, 0u, 0u };
 		R0_TICK(9);
 		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
 		R0_TICK(0);
@@ -665,13 +668,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		have = haveNext;
 		it = candIt;
 		R0_TICK(8);
-		haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, it, cand, nxt);
+		haveNext = have && r0_next_item<CAP, MODE>(p, L, total, lo, stride, it, cand, nxt);
 	}
 	__syncthreads();
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
 #if defined(VX_R0_PROFILE)
 	if (tid == 0) for (int i = 0; i < 10; ++i) atomicAdd(&p.G.largeBlocks[4 + i], prof[i] >> 10); // units of 1024 cycles
 #endif
+	return wrote;
+}
+
+template <int CAP, int MODE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_regular0(ExecParamsDev p, u32 lo)
+{
+	(void)regular0_pass<CAP, MODE>(p, lo, blockIdx.x, gridDim.x);
 }
 
 } // namespace
