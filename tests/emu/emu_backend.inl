@@ -8,6 +8,8 @@ struct Backend {
 	bool largeClass = true; // the emulation has no capacity classes; the host logic sets this for the HIP backend
 	u32 upperItemsHint = 0; // (HIP backend: sizes the launch of the levels >= 1)
 	u32* tailDone = nullptr;
+	bool tailCleaned = false;
+	void set_next_reset(u32*, u32, u32*, u32, int* const*, const u32*) {}
 	u32 slowHint[2] = { ~0u, ~0u }; // (HIP backend: sizes the launches of the general passes behind the table-driven ones)
 
 	static int device_count() { return 1; }
@@ -152,7 +154,7 @@ struct Backend {
 	u32 head_partials() const { return 0; } // the emulation counts the block classes into the header itself
 	float elapsed_ms() { return 0.f; }
 	template <typename P>
-	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32*, u32)
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32*, u32, bool = false)
 	{
 		memset(header, 0, (size_t)headerWords * 4);
 		for (u32 l = 0; l < levels; ++l) memset(p.levels[l].slotOf, 0xFF, (size_t)p.levels[l].cnt * p.levels[l].cnt * p.levels[l].cnt * 4);

@@ -697,9 +697,10 @@ struct ResetRanges {
 	u32* listCounts;          // [listWgs] listed blocks per LIST_WG block coordinates (LevelDesc::listCounts): zeroed here
 	u32 listWgs;
 	u32 start[MAX_LEVELS + 1]; // word ranges of the flat index space: [0, headerWords) header, then slotOf of level 0, 1, ...
+	int* maps[MAX_LEVELS];     // the block -> slot maps (of the run's own set, or - k_tail - of the set the next run will use)
 };
 
-__device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetRanges& r, u32 lane)
+__device__ __forceinline__ void reset_words(const ResetRanges& r, u32 lane)
 {
 	const u32 total = r.start[MAX_LEVELS];
 	// four consecutive words per lane; ranges are multiples of 4 words except possibly tiny coarse levels
@@ -712,7 +713,10 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 		u32 l = 0;
 #pragma unroll
 		for (u32 q = 1; q < MAX_LEVELS; ++q) if (i >= r.start[q]) l = q;
-		p.levels[l].slotOf[i - r.start[l]] = -1;
+		int* map = r.maps[0];
+#pragma unroll
+		for (u32 q = 1; q < MAX_LEVELS; ++q) if (l == q) map = r.maps[q];
+		map[i - r.start[l]] = -1;
 	}
 }
 
@@ -724,7 +728,7 @@ __device__ __forceinline__ void reset_words(const ExecParamsDev& p, const ResetR
 __global__ __launch_bounds__(WG) void k_reset(ExecParamsDev p, ResetRanges r)
 {
 	const u32 i = blockIdx.x * WG + threadIdx.x;
-	reset_words(p, r, i);
+	reset_words(r, i);
 	if (i < r.listWgs) r.listCounts[i] = 0;
 }
 
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 {
 	const LevelDesc& L = p.levels[0];
 	const u32 i = blockIdx.x * WG + threadIdx.x;
-	if (r.header) reset_words(p, r, i);
+	if (r.header) reset_words(r, i);
 	if (r.header && i < r.listWgs) r.listCounts[i] = 0;
 	const u32 rowsY = L.yb1 - L.yb0;
 	const bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
@@ -783,10 +787,11 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 			wgBase = tot ? atomicAdd(L.nActive, tot) : 0u;
 		}
 		__syncthreads();
+		int slotOrNone = -1;
 		if (active) {
 			u32 slot = wgBase + (u32)__popcll(m & ((1ull << lane) - 1ull));
 			for (u32 w = 0; w < wave; ++w) slot += waveActive[w];
-			L.slotOf[id] = (int)slot;
+			slotOrNone = (int)slot;
 			L.slotCoord[slot] = id;
 			L.skip[slot] = (c & BC_SKIPPED) ? 1 : 0;
 			L.ntCount[slot] = 1; // (not known yet: whoever walks the slot counts its cells; 0 would mean "no geometry")
@@ -813,6 +818,8 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 				A.slotOf[aid] = (int)aslot[l]; // visible to the next kernel
 			}
 		}
+		if (inRange) L.slotOf[id] = slotOrNone; // (level 0's map is written here for every block of the range: a run that finds its counters
+		                                        // and the maps of the levels above reset - k_tail of the run before - needs no k_reset)
 	}
 	// Two statistics, as per-workgroup partial sums that travel with the header (no atomics: the header is being zeroed by
 	// this very launch): blocks the classify pass will read - what "every distance sample once" amounts to for this grid
@@ -2183,6 +2190,7 @@ struct TailPlan {
 	u32 wgs0, wgs1, listWgs; // workgroups: general pass of level 0 | of the levels >= 1 | lists
 	u32 levels;
 	u32* slowDone;           // finished general workgroups (a header word: zeroed with the run's counters)
+	ResetRanges next;        // the counters and maps of the OTHER set, which the next run will use: put into their start state here
 };
 
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_tail(ExecParamsDev p, ListPlan plan, HeaderPublish pub, TailPlan t)
@@ -2190,13 +2198,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 	static_assert(LIST_WG == WG, "one workgroup shape for the passes of k_tail");
 	const u32 general = t.wgs0 + t.wgs1;
 	if (blockIdx.x < general) {
-		bool wrote = false;
-#if !defined(VX_TAIL_NO0)
-		if (blockIdx.x < t.wgs0) wrote = regular0_pass<REG_CAP_SMALL, 2>(p, 0u, blockIdx.x, t.wgs0);
-#endif
-#if !defined(VX_TAIL_NO1)
-		if (blockIdx.x >= t.wgs0) wrote = regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, blockIdx.x - t.wgs0, t.wgs1);
-#endif
+		const bool wrote = blockIdx.x < t.wgs0 ? regular0_pass<REG_CAP_SMALL, 2>(p, 0u, blockIdx.x, t.wgs0)
+		                                       : regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, blockIdx.x - t.wgs0, t.wgs1);
 		if (wrote) __threadfence();
 		__syncthreads();
 		if (threadIdx.x == 0) atomicAdd(t.slowDone, 1u);
@@ -2210,9 +2213,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		}
 	}
 	__syncthreads();
-#if !defined(VX_TAIL_NOL)
 	list_write_pass(p, plan, t.levels, pub, blockIdx.x - general, t.listWgs, true);
-#endif
+	if (t.next.header) {
+		const u32 lanes = t.listWgs * WG;
+		for (u32 i = (blockIdx.x - general) * WG + threadIdx.x; i * 4u < t.next.start[MAX_LEVELS] || i < t.next.listWgs; i += lanes) {
+			reset_words(t.next, i);
+			if (i < t.next.listWgs) t.next.listCounts[i] = 0;
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2434,7 +2442,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2467,6 +2475,7 @@ struct Backend {
 		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
 		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_main replaces (A/B measurements)
 		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5)); // k_main without the level-0 queue (VX_MAIN_LEVEL0=0)
+		tune.tailCleans = env_u32("VX_TAIL_CLEANS", 1); // 0: every run starts with k_reset (A/B measurements)
 		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
 		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
@@ -2720,11 +2729,28 @@ struct Backend {
 
 	// header words = 0 and every level's block -> slot map = -1: done by the first launch of the run (k_run_head)
 	ResetRanges pendingReset = {};
-	u32 headWorkgroups = 0; // of the last k_run_head launch: that many block-class partial sums sit behind the header
-	template <typename P>
-	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32* listCounts, u32 listWgs)
+	bool pendingClean = false;   // the run's counters and the maps of the levels >= 1 are in their start state already (k_tail of the run before)
+	ResetRanges nextReset = {};  // what k_tail puts into its start state for the next run (header == nullptr: nothing)
+	bool tailCleaned = false;    // the last k_tail did
+	void set_next_reset(u32* header, u32 headerWords, u32* listCounts, u32 listWgs, int* const* maps, const u32* ids)
 	{
 		ResetRanges r;
+		u32 run = headerWords;
+		r.header = header; r.headerWords = headerWords; r.partials = nullptr; r.partialCount = 0;
+		r.listCounts = listCounts; r.listWgs = listWgs;
+		r.maps[0] = nullptr;
+		r.start[0] = run; // (level 0's map is not part of a set: k_run_head writes all of it)
+		for (u32 l = 1; l < MAX_LEVELS; ++l) { r.start[l] = run; r.maps[l] = maps[l]; if (maps[l]) run += ids[l]; }
+		r.start[MAX_LEVELS] = run;
+		nextReset = r;
+	}
+	u32 headWorkgroups = 0; // of the last k_run_head launch: that many block-class partial sums sit behind the header
+	template <typename P>
+	void run_reset(const P& p, u32 levels, u32* header, u32 headerWords, u32* listCounts, u32 listWgs, bool alreadyClean = false)
+	{
+		ResetRanges r;
+		pendingClean = alreadyClean;
+		for (u32 l = 0; l < MAX_LEVELS; ++l) r.maps[l] = p.levels[l].slotOf;
 		u32 run = headerWords;
 		r.header = header; r.headerWords = headerWords;
 		r.partials = header + headerWords; r.partialCount = 0;
@@ -2772,11 +2798,11 @@ struct Backend {
 			// no classification pass: k_run_head hands out the slots, k_main's level-0 blocks form their own bitmaps
 			ResetRanges r = pendingReset;
 			pendingReset.header = nullptr;
-			if (r.header) {
+			if (r.header && !pendingClean) {
 				const u32 lanes = std::max<u32>((r.start[MAX_LEVELS] + 3) / 4, r.listWgs);
 				hipLaunchKernelGGL(k_reset, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r);
-				r.header = nullptr;
 			}
+			r.header = nullptr;
 			headWorkgroups = (L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG;
 			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r, 1u);
 			check(hipGetLastError(), "k_run_head launch");
@@ -3165,10 +3191,15 @@ struct Backend {
 		publish = HeaderPublish();
 		const bool tail = tailPending;
 		tailPending = false;
+		tailCleaned = false;
 		if (tail) {
 			// (with or without list workgroups: the general passes were left to this launch)
 			TailPlan t;
 			t.wgs0 = tailWgs[0]; t.wgs1 = tailWgs[1]; t.listWgs = wgs; t.levels = levels; t.slowDone = tailDone;
+			t.next = nextReset;
+			if (!wgs || !tune.tailCleans) t.next.header = nullptr;
+			tailCleaned = t.next.header != nullptr;
+			nextReset.header = nullptr;
 			const u32 lds = std::max<u32>(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>));
 			if (t.wgs0 + t.wgs1 + wgs) hipLaunchKernelGGL(k_tail, dim3(t.wgs0 + t.wgs1 + wgs), dim3(WG), lds, stream, dev(p), plan, wgs ? pub : HeaderPublish(), t);
 			check(hipGetLastError(), "k_tail launch");

@@ -73,6 +73,14 @@ struct vx_ctx {
 	u32 brickN = 0, brickYb0 = 0, brickZb0 = 0, brickRowsY = 0, brickPlanesZ = 0;
 	bool bricksStale = true;
 	void* dListCounts = nullptr;                         // listed blocks per LIST_WG block coordinates, all levels (LevelDesc::listCounts)
+	// Two sets of what a full run needs in its start state - the header's counters, the block -> slot maps of the levels >= 1,
+	// the list counts: a run works on one set, and its last kernel (k_tail) resets the other for the run behind it, which then
+	// starts without k_reset.  dHeader / dListCounts / lv[L].slotOf, nActive, listCounts always name the current set.
+	void* headerSet[2] = { nullptr, nullptr };
+	void* listCountSet[2] = { nullptr, nullptr };
+	int* upperMaps[2][MAX_LEVELS] = {};
+	u32 runSet = 0;
+	bool otherSetClean = false;
 	u32 listWgs = 0;
 	void* haloBuf[4] = { nullptr, nullptr, nullptr, nullptr }; // staging of the halo messages: send below, send above, receive from below, receive from above
 	size_t haloCap[4] = { 0, 0, 0, 0 };
@@ -235,6 +243,22 @@ void rebrick_blocks(vx_ctx* c, const u32* dIds, u32 count)
 }
 
 
+// the set of counters, upper-level maps and list counts the next full run works on (vx_ctx::headerSet)
+void select_run_set(vx_ctx* c, u32 set)
+{
+	c->runSet = set;
+	c->dHeader = c->headerSet[set];
+	c->dListCounts = c->listCountSet[set];
+	size_t at = 0;
+	for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) {
+		LevelDesc& d = c->lv[L];
+		d.nActive = (u32*)c->dHeader + L;
+		if (L) d.slotOf = c->upperMaps[set][L];
+		d.listCounts = (u32*)c->dListCounts + at;
+		at += ((size_t)d.cnt * d.cnt * d.cnt + LIST_WG - 1) / LIST_WG;
+	}
+}
+
 bool ensure_level_tables(vx_ctx* c)
 {
 	const u32 zb0 = c->zBegin / 16, zb1 = c->zEnd / 16, yb0 = c->yBegin / 16, yb1 = c->yEnd / 16;
@@ -263,6 +287,12 @@ bool ensure_level_tables(vx_ctx* c)
 		const size_t cap = (size_t)d.cnt * (d.yb1 > d.yb0 ? d.yb1 - d.yb0 : 0) * (d.zb1 > d.zb0 ? d.zb1 - d.zb0 : 0);
 		d.cap = (u32)cap;
 		d.slotOf = (int*)alloc(total * 4);
+		c->upperMaps[0][L] = L ? d.slotOf : nullptr;
+		c->upperMaps[1][L] = L ? (int*)alloc(total * 4) : nullptr;
+		if (L && !c->upperMaps[1][L]) return false;
+		// (level 0 has one map: runs without a reset write every entry of their block range, the entries outside it - a
+		// rank's slab - stay as they are set here)
+		if (!L && d.slotOf && !c->be.fill(d.slotOf, 0xFF, total * 4)) return false;
 		d.slotCoord = (u32*)alloc(cap * 4);
 		d.ntBits = (u32*)alloc(cap * 512);
 		d.consBits = L ? nullptr : (u32*)alloc(cap * 512);
@@ -325,7 +355,9 @@ bool ensure_level_tables(vx_ctx* c)
 		size_t wgs = 0;
 		for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) wgs += ((size_t)c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt + LIST_WG - 1) / LIST_WG;
 		c->dListCounts = alloc(wgs * 4 + 16);
-		if (!c->dListCounts) return false;
+		c->listCountSet[0] = c->dListCounts;
+		c->listCountSet[1] = alloc(wgs * 4 + 16);
+		if (!c->dListCounts || !c->listCountSet[1]) return false;
 		c->listWgs = (u32)wgs;
 		size_t at = 0; // every level's segment of the counts (the list kernel's workgroups are laid out the same way, ListPlan::wgStart)
 		for (u32 L = 0; L < c->refLevels && L < MAX_LEVELS; ++L) {
@@ -334,6 +366,8 @@ bool ensure_level_tables(vx_ctx* c)
 		}
 	}
 	c->tablesN = c->n; c->tablesZb0 = zb0; c->tablesZb1 = zb1; c->tablesYb0 = yb0; c->tablesYb1 = yb1;
+	c->otherSetClean = false;
+	select_run_set(c, 0);
 	return true;
 }
 
@@ -653,7 +687,9 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	c->dTables = c->be.alloc(TAB_F0_BYTES);
 	c->dLut = c->be.alloc(256 * 8);
 	c->dHeader = c->be.alloc((HDR_WORDS + HDR_PARTIALS) * 4); // header + the block-class partial sums of k_run_head (one word per workgroup)
-	if (!c->dTables || !c->dLut || !c->dHeader || !c->be.h2d(c->dTables, img.data(), TAB_F0_BYTES)) {
+	c->headerSet[0] = c->dHeader;
+	c->headerSet[1] = c->be.alloc((HDR_WORDS + HDR_PARTIALS) * 4);
+	if (!c->dTables || !c->dLut || !c->dHeader || !c->headerSet[1] || !c->be.h2d(c->dTables, img.data(), TAB_F0_BYTES)) {
 		vx_ctx_destroy(c);
 		return VX_ERR_DEVICE;
 	}
@@ -674,7 +710,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	free_bricks(c);
 	free_level_tables(c);
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
-	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->dHeader);
+	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->headerSet[0]); c->be.free(c->headerSet[1]);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
 	c->be.free(c->dBlobStage); c->be.free_pinned(c->hBlobStage); c->be.free(c->dWhereStage); c->be.free_pinned(c->hWhereStage);
@@ -1354,12 +1390,21 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 			for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) if (c->lv[L].matDone && !c->be.fill(c->lv[L].matDone, 0, (size_t)c->lv[L].cap * 8)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: flag reset failed");
 			c->runEpoch = 1;
 		}
+		// the set the previous run's last kernel left in its start state, if it did (then this run has no k_reset)
+		const bool clean = c->otherSetClean;
+		if (clean) select_run_set(c, c->runSet ^ 1u);
+		c->otherSetClean = false;
 		ExecParams p;
 		fill_params(c, p, levels);
 		c->be.begin_timing();
 		c->be.stage_mark(0);
 		c->be.tailDone = (u32*)c->dHeader + HDR_PUBLISHED + 1; // (k_tail's count of finished general workgroups)
-		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS, (u32*)c->dListCounts, c->listWgs); // header = 0, slot maps = -1, list counts = 0
+		c->be.run_reset(p, levels, (u32*)c->dHeader, HDR_WORDS, (u32*)c->dListCounts, c->listWgs, clean); // header = 0, slot maps = -1, list counts = 0
+		{
+			u32 ids[MAX_LEVELS];
+			for (u32 L = 0; L < MAX_LEVELS; ++L) ids[L] = L < c->refLevels ? c->lv[L].cnt * c->lv[L].cnt * c->lv[L].cnt : 0u;
+			c->be.set_next_reset((u32*)c->headerSet[c->runSet ^ 1u], HDR_WORDS, (u32*)c->listCountSet[c->runSet ^ 1u], c->listWgs, c->upperMaps[c->runSet ^ 1u], ids);
+		}
 #if defined(VX_CASE_DUMP)
 		for (u32 L = 0; L < levels; ++L) { c->be.fill(c->lv[L].caseDump, 0, (size_t)c->lv[L].cap * BLOCK_CELLS); c->be.fill(c->lv[L].trCaseDump, 0, (size_t)c->lv[L].cap * TR_CELLS * 2); }
 #endif
@@ -1388,6 +1433,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 			c->hdrPinned[HDR_PUBLISHED] = 0;
 			published = c->be.lists_publish_header(c->hdrPinned, (const u32*)c->dHeader, HDR_WORDS + partials, (u32*)c->dHeader + HDR_PUBLISHED);
 			published = c->be.run_block_lists(p, plan, levels) && published;
+			c->otherSetClean = c->be.tailCleaned;
 			c->be.stage_mark(7);
 		}
 		c->be.end_timing_record();
