@@ -827,7 +827,11 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 	// skip (:1511-1527), whether the classify pass has to read it or not.
 	const int readers = __syncthreads_count(inRange && !(c & BC_QUIET));
 	const int calculated = __syncthreads_count(inRange && !(c & BC_SKIPPED));
-	if (threadIdx.x == 0 && r.partials) r.partials[blockIdx.x] = (u32)readers | ((u32)calculated << 16);
+	if (threadIdx.x == 0 && allocate) {
+		// (the counters were reset before this launch: the sums go straight into the header, which then is all the host reads)
+		if (readers) atomicAdd(p.G.largeBlocks + 1, (u32)readers);
+		if (calculated) atomicAdd(p.G.stats + 2, (u32)calculated);
+	} else if (threadIdx.x == 0 && r.partials) r.partials[blockIdx.x] = (u32)readers | ((u32)calculated << 16);
 }
 
 constexpr int TB = 16;            // level-0 blocks per classify tile along x (256 voxels = two 128-byte lines per row)
@@ -2157,19 +2161,24 @@ __device__ __forceinline__ void list_write_pass(const ExecParamsDev& p, const Li
 	u32 rank = (u32)__popcll(mask & ((1ull << (tid & 63)) - 1ull));
 	for (u32 q = 0; q < (tid >> 6); ++q) rank += waveSum[q];
 	if (slot >= 0) listed_block_fill(L.listed[base + rank], L, id, (u32)slot, plan.idBase[l]);
-	if (w + 1 == plan.wgStart[l + 1] && tid == 0) {
+	// The header is complete when every level's total is written (everything else in it was final before the list pass):
+	// the workgroups that write a total count themselves - one returning atomic per level, not per workgroup, which on a
+	// 1024^3 grid were 1170 serialised round trips - and the last of them publishes.
+	const bool levelFinal = w + 1 == plan.wgStart[l + 1];
+	if (levelFinal && tid == 0) {
 		u32 total = base;
 		for (u32 q = 0; q < LIST_WG / 64; ++q) total += waveSum[q];
 		__hip_atomic_store(&plan.totals[l], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (read by the publishing workgroup, possibly on another XCD)
-	}
-	if (pub.host) {
-		if (tid == 0) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the total is on its way out before this workgroup counts as finished
-			baseShared = atomicAdd(pub.done, 1u) + 1u == listWgs ? 1u : 0u;
+		if (pub.host) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the total is on its way out before this level counts as finished
+			baseShared = atomicAdd(pub.done, 1u) + 1u == levels ? 1u : 0u;
 		}
+	}
+	if (pub.host && levelFinal) {
 		__syncthreads();
 		if (baseShared) for (u32 i = tid; i < pub.words; i += LIST_WG) pub.host[i] = TV_LOAD_THROUGH(pub.dev + i);
 	}
+	(void)listWgs;
 }
 
 __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPlan plan, u32 levels, HeaderPublish pub)
@@ -2803,8 +2812,8 @@ struct Backend {
 				hipLaunchKernelGGL(k_reset, dim3((lanes + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r);
 			}
 			r.header = nullptr;
-			headWorkgroups = (L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG;
-			hipLaunchKernelGGL(k_run_head, dim3(headWorkgroups), dim3(WG), 0, stream, dev(p), r, 1u);
+			headWorkgroups = 0; // (no partial sums behind the header: see k_run_head)
+			hipLaunchKernelGGL(k_run_head, dim3((L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, 1u);
 			check(hipGetLastError(), "k_run_head launch");
 			stage_mark(1);
 			return;
