@@ -325,14 +325,16 @@ def main():
     slab_voxels = n * n * planes
     surface_blocks = int(info.active_blocks[0])
     blocks_read = int(info.blocks_read)
-    # algorithmic bytes per kernel (SURVEY.md §8(d) shares); k_classify is charged what it has to read: the blocks the
-    # BF_Empty flags do not already prove surface-free (the full n^3 figure is kept beside it, see whole_execute).  k_main is
-    # everything behind the classification in one launch: material + blend of the surface blocks of level 0 and every mesh.
+    # algorithmic bytes per kernel (SURVEY.md §8(d) shares): the distance samples of the blocks the flags and sign summaries
+    # do not already prove surface-free (the full n^3 figure is kept beside it, see whole_execute), material + blend of the
+    # surface blocks of level 0 and every mesh - all of it k_main's in a single-stream run; k_classify's share in the chain
+    # of launches (VX_UPPER=0 / dense surfaces), where the regular pass is not charged the distances again.
     out_bytes_all = 48 * (int(totals[0]) + int(totals[2])) + 4 * (int(totals[1]) + int(totals[3]))
-    alg = {"k_classify": float(4096 * blocks_read),
-           "k_main": float(2 * 4096 * surface_blocks + out_bytes_all)}
-    stage_names = ["reset", "k_classify", "k_hierarchy", "k_main", "k_after_level0", "k_after_upper", "unused", "k_lists"]
-    stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
+    # (single-stream runs have no classification pass: k_run_head hands out the slots from the flags and the sign summaries,
+    # and k_main is the one reader of the distance samples - of the blocks_read blocks that are not proven surface-free)
+    alg = {"k_main": float(4096 * blocks_read + 2 * 4096 * surface_blocks + out_bytes_all)}
+    stage_names = ["k_reset+k_run_head", "-", "--", "k_main", "k_after_level0", "k_after_upper", "---", "k_lists"]
+    stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage) if not k.startswith("-")}
     single_stream = poly.stage_layout() == 1
     if not single_stream:  # (a configuration without k_main: the chain of launches, VX_UPPER=0 / VX_MAIN_LEVEL0=0)
         stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
@@ -489,13 +491,49 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / k * 1e3
         tot = np.zeros(4, np.uint64)
+        lvl0 = None
         for l in range(xi.levels):
             lv = poly.level(l, with_data=False)
-            tot += np.array([lv.infos["n_verts"].sum(), lv.infos["n_idx"].sum(), lv.infos["n_tverts"].sum(), lv.infos["n_tidx"].sum()], np.uint64)
+            row = np.array([lv.infos["n_verts"].sum(), lv.infos["n_idx"].sum(), lv.infos["n_tverts"].sum(), lv.infos["n_tidx"].sum()], np.uint64)
+            lvl0 = row if lvl0 is None else lvl0
+            tot += row
         sb = int(xi.active_blocks[0])
         out_bytes = 48 * (int(tot[0]) + int(tot[2])) + 4 * (int(tot[1]) + int(tot[3]))
         need = 4096 * int(xi.blocks_read) + 2 * 4096 * sb + out_bytes
-        return {"workload": "%d^3 'caves' style of the same generator (seed %d): 3-D noise isosurfaces in a band around the terrain height, "
+        # the same roofline block as the headline workload's: serialised stage times, algorithmic bytes per kernel, the
+        # dominant one priced against 8 TB/s (dense surfaces run the chain of launches with all capacity classes: a stage
+        # is then a group of launches - the table-driven class, the 1536-cell class, the general pass in two classes)
+        poly.set_stage_timing(True)
+        st = np.zeros(8, np.float64)
+        for _ in range(3):
+            poly.execute(levels)
+            st += poly.stage_times()
+        st /= 3
+        chain = poly.stage_layout() == 0
+        poly.set_stage_timing(False)
+        v0x, i0x = int(lvl0[0]), int(lvl0[1])
+        if chain:
+            names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
+            xalg = {"k_classify": float(4096 * int(xi.blocks_read)), "k_regular0": float(2 * 4096 * sb + 48 * v0x + 4 * i0x),
+                    "k_regular": float(48 * (int(tot[0]) - v0x) + 4 * (int(tot[1]) - i0x)), "k_transition": float(48 * int(tot[2]) + 4 * int(tot[3]))}
+        else:
+            names = ["k_reset+k_run_head", "-", "--", "k_main", "k_after_level0", "k_after_upper", "---", "k_lists"]
+            xalg = {"k_main": float(need)}
+        xms = {k: round(float(v), 4) for k, v in zip(names, st) if not k.startswith("-")}
+        xdom = max(xalg.keys(), key=lambda k: xms[k])
+        xtraffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_caves_latest.json")))
+            if pm.get("n") == n and pm.get("levels") == levels:
+                xtraffic = pm.get("hbm_bytes_per_launch", {}).get(xdom)
+        except Exception:
+            xtraffic = None
+        xach = xalg[xdom] / (xms[xdom] * 1e-3) / 1e9
+        xroof = {"kernel": xdom, "bound": "hbm", "achieved": round(xach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(xach / 8000.0, 5),
+                 "traffic": xtraffic, "algorithmic_bytes_per_launch": xalg[xdom], "avg_launch_ms": xms[xdom],
+                 "per_kernel": {k: {"ms": xms[k], "algorithmic_bytes": xalg[k], "frac": round(xalg[k] / (xms[k] * 1e-3) / 8e12, 5) if xms[k] > 0 else None} for k in xalg},
+                 "stage_ms_serialized": xms}
+        return {"roofline": xroof,"workload": "%d^3 'caves' style of the same generator (seed %d): 3-D noise isosurfaces in a band around the terrain height, "
                             "materials, LOD levels 0..%d with transition cells" % (n, seed, levels - 1),
                 "ms_per_step": round(ms, 4), "Mvoxels_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 2),
                 "surface_blocks": sb, "surface_block_share": round(sb / ((n // 16) ** 3), 4),

@@ -53,8 +53,12 @@ typedef struct vx_exec_info {
 	uint32_t levels;            /* LOD levels produced (PolygonSurface::GetLevelsCount) */
 	uint32_t retries;           /* re-runs after growing the output pools */
 	float device_ms;            /* device time of the last run, HIP events on the context's stream */
-	uint64_t total_verts;       /* vertices in the pools (regular + transition, incl. blocks dropped as empty) */
-	uint64_t total_indices;
+	uint64_t total_verts;       /* the vertex pool's cursor: vertices of all meshes (regular + transition, incl. blocks dropped as
+	                             * empty) PLUS the ranges a table-driven block of a level >= 1 had reserved when it turned out to
+	                             * hold a zero sample and was handed to the general pass (a handful of blocks per run; the
+	                             * general pass reserves again).  Byte figures derived from meshes - bench.py's roofline,
+	                             * mesh_bytes - sum the blocks' own counts (vx_download_level / vx_level_counts), not this. */
+	uint64_t total_indices;     /* the index pool's cursor, likewise */
 	uint32_t active_blocks[8];  /* surface-bearing blocks per level */
 	uint64_t algorithmic_bytes; /* n^3 + 2*4096*surface blocks + 48*V + 4*I */
 	uint32_t blocks_read;       /* level-0 blocks whose distance samples the run had to read (the others are proven

@@ -208,6 +208,43 @@ def test_hip_level_limit(poly, port):
     assert ok, msg
 
 
+def test_hip_full_runs_follow_each_other_without_a_reset(poly, port):
+    """A full run that follows a full run starts without k_reset: the last kernel of a run (k_tail) leaves the OTHER set of
+    run counters, upper-level block maps and list counts in its start state.  Level limits that change between the runs,
+    an incremental run in between and the classification-pass variant of the pipeline must all leave the next run a
+    clean set."""
+    from voxels_amd import Polygonizer, synth
+    n = 128
+    d, m, b = synth.terrain(n, 0, n, 29)
+    g = port.grid_from_dense(d, m, b)
+    ref = port.execute(g).all_levels()
+    poly.upload(d, m, b, g.block_flags())
+    for levels in (4, 2, 4, 1, 3, 4, 4):
+        poly.execute(levels)
+        ok, msg = fields.surface_equal(poly.all_levels(), ref[:levels], nrm_tol=NRM_TOL)
+        assert ok, "levels=%d: %s" % (levels, msg)
+    # an incremental run in between (it works on the current set and re-lists the blocks it rebuilt at the end of the lists,
+    # like the reference: its result is compared elsewhere), then full runs again
+    assert len(poly.execute_dirty((40, 40, 40), (72, 72, 72))) > 0
+    for levels in (3, 4):
+        poly.execute(levels)
+        ok, msg = fields.surface_equal(poly.all_levels(), ref[:levels], nrm_tol=NRM_TOL)
+        assert ok, "levels=%d behind the incremental run: %s" % (levels, msg)
+    # the same through the pipeline with a classification pass (the form dense surfaces and incremental runs use)
+    os.environ["VX_SELF_HEAD"] = "0"
+    try:
+        q = Polygonizer(device=0)
+    finally:
+        del os.environ["VX_SELF_HEAD"]
+    q.set_materials(vxo.default_lut())
+    q.upload(d, m, b, g.block_flags())
+    for levels in (4, 2, 4):
+        q.execute(levels)
+        ok, msg = fields.surface_equal(q.all_levels(), ref[:levels], nrm_tol=NRM_TOL)
+        assert ok, "classification pass, levels=%d: %s" % (levels, msg)
+    q.close()
+
+
 def test_hip_rerun_is_deterministic_per_block(poly):
     """Pool offsets may differ between runs (atomic reservation) but every block's bytes must not."""
     gold = Golden("noise64_fullrange_mat")

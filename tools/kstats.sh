@@ -12,6 +12,6 @@ i=0
 for c in "$@"; do
   i=$((i+1))
   rocprofv3 --pmc $c --kernel-trace -d "$out/pass$i" -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-isolated --serialize > "$out/pass$i.log" 2>&1
-  python tools/rocpd_summary.py "$(find "$out/pass$i" -name '*.db' | head -1)" "$out/pmc_pass$i.txt" --pmc | grep -E "k_regular|k_transition|k_material|k_classify" | grep -v "^_ZN.*kd  " | cut -c1-130
+  python tools/rocpd_summary.py "$(find "$out/pass$i" -name '*.db' | head -1)" "$out/pmc_pass$i.txt" --pmc | grep -E "k_main|k_tail|k_run_head|k_regular|k_transition|k_material|k_classify" | grep -v "^_ZN.*kd  " | cut -c1-130
   rm -rf "$out/pass$i"
 done

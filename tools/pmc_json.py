@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json from the per-pass summaries of tools/pmc_run.sh (FETCH_SIZE, WRITE_SIZE, TCC hit/miss passes).
-Usage: tools/pmc_json.py <dir with pass1.txt pass2.txt [pass3.txt]> <n> <levels> <gpus> <label of the committed copies>"""
+Usage: tools/pmc_json.py <dir with pass1.txt pass2.txt [pass3.txt]> <n> <levels> <gpus> <label of the committed copies> [target json] [profiled command]"""
 import json
 import re
 import sys
 
-CLASSES = {"k_main": "k_main", "k_classify": "k_classify", "k_material": "k_material", "k_transition": "k_transition", "k_regular0": "k_regular0",
-           "k_regular": "k_regular", "k_run_head": "k_classify", "k_run_reset": "k_classify", "k_block_class": "k_classify", "k_list": "k_lists"}
+CLASSES = {"k_main": "k_main", "k_tail": "k_tail", "k_classify": "k_classify", "k_hierarchy": "k_classify", "k_material": "k_material", "k_transition": "k_transition",
+           "k_regular0": "k_regular0", "k_regular": "k_regular", "k_run_head": "k_run_head", "k_reset": "k_run_head", "k_list": "k_lists"}
 
 
 def parse(path):
-    """-> ({kernel class: {counter: sum}}, executes) ; executes = number of k_classify dispatches"""
+    """-> ({kernel class: {counter: sum}}, executes) ; executes = number of k_run_head dispatches (one per full run, whatever its pipeline)"""
     sums, executes = {}, 0
     for line in open(path):
         parts = line.split()
@@ -22,18 +22,20 @@ def parse(path):
                         continue
                     sums.setdefault(cls, {}).setdefault(counter, 0.0)
                     sums[cls][counter] += total
-                    if key == "k_classify":
+                    if key == "k_run_head":
                         executes = samples
     return sums, executes
 
 
 def main():
     d, n, levels, gpus, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    target = sys.argv[6] if len(sys.argv) > 6 else "profiles/pmc_latest.json"
+    command = sys.argv[7] if len(sys.argv) > 7 else "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-isolated"
     fetch, ex1 = parse(d + "/pass1.txt")
     write, ex2 = parse(d + "/pass2.txt")
     out = {"n": n, "levels": levels, "gpus": gpus,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) of "
-                     "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; summaries committed as profiles/%s_pmc_*.txt" % label,
+                     "`%s`; summaries committed as profiles/%s_pmc_*.txt" % (command, label),
            "units": "FETCH_SIZE/WRITE_SIZE are KiB, summed over the dispatches of a kernel and divided by the number of polygonizations",
            "correction": "calibrated on known access patterns (tools/pmc_calib.hip, profiles/%s_pmc_calibration.txt): on gfx950 FETCH_SIZE "
                          "reports exactly half of the bytes of the 128-byte lines a kernel pulls in, for every access width tried (16 / 8 / 4 / 1 bytes "
@@ -51,7 +53,7 @@ def main():
         out["l2_hit_rate"] = {k: round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 3) for k, v in tcc.items()}
     except OSError:
         pass
-    json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
+    json.dump(out, open(target, "w"), indent=1)
     print(json.dumps(out["hbm_bytes_per_launch"]))
 
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# After `gpurun -- bash tools/profiles_run.sh gpurun_out/prof`: copy the summaries into profiles/<label>_* (tracked) and
+# rebuild profiles/pmc_latest.json / pmc_caves_latest.json from the counter passes.  Usage: bash tools/profiles_collect.sh <dir> <label>
+set -e
+cd "$(dirname "$0")/.."
+d=${1:-gpurun_out/prof}; l=${2:-r04}
+cp $d/gputests.log profiles/${l}_gputests.log
+cp $d/selftest.txt profiles/${l}_selftest.txt
+cp $d/bench_default.json profiles/${l}_bench_default.json
+cp $d/ks/kernel_stats_serialized.txt profiles/${l}_kernel_stats_serialized.txt
+for i in 1 2; do cp $d/ks/pmc_pass$i.txt profiles/${l}_sq_pass$i.txt; done
+for i in 1 2 3; do cp $d/pmc/pass$i.txt profiles/${l}_pmc_pass$i.txt; done
+for i in 1 2; do cp $d/pmc_caves/pass$i.txt profiles/${l}_pmc_caves_pass$i.txt; done
+cp $d/tl/timeline_overlapped.txt profiles/${l}_timeline_1024.txt
+cp $d/tls/timeline_128.txt profiles/${l}_timeline_128.txt
+cp $d/tlslab/timeline_slab_8_3.txt profiles/${l}_timeline_slab_8_3.txt
+cp $d/tlc/timeline_caves.txt profiles/${l}_timeline_caves.txt
+cp $d/slab_time_y.txt profiles/${l}_slab_time_y.txt
+cp $d/quick_times.txt profiles/${l}_quick_times.txt
+python tools/pmc_json.py $d/pmc 1024 4 1 $l profiles/pmc_latest.json
+python tools/pmc_json.py $d/pmc_caves 1024 4 1 ${l}_caves profiles/pmc_caves_latest.json "python tools/caves_run.py 1024 4 3"
+ls profiles | grep "^${l}_"
