@@ -271,8 +271,8 @@ int vx_selftest(vx_ctx* ctx, uint32_t results[16]);
 int vx_set_stage_timing(vx_ctx* ctx, int enable);
 /* What the eight slots of vx_stage_times meant in the last run with stage timing: 0 = the chain of launches (reset + block
  * classes, classify, hierarchy, material, regular level 0, regular levels >= 1, transition, block lists); 1 = the single-stream
- * form (reset + block classes, classify, hierarchy, k_main, what follows k_main for level 0, ... for the levels >= 1, nothing,
- * block lists). */
+ * form (k_reset + k_run_head, nothing, nothing, k_main, what follows k_main for level 0, ... for the levels >= 1, nothing,
+ * block lists - with stage timing the parts of k_tail are launches of their own, so that they can be timed). */
 int vx_stage_layout(vx_ctx* ctx, int* layout);
 /* Diagnostics: the first `count` 32-bit words of the run's device header (queue heads, counters), copied on a stream of
  * its own so that it also works - from another host thread - while a run is in flight. */

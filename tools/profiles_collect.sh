@@ -13,7 +13,7 @@ for i in 1 2 3; do cp $d/pmc/pass$i.txt profiles/${l}_pmc_pass$i.txt; done
 for i in 1 2; do cp $d/pmc_caves/pass$i.txt profiles/${l}_pmc_caves_pass$i.txt; done
 cp $d/tl/timeline_overlapped.txt profiles/${l}_timeline_1024.txt
 cp $d/tls/timeline_128.txt profiles/${l}_timeline_128.txt
-cp $d/tlslab/timeline_slab_8_3.txt profiles/${l}_timeline_slab_8_3.txt
+grep -v "^W2026\|simple_timer" $d/tlslab.log > profiles/${l}_timeline_slab_8_3.txt
 cp $d/tlc/timeline_caves.txt profiles/${l}_timeline_caves.txt
 cp $d/slab_time_y.txt profiles/${l}_slab_time_y.txt
 cp $d/quick_times.txt profiles/${l}_quick_times.txt
