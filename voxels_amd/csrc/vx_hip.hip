@@ -743,9 +743,19 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 	if (r.header) reset_words(r, i);
 	if (r.header && i < r.listWgs) r.listCounts[i] = 0;
 	const u32 rowsY = L.yb1 - L.yb0;
-	const bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
+	bool inRange = i < L.cnt * rowsY * (L.zb1 - L.zb0);
 	const u32 ii = inRange ? i : 0u;
-	const u32 bx = ii % L.cnt, by = L.yb0 + (ii / L.cnt) % rowsY, bz = L.zb0 + ii / (L.cnt * rowsY);
+	u32 bx = ii % L.cnt, by = L.yb0 + (ii / L.cnt) % rowsY, bz = L.zb0 + ii / (L.cnt * rowsY);
+	// allocate: a workgroup is an 8 x 8 x 4 box of blocks at an aligned place (lane = x | y << 3 | z << 6), so that the ancestors
+	// of its blocks on the levels 1 and 2 are its own business and the ancestor on level 3 that of two workgroups
+	u32 boxX = 0, boxY = 0, boxZ = 0;
+	if (allocate) {
+		const u32 nx = (L.cnt + 7u) >> 3, y0 = L.yb0 >> 3, ny = ((L.yb1 + 7u) >> 3) - y0, z0 = L.zb0 >> 2;
+		boxX = blockIdx.x % nx; boxY = y0 + (blockIdx.x / nx) % ny; boxZ = z0 + blockIdx.x / (nx * ny);
+		const u32 x = boxX * 8u + (threadIdx.x & 7u), y = boxY * 8u + ((threadIdx.x >> 3) & 7u), z = boxZ * 4u + (threadIdx.x >> 6);
+		inRange = x < L.cnt && y >= L.yb0 && y < L.yb1 && z >= L.zb0 && z < L.zb1;
+		bx = min(x, L.cnt - 1u); by = min(y, L.cnt - 1u); bz = min(z, L.cnt - 1u); // (lanes outside the range read a block that exists)
+	}
 	const u32 id = block_coord_id(bx, by, bz, L.cnt);
 	u32 all = 1u; // AND over the 27 BF_Empty flags (neighbour coordinates clamped like the reference's)
 #pragma unroll
@@ -774,49 +784,86 @@ __global__ __launch_bounds__(WG) void k_run_head(ExecParamsDev p, ResetRanges r,
 	if (signAll == signAny && signAll != 0u) c |= BC_QUIET | (signAll == 2u ? (u32)BC_NEGATIVE : 0u);
 	if (inRange) p.G.blockClass[id] = (u8)c;
 	if (allocate) {
+		// Level 0: ballot-compacted slots, one reservation per workgroup.  The ancestors on the levels 1 and 2: which of the box's
+		// 4 x 4 x 2 / 2 x 2 x 1 ancestors have an active block below them is a mask in LDS; their slots are reserved with one
+		// atomic per level and workgroup and handed out by rank - no claim is needed, nobody else has blocks below them.
+		// Levels >= 3: one lane per workgroup claims (compare-and-swap, all levels at once) - two workgroups share an
+		// ancestor on level 3, 16 on level 4.  All reservations of a workgroup travel together: one round trip.
+		// (One compare-and-swap per active block and level, as k_classify does it, was 18 of this kernel's 27 us on the 1024^3
+		// bench terrain.)
 		__shared__ u32 waveActive[WG / 64];
-		__shared__ u32 wgBase;
+		__shared__ u32 below[3];      // [1], [2]: bit per ancestor of the box on that level; [0]: any active block
+		__shared__ u32 firstSlot[3];  // first slot of the box's blocks on the levels 0, 1, 2
+		if (threadIdx.x < 3) below[threadIdx.x] = 0;
+		__syncthreads();
 		const bool active = inRange && !(c & BC_QUIET);
 		const unsigned long long m = __ballot(active);
 		const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 		if (lane == 0) waveActive[wave] = (u32)__popcll(m);
+		if (active) {
+			const u32 lx = threadIdx.x & 7u, ly = (threadIdx.x >> 3) & 7u, lz = threadIdx.x >> 6;
+			atomicOr(&below[1], 1u << ((lx >> 1) | ((ly >> 1) << 2) | ((lz >> 1) << 4)));
+			atomicOr(&below[2], 1u << ((lx >> 2) | ((ly >> 2) << 1)));
+			below[0] = 1u;
+		}
 		__syncthreads();
+		const u32 levelsRun = p.G.levels;
 		if (threadIdx.x == 0) {
 			u32 tot = 0;
 			for (u32 w = 0; w < (u32)(WG / 64); ++w) tot += waveActive[w];
-			wgBase = tot ? atomicAdd(L.nActive, tot) : 0u;
+			firstSlot[0] = tot ? atomicAdd(L.nActive, tot) : 0u;
 		}
-		__syncthreads();
-		int slotOrNone = -1;
-		if (active) {
-			u32 slot = wgBase + (u32)__popcll(m & ((1ull << lane) - 1ull));
-			for (u32 w = 0; w < wave; ++w) slot += waveActive[w];
-			slotOrNone = (int)slot;
-			L.slotCoord[slot] = id;
-			L.skip[slot] = (c & BC_SKIPPED) ? 1 : 0;
-			L.ntCount[slot] = 1; // (not known yet: whoever walks the slot counts its cells; 0 would mean "no geometry")
-			// the ancestors: all levels are tried at once (see k_classify)
+		if ((threadIdx.x == 1u || threadIdx.x == 2u) && threadIdx.x < levelsRun) {
+			const u32 cnt = (u32)__popc(below[threadIdx.x]);
+			firstSlot[threadIdx.x] = cnt ? atomicAdd(p.levels[threadIdx.x].nActive, cnt) : 0u;
+		}
+		if (threadIdx.x == 64u && below[0]) {
+			// the box's one ancestor per level >= 3
 			int won[MAX_LEVELS];
 #pragma unroll
-			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+			for (u32 l = 3; l < (u32)MAX_LEVELS; ++l) {
 				won[l] = 0;
-				if (l < p.G.levels) {
+				if (l < levelsRun) {
 					const LevelDesc& A = p.levels[l];
-					const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+					const u32 px = (boxX * 8u) >> l, py = (boxY * 8u) >> l, pz = (boxZ * 4u) >> l;
 					if (px < A.cnt && py < A.cnt && pz < A.cnt) won[l] = atomicCAS(&A.slotOf[block_coord_id(px, py, pz, A.cnt)], -1, -2) == -1 ? 1 : 0;
 				}
 			}
 			u32 aslot[MAX_LEVELS];
 #pragma unroll
-			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) if (won[l]) aslot[l] = atomicAdd(p.levels[l].nActive, 1u);
+			for (u32 l = 3; l < (u32)MAX_LEVELS; ++l) if (won[l]) aslot[l] = atomicAdd(p.levels[l].nActive, 1u);
 #pragma unroll
-			for (u32 l = 1; l < (u32)MAX_LEVELS; ++l) {
+			for (u32 l = 3; l < (u32)MAX_LEVELS; ++l) {
 				if (!won[l]) continue;
 				const LevelDesc& A = p.levels[l];
-				const u32 aid = block_coord_id(bx >> l, by >> l, bz >> l, A.cnt);
+				const u32 aid = block_coord_id((boxX * 8u) >> l, (boxY * 8u) >> l, (boxZ * 4u) >> l, A.cnt);
 				A.slotCoord[aslot[l]] = aid;
 				A.slotOf[aid] = (int)aslot[l]; // visible to the next kernel
 			}
+		}
+		__syncthreads();
+		int slotOrNone = -1;
+		if (active) {
+			u32 slot = firstSlot[0] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+			for (u32 w = 0; w < wave; ++w) slot += waveActive[w];
+			slotOrNone = (int)slot;
+			L.slotCoord[slot] = id;
+			L.skip[slot] = (c & BC_SKIPPED) ? 1 : 0;
+			L.ntCount[slot] = 1; // (not known yet: whoever walks the slot counts its cells; 0 would mean "no geometry")
+		}
+		if (threadIdx.x < 32u && 1u < levelsRun && ((below[1] >> threadIdx.x) & 1u)) {
+			const LevelDesc& A = p.levels[1];
+			const u32 j = threadIdx.x, aslot = firstSlot[1] + (u32)__popc(below[1] & ((1u << j) - 1u));
+			const u32 aid = block_coord_id(boxX * 4u + (j & 3u), boxY * 4u + ((j >> 2) & 3u), boxZ * 2u + (j >> 4), A.cnt);
+			A.slotCoord[aslot] = aid;
+			A.slotOf[aid] = (int)aslot;
+		}
+		if (threadIdx.x >= 32u && threadIdx.x < 36u && 2u < levelsRun && ((below[2] >> (threadIdx.x - 32u)) & 1u)) {
+			const LevelDesc& A = p.levels[2];
+			const u32 j = threadIdx.x - 32u, aslot = firstSlot[2] + (u32)__popc(below[2] & ((1u << j) - 1u));
+			const u32 aid = block_coord_id(boxX * 2u + (j & 1u), boxY * 2u + (j >> 1), boxZ, A.cnt);
+			A.slotCoord[aslot] = aid;
+			A.slotOf[aid] = (int)aslot;
 		}
 		if (inRange) L.slotOf[id] = slotOrNone; // (level 0's map is written here for every block of the range: a run that finds its counters
 		                                        // and the maps of the levels above reset - k_tail of the run before - needs no k_reset)
@@ -2813,7 +2860,9 @@ struct Backend {
 			}
 			r.header = nullptr;
 			headWorkgroups = 0; // (no partial sums behind the header: see k_run_head)
-			hipLaunchKernelGGL(k_run_head, dim3((L.cnt * rowsY * (L.zb1 - L.zb0) + WG - 1) / WG), dim3(WG), 0, stream, dev(p), r, 1u);
+			// (workgroups are 8 x 8 x 4 boxes of blocks at aligned places that cover the block range)
+			const u32 boxes = ((L.cnt + 7u) >> 3) * (((L.yb1 + 7u) >> 3) - (L.yb0 >> 3)) * (((L.zb1 + 3u) >> 2) - (L.zb0 >> 2));
+			hipLaunchKernelGGL(k_run_head, dim3(boxes), dim3(WG), 0, stream, dev(p), r, 1u);
 			check(hipGetLastError(), "k_run_head launch");
 			stage_mark(1);
 			return;
