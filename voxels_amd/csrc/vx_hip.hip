@@ -2261,7 +2261,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		if (threadIdx.x == 0) atomicAdd(t.slowDone, 1u);
 		return;
 	}
-	if (threadIdx.x == 0) {
+	// (nothing was handed on - the rule on a terrain: the general workgroups have nothing to write, and nobody waits for them)
+	if (threadIdx.x == 0 && (TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1)) != 0u) {
 		u32 spins = 0;
 		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
 			__builtin_amdgcn_s_sleep(4);
@@ -3042,7 +3043,7 @@ struct Backend {
 	u32 tailWgs[2] = { 0, 0 };
 	u32* tailDone = nullptr;  // header word for k_tail's counter (set by the host with the header)
 	u32 slowHint[2] = { ~0u, ~0u };
-	u32 slow_grid(u32 full, int which) const { return slowHint[which] == ~0u ? full : std::max<u32>(1u, std::min<u32>(full, std::max<u32>(slowHint[which] + slowHint[which] / 4, 32u))); }
+	u32 slow_grid(u32 full, int which) const { return slowHint[which] == ~0u ? full : std::max<u32>(1u, std::min<u32>(full, slowHint[which] ? std::max<u32>(slowHint[which] + slowHint[which] / 4, 32u) : 2u)); }
 	u32 upperItemsHint = 0; // upper-queue items of the previous full run of this context (0 = unknown)
 	bool upperDone = false;  // inside run_overlapped_tail: k_main did the first capacity class of the levels 1 .. fastEnd - 1
 	bool level0Done = false; // ... and the first capacity class of level 0
