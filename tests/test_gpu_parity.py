@@ -572,6 +572,61 @@ def test_hip_halo_exchange_group(port, world, axis):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("axis", ["y", "z"])
+def test_hip_halo_exchange_after_a_neighbour_changed(port, axis):
+    """A rank whose own rows did NOT change keeps its mirrors; when its neighbour's rows change, the exchange brings new halo
+    rows into those mirrors - and the sign summaries of the halo block layer, which decide what the last owned block layer
+    polygonizes at all, have to follow them (refresh_halo_layers).  Two slabs of one terrain run once; then the upper rank
+    replaces its rows by those of another terrain, the ranks exchange, and the union must be the surface of the mixed grid."""
+    import torch
+    from voxels_amd import Polygonizer, synth
+    from voxels_amd.slab import SlabBuffers, merge_rank_levels
+    n, levels, world = 128, 3, 2
+    dev = torch.device("cuda", 0)
+    d, m, b = synth.terrain(n, 0, n, 3)
+    d2, m2, b2 = synth.terrain(n, 0, n, 19)
+    half = n // 2
+    mixed = [np.ascontiguousarray(a.copy()) for a in (d, m, b)]
+    for a, a2 in zip(mixed, (d2, m2, b2)):
+        if axis == "z":
+            a[half:] = a2[half:]
+        else:
+            a[:, half:] = a2[:, half:]
+    ref = port.execute(port.grid_from_dense(*mixed)).all_levels()
+    flags0, flags1 = synth.block_empty_flags(d), synth.block_empty_flags(mixed[0])
+    polys, slabs = [], []
+    for r in range(world):
+        slab = SlabBuffers(torch, n, r, world, dev, axis=axis)
+        slab.fill_from_full(d, m, b, flags0)
+        p = Polygonizer(device=0)
+        p.set_materials(vxo.default_lut())
+        slab.attach(p)
+        p.execute(levels)   # mirrors and sign summaries of the first terrain are current on both ranks
+        polys.append(p)
+        slabs.append(slab)
+    # the upper rank's own rows change (it tells the library so); the lower rank is untouched and keeps its mirrors
+    up = slabs[1]
+    sl = slice(up.z0, up.z1)
+    nb = n // 16
+    if axis == "z":
+        per = flags1.size // world
+        up.fill_own(np.ascontiguousarray(mixed[0][sl]), np.ascontiguousarray(mixed[1][sl]), np.ascontiguousarray(mixed[2][sl]), flags1[per:])
+    else:
+        own = np.zeros_like(flags1).reshape(nb, nb, nb)
+        own[:, up.z0 // 16:up.z1 // 16] = flags1.reshape(nb, nb, nb)[:, up.z0 // 16:up.z1 // 16]
+        up.fill_own(np.ascontiguousarray(mixed[0][:, sl]), np.ascontiguousarray(mixed[1][:, sl]), np.ascontiguousarray(mixed[2][:, sl]), own.reshape(-1))
+    torch.cuda.synchronize()
+    polys[1].invalidate()
+    Polygonizer.halo_exchange_group(polys)
+    parts = []
+    for p in polys:
+        p.execute(levels)
+        parts.append(p.all_levels())
+    ok, msg = fields.surface_equal(merge_rank_levels(parts), ref[:levels], nrm_tol=NRM_TOL)
+    assert ok, msg
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [256])
 def test_hip_device_terrain(n):
     """§8(f) row 3: k_terrain_height / k_terrain_fill + k_edit_flags reproduce vxs_terrain + vxs_block_empty_flags byte for

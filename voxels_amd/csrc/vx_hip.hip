@@ -2284,8 +2284,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 // k_halo_move: the pieces of the halo messages of one side pair (below / above) between their fields and contiguous
 // staging buffers (HaloMove, tv_block.h): blockIdx.y picks the message, one workgroup per row (n bytes of a voxel field,
 // cnt bytes of the flag array).  Unpacking also writes the rows into the brick mirrors (tv_core.h GridView) and the lattice
-// copies when the view carries them, so an exchange is two launches around the RCCL batch: pack, unpack.  (The sign
-// summaries of the halo block layers stay "unknown": those blocks are never resident as a whole.)
+// copies when the view carries them, so an exchange is two launches around the RCCL batch: pack, unpack - and one mirror
+// pass over the halo block layers behind the unpack (refresh_halo_layers, vx_host.inl), which brings their sign summaries up
+// to date: the summary of the plane that is resident is exact, and k_run_head relies on it.
 // ------------------------------------------------------------------------------------------------------
 struct HaloPair { HaloMove m[2]; };
 

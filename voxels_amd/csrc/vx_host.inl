@@ -1145,6 +1145,30 @@ GridView halo_view(const vx_ctx* c)
 	return g;
 }
 
+// Behind an unpack that found the mirrors current: the halo block layers once more through the mirror pass.  The unpack has
+// written the received rows into the bricks and the lattice copies already; what it cannot keep current is the layers'
+// sign summaries (blockSign), which k_run_head reads for the blocks of the last owned layer - exact for the plane that is
+// resident since round 4 (rebrick_row), so they have to follow the rows.  Two block layers: ~20 us at 1024^3.
+void refresh_halo_layers(vx_ctx* c)
+{
+#if defined(VX_NO_HALO_REFRESH) // (tools builds: shows that tests/test_gpu_parity.py::test_hip_halo_exchange_after_a_neighbour_changed needs it)
+	return;
+#endif
+	if (!c->be.wants_bricks() || c->bricksStale || !c->dBrick[0] || c->slabAxis == 0) return;
+	int dr[4], mr[4];
+	resident_ranges(c, dr, mr);
+	const bool alongY = c->slabAxis == 2;
+	const int yb0 = (int)c->brickYb0, yb1 = yb0 + (int)c->brickRowsY, zb0 = (int)c->brickZb0, zb1 = zb0 + (int)c->brickPlanesZ;
+	const int own0 = (int)(alongY ? c->yBegin : c->zBegin) / 16, own1 = (int)(alongY ? c->yEnd : c->zEnd) / 16;
+	auto layers = [&](int l0, int l1) {
+		if (l1 <= l0) return;
+		const int box[4] = { alongY ? l0 : yb0, alongY ? l1 : yb1, alongY ? zb0 : l0, alongY ? zb1 : l1 };
+		c->be.run_rebrick(resident_view(c), dr, mr, mirror_state(c), box, nullptr, 0);
+	};
+	layers(alongY ? yb0 : zb0, own0);
+	layers(own1, alongY ? yb1 : zb1);
+}
+
 size_t halo_move_bytes(const HaloMove& mv)
 {
 	size_t s = 0;
@@ -1198,6 +1222,7 @@ int vx_halo_exchange(vx_ctx* c)
 	                                    pl.hasHi ? c->haloBuf[3] : nullptr, pl.hasHi ? halo_move_bytes(pl.recvHi) : 0);
 	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange: " + c->be.error());
 	c->be.run_halo_moves(pl.hasLo ? &pl.recvLo : nullptr, pl.hasHi ? &pl.recvHi : nullptr, halo_view(c), mirror_state(c), alongY);
+	refresh_halo_layers(c);
 	c->haveSurface = false;
 	return VX_OK;
 }
@@ -1229,6 +1254,7 @@ int vx_halo_exchange_group(vx_ctx* const* ctxs, int count)
 		VX_ENTER(c);
 		if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_halo_exchange_group: copy failed: " + c->be.error());
 		c->be.run_halo_moves(plans[(size_t)i].hasLo ? &plans[(size_t)i].recvLo : nullptr, plans[(size_t)i].hasHi ? &plans[(size_t)i].recvHi : nullptr, halo_view(c), mirror_state(c), c->slabAxis == 2);
+		refresh_halo_layers(c);
 		c->haveSurface = false;
 	}
 	return VX_OK;
