@@ -2,7 +2,9 @@
 // per-lane logic and the reason why it is exact), written for gfx950.  Included by vx_hip.hip behind vx_regular0.inl,
 // whose work distribution it shares: persistent workgroups stride over the level-0 slots, the next block's 19^3
 // distances, 17^3 materials + blends and bitmap are requested into registers while the current block emits.  A block in whose staged samples a lane finds a zero byte is appended to Globals::slowItems[0] and left to
-// k_regular0<.., 2>, launched right behind on the same stream.
+// k_regular0<.., 2>, launched right behind on the same stream (or to the first workgroups of k_tail).  f0_walk is the body:
+// k_regular0_fast strides over all slots, k_main walks batches of consecutive slots taken from its queue - and there,
+// where no classification pass ran, a block forms its own non-trivial bitmap first (SELF: f0_self_bits, one barrier more).
 //
 // Per block: deposit (+ zero test) | popcount prefix + compact cell list | cells: table-driven, no loop over table
 // vertices, wave-contiguous ranges, DPP scans | bases + pool reservations + vertex / triangle descriptors | one lane =

@@ -1,7 +1,16 @@
 // vx_hip.hip — gfx950 (MI355X / CDNA4) kernels and HIP backend of libvoxels_hip.so.
 //
-// One polygonization = a handful of kernels on three streams of one context, no host round trip in between (work
-// lists and output offsets live in device memory):
+// A full run of a terrain-like grid is THREE launches on one stream:
+//   k_run_head    what the BF_Empty flags and the sign summaries say about a block; the blocks that are not quiet get their
+//                 level-0 slots and their ancestors the slots of the levels above (workgroup = an aligned 8 x 8 x 4 box)
+//   k_main        (vx_main.inl) every block of every level: two queues handed out to persistent workgroups - the level-0
+//                 slots, and [material | regular | transition] blocks of the levels >= 1 in dependency order, waiting for
+//                 each other through per-block flags (write-through stores, polled loads, no fences)
+//   k_tail        the general passes over what the table-driven blocks handed on, the result's block tables, the header
+//                 into page-locked host memory, and the start state of the counters / maps the NEXT run will use
+// (k_reset in front of the first run of a context).  Dense surfaces (blocks beyond the first capacity class), incremental
+// runs and grids beyond 1024^3 run the same per-block bodies as a chain of kernels on three to five streams, no host round
+// trip in between (work lists and output offsets live in device memory):
 //   k_run_head    counters / slot maps reset; what the BF_Empty flags and the sign summaries say about a block
 //   k_classify    stream over the density field, skipping blocks the flags prove quiet: 16-byte coalesced loads, sign
 //                 bits packed to bit-masks in LDS, cells classified bit-parallel (256 per lane); emits the

@@ -1,4 +1,6 @@
-// vx_main.inl — k_main: everything a full run does behind the classification as ONE launch (gfx950).  Included by vx_hip.hip
+// vx_main.inl — k_main: everything a full run does between k_run_head (slots) and k_tail (lists) as ONE launch (gfx950).
+// There is no classification pass in front of it: level-0 blocks form their own bitmaps (f0_walk<.., SELF>), level-1
+// material blocks their children's (mat_block, selfChild).  Included by vx_hip.hip
 // behind the passes whose per-block bodies it calls: f0_walk (table-driven regular cells of level-0 blocks, vx_fast0.inl),
 // mat_block (the material vote of one block of a level >= 1, vx_hip.hip), f1_block (the table-driven regular cells of one
 // block of a level 1..3, vx_fast1.inl), tr_block (the transition cells of one block, vx_hip.hip).
