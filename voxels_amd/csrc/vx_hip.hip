@@ -253,77 +253,136 @@ __device__ __forceinline__ u32 sign_nibble(u32 d) { return (((d & 0x80808080u) >
 
 // ------------------------------------------------------------------------------------------------------
 // k_decode_grid: Grid file format v1 -> dense fields (DecompressBlock, src/VoxelGrid.cpp:674-694, for all blocks at
-// once).  One workgroup per 16^3 block, one stream (distance, material, blend) after the other: run lengths ->
-// exclusive scan = run starts; lane t owns the 16-byte voxel row t of the block (y = t & 15, z = t >> 4), finds the
-// run that covers its first voxel by binary search and walks on from there; one 16-byte store per lane and stream.
+// once).  One workgroup per EIGHT x-neighbour blocks, one stream (distance, material, blend) after the other.
+//   * Streams of up to 32 runs - nearly every stream of a terrain: a run is at most 255 voxels long, so a CONSTANT block is
+//     17 runs, which is why "a handful of runs" has to mean 32 and not 16 - are walked from LDS: the workgroup fetches the
+//     records' places, then the flag words and the first 64 bytes of all 24 streams (two dependent round trips for eight
+//     blocks), and lane = (block tid & 7, row group tid >> 3) fills its 8 voxel rows - a row inside one run without a walk -
+//     so that the eight lanes of a row write the 128-byte line the eight blocks share in the dense field.
+//   * The other streams, one after the other with the whole workgroup: run lengths -> exclusive scan = run starts; lane t
+//     owns the 16-byte voxel row t of the block (y = t & 15, z = t >> 4), finds the run that covers its first voxel by
+//     binary search and walks on from there; raw streams are copied.
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_stream_whole_block(const u8* src, u32 sz, bool raw, u8* out, u16* starts, u8* vals, u32* scanScratch, const u32 tid)
+{
+	u32 b[4] = { 0, 0, 0, 0 };
+	if (raw) {
+		// raw: 4096 bytes, row t at offset 16 t (the stream itself is not aligned)
+#pragma unroll
+		for (u32 i = 0; i < 16; ++i) if (tid * 16 + i < sz) b[i >> 2] |= (u32)src[tid * 16 + i] << ((i & 3) * 8);
+	} else {
+		const u32 pairs = sz >> 1; // <= 2048
+#pragma unroll
+		for (u32 i = 0; i < 8; ++i) {
+			const u32 q = tid * 8 + i;
+			u32 len = 0, val = 0;
+			if (q < pairs) { len = src[2 * q]; val = src[2 * q + 1]; }
+			starts[q] = (u16)len;
+			vals[q] = (u8)val;
+		}
+		__syncthreads();
+		const u32 total = block_exclusive_scan_u16(starts, pairs, scanScratch);
+		// last run whose start is <= the row's first voxel
+		const u32 q0 = tid * 16;
+		u32 lo = 0, hi = pairs; // invariant: starts[lo] <= q0 (starts[0] == 0), answer in [lo, hi)
+		while (hi - lo > 1) {
+			const u32 mid = (lo + hi) >> 1;
+			if (starts[mid] <= q0) lo = mid; else hi = mid;
+		}
+		u32 r = lo;
+#pragma unroll
+		for (u32 i = 0; i < 16; ++i) {
+			const u32 pos = q0 + i;
+			while (r + 1 < pairs && starts[r + 1] <= pos) ++r;
+			const u32 v = (pairs && pos < total) ? vals[r] : 0u;
+			b[i >> 2] |= v << ((i & 3) * 8);
+		}
+		__syncthreads(); // the run tables are reused by the next stream
+	}
+	*(uint4*)out = make_uint4(b[0], b[1], b[2], b[3]);
+}
+
+constexpr u32 DECODE_SHORT_RUNS = 32; // streams up to this many runs are walked from LDS (a constant block: 17 runs of <= 255 voxels)
+
 __global__ __launch_bounds__(WG) void k_decode_grid(const u8* blob, const unsigned long long* where, u32 n, i8* dist, u8* mat, u8* blend, u8* flags)
 {
 	__shared__ u16 starts[2048 + 8];
 	__shared__ u8 vals[2048];
 	__shared__ u32 scanScratch[8];
-	const u32 id = blockIdx.x, nb = n >> 4, tid = threadIdx.x;
-	const u8* rec = blob + where[2 * (size_t)id];
-	const unsigned long long sizes = where[2 * (size_t)id + 1];
-	const u32 fl = (u32)rec[0] | ((u32)rec[1] << 8) | ((u32)rec[2] << 16) | ((u32)rec[3] << 24);
-	if (tid == 0) flags[id] = (u8)(fl & 1u);
-	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
-	const size_t rowOff = ((size_t)(bz * 16 + (tid >> 4)) * n + by * 16 + (tid & 15)) * n + bx * 16;
-	const u8* src = rec + 4;
+	__shared__ unsigned long long recAt[8], recSizes[8]; // per block of this workgroup: offset of its record, its three stream sizes
+	__shared__ u32 recFlags[8];
+	__shared__ u8 runs[8][3][2 * DECODE_SHORT_RUNS];     // the first runs of every stream (all of a short one)
+	__shared__ u32 wholeMask[3];                         // per stream: the blocks that take the whole-workgroup path
+	const u32 nb = n >> 4, tid = threadIdx.x, groups = (nb + 7u) >> 3;
+	const u32 gx = blockIdx.x % groups, by = (blockIdx.x / groups) % nb, bz = blockIdx.x / (groups * nb);
+	const u32 firstId = (bz * nb + by) * nb + gx * 8u, count = min(8u, nb - gx * 8u);
+	// two dependent round trips in all: the records' places, then their flags and the heads of their streams
+	if (tid < 16) { const u32 b = tid >> 1; const unsigned long long v = b < count ? where[2 * (size_t)(firstId + b) + (tid & 1u)] : 0ull; if (tid & 1u) recSizes[b] = v; else recAt[b] = v; }
+	if (tid < 3) wholeMask[tid] = 0;
+	__syncthreads();
+	constexpr u32 PER_BLOCK = 4u + 3u * 2u * DECODE_SHORT_RUNS;
+	for (u32 q = tid; q < 8u * PER_BLOCK; q += WG) {
+		const u32 b = q / PER_BLOCK, j = q % PER_BLOCK; // j < 4: a byte of the record's flag word; else stream (j - 4) / 64, byte (j - 4) % 64
+		if (b >= count) continue;
+		const u8* rec = blob + recAt[b];
+		if (j < 4u) { ((u8*)&recFlags[b])[j] = rec[j]; continue; }
+		const u32 st = (j - 4u) / (2u * DECODE_SHORT_RUNS), at = (j - 4u) % (2u * DECODE_SHORT_RUNS);
+		const unsigned long long sizes = recSizes[b];
+		u32 before = 4;
+		for (u32 t = 0; t < st; ++t) before += (u32)((sizes >> (16 * t)) & 0xFFFFu);
+		if (at < (u32)((sizes >> (16 * st)) & 0xFFFFu)) runs[b][st][at] = rec[before + at];
+	}
+	__syncthreads();
+	if (tid < 8 && tid < count) {
+		flags[firstId + tid] = (u8)(recFlags[tid] & 1u);
+		for (u32 st = 0; st < 3; ++st) {
+			const u32 sz = (u32)((recSizes[tid] >> (16 * st)) & 0xFFFFu);
+			if (((recFlags[tid] >> (st + 1)) & 1u) || (sz >> 1) > DECODE_SHORT_RUNS) atomicOr(&wholeMask[st], 1u << tid);
+		}
+	}
+	__syncthreads();
+	const u32 blk = tid & 7u, bx = gx * 8u + blk;
 #pragma unroll 1
 	for (u32 s = 0; s < 3; ++s) {
-		const u32 sz = (u32)((sizes >> (16 * s)) & 0xFFFFu);
-		u8* out = (s == 0 ? (u8*)dist : (s == 1 ? mat : blend)) + rowOff;
-		u32 b[4] = { 0, 0, 0, 0 };
-		if ((fl >> (s + 1)) & 1u) {
-			// raw: 4096 bytes, row t at offset 16 t (the stream itself is not aligned)
+		u8* field = s == 0 ? (u8*)dist : (s == 1 ? mat : blend);
+		const u32 whole = wholeMask[s];
+		if (blk < count && !((whole >> blk) & 1u)) {
+			// the lane walks the runs (LDS, uniform among the lanes of a block) for its rows it * 32 + (tid >> 3), ascending
+			const u32 pairs = (u32)((recSizes[blk] >> (16 * s)) & 0xFFFFu) >> 1;
+			const u8* rl = runs[blk][s];
+			u32 r = 0, end = pairs ? (u32)rl[0] : 0u; // run r ends in front of voxel `end`
+#pragma unroll 1
+			for (u32 it = 0; it < 8; ++it) {
+				const u32 row = it * 32u + (tid >> 3), q0 = row * 16u;
+				u32 b[4] = { 0, 0, 0, 0 };
+				while (r < pairs && q0 >= end) { ++r; if (r < pairs) end += (u32)rl[2 * r]; }
+				if (r >= pairs || q0 + 16u <= end) {
+					// the whole row lies in one run (nearly every row of such a block), or behind the last one
+					const u32 x = r < pairs ? (u32)rl[2 * r + 1] * 0x01010101u : 0u;
+					b[0] = b[1] = b[2] = b[3] = x;
+				} else {
 #pragma unroll
-			for (u32 i = 0; i < 16; ++i) if (tid * 16 + i < sz) b[i >> 2] |= (u32)src[tid * 16 + i] << ((i & 3) * 8);
-		} else if ((sz >> 1) <= 16u) {
-			// a handful of runs (the blocks away from the surface: one or two): every lane walks them itself - uniform addresses,
-			// no LDS, no barrier (most blocks of a terrain take this path three times and are bound by their stores)
-			const u32 pairs = sz >> 1, q0 = tid * 16;
-			u32 start = 0, r = 0; // the run covering the row's first voxel, then voxel by voxel from there
-			for (; r < pairs; ++r) { const u32 len = src[2 * r]; if (start + len > q0) break; start += len; }
-			u32 end = r < pairs ? start + (u32)src[2 * r] : 0u;
-#pragma unroll
-			for (u32 i = 0; i < 16; ++i) {
-				const u32 pos = q0 + i;
-				while (r < pairs && pos >= end) { ++r; if (r < pairs) end += (u32)src[2 * r]; }
-				const u32 x = r < pairs ? (u32)src[2 * r + 1] : 0u;
-				b[i >> 2] |= x << ((i & 3) * 8);
+					for (u32 i = 0; i < 16; ++i) {
+						const u32 pos = q0 + i;
+						while (r < pairs && pos >= end) { ++r; if (r < pairs) end += (u32)rl[2 * r]; }
+						const u32 x = r < pairs ? (u32)rl[2 * r + 1] : 0u;
+						b[i >> 2] |= x << ((i & 3) * 8);
+					}
+				}
+				*(uint4*)(field + ((size_t)(bz * 16u + (row >> 4)) * n + by * 16u + (row & 15u)) * n + bx * 16u) = make_uint4(b[0], b[1], b[2], b[3]);
 			}
-		} else {
-			const u32 pairs = sz >> 1; // <= 2048
-#pragma unroll
-			for (u32 i = 0; i < 8; ++i) {
-				const u32 q = tid * 8 + i;
-				u32 len = 0, val = 0;
-				if (q < pairs) { len = src[2 * q]; val = src[2 * q + 1]; }
-				starts[q] = (u16)len;
-				vals[q] = (u8)val;
-			}
-			__syncthreads();
-			const u32 total = block_exclusive_scan_u16(starts, pairs, scanScratch);
-			// last run whose start is <= the row's first voxel
-			const u32 q0 = tid * 16;
-			u32 lo = 0, hi = pairs; // invariant: starts[lo] <= q0 (starts[0] == 0), answer in [lo, hi)
-			while (hi - lo > 1) {
-				const u32 mid = (lo + hi) >> 1;
-				if (starts[mid] <= q0) lo = mid; else hi = mid;
-			}
-			u32 r = lo;
-#pragma unroll
-			for (u32 i = 0; i < 16; ++i) {
-				const u32 pos = q0 + i;
-				while (r + 1 < pairs && starts[r + 1] <= pos) ++r;
-				const u32 v = (pairs && pos < total) ? vals[r] : 0u;
-				b[i >> 2] |= v << ((i & 3) * 8);
-			}
-			__syncthreads(); // the run tables are reused by the next stream
 		}
-		*(uint4*)out = make_uint4(b[0], b[1], b[2], b[3]);
-		src += sz;
+		// the blocks with longer run lists or raw streams: one at a time, all lanes (uniform loop: the mask is the workgroup's)
+		u32 todo = whole;
+		while (todo) {
+			const u32 k = (u32)__builtin_ctz(todo);
+			todo &= todo - 1u;
+			const unsigned long long sizesk = recSizes[k];
+			u32 before = 4;
+			for (u32 t = 0; t < s; ++t) before += (u32)((sizesk >> (16 * t)) & 0xFFFFu);
+			const size_t rowOff = ((size_t)(bz * 16u + (tid >> 4)) * n + by * 16u + (tid & 15u)) * n + (gx * 8u + k) * 16u;
+			decode_stream_whole_block(blob + recAt[k] + before, (u32)((sizesk >> (16 * s)) & 0xFFFFu), ((recFlags[k] >> (s + 1)) & 1u) != 0u, field + rowOff, starts, vals, scanScratch, tid);
+		}
 	}
 }
 
@@ -2740,7 +2799,7 @@ struct Backend {
 	void run_decode_grid(const u8* blob, const uint64_t* where, u32 n, i8* dist, u8* mat, u8* blend, u8* flags)
 	{
 		const u32 nb = n / 16;
-		hipLaunchKernelGGL(k_decode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, blob, (const unsigned long long*)where, n, dist, mat, blend, flags);
+		hipLaunchKernelGGL(k_decode_grid, dim3(((nb + 7) / 8) * nb * nb), dim3(WG), 0, stream, blob, (const unsigned long long*)where, n, dist, mat, blend, flags);
 		check(hipGetLastError(), "k_decode_grid launch");
 	}
 	bool d2d(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(D2D)"); }
