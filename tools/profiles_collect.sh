@@ -17,6 +17,8 @@ grep -v "^W2026\|simple_timer" $d/tlslab.log > profiles/${l}_timeline_slab_8_3.t
 cp $d/tlc/timeline_caves.txt profiles/${l}_timeline_caves.txt
 cp $d/slab_time_y.txt profiles/${l}_slab_time_y.txt
 cp $d/quick_times.txt profiles/${l}_quick_times.txt
+cp $d/stress.txt profiles/${l}_stress.txt
+cp $d/decode_kernel_stats.txt profiles/${l}_decode_kernel_stats.txt
 python tools/pmc_json.py $d/pmc 1024 4 1 $l profiles/pmc_latest.json
 python tools/pmc_json.py $d/pmc_caves 1024 4 1 ${l}_caves profiles/pmc_caves_latest.json "python tools/caves_run.py 1024 4 3"
 ls profiles | grep "^${l}_"

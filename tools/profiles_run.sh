@@ -2,7 +2,7 @@
 # Everything a round's profiles/ holds, from ONE GPU call: GPU test log, default bench line, serialised kernel stats + SQ
 # counter passes, HBM traffic passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss) of the headline workload and of the second
 # ('caves') workload, stream timelines (1024^3, 128^3, one rank's slab of an 8-rank job, caves), per-rank slab times, the
-# small-run times, device arithmetic self-test.  Usage (GPU box): bash tools/profiles_run.sh <outdir>
+# small-run times, a stress of 100 000 consecutive runs, the grid-file decode kernel alone, device arithmetic self-test.  Usage (GPU box): bash tools/profiles_run.sh <outdir>
 # Afterwards, here: bash tools/profiles_collect.sh <outdir> <label>   (copies the summaries into profiles/<label>_*)
 cd "$GRAFT_REPO_ROOT"
 out=${1:-gpurun_out/prof}
@@ -19,4 +19,6 @@ timeout 300 bash tools/timeline_slab.sh $out/tlslab 8 3 > $out/tlslab.log 2>&1
 timeout 300 bash tools/timeline_caves.sh $out/tlc > $out/tlc.log 2>&1
 timeout 600 python tools/slab_time.py y > $out/slab_time_y.txt 2>&1
 timeout 300 python tools/quick_times.py > $out/quick_times.txt 2>&1
+timeout 300 python tools/stress_runs.py 40000 4000 2>&1 | grep -v amdgpu.ids > $out/stress.txt
+(cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 300 rocprofv3 --kernel-trace --stats -d $out/dec -o k -- python tools/decode_only.py > $out/dec.log 2>&1; python tools/rocpd_summary.py "$(find $out/dec -name '*.db' | head -1)" $out/decode_kernel_stats_full.txt > /dev/null 2>&1; grep -v "^W2026\|simple_timer" $out/decode_kernel_stats_full.txt | cut -c1-150 | head -8 > $out/decode_kernel_stats.txt; rm -rf $out/dec)
 tail -3 $out/gputests.log; cat $out/selftest.txt; head -c 400 $out/bench_default.json; echo; head -12 $out/ks.log; tail -4 $out/slab_time_y.txt; tail -1 $out/quick_times.txt
