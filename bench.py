@@ -55,13 +55,15 @@ def mem_available_gb():
     return 0.0
 
 
-def cpu_baseline(n, seed):
+def cpu_baseline(n, seed, levels=4):
     """The unmodified reference (oracle/_ref) — or the port when _ref is absent — on the host cores: the SAME grid as the
     GPU run when the host has the memory for it (else a sub-world), all cores, plus a one-thread figure on a bounded
     sub-world.  The reference cannot limit LOD levels: it always produces log2(n/16)+1 of them (stated in `sample`).
-    Reported baseline only; never part of the product path."""
+    Reported baseline only; never part of the product path.  When the grid is the GPU run's, the first `levels` levels of
+    what the reference produced are digested (voxels_amd/digest.py: every byte of every mesh, ids, corners, counts) so that
+    the caller can compare them with the GPU run's: `_digest` in the returned dict (popped by the caller)."""
     import vxo
-    from voxels_amd import synth
+    from voxels_amd import digest, synth
     oracle = vxo.load_ref() or vxo.load_port()
     if oracle is None:
         return None
@@ -84,13 +86,15 @@ def cpu_baseline(n, seed):
                 counts["levels"] = len(lv)
                 counts["verts"] = int(sum(len(l.verts) for l in lv))
                 counts["indices"] = int(sum(len(l.idx) for l in lv))
+                counts["_digest"] = digest.surface_digest(lv[:levels])
             s.destroy()
             best = dt if best is None else min(best, dt)
         return best
 
     t_all = run(big, cores, 2, count=(big == n))
     t_one = run(256, 1, 1)
-    return {"value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": oracle.kind, "counts": counts or None,
+    ref_digest = counts.pop("_digest", None)
+    return {"_digest": ref_digest, "value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": oracle.kind, "counts": counts or None,
             "one_thread": {"value": round(256 ** 3 / t_one / 1e6, 3), "unit": "Mvoxels/s", "cores": 1,
                            "sample": "256^3 sub-world of the same seeded terrain, all 5 reference LOD levels, 1 run of %.1f s" % t_one},
             "sample": "%s of the same seeded terrain, all %d reference LOD levels (the reference cannot limit levels; the GPU "
@@ -279,21 +283,28 @@ def main():
         mine = digest.surface_digest(poly.all_levels())
         tsum = torch.from_numpy(digest.pack(mine)).to(dev)
         dist_pkg.all_reduce(tsum, op=dist_pkg.ReduceOp.SUM)
-        summed = digest.unpack(tsum.cpu().numpy(), levels)
+        summed = digest.unpack(tsum.cpu().numpy(), mine[0].shape[0])  # (the levels the run produced: fewer than requested on small grids)
         verdict = torch.zeros(1, dtype=torch.int32, device=dev)
         if rank == 0:
-            whole_poly = Polygonizer(device=local_rank)
-            whole_poly.set_materials(synth.default_lut())
-            whole_poly.create_terrain(n, seed)
-            whole_poly.execute(levels)
-            ref = digest.surface_digest(whole_poly.all_levels())
-            whole_poly.close()
-            equal = digest.digests_equal(summed, ref)
-            verdict[0] = 1 if equal else 0
-            multi_gpu_check = {"result": "equal" if equal else "DIFFERENT",
-                               "totals_per_level_blocks_verts_indices_tverts_tindices": summed[0].tolist(),
-                               "hash": "%016x" % int(summed[1]), "reference": "whole-grid run of the same library on rank 0's GPU",
-                               "reference_totals": ref[0].tolist(), "reference_hash": "%016x" % int(ref[1])}
+            # (whatever happens here, rank 0 reaches the broadcast below: the other ranks are waiting in it)
+            try:
+                whole_poly = Polygonizer(device=local_rank)
+                whole_poly.set_materials(synth.default_lut())
+                whole_poly.create_terrain(n, seed)
+                whole_poly.execute(levels)
+                ref = digest.surface_digest(whole_poly.all_levels())
+                whole_poly.close()
+                equal = digest.digests_equal(summed, ref)
+                verdict[0] = 1 if equal else 0
+                multi_gpu_check = {"result": "equal" if equal else "DIFFERENT",
+                                   "kind": "self-consistency of the sharded run (the whole-grid run of the SAME library is the reference here; the "
+                                           "whole-grid run is what tests/ and parity_vs_reference compare with the oracle)",
+                                   "totals_per_level_blocks_verts_indices_tverts_tindices": summed[0].tolist(),
+                                   "hash": "%016x" % int(summed[1]), "reference": "whole-grid run of the same library on rank 0's GPU",
+                                   "reference_totals": ref[0].tolist(), "reference_hash": "%016x" % int(ref[1])}
+            except Exception as e:  # noqa: BLE001
+                verdict[0] = 0
+                multi_gpu_check = {"result": "ERROR", "error": str(e)[-300:]}
         dist_pkg.broadcast(verdict, 0)
         if int(verdict.item()) != 1:
             if rank == 0:
@@ -479,6 +490,44 @@ def main():
                 "note": "the headline step runs on a resident, unchanged grid (SURVEY.md §8(d)); after a change of the whole grid "
                         "the first run also rebuilds the mirrors - the one place where all n^3 samples of the three fields are read"}
 
+    # ---- the same step with the inputs NOT resident in the 256 MiB memory-side cache: the timed loop above polygonizes one
+    #      grid over and over, so the ~0.4 GB of bricks a run reads may be served by the Infinity Cache (FETCH_SIZE counts
+    #      fabric requests, MALL hits included).  Here two resident grids of different seeds (two contexts, two sets of
+    #      mirrors and pools) are polygonized alternately: between two runs on a grid the other run moves ~1 GB (its inputs +
+    #      its meshes) through the memory side.  Reported beside the headline; see DESIGN.md §6. ------------------------------
+    uncached = None
+    if world == 1 and not args.serialize and not args.no_extra:
+        try:
+            other = Polygonizer(device=local_rank)
+            other.set_stream(torch.cuda.current_stream().cuda_stream)
+            other.set_materials(synth.default_lut())
+            other.create_terrain(n, seed + 1)
+            for _ in range(3):
+                poly.execute(levels); oi = other.execute(levels)
+            torch.cuda.synchronize()
+            k = max(10, min(args.steps, 50))
+            ta = time.perf_counter()
+            for _ in range(k):
+                poly.execute(levels); other.execute(levels)
+            torch.cuda.synchronize()
+            alt_ms = (time.perf_counter() - ta) / (2 * k) * 1e3
+            # the second grid alone, back to back (its surface differs a little from the headline grid's: the pair's expected mean)
+            tb = time.perf_counter()
+            for _ in range(k):
+                other.execute(levels)
+            torch.cuda.synchronize()
+            other_ms = (time.perf_counter() - tb) / k * 1e3
+            other.close()
+            expected = 0.5 * (ms_per_step + other_ms)
+            uncached = {"ms_per_step_alternating_two_grids": round(alt_ms, 4), "ms_per_step_second_grid_alone": round(other_ms, 4),
+                        "ms_per_step_headline_grid_alone": round(ms_per_step, 4), "slowdown_vs_mean_of_the_two_alone": round(alt_ms / expected, 4),
+                        "second_grid": {"seed": seed + 1, "active_blocks": [int(x) for x in oi.active_blocks[:levels]], "verts": int(oi.total_verts), "indices": int(oi.total_indices)},
+                        "Mvoxels_per_s": round(n ** 3 / (alt_ms * 1e-3) / 1e6, 2),
+                        "note": "two resident %d^3 grids (seeds %d, %d) in two contexts, polygonized alternately: no input line of a run was "
+                                "touched since the other grid's run moved its own inputs and ~0.5 GB of meshes through the memory side" % (n, seed, seed + 1)}
+        except Exception as e:  # noqa: BLE001
+            uncached = {"error": str(e)[-300:]}
+
     # ---- a second workload whose figure does not rest on a sparse surface: the "caves" style of the generator puts surface
     #      into a large share of all blocks (parity-tested like the terrain, tests/test_gpu_parity.py) ---------------------
     extra = None
@@ -573,16 +622,37 @@ def main():
                                           "compare those rounds with ms_per_step_with_halo_exchange)",
                        "multi_gpu_check": (multi_gpu_check["result"] if multi_gpu_check else None), "multi_gpu_check_detail": multi_gpu_check,
                        ("ms_per_step_without_halo_exchange" if args.halo_every_step else "ms_per_step_with_halo_exchange"): (round(ms_other, 4) if ms_other is not None else None),
-                       "cold": cold},
+                       "cold": cold, "steady_state_uncached": uncached},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not args.serialize:
             de = dropin_e2e(poly)
             if de:
                 out["config"]["e2e_ms"]["libVoxels_Polygonizer_Execute"] = de
-            cb = cpu_baseline(n, seed)
+            cb = cpu_baseline(n, seed, levels)
             if cb:
+                # SURVEY.md §8(c) at bench scale: the reference itself polygonized this very grid a moment ago - the digest of
+                # its levels 0..levels-1 (every byte of every mesh incl. normals, block ids, corners, counts) must be the
+                # digest of what the GPU path produces for the same grid.  A difference fails the bench.
+                ref_digest = cb.pop("_digest", None)
                 out["cpu_baseline"] = cb
+                if ref_digest is not None:
+                    from voxels_amd import digest
+                    poly.create_terrain(n, seed)
+                    poly.execute(levels)
+                    mine = digest.surface_digest(poly.all_levels())
+                    equal = digest.digests_equal(mine, ref_digest)
+                    out["parity_vs_reference"] = "equal" if equal else "DIFFERENT"
+                    out["config"]["parity_vs_reference_detail"] = {
+                        "checked": "levels 0..%d of the %d^3 bench grid: GPU run vs the %s (oracle/_ref = the unmodified reference sources) run of cpu_baseline, "
+                                   "order-independent 64-bit digest over every byte of every mesh (positions, secondary positions, normals, texture bytes, "
+                                   "indices, transition meshes), block ids, corners and counts" % (levels - 1, n, cb["kind"]),
+                        "totals_per_level_blocks_verts_indices_tverts_tindices": mine[0].tolist(), "hash": "%016x" % int(mine[1]),
+                        "reference_totals": ref_digest[0].tolist(), "reference_hash": "%016x" % int(ref_digest[1])}
+                    if not equal:
+                        sys.stderr.write("parity vs reference FAILED: %s\n" % json.dumps(out["config"]["parity_vs_reference_detail"]))
+                        print(json.dumps(out))
+                        raise SystemExit(4)
                 # the reference and the drop-in library polygonized the same grid in this run: their counts must agree
                 rc = cb.get("counts")
                 if rc and de and "verts" in de:

@@ -163,6 +163,16 @@ struct Backend {
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	template <typename P> bool single_stream(const P&, u32) const { return false; } // (HIP backend: one launch behind the classification)
 	template <typename P> void run_main_staged(const P&, u32) {}
+	// (HIP backend: incremental runs as three launches; the emulation walks the chain with work lists)
+	template <typename P> bool dirty_fused_applies(const P&, u32, bool) const { return false; }
+	struct DirtyLaunch {
+		u32 lo[MAX_LEVELS][3], hi[MAX_LEVELS][3], start[MAX_LEVELS + 1];
+		u32* work; u32* info; u32* ticket; u32 ticketTarget;
+		u32* header; u32 resetFrom, resetTo, poolVerts, poolIdx;
+		u32* roleTicket; u32* slowDone;
+		BlockRecord* hostRecs; u32* hostHeader; u32 headerWords, publishedWord;
+	};
+	template <typename P> void run_dirty_fused(const P&, u32, const DirtyLaunch&) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
 	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange

@@ -370,6 +370,39 @@ def test_hip_carve_modify_matches_reference_fixture(poly, port):
     assert np.array_equal(poly.stats(), gold.stats)
 
 
+def test_hip_incremental_runs_as_chain_of_launches(port):
+    """Incremental runs are three launches by default (k_dirty_head | k_main<true> | k_dirty_tail); the chain of launches
+    with work lists remains for surfaces with blocks beyond the first capacity class.  The same chain of edits through a
+    context that is told to use the chain (VX_DIRTY_FUSED=0), against the oracle."""
+    from voxels_amd import Polygonizer, synth
+    n = 128
+    os.environ["VX_DIRTY_FUSED"] = "0"
+    try:
+        q = Polygonizer(device=0)
+    finally:
+        del os.environ["VX_DIRTY_FUSED"]
+    q.set_materials(vxo.default_lut())
+    d0, m0, b0 = synth.terrain(n, seed=33)
+    g = port.grid_from_dense(d0, m0, b0)
+    s = port.execute(g)
+    q.upload(*g.read_dense(), g.block_flags())
+    q.execute()
+    c = n / 2.0
+    col = d0[:, n // 2, n // 2]
+    zs = float(np.argmax(col >= 0)) if (col >= 0).any() else c
+    for t, pos, ext, r in ((2, (c, c, zs), (30, 30, 30), 14.0), (0, (c + 9, c - 11, zs + 3), (16, 16, 16), 6.0), (2, (c - 20, c + 4, zs - 2), (12, 12, 12), 5.0)):
+        mn, mx = g.inject_ball(pos, ext, r, t)
+        ref_ids = port.execute_modify(g, s, mn, mx)
+        a, bq = q.inject_ball(pos, ext, r, t)
+        assert np.array_equal(a, mn) and np.array_equal(bq, mx)
+        got = q.execute_dirty(mn, mx)
+        assert np.array_equal(got, ref_ids)
+        ok, msg = fields.surface_equal(q.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+        assert ok, msg
+        assert np.array_equal(q.stats(), s.stats())
+    q.close()
+
+
 @pytest.mark.parametrize("n", [64, 256])
 def test_hip_repeated_edits_vs_port(poly, port, n):
     """Chained edits with incremental runs: device-resident caches persist like the reference's PolygonMap caches."""

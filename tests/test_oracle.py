@@ -117,6 +117,26 @@ def test_port_vs_reference_live(port, ref, seed):
     assert np.array_equal(sr.stats(), sp.stats())
 
 
+def test_port_vs_reference_live_256(port, ref):
+    """The same pin at a size where every reference level (5 at 256^3) has interior blocks, transition faces on three
+    levels and LOD chains of length 1..4: the bench generator's terrain (what the 512^3 / 1024^3 GPU parity tests compare
+    the port with) and a full-range field (LOD chains that end on voxels, degenerate triangles)."""
+    from voxels_amd import synth
+    n = 256
+    d, m, b = synth.terrain(n)
+    gr, gp = ref.grid_from_dense(d, m, b), port.grid_from_dense(d, m, b)
+    assert np.array_equal(gr.block_flags(), gp.block_flags())
+    sr, sp = ref.execute(gr), port.execute(gp)
+    assert_same(sr.all_levels(), sp.all_levels())
+    assert np.array_equal(sr.stats(), sp.stats())
+    sr.destroy(); sp.destroy()
+    q = fields.quantize_full_range(fields.smooth_noise(n, 77, scale=24, amp=3.0))
+    gr, gp = ref.grid_from_dense(q, m, b), port.grid_from_dense(q, m, b)
+    sr, sp = ref.execute(gr), port.execute(gp)
+    assert_same(sr.all_levels(), sp.all_levels())
+    assert np.array_equal(sr.stats(), sp.stats())
+
+
 def test_port_vs_reference_edit_and_pack(port, ref):
     n = 48 if False else 64
     f = fields.terrain_field(n, 31)

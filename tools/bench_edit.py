@@ -51,7 +51,33 @@ def main():
     ids2 = q.execute_dirty(mn2, mx2)
     assert np.array_equal(ids, ids2) and np.array_equal(mn, mn2)
     g.inject_ball(pos2, (30.0, 30.0, 30.0), 12.0, 2)
+    # steady state (BASELINE config 5): a chain of r = 20 carves along the surface, per call wall time and device time - on the
+    # three-launch path (k_dirty_head | k_main<true> | k_dirty_tail) and, in a second context, on the chain of launches
+    steady = {}
+    for label, env in (("fused", None), ("chain", "0")):
+        if env is not None:
+            os.environ["VX_DIRTY_FUSED"] = env
+        w = Polygonizer()
+        os.environ.pop("VX_DIRTY_FUSED", None)
+        w.set_materials(vxo.default_lut())
+        w.upload(*pre, oracle.grid_from_dense(*pre).block_flags())
+        w.execute(0)
+        calls, devs, blocks = [], [], 0
+        for k in range(12):
+            pk = (pos[0] + 23.0 * (k % 4) - 30.0, pos[1] + 19.0 * (k // 4) - 20.0, pos[2] + 2.0 * (k % 3))
+            a, bq = w.inject_ball(pk, ext, r, 2)
+            t = time.perf_counter(); got = w.execute_dirty(a, bq); dt = time.perf_counter() - t
+            if k >= 2:
+                calls.append(dt * 1e3); devs.append(w.info.device_ms); blocks += got.size
+        steady[label] = (float(np.mean(calls)), float(np.min(calls)), float(np.mean(devs)), blocks / len(calls), w)
+    from voxels_amd import digest
+    da, db = digest.surface_digest(steady["fused"][4].all_levels()), digest.surface_digest(steady["chain"][4].all_levels())
+    assert digest.digests_equal(da, db), "the two incremental paths disagree"
     print("grid %d^3, IT_Subtract ball r=%g, extents %s: %d blocks changed, %d blocks rebuilt" % (n, r, ext, bids.size, ids.size))
+    for label in ("fused", "chain"):
+        m, lo, dv, nb, _ = steady[label]
+        print("  steady state, %s path: vx_polygonize_dirty %.4f ms per call (best %.4f), device %.4f ms, %.0f blocks rebuilt per call" % (label, m, lo, dv, nb))
+    print("  surfaces after the 12 edits: equal on both paths (digest %016x)" % int(da[1]))
     print("  device edit (vx_grid_inject_ball, incl. BF_Empty refresh): %7.3f ms" % (t_dev * 1e3))
     print("  incremental polygonization (vx_polygonize_dirty)          : %7.3f ms (device %.3f ms)" % (t_poly * 1e3, dev1))
     print("  second edit (r=12): device edit %.3f ms, vx_polygonize_dirty %.3f ms (device %.3f ms), %d blocks rebuilt" % (t_dev2 * 1e3, t_poly2 * 1e3, dev2, idsb.size))

@@ -413,25 +413,40 @@ TV_HD unsigned long long lut_row(const u8* lut, u32 materialId)
 	return row;
 }
 
-TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVertex* out)
+#if defined(__HIPCC__)
+// a packed vertex in registers: the twelve dwords of a PolyVertex (three 16-byte pieces); device code only
+struct VertexRegs { u32 w[12]; };
+__device__ __forceinline__ void pack_vertex_regs(const RawVertex& r, unsigned long long row, VertexRegs& o)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
 	const float k = 1.f / 256.f;
 	u32 f = r.flags;
 	if (f) f = (f >> 3) | ((f & 7u) << 3);
-#if defined(__HIP_DEVICE_COMPILE__)
 	// texture bytes {0, blend, Ids1[1], Ids0[1] | Ids1[2], Ids1[0], Ids0[2], Ids0[0]} picked out of the row with two
-	// byte permutes (selector 0..3 = low dword, 4..7 = high dword, 0x0C = constant 0); the vertex leaves as three
-	// aligned 16-byte stores (a member-wise copy is split at the member boundaries: 12 + 16 + 12 + 8 bytes)
+	// byte permutes (selector 0..3 = low dword, 4..7 = high dword, 0x0C = constant 0)
 	const u32 lo = (u32)row, hi = (u32)(row >> 32);
 	const bool ok = ((hi >> 16) & 0xFFu) != 0;
 	u32 t0 = __builtin_amdgcn_perm(hi, lo, 0x01040C0Cu) | (((r.mat >> 8) & 0xFFu) << 8);
 	u32 t1 = __builtin_amdgcn_perm(hi, lo, 0x00020305u);
 	if (!ok) { t0 = 0; t1 = 0; }
+	o.w[0] = __float_as_uint(r.p[0] * k); o.w[1] = __float_as_uint(r.p[2] * k); o.w[2] = __float_as_uint(r.p[1] * k); o.w[3] = __float_as_uint(r.s[0] * k);
+	o.w[4] = __float_as_uint(r.s[2] * k); o.w[5] = __float_as_uint(r.s[1] * k); o.w[6] = f; o.w[7] = __float_as_uint(r.n[0]);
+	o.w[8] = __float_as_uint(r.n[1]); o.w[9] = __float_as_uint(r.n[2]); o.w[10] = t0; o.w[11] = t1;
+#endif
+}
+#endif
+
+TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVertex* out)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	// the vertex leaves as three aligned 16-byte stores (a member-wise copy is split at the member boundaries: 12 + 16 + 12 + 8 bytes)
+	VertexRegs o;
+	pack_vertex_regs(r, row, o);
 	typedef u32 __attribute__((ext_vector_type(4))) v4u;
 	v4u* dst = (v4u*)out;
-	const v4u a = { __float_as_uint(r.p[0] * k), __float_as_uint(r.p[2] * k), __float_as_uint(r.p[1] * k), __float_as_uint(r.s[0] * k) };
-	const v4u b = { __float_as_uint(r.s[2] * k), __float_as_uint(r.s[1] * k), f, __float_as_uint(r.n[0]) };
-	const v4u c = { __float_as_uint(r.n[1]), __float_as_uint(r.n[2]), t0, t1 };
+	const v4u a = { o.w[0], o.w[1], o.w[2], o.w[3] };
+	const v4u b = { o.w[4], o.w[5], o.w[6], o.w[7] };
+	const v4u c = { o.w[8], o.w[9], o.w[10], o.w[11] };
 	// The meshes are written once and not read again by the run: streaming (non-temporal) stores keep them from
 	// displacing the voxel lines the neighbouring blocks are about to read.  Measured at 1024^3: level-0 pass 0.196 ->
 	// 0.181 ms, levels >= 1 0.128 -> 0.115, the whole step 0.498 -> 0.463.
@@ -439,6 +454,9 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	TV_STREAM_STORE(&dst[1], b);
 	TV_STREAM_STORE(&dst[2], c);
 #else
+	const float k = 1.f / 256.f;
+	u32 f = r.flags;
+	if (f) f = (f >> 3) | ((f & 7u) << 3);
 	PolyVertex o;
 	o.pos[0] = r.p[0] * k; o.pos[1] = r.p[2] * k; o.pos[2] = r.p[1] * k;
 	o.sec[0] = r.s[0] * k; o.sec[1] = r.s[2] * k; o.sec[2] = r.s[1] * k;
@@ -459,6 +477,19 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 	*out = o;
 #endif
 }
+
+// Where a packed vertex goes: to its record in memory (three 16-byte stores of the lane), or - device only - into the
+// lane's registers, from where a whole wave's records leave together as whole lines (wave_store_records, vx_hip.hip)
+struct VertexToMemory {
+	PolyVertex* out;
+	TV_HD void operator()(const RawVertex& r, unsigned long long row) const { pack_vertex_row(r, row, out); }
+};
+#if defined(__HIPCC__)
+struct VertexToRegs {
+	VertexRegs* regs;
+	__device__ __forceinline__ void operator()(const RawVertex& r, unsigned long long row) const { pack_vertex_regs(r, row, *regs); }
+};
+#endif
 
 TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out) { pack_vertex_row(r, lut_row(lut, r.mat), out); }
 

@@ -211,8 +211,8 @@ TV_HD void f0_describe(ST& st, const F0Tables& T, u32 k, u32 base, u32 chunkV, u
 
 // ---- one lane = one new vertex (reg_edge_vertex of tv_core.h at level 0 for a vertex strictly inside its edge) ---------
 // desc = cell id | edge index << 12; (ox,oy,oz) = the block's origin in voxels
-template <typename ST>
-TV_HD void f0_vertex(const ST& st, const F0Tables& T, u32 desc, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
+template <typename ST, typename SINK>
+TV_HD void f0_vertex(const ST& st, const F0Tables& T, u32 desc, int ox, int oy, int oz, unsigned long long lutRow, const SINK& sink)
 {
 	const u32 c = desc & 0xFFFu;
 	const F0Edge e = T.edge[desc >> 12];
@@ -250,7 +250,12 @@ TV_HD void f0_vertex(const ST& st, const F0Tables& T, u32 desc, int ox, int oy, 
 	const float wt = (float)t / 256.f, wu = (float)u / 256.f;
 	rv.n[0] = N0[0] * wt + N1[0] * wu; rv.n[1] = N0[1] * wt + N1[1] * wu; rv.n[2] = N0[2] * wt + N1[2] * wu;
 	normalize_fix_zero(rv.n);
-	pack_vertex_row(rv, lutRow, out);
+	sink(rv, lutRow);
+}
+template <typename ST>
+TV_HD void f0_vertex(const ST& st, const F0Tables& T, u32 desc, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
+{
+	f0_vertex(st, T, desc, ox, oy, oz, lutRow, VertexToMemory{ out });
 }
 
 // ---- one lane = one triangle of the chunk: its three indices --------------------------------------------------------

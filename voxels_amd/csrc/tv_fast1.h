@@ -61,8 +61,8 @@ struct F1HostSampler {
 
 // ---- one lane = one new vertex (reg_edge_vertex of tv_core.h, for a cell without zero corner samples) ---------------
 // desc = cell id | edge index << 12; (ox,oy,oz) = the block's origin in voxels; returns "strictly inside its level-0 edge"
-template <typename ST, typename SMP>
-TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16* blockCache, u32 desc, int level, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
+template <typename ST, typename SMP, typename SINK>
+TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16* blockCache, u32 desc, int level, int ox, int oy, int oz, unsigned long long lutRow, const SINK& sink)
 {
 	typedef typename SMP::Off Off;
 	const u32 c = desc & 0xFFFu;
@@ -116,8 +116,13 @@ TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16*
 	rv.n[0] = N0[0] * wt + N1[0] * wu; rv.n[1] = N0[1] * wt + N1[1] * wu; rv.n[2] = N0[2] * wt + N1[2] * wu;
 	normalize_fix_zero(rv.n);
 	finish_secondary(rv, mult);
-	pack_vertex_row(rv, lutRow, out);
+	sink(rv, lutRow);
 	return interior;
+}
+template <typename ST, typename SMP>
+TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16* blockCache, u32 desc, int level, int ox, int oy, int oz, unsigned long long lutRow, PolyVertex* out)
+{
+	return f1_vertex(st, T, smp, blockCache, desc, level, ox, oy, oz, lutRow, VertexToMemory{ out });
 }
 
 #if !defined(__HIPCC__)

@@ -198,6 +198,7 @@ __device__ __forceinline__ R0Candidate f0_peek(const ExecParamsDev& p, const Lev
 	c.valid = (it < limit && item < total) ? 1u : 0u;
 	if (!c.valid) item = 0;
 	c.slot = item;
+	if (!REMAP && p.G.dirty) c.slot = p.G.workItems[0][item]; // (uniform; k_main of an incremental run: the queue hands out entries of the level's work list)
 	c.ntc = L.ntCount[c.slot];
 	c.skip = L.skip[c.slot];
 	c.coord = L.slotCoord[c.slot];
@@ -363,11 +364,24 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
 						if (!requested) { if (haveNext) f0_request<SELF>(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
+#if !defined(VX_WAVE_STORE)
 						if (j < vEnd) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
 							const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
 							f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), vOut + j);
 						}
+#else
+						const u32 jw = r0_uniform(base + ((u32)tid & ~63u)); // the wave's first vertex: its 64 records leave as whole lines
+						if (jw < vEnd) {
+							VertexRegs vr;
+							if (j < vEnd) {
+								const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
+								const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
+								f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), VertexToRegs{ &vr });
+							}
+							wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
+						}
+#endif
 						if (j < tEnd) {
 							u32 ids[3];
 							f0_triangle(st, T, j, ids);

@@ -46,7 +46,7 @@ typedef BrickSamplerT<u32> F1BrickSampler; // valid while a mirror is smaller th
 // come from the run's flat list.
 template <int CAP, bool GATED>
 __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables& T, const F1BrickSampler& smp, Fast1State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
-                                         u32 level, u32 slot, u32 coord, u32 ntc, u32 lo, const int tid, const bool matKnown = false)
+                                         u32 level, u32 slot, u32 coord, u32 ntc, u32 lo, const int tid)
 {
 	typedef R0<CAP> K;
 	const u32 lane = (u32)tid & 63u, wave = (u32)tid >> 6;
@@ -75,28 +75,19 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	const u16* csrc = L.cache + (size_t)slot * BLOCK_CELLS;
 	u32 bitsWord = 0;
 	uint4 c0, c1;
-	const bool early = GATED && matKnown; // every material block of the launch is published: bitmap, cache block and cell count are requested with the samples
-	if (early) {
-		const u32 flagLow = (u32)TV_LOAD_THROUGH(L.matDone + slot);
-		bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
-		c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
-		ntc = r0_uniform(flagLow);
-	} else if (GATED) {
+	if (GATED) {
+		// the flag carries this run's tag or the wait goes on: no word of an older run is ever taken for the cell count
 		if (tid == 0) st.zero = wait_done(L.matDone + slot, p.G.epoch, p.G.giveUp);
 		acquire_and_meet(tid < 64);
 		ntc = r0_uniform(st.zero);
-	}
-	if (GATED) {
 		if (ntc > (u32)CAP || (lo && ntc <= lo)) return;
 		if (ntc == 0) {
 			if (tid == 0) reg_write_empty_record(L, slot);
 			return;
 		}
 	}
-	if (!early) {
-		bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
-		c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
-	}
+	bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
+	c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
 
 	// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
 	{
@@ -218,11 +209,24 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 			u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 			for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
 				const u32 j = base + (u32)tid;
+#if !defined(VX_WAVE_STORE)
 				if (j < vEnd) {
 					const u32 desc = st.vdesc[j];
 					const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
 					if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
 				}
+#else
+				const u32 jw = r0_uniform(base + ((u32)tid & ~63u)); // the wave's first vertex: its 64 records leave as whole lines
+				if (jw < vEnd) {
+					VertexRegs vr;
+					if (j < vEnd) {
+						const u32 desc = st.vdesc[j];
+						const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
+						if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, VertexToRegs{ &vr })) notInterior = 1;
+					}
+					wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
+				}
+#endif
 				if (j < tEnd) {
 					u32 ids[3];
 					f0_triangle(st, T, j, ids);

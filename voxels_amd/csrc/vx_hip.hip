@@ -122,6 +122,37 @@ __device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indice
 #endif
 }
 
+// ---- a wave's vertex records as whole lines ------------------------------------------------------------------------------
+// One lane = one vertex leaves 64 records of 48 bytes per wave: as three 16-byte stores per lane every store instruction
+// touches all 24 lines of the wave's 3 KB with a third of each (partial writes that the streaming path does not merge:
+// WRITE_SIZE was 1.26 x the mesh bytes).  Here the 192 pieces of 16 bytes are first dealt to the lanes in address order -
+// piece q = 3 * lane + part goes to lane q & 63 for store q >> 6; as 3 is coprime to 64 every part is ONE ds_permute_b32 per
+// dword (a lane-to-lane move through the LDS crossbar, no LDS memory), twelve in all, and a lane picks the part (lane + store) % 3
+// of what arrived - so that each of the three stores writes 1 KB of consecutive addresses.
+// All 64 lanes of the wave must call (lanes at and behind `count` pass anything); `first` = record of lane 0, `count` >= 1.
+__device__ __forceinline__ void wave_store_records(PolyVertex* first, u32 count, const VertexRegs& r)
+{
+	const u32 lane = (u32)threadIdx.x & 63u;
+	const int to0 = (int)(((3u * lane) & 63u) << 2), to1 = (int)(((3u * lane + 1u) & 63u) << 2), to2 = (int)(((3u * lane + 2u) & 63u) << 2);
+	const u32 m = lane % 3u;
+	typedef u32 __attribute__((ext_vector_type(4))) v4u;
+	v4u s0, s1, s2;
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		const u32 t0 = (u32)__builtin_amdgcn_ds_permute(to0, (int)r.w[d]);
+		const u32 t1 = (u32)__builtin_amdgcn_ds_permute(to1, (int)r.w[4 + d]);
+		const u32 t2 = (u32)__builtin_amdgcn_ds_permute(to2, (int)r.w[8 + d]);
+		s0[d] = m == 0u ? t0 : (m == 1u ? t1 : t2);
+		s1[d] = m == 0u ? t1 : (m == 1u ? t2 : t0);
+		s2[d] = m == 0u ? t2 : (m == 1u ? t0 : t1);
+	}
+	v4u* dst = (v4u*)first + lane;
+	const u32 pieces = count * 3u;
+	if (lane < pieces) TV_STREAM_STORE(dst, s0);
+	if (lane + 64u < pieces) TV_STREAM_STORE(dst + 64, s1);
+	if (lane + 128u < pieces) TV_STREAM_STORE(dst + 128, s2);
+}
+
 // ---- dependencies between workgroups of ONE launch (k_main): LevelDesc::matDone ----------------------------------------
 // Producer: the payload leaves through write-through (sc1) stores, every storing wave drains them, the workgroup meets and
 // ONE lane stores the 8-byte word epoch << 32 | payload.  Consumer: ONE lane polls the word (relaxed, agent scope, s_sleep
@@ -1264,7 +1295,9 @@ template <bool GATED>
 // selfChild (level 1): the children's consistency bitmaps are not read but formed here, from the children's own samples -
 // the run has no classification pass (k_run_head<allocate>), and the level-0 blocks that form their bitmaps themselves run
 // beside this block, in no order.
-__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid, const bool selfChild = false)
+// boxLo / boxHi (incremental runs inside k_main): only the children inside this box of block coordinates are part of the run and
+// publish; the others' caches are what earlier launches left.
+__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid, const bool selfChild = false, const u32* boxLo = nullptr, const u32* boxHi = nullptr)
 {
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
@@ -1481,7 +1514,15 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	__syncthreads();
 	if (GATED && level >= 2u) {
 		// the children's cache blocks are written by other workgroups of this launch (the level below comes first in the queue)
-		if (tid < 8) { const int c = st.childSlot[tid]; if (c >= 0) (void)wait_done(C.matDone + c, p.G.epoch, p.G.giveUp); }
+		if (tid < 8) {
+			const int c = st.childSlot[tid];
+			bool inRun = true;
+			if (boxLo) {
+				const u32 cx = bx * 2 + (tid & 1), cy = by * 2 + ((tid >> 1) & 1), cz = bz * 2 + (tid >> 2);
+				inRun = cx >= boxLo[0] && cx < boxHi[0] && cy >= boxLo[1] && cy < boxHi[1] && cz >= boxLo[2] && cz < boxHi[2];
+			}
+			if (c >= 0 && inRun) (void)wait_done(C.matDone + c, p.G.epoch, p.G.giveUp);
+		}
 		acquire_and_meet(tid < 64);
 	}
 	// ---- vote.  A lane takes VB cells per trip and requests ALL their child entries before it looks at any: children
@@ -2349,6 +2390,214 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Incremental runs as three launches (TransVoxelRun::Execute with a Modification, src/TransVoxelImpl.cpp:385-466, :468-538):
+//   k_dirty_head   one workgroup per level-0 block of the dirty box (:429-465: the touched blocks plus one ring): its bitmap
+//                  from the sign masks of its 17 x 17 sample rows, slot (a new one when the block turns active: then its
+//                  ancestors are activated as k_hierarchy does), accumulated consistency bits (:757: only ever set).  The
+//                  workgroup that finishes last puts the run's counters into their start state (pool cursors behind what the
+//                  pools hold) and lists, per level, the active slots among the box's blocks (Globals::workItems).
+//   k_main<true>   the two queues over those lists (vx_main.inl)
+//   k_dirty_tail   the general passes over what k_main handed on, then the rebuilt blocks' records and the header straight
+//                  into page-locked host memory: the host's one wait is the kernel's completion.
+// The box travels as launch arguments; nothing is uploaded, nothing is copied back behind the kernels.
+// ------------------------------------------------------------------------------------------------------
+struct DirtyPlan {
+	u32 lo[MAX_LEVELS][3], hi[MAX_LEVELS][3]; // per level: the dirty box in block coordinates (internal axes x, y, z), [lo, hi)
+	u32 start[MAX_LEVELS + 1];                // per level: its segment of the work array (start[l + 1] - start[l] = blocks in the box)
+	u32 levels;
+	u32* work;                                // [start[levels]] out: per level the active slots among the box's blocks
+	u32* info;                                // [start[1]] scratch, per dirty level-0 block: bit 0 = not skipped by the emptiness rule, bit 1 = beyond the first capacity class
+	u32* ticket;                              // finished workgroups of this kernel, counted over all its launches (never reset)
+	u32 ticketTarget;                         // ... the value the last workgroup of this launch brings it to
+	u32* header;                              // the run's counters: words [resetFrom, resetTo) start at zero,
+	u32 resetFrom, resetTo;
+	u32 poolVerts, poolIdx;                   // ... the pool cursors behind what the pools hold
+};
+
+__global__ __launch_bounds__(WG) void k_dirty_head(ExecParamsDev p, DirtyPlan d)
+{
+	__shared__ u32 rowMask[292];
+	__shared__ u32 sh[8];
+	const LevelDesc& L = p.levels[0];
+	const GridView& g = p.G.grid;
+	const int tid = (int)threadIdx.x, n = g.n;
+	{
+		const u32 k = blockIdx.x;
+		const u32 dx = d.hi[0][0] - d.lo[0][0], dy = d.hi[0][1] - d.lo[0][1];
+		const u32 bx = d.lo[0][0] + k % dx, by = d.lo[0][1] + (k / dx) % dy, bz = d.lo[0][2] + k / (dx * dy);
+		const u32 id = block_coord_id(bx, by, bz, L.cnt);
+		// sign masks of the 17 x 17 sample rows the block's cells read (clamped at the grid's far side like every fetch, :1194-1201)
+		uint4 lo[2];
+		i8 far[2];
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int r = min(tid + q * WG, 288), kk = r / 17, j = r - kk * 17;
+			const int y = min((int)(by * 16) + j, n - 1), z = min((int)(bz * 16) + kk, n - 1);
+			lo[q] = *(const uint4*)(g.bDist + brick_offset(g, (int)(bx * 16), y, z));
+			far[q] = g.bDist[brick_offset(g, min((int)(bx * 16) + 16, n - 1), y, z)];
+		}
+		// the emptiness rule (:1511-1527): the 27 flags around the block
+		u32 flag = 1u;
+		if (tid < 27) {
+			const u32 cx = (u32)clampi((int)bx + (tid % 3) - 1, 0, (int)L.cnt - 1), cy = (u32)clampi((int)by + ((tid / 3) % 3) - 1, 0, (int)L.cnt - 1), cz = (u32)clampi((int)bz + (tid / 9) - 1, 0, (int)L.cnt - 1);
+			flag = p.G.emptyFlags[block_coord_id(cx, cy, cz, L.cnt)] ? 1u : 0u;
+		}
+		int slot = L.slotOf[id]; // (level 0's entries are only ever written by the block's own workgroup)
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int r = tid + q * WG;
+			if (r < 289) rowMask[r] = sign_nibble(lo[q].x) | (sign_nibble(lo[q].y) << 4) | (sign_nibble(lo[q].z) << 8) | (sign_nibble(lo[q].w) << 12) | ((((u32)far[q] >> 7) & 1u) << 16);
+		}
+		if (tid < 8) sh[tid] = 0;
+		__syncthreads();
+		const bool skipped = __syncthreads_and(flag != 0u) != 0;
+		const int y = tid & 15, z = tid >> 4;
+		const u32 a = rowMask[z * 17 + y], b2 = rowMask[z * 17 + y + 1], c = rowMask[(z + 1) * 17 + y], e = rowMask[(z + 1) * 17 + y + 1];
+		const u32 A = a & b2 & c & e, O = a | b2 | c | e;
+		const u32 nt = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
+		u32 cnt = (u32)__popc(nt);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) cnt += (u32)__shfl_xor((int)cnt, o, 64);
+		if ((tid & 63) == 0 && cnt) atomicAdd(&sh[0], cnt);
+		__syncthreads();
+		const u32 cells = sh[0];
+		bool fresh = false;
+		if (slot < 0 && cells) {
+			if (tid == 0) {
+				const u32 s = atomicAdd(L.nActive, 1u);
+				L.slotOf[id] = (int)s;
+				L.slotCoord[s] = id;
+				sh[1] = s;
+				// a block that turns active: its ancestors become active (k_hierarchy)
+				for (u32 l = 1; l < d.levels; ++l) {
+					const LevelDesc& U = p.levels[l];
+					const u32 px = bx >> l, py = by >> l, pz = bz >> l;
+					if (px >= U.cnt || py >= U.cnt || pz >= U.cnt) break;
+					const u32 uid = block_coord_id(px, py, pz, U.cnt);
+					if (atomicCAS(&U.slotOf[uid], -1, -2) != -1) break; // somebody else owns this ancestor chain
+					const u32 us = atomicAdd(U.nActive, 1u);
+					U.slotCoord[us] = uid;
+					__hip_atomic_store(&U.slotOf[uid], (int)us, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			__syncthreads();
+			slot = (int)sh[1];
+			fresh = true;
+		}
+		if (slot >= 0) {
+			// (publish_level0_block of tv_block.h, one cell row per lane)
+			if (tid == 0) { L.skip[slot] = skipped ? 1 : 0; L.ntCount[slot] = (u16)cells; }
+			((u16*)(L.ntBits + (size_t)slot * 128))[tid] = (u16)nt;
+			u16* cons = (u16*)(L.consBits + (size_t)slot * 128) + tid;
+			const u32 add = skipped ? 0u : nt;
+			*cons = (u16)(fresh ? add : ((u32)*cons | add));
+		}
+		if (tid == 0) {
+			p.G.blockClass[id] = 0; // whatever a full run knew about the block without reading it no longer holds
+			d.info[k] = (skipped ? 0u : 1u) | ((slot >= 0 && cells > (u32)LARGE_THRESHOLD) ? 2u : 0u);
+		}
+	}
+	// ---- the workgroup that finishes last: counters, work lists --------------------------------------------------------------
+	__threadfence();
+	__syncthreads();
+	if (tid == 0) sh[2] = atomicAdd(d.ticket, 1u) + 1u == d.ticketTarget ? 1u : 0u;
+	__syncthreads();
+	if (!sh[2]) return;
+	__threadfence();
+	for (u32 i = d.resetFrom + (u32)tid; i < d.resetTo; i += WG) d.header[i] = 0;
+	__syncthreads();
+	u32 notSkipped = 0, large = 0;
+	for (u32 i = (u32)tid; i < d.start[1]; i += WG) { const u32 v = TV_LOAD_THROUGH(d.info + i); notSkipped += v & 1u; large += (v >> 1) & 1u; }
+	{
+		u32 v = notSkipped | (large << 16);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
+		if ((tid & 63) == 0) atomicAdd(&sh[3], v);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		p.P.cursors[CUR_V] = d.poolVerts; p.P.cursors[CUR_I] = d.poolIdx;
+		p.G.stats[2] = sh[3] & 0xFFFFu;
+		*p.G.largeBlocks = sh[3] >> 16;
+	}
+	for (u32 l = 0; l < d.levels; ++l) {
+		const LevelDesc& U = p.levels[l];
+		const u32 V = d.start[l + 1] - d.start[l], dx = d.hi[l][0] - d.lo[l][0], dy = d.hi[l][1] - d.lo[l][1];
+		u32 count = 0;
+		for (u32 base = 0; base < V; base += WG) {
+			const u32 i = base + (u32)tid;
+			int slot = -1;
+			if (i < V) slot = TV_LOAD_THROUGH(&U.slotOf[block_coord_id(d.lo[l][0] + i % dx, d.lo[l][1] + (i / dx) % dy, d.lo[l][2] + i / (dx * dy), U.cnt)]);
+			const unsigned long long m = __ballot(slot >= 0);
+			__syncthreads(); // (sh[4..7] of the previous trip are read)
+			if ((tid & 63) == 0) sh[4 + (tid >> 6)] = (u32)__popcll(m);
+			__syncthreads();
+			u32 rank = (u32)__popcll(m & ((1ull << (tid & 63)) - 1ull)), tot = 0;
+			for (u32 w = 0; w < (u32)(WG / 64); ++w) { if (w < ((u32)tid >> 6)) rank += sh[4 + w]; tot += sh[4 + w]; }
+			if (slot >= 0) d.work[d.start[l] + count + rank] = (u32)slot;
+			count += tot;
+		}
+		if (tid == 0) p.G.workCount[l] = count;
+	}
+}
+
+struct DirtyTailPlan {
+	u32 wgs0, wgs1, gatherWgs; // workgroups: general pass of level 0 | of the levels >= 1 | record gather
+	u32 levels;
+	u32* roleTicket;           // header words (zero at launch): roles are handed out in the order the workgroups arrive,
+	u32* slowDone;             //   finished general workgroups
+	u32 start[MAX_LEVELS + 1];
+	const u32* work;
+	BlockRecord* hostRecs;     // page-locked: [start[levels]] the records of the rebuilt blocks, per level in work-list order
+	u32* hostHeader;           // page-locked: the run's header
+	const u32* devHeader;
+	u32 headerWords, publishedWord;
+};
+
+// Roles by ticket, not by blockIdx: the gather workgroups wait for the general ones, and a wait may only depend on workgroups that
+// are already running - whoever arrives first takes the general roles, whatever its place in the grid.
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_dirty_tail(ExecParamsDev p, DirtyTailPlan t)
+{
+	__shared__ u32 role;
+	const u32 general = t.wgs0 + t.wgs1;
+	if (threadIdx.x == 0) role = atomicAdd(t.roleTicket, 1u);
+	__syncthreads();
+	const u32 ticket = r0_uniform(role);
+	if (ticket < general) {
+		const bool wrote = ticket < t.wgs0 ? regular0_pass<REG_CAP_SMALL, 2>(p, 0u, ticket, t.wgs0)
+		                                   : regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, ticket - t.wgs0, t.wgs1);
+		if (wrote) __threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) atomicAdd(t.slowDone, 1u);
+		return;
+	}
+	const u32 gw = ticket - general;
+	if (threadIdx.x == 0 && (TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1)) != 0u) {
+		u32 spins = 0;
+		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
+			__builtin_amdgcn_s_sleep(4);
+			if (++spins > (u32)WAIT_SPINS) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
+		}
+	}
+	__syncthreads();
+	// one record = 32 dwords: eight records per trip and workgroup
+	static_assert(sizeof(BlockRecord) == 128, "a record is 32 dwords");
+	const u32 total = t.start[t.levels];
+	for (u32 pos = gw * 8u + (threadIdx.x >> 5); pos < total; pos += t.gatherWgs * 8u) {
+		u32 l = 0;
+		for (u32 q = 1; q < t.levels; ++q) if (pos >= t.start[q]) l = q;
+		if (pos - t.start[l] >= TV_LOAD_THROUGH(p.G.workCount + l)) continue;
+		const u32 slot = t.work[pos];
+		((u32*)(t.hostRecs + pos))[threadIdx.x & 31u] = TV_LOAD_THROUGH((const u32*)(p.levels[l].records + slot) + (threadIdx.x & 31u));
+	}
+	if (gw == 0) {
+		for (u32 i = threadIdx.x; i < t.headerWords; i += WG) if (i != t.publishedWord) t.hostHeader[i] = TV_LOAD_THROUGH(t.devHeader + i);
+		__syncthreads();
+		if (threadIdx.x == 0) { __threadfence_system(); t.hostHeader[t.publishedWord] = 1u; }
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_halo_move: the pieces of the halo messages of one side pair (below / above) between their fields and contiguous
 // staging buffers (HaloMove, tv_block.h): blockIdx.y picks the message, one workgroup per row (n bytes of a voxel field,
 // cnt bytes of the flag array).  Unpacking also writes the rows into the brick mirrors (tv_core.h GridView) and the lattice
@@ -2568,7 +2817,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2605,6 +2854,7 @@ struct Backend {
 		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
 		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
+		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1); // 0: incremental runs as the chain of launches with work lists (A/B measurements, tests of that path)
 		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
 		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
 		tune.mainBatch = std::max<u32>(1, env_u32("VX_MAIN_BATCH", 2));
@@ -2653,7 +2903,8 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")
-		    || !check(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_main<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main)")
+		    || !check(hipFuncSetAttribute((const void*)k_main<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main, incremental)")) {
 			err = lastError;
 			return false;
 		}
@@ -3144,8 +3395,63 @@ struct Backend {
 		// number is correct - a workgroup that finds the queues empty leaves - but every workgroup costs a dequeue)
 		u32 grid = (u32)std::min<unsigned long long>(items, (unsigned long long)cus * (withLevel0 ? tune.mainWgsPerCu : tune.upWgsPerCu));
 		if (!withLevel0 && upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
-		launch_with_event(k_main, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
+		launch_with_event(k_main<false>, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
 		check(hipGetLastError(), "k_main launch");
+	}
+
+	// ---- incremental runs as three launches (k_dirty_head | k_main<true> | k_dirty_tail) -------------------------------------------
+	// where the table-driven passes apply and no block beyond the first capacity class is expected (a run that meets one says so
+	// in its header and is repeated as the chain of launches)
+	template <typename P>
+	bool dirty_fused_applies(const P& p, u32 levels, bool largeExpected) const
+	{
+		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
+		return tune.dirtyFused && tune.upper && tune.fast0 && tune.fast1 && !tune.forceWide && !largeExpected && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+	}
+	struct DirtyLaunch {
+		u32 lo[MAX_LEVELS][3], hi[MAX_LEVELS][3], start[MAX_LEVELS + 1];
+		u32* work; u32* info; u32* ticket; u32 ticketTarget;
+		u32* header; u32 resetFrom, resetTo, poolVerts, poolIdx;
+		u32* roleTicket; u32* slowDone;
+		BlockRecord* hostRecs; u32* hostHeader; u32 headerWords, publishedWord;
+	};
+	template <typename P>
+	void run_dirty_fused(const P& p, u32 levels, const DirtyLaunch& q)
+	{
+		DirtyPlan d;
+		memset(&d, 0, sizeof(d));
+		memcpy(d.lo, q.lo, sizeof(d.lo)); memcpy(d.hi, q.hi, sizeof(d.hi)); memcpy(d.start, q.start, sizeof(d.start));
+		d.levels = levels; d.work = q.work; d.info = q.info; d.ticket = q.ticket; d.ticketTarget = q.ticketTarget;
+		d.header = q.header; d.resetFrom = q.resetFrom; d.resetTo = q.resetTo; d.poolVerts = q.poolVerts; d.poolIdx = q.poolIdx;
+		hipLaunchKernelGGL(k_dirty_head, dim3(q.start[1]), dim3(WG), 0, stream, dev(p), d);
+		check(hipGetLastError(), "k_dirty_head launch");
+		MainPlan plan;
+		memset(&plan, 0, sizeof(plan));
+		plan.levels = levels;
+		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
+		plan.level0 = 1u;
+		const u32 slots = (u32)cus * tune.mainWgsPerCu;
+		plan.batch = q.start[1] > 2u * slots ? tune.mainBatch : 1u; // (few blocks: every one its own workgroup)
+		plan.upperNum = tune.mainUpperNum; plan.upperDen = tune.mainUpperDen;
+		memcpy(plan.boxLo, q.lo, sizeof(plan.boxLo)); memcpy(plan.boxHi, q.hi, sizeof(plan.boxHi));
+		u32 items = q.start[1], upperVol = 0;
+		for (u32 l = 1; l < levels; ++l) {
+			const u32 v = q.start[l + 1] - q.start[l];
+			items += v * (1u + (l < plan.fastEnd ? 1u : 0u) + (p.levels[l].hasTransitions ? 1u : 0u));
+			if (l >= plan.fastEnd) upperVol += v;
+		}
+		hipLaunchKernelGGL(k_main<true>, dim3(std::max<u32>(1u, std::min<u32>(items, slots))), dim3(WG), UP_TAB_LDS + MAIN_STATE_LDS, stream, dev(p), plan);
+		check(hipGetLastError(), "k_main (incremental) launch");
+		DirtyTailPlan t;
+		memset(&t, 0, sizeof(t));
+		t.wgs0 = 8u; t.wgs1 = std::max<u32>(8u, std::min<u32>(upperVol, 64u));
+		t.gatherWgs = std::max<u32>(1u, std::min<u32>((q.start[levels] + 7u) / 8u, 64u));
+		t.levels = levels; t.roleTicket = q.roleTicket; t.slowDone = q.slowDone;
+		memcpy(t.start, q.start, sizeof(t.start));
+		t.work = q.work; t.hostRecs = q.hostRecs; t.hostHeader = q.hostHeader; t.devHeader = q.header; t.headerWords = q.headerWords; t.publishedWord = q.publishedWord;
+		const u32 lds = std::max<u32>(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>));
+		hipLaunchKernelGGL(k_dirty_tail, dim3(t.wgs0 + t.wgs1 + t.gatherWgs), dim3(WG), lds, stream, dev(p), t);
+		check(hipGetLastError(), "k_dirty_tail launch");
 	}
 
 	// the same as the single-stream branch of run_overlapped_tail with stage marks in between (vx_set_stage_timing)

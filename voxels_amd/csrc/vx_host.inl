@@ -92,6 +92,8 @@ struct vx_ctx {
 	void *dLut = nullptr, *dTables = nullptr, *dHeader = nullptr; // header (HDR_WORDS u32): slot counts | vertex cursor | index cursor | overflow | stats[20] | workCount[8], one line each
 	void *dDirty = nullptr, *dWork = nullptr, *dGather = nullptr;  // incremental runs: dirty block coords, work items, gathered records
 	u32 dirtyCap = 0;
+	void* dDirtyTicket = nullptr; // incremental runs as three launches: k_dirty_head's count of finished workgroups over all its launches
+	u32 dirtyTickets = 0;         // ... and what the host knows it to be
 	// level tables
 	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0, tablesYb0 = 0, tablesYb1 = 0;
 	u32 refLevels = 0;
@@ -713,6 +715,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->headerSet[0]); c->be.free(c->headerSet[1]);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
+	c->be.free(c->dDirtyTicket);
 	c->be.free(c->dBlobStage); c->be.free_pinned(c->hBlobStage); c->be.free(c->dWhereStage); c->be.free_pinned(c->hWhereStage);
 	arena_recycle(c->hostArena);
 	for (void* hb : c->haloBuf) c->be.free(hb);
@@ -1663,6 +1666,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	std::vector<EmittedBlock> kept[MAX_LEVELS];
 	u32 nextId = c->nextId;
 	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
+	u32 boxLo[MAX_LEVELS][3] = {}, boxHi[MAX_LEVELS][3] = {}; // the levels' dirty boxes in block coordinates (output axes)
 	const float ext = (float)c->n;
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
@@ -1674,6 +1678,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			lo[k] = std::min(std::max(lo[k], 0.f), ext);
 			hi[k] = std::min(std::max(hi[k], 0.f), ext);
 		}
+		for (int k = 0; k < 3; ++k) { boxLo[L][k] = (u32)(lo[k] / bm); boxHi[L][k] = std::max((u32)(hi[k] / bm), boxLo[L][k]); }
 		kept[L].reserve(c->blocks[L].size());
 		for (const EmittedBlock& e : c->blocks[L])
 			if (!(e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2])) kept[L].push_back(e);
@@ -1698,17 +1703,78 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		c->dGather = c->be.alloc((size_t)c->dirtyCap * sizeof(BlockRecord));
 		if (!c->dDirty || !c->dWork || !c->dGather) { c->dirtyCap = 0; return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: allocation failed"); }
 	}
-	if (total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
 	u32 prevActive[MAX_LEVELS];
 	for (u32 L = 0; L < MAX_LEVELS; ++L) prevActive[L] = c->hdr[L];
 	u32 retries = 0;
 	float ms = 0.f;
+	std::vector<BlockRecord> recs(total);
+	// Three launches where the table-driven passes apply (k_dirty_head | k_main<true> | k_dirty_tail, vx_hip.hip): the box goes
+	// out as launch arguments, records and header come back through page-locked memory written by the last kernel.  A run
+	// that meets a block beyond the first capacity class says so in its header and is repeated as the chain of launches.
+	bool fused = false, uploaded = false;
+	{
+		ExecParams p0;
+		fill_params(c, p0, levels);
+		fused = total && cnt[0] && c->be.dirty_fused_applies(p0, levels, c->largeHint);
+	}
+	if (fused) {
+		if (!c->dDirtyTicket) {
+			c->dDirtyTicket = c->be.alloc(64);
+			if (!c->dDirtyTicket || !c->be.fill(c->dDirtyTicket, 0, 64)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: allocation failed");
+			c->dirtyTickets = 0;
+		}
+		if (total > c->hRecCap) {
+			c->be.free_pinned(c->hRecs);
+			c->hRecCap = (size_t)c->dirtyCap;
+			c->hRecs = (BlockRecord*)c->be.alloc_pinned(c->hRecCap * sizeof(BlockRecord));
+			if (!c->hRecs) { c->hRecCap = 0; return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pinned allocation failed"); }
+		}
+		if (!c->hdrPinned) c->hdrPinned = (u32*)c->be.alloc_pinned((HDR_WORDS + HDR_PARTIALS) * 4);
+		if (!c->hdrPinned) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: pinned allocation failed");
+	}
 	for (;;) {
 		ExecParams p;
+		if (fused && ++c->runEpoch == 0) {
+			// (k_main's dependency flags carry the run's tag; on wrap-around they start over)
+			for (u32 L = 1; L < c->refLevels && L < MAX_LEVELS; ++L) if (c->lv[L].matDone && !c->be.fill(c->lv[L].matDone, 0, (size_t)c->lv[L].cap * 8)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: flag reset failed");
+			c->runEpoch = 1;
+		}
 		fill_params(c, p, levels);
 		p.G.dirty = 1;
 		c->be.largeClass = true;
 		for (u32 L = 0; L < levels; ++L) { p.G.workItems[L] = (const u32*)c->dWork + start[L]; p.G.prevActive[L] = prevActive[L]; }
+		if (fused) {
+			Backend::DirtyLaunch q;
+			memset(&q, 0, sizeof(q));
+			for (u32 L = 0; L < levels; ++L) {
+				// (boxLo / boxHi are output coordinates, Y up: internal y = output z, internal z = output y)
+				q.lo[L][0] = boxLo[L][0]; q.lo[L][1] = boxLo[L][2]; q.lo[L][2] = boxLo[L][1];
+				q.hi[L][0] = boxHi[L][0]; q.hi[L][1] = boxHi[L][2]; q.hi[L][2] = boxHi[L][1];
+			}
+			for (u32 L = 0; L <= MAX_LEVELS; ++L) q.start[L] = start[L < levels ? L : levels];
+			q.work = (u32*)c->dWork; q.info = (u32*)c->dDirty;
+			q.ticket = (u32*)c->dDirtyTicket; c->dirtyTickets += cnt[0]; q.ticketTarget = c->dirtyTickets;
+			q.header = (u32*)c->dHeader; q.resetFrom = HDR_CURSORS; q.resetTo = HDR_WORDS; q.poolVerts = c->poolVerts; q.poolIdx = c->poolIdx;
+			q.roleTicket = (u32*)c->dHeader + HDR_PUBLISHED + 2; q.slowDone = (u32*)c->dHeader + HDR_PUBLISHED + 1;
+			q.hostRecs = c->hRecs; q.hostHeader = c->hdrPinned; q.headerWords = HDR_WORDS; q.publishedWord = HDR_PUBLISHED;
+			c->hdrPinned[HDR_PUBLISHED] = 0;
+			c->be.begin_timing();
+			c->be.run_dirty_fused(p, levels, q);
+			c->be.end_timing_record();
+			if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
+			ms = c->be.elapsed_ms();
+			if (c->hdrPinned[HDR_PUBLISHED] == 0) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's header did not arrive (internal error)");
+			memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
+			if (c->hdr[HDR_GIVEUP]) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: a dependency wait inside the run timed out (internal error)");
+			if (c->hdr[HDR_LARGE]) { fused = false; c->largeHint = true; continue; } // a block beyond the first capacity class: once more, as the chain with all classes
+			const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
+			if (!overflow) { if (total) memcpy(recs.data(), c->hRecs, (size_t)total * sizeof(BlockRecord)); break; }
+			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
+			if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+			continue;
+		}
+		if (!uploaded && total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
+		uploaded = true;
 		c->be.begin_timing();
 		c->be.stage_mark(0);
 		{
@@ -1735,13 +1801,14 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		ms = c->be.end_timing_ms();
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
-		if (!overflow) break;
+		if (!overflow) {
+			if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
+			break;
+		}
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 		if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
-	std::vector<BlockRecord> recs(total);
-	if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
 	c->deviceLists = false;
 	u32 trivialBlocks = c->hdr[HDR_STATS + 2];

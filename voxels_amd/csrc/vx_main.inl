@@ -43,8 +43,17 @@ struct MainPlan {
 	                // (k_run_head<allocate>): level-0 blocks and level-1 material blocks form the bitmaps they need
 	u32 batch;      // level-0 slots per dequeue
 	u32 upperNum, upperDen; // workgroups with blockIdx % upperDen < upperNum prefer the upper queue
+	// incremental runs (k_main<true>, vx_polygonize_dirty): the queues hand out the entries of the levels' work lists
+	// (Globals::workItems / workCount, written by k_dirty_head); a material block only waits for the children that are part of
+	// this run - those inside the dirty box of their level ([boxLo, boxHi) in block coordinates x, y, z)
+	u32 boxLo[MAX_LEVELS][3], boxHi[MAX_LEVELS][3];
 };
 
+// DIRTY: the incremental run's form (TransVoxelRun::Execute with a Modification, src/TransVoxelImpl.cpp:429-465): the same two
+// queues over the work lists k_dirty_head wrote - level-0 blocks with the bitmaps the head formed (no SELF), material blocks
+// that keep the old cache contents where the reference does (mat_block: defineAll), and the levels beyond the lattice copies
+// handed to the general pass of the run's last kernel through Globals::slowItems[1].
+template <bool DIRTY>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_main(ExecParamsDev p, MainPlan plan)
 {
 	u8* tab = smem;
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	u32 run = 0;
 #pragma unroll
 	for (u32 l = 0; l < MAX_LEVELS; ++l) {
-		if (l >= 1 && l < plan.levels) run += p.G.slotCounts[l];
+		if (l >= 1 && l < plan.levels) run += DIRTY ? p.G.workCount[l] : p.G.slotCounts[l];
 		matEnd[l] = r0_uniform(run);
 	}
 	const u32 matTotal = matEnd[MAX_LEVELS - 1];
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		if (l < plan.levels && p.levels[l].hasTransitions) trTotal = matEnd[l];
 	}
 	const u32 upperTotal = matTotal + regTotal + trTotal;
-	const u32 total0 = plan.level0 ? r0_uniform(p.G.slotCounts[0]) : 0u;
+	const u32 total0 = plan.level0 ? r0_uniform(DIRTY ? p.G.workCount[0] : p.G.slotCounts[0]) : 0u;
 
 	const GridView& g = p.G.grid;
 	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			if (first >= total0) { level0Left = false; continue; }
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (visible after the walk's first barrier)
 			MAIN_TICK(1);
-			f0_walk<REG_CAP_SMALL, false, true>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
+			f0_walk<REG_CAP_SMALL, false, !DIRTY>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
 			MAIN_TICK(2);
 			continue;
 		}
@@ -123,9 +132,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		u32 level = 1, base = 0;
 #pragma unroll
 		for (u32 l = 1; l + 1 < MAX_LEVELS; ++l) if (f >= matEnd[l]) { level = l + 1; base = matEnd[l]; }
-		const u32 slot = f - base;
+		u32 slot = f - base;
+		if (DIRTY) slot = r0_uniform(p.G.workItems[level][slot]);
 		if (isMat) {
-			mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
+			if (DIRTY) {
+				mat_block<true>(p, level, slot, *(MatLds*)state, tid, false, plan.boxLo[level - 1u], plan.boxHi[level - 1u]);
+				// a level without a lattice copy has no table-driven regular pass: the general pass of the run's last kernel takes the block
+				if (level >= plan.fastEnd && tid0 == 0) p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
+			} else
+				mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
 			MAIN_TICK(3);
 			continue;
 		}
