@@ -237,6 +237,11 @@ int vx_host_meshes_acquire(vx_ctx* ctx, vx_host_meshes* meshes);
 void vx_host_meshes_release(void* arena);
 /* frees the recycled arenas of this process (optional; e.g. before unloading the library) */
 void vx_host_meshes_trim(void);
+/* Page-locks an arena for at least n_verts vertices and n_indices indices ahead of time and puts it into the process's
+ * recycling list: the first vx_host_meshes_acquire of that size then finds it instead of page-locking inside the call
+ * (locking 0.5 GB takes ~130 ms on the bench host, copying into it 9 ms).  What InitializeVoxels does when
+ * VOXELS_PREWARM_MB is set (reference src/Voxels.cpp:35-60 is where an application pays one-time costs). */
+int vx_host_meshes_reserve(vx_ctx* ctx, uint64_t n_verts, uint64_t n_indices);
 /* The same lists as a device-resident table: what PushBlocksToResult (src/TransVoxelImpl.cpp:1266-1293) assembles per
  * block — ranges of its 1 + 6 meshes in the pools, id (:149-152), Y-up corners (:1283-1293) — for the blocks of one level
  * in GetBlockForLevel order (:395-401; blocks without a regular vertex are left out, :1274).  A full run writes the

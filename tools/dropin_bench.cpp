@@ -36,7 +36,9 @@ int main(int argc, char** argv)
 	std::vector<char> blob((size_t)size);
 	if (fread(blob.data(), 1, (size_t)size, f) != (size_t)size) { fclose(f); return 2; }
 	fclose(f);
+	const auto i0 = std::chrono::steady_clock::now();
 	if (InitializeVoxels(VOXELS_VERSION, &Quiet, nullptr) != IE_Ok) return 3;
+	const double initMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - i0).count(); // (one-time costs: device context, optional arena)
 	Mats mats;
 	Polygonizer poly;
 	double best = 1e30, first = 0;
@@ -65,8 +67,8 @@ int main(int argc, char** argv)
 		s->Destroy();
 		g->Destroy();
 	}
-	printf("{\"execute_ms_best\": %.3f, \"execute_ms_first\": %.3f, \"runs\": %d, \"levels\": %u, \"verts\": %llu, \"indices\": %llu, \"grid_file_bytes\": %ld}\n",
-	       best, first, runs, levels, verts, indices, size);
+	printf("{\"execute_ms_best\": %.3f, \"execute_ms_first\": %.3f, \"initialize_ms\": %.3f, \"prewarm_mb\": %d, \"runs\": %d, \"levels\": %u, \"verts\": %llu, \"indices\": %llu, \"grid_file_bytes\": %ld}\n",
+	       best, first, initMs, getenv("VOXELS_PREWARM_MB") ? atoi(getenv("VOXELS_PREWARM_MB")) : 0, runs, levels, verts, indices, size);
 	DeinitializeVoxels();
 	return 0;
 }

@@ -342,7 +342,9 @@ class Polygonizer:
         mx = np.ascontiguousarray(max_corner, np.float32)
         info = ExecInfo()
         cap = 1 << 20
-        ids = np.zeros(cap, np.uint32)
+        ids = getattr(self, "_dirty_ids", None)  # (kept: allocating and zeroing 4 MB per call cost more than a small incremental run)
+        if ids is None:
+            ids = self._dirty_ids = np.zeros(cap, np.uint32)
         cnt = C.c_uint32()
         self._check(self._lib.vx_polygonize_dirty(self._h, _ptr(mn), _ptr(mx), C.byref(info), _ptr(ids), cap, C.byref(cnt)),
                     "vx_polygonize_dirty")

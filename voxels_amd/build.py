@@ -36,7 +36,8 @@ def build_hip(force=False, verbose=True):
     # wrong vertices now and then).  VX_ALLOW_SCRATCH=1 lifts the check for experiments.
     bad = [(k, v["ScratchSize"]) for k, v in table.items() if v.get("ScratchSize", 0)]
     # the gate must not pass because the remark format changed and nothing was parsed
-    missing = [k for k in ("k_regular0", "k_regular", "k_transition", "k_classify", "k_material") if not any(k in name and "ScratchSize" in v for name, v in table.items())]
+    missing = [k for k in ("k_regular0", "k_regular", "k_transition", "k_classify", "k_material", "k_main", "k_tail", "k_run_head", "k_dirty_head", "k_dirty_tail")
+               if not any(k in name and "ScratchSize" in v for name, v in table.items())]
     if missing:
         os.remove(out)
         raise RuntimeError("kernel resource remarks not found for %s: the no-scratch policy cannot be checked (hipcc remark format changed?)" % missing)
@@ -47,36 +48,48 @@ def build_hip(force=False, verbose=True):
     if bad and not os.environ.get("VX_ALLOW_SCRATCH"):
         # A frame can be reserved without ever being touched (spill slots of scalar registers that were all turned into
         # vector-register lanes afterwards): what the policy forbids is scratch TRAFFIC, so a flagged kernel passes if its
-        # code holds no scratch instruction.  The check reads the assembly of a second, device-only compile.
-        bad = [(k, n) for k, n in bad if _executes_scratch(hipcc, k)]
+        # code holds no instruction that can reach the private segment.  One device-only compile to assembly serves all
+        # flagged kernels.
+        touching = _kernels_touching_scratch(hipcc, [k for k, _ in bad])
+        bad = [(k, n) for k, n in bad if k in touching]
     if bad and not os.environ.get("VX_ALLOW_SCRATCH"):
         os.remove(out)
         raise RuntimeError("kernels using scratch memory: %s" % bad)
     return out
 
 
-def _executes_scratch(hipcc, kernel):
-    """Does the gfx950 code of `kernel` (mangled name) contain scratch or private-buffer instructions?"""
+def _kernels_touching_scratch(hipcc, kernels):
+    """Which of `kernels` (mangled names) hold an instruction that can reach the private segment: any scratch_* instruction,
+    or any buffer_* access whose resource is the private-segment descriptor (s[0:3] under the default calling convention -
+    also the constant-offset forms without `offen`).  A kernel whose code cannot be found counts as touching."""
+    import re
     import tempfile
+    touching = set(kernels)
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "vx.s")
         flags = [f for f in HIP_FLAGS if f not in ("-shared", "-fPIC", "-ldl")]
         r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "vx_hip.hip")], cwd=CSRC, capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(asm):
-            return True
-        inside, found_label = False, False
+            return touching
+        current, dirty, seen = None, False, set()
         with open(asm) as f:
             for line in f:
-                if line.startswith(kernel + ":"):
-                    inside, found_label = True, True
+                m = re.match(r"^(\S+):", line)
+                if m and m.group(1) in touching | seen:
+                    current, dirty = m.group(1), False
+                    seen.add(current)
                     continue
-                if inside:
-                    if line.startswith(".Lfunc_end"):
-                        break
-                    code = line.split(";")[0]
-                    if "scratch_" in code or ("buffer_" in code and "offen" in code and "s[0:3]" in code):
-                        return True
-        return not found_label
+                if current is None:
+                    continue
+                if line.startswith(".Lfunc_end"):
+                    if not dirty:
+                        touching.discard(current)
+                    current = None
+                    continue
+                code = line.split(";")[0]
+                if "scratch_" in code or (re.search(r"\bbuffer_(load|store|atomic)", code) and re.search(r"s\[0:3\]", code)):
+                    dirty = True
+    return touching
 
 
 def kernel_resources(remarks):

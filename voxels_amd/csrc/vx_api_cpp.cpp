@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -330,7 +331,7 @@ struct DeviceState
 	// helper contexts for slabs of n / count rows (created on first use, kept); false: the grid is not cut that way
 	bool EnsureHelpers(unsigned n, unsigned count)
 	{
-		if (count < 2 || (n / 16) % count) return false;
+		if (count < 2 || n < 16 * count || (n / 16) % count) return false; // (every helper needs at least one block layer)
 		int devices = 0;
 		if (vx_device_count(&devices) != VX_OK || devices < 1) return false;
 		while (Helpers.size() < count) {
@@ -341,8 +342,17 @@ struct DeviceState
 		return true;
 	}
 
+	// InitializeVoxels brings one context up ahead of time (HIP runtime, code objects, the context's constant tables: ~0.3 s that
+	// would otherwise land on the application's first Execute); the first Polygonizer adopts it.
+	static std::mutex& PrewarmLock() { static std::mutex m; return m; }
+	static std::shared_ptr<DeviceState>& Prewarmed() { static std::shared_ptr<DeviceState> d; return d; }
+
 	static std::shared_ptr<DeviceState> Create()
 	{
+		{
+			std::lock_guard<std::mutex> g(PrewarmLock());
+			if (Prewarmed()) { std::shared_ptr<DeviceState> d; d.swap(Prewarmed()); return d; }
+		}
 		std::shared_ptr<DeviceState> d(new DeviceState);
 		if (vx_ctx_create(0, &d->Ctx) != VX_OK) {
 			d->Ctx = nullptr;
@@ -471,7 +481,7 @@ public:
 	{
 		const unsigned n = g->Size(), rows = n / devices;
 		unsigned helperLevels = 1;
-		for (unsigned m = rows / 16; !(m & 1u); m >>= 1) ++helperLevels; // coarsest block that divides the slab (and its origin)
+		for (unsigned m = rows / 16; m && !(m & 1u); m >>= 1) ++helperLevels; // coarsest block that divides the slab (and its origin); (rows >= 16: EnsureHelpers)
 		unsigned refLevels = 1;
 		for (unsigned v = n / 16; v >>= 1;) ++refLevels;
 		if (helperLevels > refLevels) helperLevels = refLevels;
@@ -485,7 +495,15 @@ public:
 			if (m) { memcpy(lut + id * 6, m->DiffuseIds0, 3); memcpy(lut + id * 6 + 3, m->DiffuseIds1, 3); }
 		}
 		std::vector<HelperResult> res(devices);
-		std::vector<std::thread> threads;
+		// (the helpers read `flags`, `lut`, `valid` and `g`: whatever happens below - a thread that cannot be started, an
+		// allocation that fails - every started thread is joined before those go out of scope)
+		struct Joiner {
+			std::vector<std::thread> threads;
+			void join() { for (std::thread& t : threads) if (t.joinable()) t.join(); }
+			~Joiner() { join(); }
+		} helpers;
+		std::vector<std::thread>& threads = helpers.threads;
+		threads.reserve(devices);
 		for (unsigned i = 0; i < devices; ++i)
 			threads.emplace_back(&TransVoxelImpl::RunHelper, Device->Helpers[i], (const VoxelGrid*)g, (const uint8_t*)flags.data(), (const uint8_t*)lut, (const uint8_t*)valid, i * rows, (i + 1) * rows, helperLevels, &res[i]);
 		// the primary, on the calling thread
@@ -513,7 +531,7 @@ public:
 			}
 			FillStats(ctx, s->Stats);
 		}
-		for (std::thread& t : threads) t.join();
+		helpers.join();
 		for (unsigned i = 0; i < devices; ++i) { s->ShardMeshes.push_back(res[i].Meshes); ok = ok && res[i].Ok; } // (the surface owns the copies from here on)
 		if (!ok) { Log(LS_Error, vx_last_error(ctx)); for (vx_ctx* h : Device->Helpers) if (h && *vx_last_error(h)) Log(LS_Error, vx_last_error(h)); return nullptr; }
 		// the finer levels: every helper's blocks, merged by id (ids number the blocks of the whole grid: = GetBlockForLevel order)
@@ -649,11 +667,28 @@ extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage lo
 	char buffer[128];
 	snprintf(buffer, sizeof(buffer), "Voxels library initialized - ver. %#010x (MI355X / %s)", VOXELS_VERSION, vx_backend());
 	Voxels::Log(Voxels::LS_Info, buffer);
+	// One-time costs belong here, not into the application's first Execute (408 ms at 1024^3 without this: HIP runtime and
+	// code objects ~0.25 s, page-locking the first mesh arena ~0.13 s).  VOXELS_NO_PREWARM=1 skips the context,
+	// VOXELS_PREWARM_MB=<n> also page-locks an arena for n MB of meshes (vertices : indices as 5 : 1 by bytes).
+	if (!getenv("VOXELS_NO_PREWARM")) {
+		std::shared_ptr<Voxels::DeviceState> d = Voxels::DeviceState::Create();
+		if (d) {
+			const char* mb = getenv("VOXELS_PREWARM_MB");
+			const uint64_t bytes = mb ? (uint64_t)atoll(mb) << 20 : 0;
+			if (bytes) (void)vx_host_meshes_reserve(d->Ctx, bytes * 5 / 6 / sizeof(Voxels::PolygonVertex), bytes / 6 / 4);
+			std::lock_guard<std::mutex> g(Voxels::DeviceState::PrewarmLock());
+			Voxels::DeviceState::Prewarmed() = d;
+		}
+	}
 	return Voxels::IE_Ok;
 }
 
 extern "C" void DeinitializeVoxels()
 {
+	{
+		std::lock_guard<std::mutex> g(Voxels::DeviceState::PrewarmLock());
+		Voxels::DeviceState::Prewarmed().reset();
+	}
 	vx_host_meshes_trim();
 	Voxels::Log(Voxels::LS_Info, "Voxels library deinitialized");
 	Voxels::g_Logger = nullptr;

@@ -2299,7 +2299,13 @@ __device__ __forceinline__ void list_write_pass(const ExecParamsDev& p, const Li
 	const u32 l = list_level_of(plan, levels, w), tid = threadIdx.x;
 	const LevelDesc& L = p.levels[l];
 	const u32 id = (w - plan.wgStart[l]) * LIST_WG + tid;
-	const int slot = listed_block_slot(L, id);
+	// (countsThrough = inside k_tail: records and counts may come from the general workgroups of this very launch, on another
+	// XCD - every read of them goes past the caches that no other XCD's store refreshes)
+	int slot = listed_block_slot(L, id);
+	if (countsThrough) {
+		slot = id < L.cnt * L.cnt * L.cnt ? L.slotOf[id] : -1;
+		if (slot >= 0 && TV_LOAD_THROUGH(&L.records[slot].vCount) == 0u) slot = -1;
+	}
 	// listed blocks of this level in the workgroups before this one
 	u32 before = 0;
 	for (u32 q = plan.wgStart[l] + tid; q < w; q += LIST_WG) before += countsThrough ? TV_LOAD_THROUGH(plan.counts + q) : plan.counts[q];
@@ -2316,7 +2322,19 @@ __device__ __forceinline__ void list_write_pass(const ExecParamsDev& p, const Li
 	__syncthreads();
 	u32 rank = (u32)__popcll(mask & ((1ull << (tid & 63)) - 1ull));
 	for (u32 q = 0; q < (tid >> 6); ++q) rank += waveSum[q];
-	if (slot >= 0) listed_block_fill(L.listed[base + rank], L, id, (u32)slot, plan.idBase[l]);
+	if (slot >= 0) {
+		ListedBlock& out = L.listed[base + rank];
+		listed_block_fill(out, L, id, (u32)slot, plan.idBase[l]);
+		if (countsThrough) {
+			static_assert(sizeof(BlockRecord) == 128 && offsetof(ListedBlock, rec) == 0, "a record is eight 16-byte pieces at the head of a listed block");
+#pragma unroll
+			for (u32 q = 0; q < 8; ++q) { // (list entries are 156 bytes apart: dword stores)
+				const uint4 v = load16_through(L.records + slot, q * 16u);
+				u32* dst = (u32*)&out.rec + q * 4u;
+				dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+			}
+		}
+	}
 	// The header is complete when every level's total is written (everything else in it was final before the list pass):
 	// the workgroups that write a total count themselves - one returning atomic per level, not per workgroup, which on a
 	// 1024^3 grid were 1170 serialised round trips - and the last of them publishes.
@@ -2346,32 +2364,46 @@ __global__ __launch_bounds__(LIST_WG) void k_list_write(ExecParamsDev p, ListPla
 // k_tail: what follows k_main in a single-stream run, as ONE launch (a launch behind k_main costs ~4.5 us on this chip
 // whether it finds work or not - three of them were a tenth of a 128^3 run): the general passes over what the table-driven
 // level-0 blocks and the table-driven blocks of the levels >= 1 handed on (blocks with a zero sample: none, or a handful)
-// as the first workgroups, the block lists as the rest.  The list workgroups need every record: they wait until the
-// general workgroups - which wait for nobody, and are dispatched first - have counted themselves done.  A general
-// workgroup that wrote something makes it visible device-wide first (records and list counts are read by list workgroups
-// on other XCDs; those have not touched the lines before the wait, so their L2 holds no older copy).
+// and the block lists.  The list workgroups need every record: they wait until the general workgroups - which wait for
+// nobody - have counted themselves done (roles: see the kernel).  A general workgroup that wrote something makes it visible
+// device-wide first (records and list counts are read by list workgroups on other XCDs: through write-through loads where
+// the list pass reads what this launch wrote).
 // ------------------------------------------------------------------------------------------------------
 struct TailPlan {
 	u32 wgs0, wgs1, listWgs; // workgroups: general pass of level 0 | of the levels >= 1 | lists
 	u32 levels;
 	u32* slowDone;           // finished general workgroups (a header word: zeroed with the run's counters)
+	u32* roleTicket;         // (the header word behind it) roles handed out in order of arrival, see below
 	ResetRanges next;        // the counters and maps of the OTHER set, which the next run will use: put into their start state here
 };
 
+// Roles.  Nothing was handed on (the rule on a terrain; two header words say so): the general workgroups find nothing, the list
+// workgroups wait for nobody, and a workgroup's role is its place in the grid.  Something was handed on: the list workgroups
+// wait for the general ones - and a wait may only depend on workgroups that are already running, whatever order the hardware
+// dispatches them in - so every workgroup draws a ticket and the first `general` tickets are the general passes (one returning
+// atomic per workgroup on one address: ~10 us at 1024^3, paid only by runs that met a block with a zero sample).
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_tail(ExecParamsDev p, ListPlan plan, HeaderPublish pub, TailPlan t)
 {
 	static_assert(LIST_WG == WG, "one workgroup shape for the passes of k_tail");
+	__shared__ u32 roleSh[2];
 	const u32 general = t.wgs0 + t.wgs1;
-	if (blockIdx.x < general) {
-		const bool wrote = blockIdx.x < t.wgs0 ? regular0_pass<REG_CAP_SMALL, 2>(p, 0u, blockIdx.x, t.wgs0)
-		                                       : regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, blockIdx.x - t.wgs0, t.wgs1);
+	if (threadIdx.x == 0) {
+		const u32 handed = TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1);
+		roleSh[0] = handed;
+		roleSh[1] = handed ? atomicAdd(t.roleTicket, 1u) : blockIdx.x;
+	}
+	__syncthreads();
+	const bool handedOn = r0_uniform(roleSh[0]) != 0u;
+	const u32 role = r0_uniform(roleSh[1]);
+	if (role < general) {
+		const bool wrote = role < t.wgs0 ? regular0_pass<REG_CAP_SMALL, 2>(p, 0u, role, t.wgs0)
+		                                 : regular_pass<REG_CAP_SMALL, 2>(p, 1u, t.levels, 0u, role - t.wgs0, t.wgs1);
 		if (wrote) __threadfence();
 		__syncthreads();
 		if (threadIdx.x == 0) atomicAdd(t.slowDone, 1u);
 		return;
 	}
-	// (nothing was handed on - the rule on a terrain: the general workgroups have nothing to write, and nobody waits for them)
-	if (threadIdx.x == 0 && (TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1)) != 0u) {
+	if (threadIdx.x == 0 && handedOn) {
 		u32 spins = 0;
 		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
 			__builtin_amdgcn_s_sleep(4);
@@ -2379,10 +2411,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		}
 	}
 	__syncthreads();
-	list_write_pass(p, plan, t.levels, pub, blockIdx.x - general, t.listWgs, true);
+	list_write_pass(p, plan, t.levels, pub, role - general, t.listWgs, true);
 	if (t.next.header) {
 		const u32 lanes = t.listWgs * WG;
-		for (u32 i = (blockIdx.x - general) * WG + threadIdx.x; i * 4u < t.next.start[MAX_LEVELS] || i < t.next.listWgs; i += lanes) {
+		for (u32 i = (role - general) * WG + threadIdx.x; i * 4u < t.next.start[MAX_LEVELS] || i < t.next.listWgs; i += lanes) {
 			reset_words(t.next, i);
 			if (i < t.next.listWgs) t.next.listCounts[i] = 0;
 		}
@@ -2520,24 +2552,31 @@ __global__ __launch_bounds__(WG) void k_dirty_head(ExecParamsDev p, DirtyPlan d)
 		p.G.stats[2] = sh[3] & 0xFFFFu;
 		*p.G.largeBlocks = sh[3] >> 16;
 	}
-	for (u32 l = 0; l < d.levels; ++l) {
-		const LevelDesc& U = p.levels[l];
-		const u32 V = d.start[l + 1] - d.start[l], dx = d.hi[l][0] - d.lo[l][0], dy = d.hi[l][1] - d.lo[l][1];
-		u32 count = 0;
-		for (u32 base = 0; base < V; base += WG) {
-			const u32 i = base + (u32)tid;
-			int slot = -1;
-			if (i < V) slot = TV_LOAD_THROUGH(&U.slotOf[block_coord_id(d.lo[l][0] + i % dx, d.lo[l][1] + (i / dx) % dy, d.lo[l][2] + i / (dx * dy), U.cnt)]);
-			const unsigned long long m = __ballot(slot >= 0);
-			__syncthreads(); // (sh[4..7] of the previous trip are read)
-			if ((tid & 63) == 0) sh[4 + (tid >> 6)] = (u32)__popcll(m);
-			__syncthreads();
-			u32 rank = (u32)__popcll(m & ((1ull << (tid & 63)) - 1ull)), tot = 0;
-			for (u32 w = 0; w < (u32)(WG / 64); ++w) { if (w < ((u32)tid >> 6)) rank += sh[4 + w]; tot += sh[4 + w]; }
-			if (slot >= 0) d.work[d.start[l] + count + rank] = (u32)slot;
-			count += tot;
+	// the work lists: a wave per level (levels beyond the fourth: a second turn), 64 coordinates of the level's box per step, four
+	// steps' slots requested together; the list keeps the box's coordinate order
+	{
+		const u32 lane = (u32)tid & 63u;
+		for (u32 l = (u32)tid >> 6; l < d.levels; l += (u32)(WG / 64)) {
+			const LevelDesc& U = p.levels[l];
+			const u32 V = d.start[l + 1] - d.start[l], dx = d.hi[l][0] - d.lo[l][0], dy = d.hi[l][1] - d.lo[l][1];
+			u32 count = 0;
+			for (u32 base = 0; base < V; base += 256u) {
+				int slot[4];
+#pragma unroll
+				for (u32 q = 0; q < 4; ++q) {
+					const u32 i = min(base + q * 64u + lane, V - 1u);
+					slot[q] = TV_LOAD_THROUGH(&U.slotOf[block_coord_id(d.lo[l][0] + i % dx, d.lo[l][1] + (i / dx) % dy, d.lo[l][2] + i / (dx * dy), U.cnt)]);
+				}
+#pragma unroll
+				for (u32 q = 0; q < 4; ++q) {
+					const bool have = base + q * 64u + lane < V && slot[q] >= 0;
+					const unsigned long long m = __ballot(have);
+					if (have) d.work[d.start[l] + count + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)slot[q];
+					count += (u32)__popcll(m);
+				}
+			}
+			if (lane == 0) p.G.workCount[l] = count;
 		}
-		if (tid == 0) p.G.workCount[l] = count;
 	}
 }
 
@@ -3444,7 +3483,13 @@ struct Backend {
 		check(hipGetLastError(), "k_main (incremental) launch");
 		DirtyTailPlan t;
 		memset(&t, 0, sizeof(t));
-		t.wgs0 = 8u; t.wgs1 = std::max<u32>(8u, std::min<u32>(upperVol, 64u));
+		// a general workgroup per block that could be handed on (zero samples on a carved surface are not rare: the ball brush puts
+		// them wherever x^2 + y^2 + z^2 = r^2 has lattice solutions, and a general block takes 40-60 us): they all run side by side,
+		// the ones that find nothing leave at once
+		u32 upperAll = 0;
+		for (u32 l = 1; l < levels; ++l) upperAll += q.start[l + 1] - q.start[l];
+		t.wgs0 = std::max<u32>(8u, std::min<u32>(q.start[1], 192u)); t.wgs1 = std::max<u32>(8u, std::min<u32>(upperAll, 192u));
+		(void)upperVol;
 		t.gatherWgs = std::max<u32>(1u, std::min<u32>((q.start[levels] + 7u) / 8u, 64u));
 		t.levels = levels; t.roleTicket = q.roleTicket; t.slowDone = q.slowDone;
 		memcpy(t.start, q.start, sizeof(t.start));
@@ -3629,7 +3674,7 @@ struct Backend {
 		if (tail) {
 			// (with or without list workgroups: the general passes were left to this launch)
 			TailPlan t;
-			t.wgs0 = tailWgs[0]; t.wgs1 = tailWgs[1]; t.listWgs = wgs; t.levels = levels; t.slowDone = tailDone;
+			t.wgs0 = tailWgs[0]; t.wgs1 = tailWgs[1]; t.listWgs = wgs; t.levels = levels; t.slowDone = tailDone; t.roleTicket = tailDone + 1;
 			t.next = nextReset;
 			if (!wgs || !tune.tailCleans) t.next.header = nullptr;
 			tailCleaned = t.next.header != nullptr;

@@ -1663,7 +1663,8 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	// Nothing of the context's surface state (block lists, id counter) is touched before the device run has succeeded:
 	// the lists without the dropped blocks are built aside and swapped in at the end.
 	std::vector<u32> coords, ids;
-	std::vector<EmittedBlock> kept[MAX_LEVELS];
+	std::vector<EmittedBlock> fresh[MAX_LEVELS];                 // the rebuilt blocks, in list order
+	float dropLo[MAX_LEVELS][3] = {}, dropHi[MAX_LEVELS][3] = {}; // per level: blocks whose minimal corner lies in here are dropped (:443-450)
 	u32 nextId = c->nextId;
 	u32 start[MAX_LEVELS + 1] = { 0 }, cnt[MAX_LEVELS] = { 0 };
 	u32 boxLo[MAX_LEVELS][3] = {}, boxHi[MAX_LEVELS][3] = {}; // the levels' dirty boxes in block coordinates (output axes)
@@ -1679,9 +1680,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			hi[k] = std::min(std::max(hi[k], 0.f), ext);
 		}
 		for (int k = 0; k < 3; ++k) { boxLo[L][k] = (u32)(lo[k] / bm); boxHi[L][k] = std::max((u32)(hi[k] / bm), boxLo[L][k]); }
-		kept[L].reserve(c->blocks[L].size());
-		for (const EmittedBlock& e : c->blocks[L])
-			if (!(e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2])) kept[L].push_back(e);
+		for (int k = 0; k < 3; ++k) { dropLo[L][k] = lo[k]; dropHi[L][k] = hi[k]; }
 		start[L] = (u32)coords.size();
 		for (u32 z = (u32)(lo[1] / bm); z < (u32)(hi[1] / bm); ++z)      // internal z = output y
 		for (u32 y = (u32)(lo[2] / bm); y < (u32)(hi[2] / bm); ++y)
@@ -1770,7 +1769,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 			if (!overflow) { if (total) memcpy(recs.data(), c->hRecs, (size_t)total * sizeof(BlockRecord)); break; }
 			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
-			if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+			// (appended blocks fill the pools' slack edit after edit: growing by half keeps overflows - a repeated run, a copy of
+			// the pools and an allocation, ~1 ms - rare; vx_compact_pools gives dead ranges back)
+			if (!grow_pools_keeping(c, usedV + usedV / 2 + 1024, usedI + usedI / 2 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 			continue;
 		}
 		if (!uploaded && total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
@@ -1806,7 +1807,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			break;
 		}
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
-		if (!grow_pools_keeping(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+		if (!grow_pools_keeping(c, usedV + usedV / 2 + 1024, usedI + usedI / 2 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
@@ -1830,11 +1831,20 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			e.rec = r;
 			e.id = ids[start[L] + k];
 			block_corners(d, coord, e.minc, e.maxc);
-			kept[L].push_back(std::move(e));
+			fresh[L].push_back(std::move(e));
 		}
 		if (L) trivialBlocks += cnt[L];
 	}
-	for (u32 L = 0; L < levels; ++L) c->blocks[L].swap(kept[L]);
+	// the lists change in place, now that nothing can fail any more: the dropped blocks leave (everything behind the first of
+	// them moves up, nothing is copied in front of it), the rebuilt ones are appended (:1274-1293)
+	for (u32 L = 0; L < levels; ++L) {
+		std::vector<EmittedBlock>& list = c->blocks[L];
+		const float* lo = dropLo[L];
+		const float* hi = dropHi[L];
+		list.erase(std::remove_if(list.begin(), list.end(), [lo, hi](const EmittedBlock& e) {
+			return e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2]; }), list.end());
+		list.insert(list.end(), fresh[L].begin(), fresh[L].end());
+	}
 	c->nextId = nextId;
 	c->stats[0] = total;
 	c->stats[2] = c->hdr[HDR_STATS + 0];
@@ -1969,6 +1979,16 @@ int vx_host_meshes_acquire(vx_ctx* c, vx_host_meshes* m)
 }
 
 void vx_host_meshes_release(void* arena) { arena_recycle((HostArena*)arena); }
+
+int vx_host_meshes_reserve(vx_ctx* c, uint64_t n_verts, uint64_t n_indices)
+{
+	VX_ENTER(c);
+	if (!c) return VX_ERR_INVALID;
+	HostArena* a = arena_get(c, (size_t)n_verts, (size_t)n_indices);
+	if (!a) return fail(c, VX_ERR_DEVICE, "vx_host_meshes_reserve: page-locked allocation failed");
+	arena_recycle(a);
+	return VX_OK;
+}
 
 void vx_host_meshes_trim(void)
 {
