@@ -108,7 +108,7 @@ struct Pools {
 // levels >= 1 read 17 contiguous bytes per sample row instead of 17 bytes that are 2^L apart.  Same brick
 // layout as the grid's mirrors (tv_core.h brick_local): the 16^3 lattice samples of a level-L block are 4 KB of
 // consecutive addresses; the far samples live in one more brick along every axis.
-enum { PYRAMID_LEVELS = 4 }; // levels 1..3 have a lattice copy; coarser levels (at most 64 blocks) gather from the grid
+enum { PYRAMID_LEVELS = 7 }; // levels 1..6 have a lattice copy (every level of a grid up to 1024^3: the table-driven passes cover them all; round 4 stopped at 3 and left the coarser levels - few blocks, but 100 us each in the general pass - to gather from the grid)
 struct PyramidLevel {
 	i8* data;             // nullptr: no copy of this level
 	u32 bricksX, bricksY; // bricks per row of bricks, rows of bricks per plane of bricks
@@ -153,7 +153,7 @@ struct Globals {
 	// scratch, rebuilt by every full run from emptyFlags + one sample per empty block (level-0 blocks, [cnt0^3]):
 	u8* blockClass;                   // BC_* bits: what the classify pass may assume without reading the block
 	const u16* blockSign;             // per level-0 block, kept with the grid's mirrors: eight 2-bit sign summaries (MirrorState)
-	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..3]: lattice copies of the distance field for the coarser levels (GPU backend)
+	PyramidLevel pyr[PYRAMID_LEVELS]; // [1..]: lattice copies of the distance field for the coarser levels (GPU backend)
 	XPlanes xp[XPLANE_LEVELS];        // yz-planes of the lattices 0..2 at every 32nd x (the x faces of the transition pass)
 	// full runs: blocks the fast regular passes (tv_fast0.h, tv_fast1.h) hand on to the general pass (a zero sample, a LOD
 	// chain ending on a voxel).  [0]: level-0 slots; [1]: level << 24 | slot for the levels >= 1

@@ -492,100 +492,175 @@ __global__ __launch_bounds__(WG) void k_copy_segments(const u32* seg, const u32*
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_encode_grid: dense fields -> Grid file format v1 (CompressBlock for every stream of every block).  One workgroup
-// per block; lane t owns the 16-byte row t (codec order).  Run starts = value changes and every 255 voxels inside a
-// constant stretch (start of the stretch by a workgroup-wide max-scan); run ids by an exclusive scan of the start
-// counts; a run's length is the distance to the next start.  Pass 1 (blob == nullptr) writes sizes + flags, pass 2
-// writes the records at the offsets the host derived from them.
+// k_encode_grid: dense fields -> Grid file format v1 (CompressBlock, src/VoxelGrid.cpp:610-672, for every stream of every
+// block).  One workgroup per EIGHT x-neighbour blocks, like k_decode_grid: a voxel row of the eight blocks is one 128-byte line
+// of the dense field, and lane (block tid & 7, row group tid >> 3) fetches eight of its block's rows - whole lines per
+// request, where one block per workgroup read an eighth of every line it touched (and its seven x-neighbours, dealt to the
+// other seven XCDs, fetched the same lines again: 3.45 ms per pass at 1024^3 for 3.2 GB of fields).
+//   * A stream whose 4096 bytes are one value - most streams of a terrain - is 16 runs of 255 and one of 16: written without
+//     a scan.  Pass 1 leaves "constant, value" per stream in the block's fourth meta word; pass 2 does not read such a
+//     stream again.
+//   * Any other stream goes through the codec's rule with the whole workgroup, block by block, out of LDS: lane t owns the
+//     16-byte row t (codec order).  Run starts = value changes and every 255 voxels inside a constant stretch (start of the
+//     stretch by a workgroup-wide max-scan); run ids by an exclusive scan of the start counts; a run's length is the
+//     distance to the next start; beyond 2048 runs the stream is stored raw.
+// Pass 1 (blob == nullptr) writes sizes + flags, pass 2 writes the records at the offsets the host derived from them.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_encode_grid(GridView g, u32* meta, const unsigned long long* where, u8* blob)
 {
+	__shared__ __attribute__((aligned(16))) u8 rowsLds[8][4096]; // the current stream of the eight blocks, codec order
 	__shared__ u8 lastOfRow[WG];
 	__shared__ int waveMax[WG / 64];
 	__shared__ u32 waveSum[WG / 64];
 	__shared__ u16 startPos[2048 + 2];
 	__shared__ u8 vals[2048];
-	const u32 n = (u32)g.n, nb = n >> 4, id = blockIdx.x, t = threadIdx.x;
-	const u32 bx = id % nb, by = (id / nb) % nb, bz = id / (nb * nb);
-	const size_t rowOff = ((size_t)(bz * 16 + (t >> 4)) * n + by * 16 + (t & 15)) * n + bx * 16;
-	u8* dst = blob ? blob + where[id] + 4 : nullptr;
-	u32 flags = 0;
+	__shared__ u32 notConst[8];  // per block: the current stream holds more than one value
+	__shared__ u32 blockFlags[8]; // per block: BF_Empty | raw bits
+	__shared__ u32 recOff[8];     // per block: bytes of the record's streams written so far
+	__shared__ u32 hint[8];       // pass 2: the fourth meta word pass 1 left
+	const u32 n = (u32)g.n, nb = n >> 4, t = threadIdx.x, groups = (nb + 7u) >> 3;
+	const u32 gx = blockIdx.x % groups, by = (blockIdx.x / groups) % nb, bz = blockIdx.x / (groups * nb);
+	const u32 firstId = (bz * nb + by) * nb + gx * 8u, count = min(8u, nb - gx * 8u);
+	const u32 blk = t & 7u, rg = t >> 3;
+	if (t < 8) { blockFlags[t] = 0; recOff[t] = 0; hint[t] = (blob && t < count) ? meta[(firstId + t) * 4u + 3u] : 0u; }
+	__syncthreads();
 #pragma unroll 1
 	for (u32 s = 0; s < 3; ++s) {
-		const u8* src = (s == 0 ? (const u8*)g.dist : (s == 1 ? g.mat : g.blend)) + rowOff;
-		const uint4 rawRow = *(const uint4*)src;
-		u8 v[16];
-		memcpy(v, &rawRow, 16);
-		__syncthreads(); // LDS of the previous stream is free
-		lastOfRow[t] = v[15];
-		__syncthreads();
-		u8 prev = t ? lastOfRow[t - 1] : (u8)~v[0]; // voxel 0 always starts a run
-		int lastStart = -1;
+		const u8* field = s == 0 ? (const u8*)g.dist : (s == 1 ? g.mat : g.blend);
+		// pass 2: a stream pass 1 found constant is not read again
+		const u32 myHint = hint[blk];
+		const bool known = blob && ((myHint >> (4u + s)) & 1u);
+		uint4 r[8];
 #pragma unroll
-		for (int j = 0; j < 16; ++j) { if (v[j] != prev) lastStart = (int)t * 16 + j; prev = v[j]; }
-		int incl = lastStart;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((int)(t & 63) >= d) incl = max(incl, o); }
-		if ((t & 63) == 63) waveMax[t >> 6] = incl;
-		__syncthreads();
-		int start = __shfl_up(incl, 1);
-		if ((t & 63) == 0) start = -1;
-		for (u32 w = 0; w < (t >> 6); ++w) start = max(start, waveMax[w]);
-		u32 startMask = 0; // which of this row's voxels start a run
-		prev = t ? lastOfRow[t - 1] : (u8)~v[0];
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			const int pos = (int)t * 16 + j;
-			if (v[j] != prev) start = pos;
-			prev = v[j];
-			if ((pos - start) % 255 == 0) startMask |= 1u << j;
+		for (u32 it = 0; it < 8; ++it) {
+			const u32 row = it * 32u + rg;
+			r[it] = make_uint4(0, 0, 0, 0);
+			if (blk < count && !known) r[it] = *(const uint4*)(field + ((size_t)(bz * 16u + (row >> 4)) * n + by * 16u + (row & 15u)) * n + (gx * 8u + blk) * 16u);
 		}
-		// exclusive scan of the start counts -> id of this row's first run; total = number of runs
-		const u32 mine = (u32)__popc(startMask);
-		u32 inclSum = mine;
+		__syncthreads(); // the rows of the previous stream are no longer read
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inclSum, d); if ((int)(t & 63) >= d) inclSum += o; }
-		if ((t & 63) == 63) waveSum[t >> 6] = inclSum;
+		for (u32 it = 0; it < 8; ++it) *(uint4*)&rowsLds[blk][(it * 32u + rg) * 16u] = r[it];
+		if (t < 8) notConst[t] = 0;
 		__syncthreads();
-		u32 base = inclSum - mine, runs = 0;
-		for (u32 w = 0; w < WG / 64; ++w) { if (w < (t >> 6)) base += waveSum[w]; runs += waveSum[w]; }
-		const bool raw = runs > 2048u;
-		const u32 sz = raw ? 4096u : 2u * runs;
-		if (raw) flags |= 2u << s;
-		if (!blob) {
-			if (t == 0) meta[id * 4 + s] = sz;
-		} else if (raw) {
+		const u32 first = known ? ((myHint >> (8u + 8u * s)) & 0xFFu) : (u32)rowsLds[blk][0];
+		{
+			const u32 f4 = first * 0x01010101u;
+			u32 diff = 0;
 #pragma unroll
-			for (int j = 0; j < 16; ++j) dst[t * 16 + j] = v[j];
-		} else {
-			u32 r = base;
-			u32 m = startMask;
-			while (m) {
-				const int j = __builtin_ctz(m);
-				m &= m - 1;
-				startPos[r] = (u16)(t * 16 + j);
-				vals[r] = v[j];
-				++r;
+			for (u32 it = 0; it < 8; ++it) diff |= (r[it].x ^ f4) | (r[it].y ^ f4) | (r[it].z ^ f4) | (r[it].w ^ f4);
+			const unsigned long long m = __ballot(diff != 0u && !known && blk < count);
+			if ((t & 63u) < 8u && ((m >> (t & 63u)) & 0x0101010101010101ull)) notConst[t & 63u] = 1u; // (lanes b, b + 8, ... of a wave belong to block b)
+		}
+		__syncthreads();
+		// ---- constant streams: 16 x { 255, v } + { 16, v }; BF_Empty <=> the value is not zero -------------------------
+		if (t < 8 && t < count && !notConst[t]) {
+			if (!blob) {
+				meta[(firstId + t) * 4u + s] = 34u;
+				hint[t] |= (1u << (4u + s)) | (first << (8u + 8u * s)); // (pass 1: collected here, stored with the flags)
 			}
-			if (t == 0) startPos[runs] = 4096;
+			if (s == 0 && first != 0u) blockFlags[t] |= 1u;
+		}
+		if (blob && t < 8u * 17u) {
+			const u32 b = t / 17u, k = t % 17u;
+			if (b < count && !notConst[b]) {
+				const u32 h = hint[b];
+				const u32 v = ((h >> (4u + s)) & 1u) ? ((h >> (8u + 8u * s)) & 0xFFu) : (u32)rowsLds[b][0];
+				u8* dst = blob + where[firstId + b] + 4 + recOff[b];
+				dst[2 * k] = (u8)(k < 16u ? 255u : 16u);
+				dst[2 * k + 1] = (u8)v;
+			}
+		}
+		__syncthreads();
+		if (t < 8 && t < count && !notConst[t]) recOff[t] += 34u;
+		// ---- the other streams: one block at a time, all lanes (uniform loop: the flags are the workgroup's) -------------
+		for (u32 b = 0; b < count; ++b) {
+			if (!notConst[b]) continue;
+			__syncthreads(); // LDS scratch of the previous block is free
+			u8 v[16];
+			{
+				const uint4 rawRow = *(const uint4*)&rowsLds[b][t * 16u];
+				memcpy(v, &rawRow, 16);
+			}
+			u8* dst = blob ? blob + where[firstId + b] + 4 + recOff[b] : nullptr;
+			lastOfRow[t] = v[15];
 			__syncthreads();
-			for (u32 q = t; q < runs; q += WG) {
-				dst[2 * q] = (u8)(startPos[q + 1] - startPos[q]);
-				dst[2 * q + 1] = vals[q];
+			u8 prev = t ? lastOfRow[t - 1] : (u8)~v[0]; // voxel 0 always starts a run
+			int lastStart = -1;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) { if (v[j] != prev) lastStart = (int)t * 16 + j; prev = v[j]; }
+			int incl = lastStart;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((int)(t & 63) >= d) incl = max(incl, o); }
+			if ((t & 63) == 63) waveMax[t >> 6] = incl;
+			__syncthreads();
+			int start = __shfl_up(incl, 1);
+			if ((t & 63) == 0) start = -1;
+			for (u32 w = 0; w < (t >> 6); ++w) start = max(start, waveMax[w]);
+			u32 startMask = 0; // which of this row's voxels start a run
+			prev = t ? lastOfRow[t - 1] : (u8)~v[0];
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const int pos = (int)t * 16 + j;
+				if (v[j] != prev) start = pos;
+				prev = v[j];
+				if ((pos - start) % 255 == 0) startMask |= 1u << j;
+			}
+			// exclusive scan of the start counts -> id of this row's first run; total = number of runs
+			const u32 mine = (u32)__popc(startMask);
+			u32 inclSum = mine;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inclSum, d); if ((int)(t & 63) >= d) inclSum += o; }
+			if ((t & 63) == 63) waveSum[t >> 6] = inclSum;
+			__syncthreads();
+			u32 base = inclSum - mine, runs = 0;
+			for (u32 w = 0; w < WG / 64; ++w) { if (w < (t >> 6)) base += waveSum[w]; runs += waveSum[w]; }
+			const bool raw = runs > 2048u;
+			const u32 sz = raw ? 4096u : 2u * runs;
+			if (!blob) {
+				if (t == 0) meta[(firstId + b) * 4u + s] = sz;
+			} else if (raw) {
+#pragma unroll
+				for (int j = 0; j < 16; ++j) dst[t * 16 + j] = v[j];
+			} else {
+				u32 q = base;
+				u32 m = startMask;
+				while (m) {
+					const int j = __builtin_ctz(m);
+					m &= m - 1;
+					startPos[q] = (u16)(t * 16 + j);
+					vals[q] = v[j];
+					++q;
+				}
+				if (t == 0) startPos[runs] = 4096;
+				__syncthreads();
+				for (u32 k = t; k < runs; k += WG) {
+					dst[2 * k] = (u8)(startPos[k + 1] - startPos[k]);
+					dst[2 * k + 1] = vals[k];
+				}
+			}
+			bool same = true;
+			if (s == 0) {
+				const int firstSample = (int)(i8)rowsLds[b][0];
+#pragma unroll
+				for (int j = 0; j < 16; ++j) same = same && (firstSample * (int)(i8)v[j] > 0);
+			}
+			const int allSame = __syncthreads_and(same ? 1 : 0);
+			if (t == 0) {
+				if (raw) blockFlags[b] |= 2u << s;
+				if (s == 0 && allSame && !raw) blockFlags[b] |= 1u;
+				recOff[b] += sz;
 			}
 		}
-		if (s == 0) {
-			const i8 firstSample = *(const i8*)((const u8*)g.dist + ((size_t)(bz * 16) * n + by * 16) * n + bx * 16);
-			bool same = true;
-#pragma unroll
-			for (int j = 0; j < 16; ++j) same = same && ((int)firstSample * (int)(i8)v[j] > 0);
-			if (__syncthreads_and(same ? 1 : 0) && !raw) flags |= 1u;
-		}
-		if (dst) dst += sz;
 	}
-	if (t == 0) {
-		if (!blob) meta[id * 4 + 3] = flags;
-		else { u8* rec = blob + where[id]; rec[0] = (u8)flags; rec[1] = 0; rec[2] = 0; rec[3] = 0; }
+	__syncthreads();
+	if (t < 8 && t < count) {
+		// (pass 2 takes BF_Empty of a stream it did not read from pass 1's word)
+		if (!blob) meta[(firstId + t) * 4u + 3u] = blockFlags[t] | (hint[t] & ~0xFu);
+		else {
+			const u32 fl = blockFlags[t] | (((hint[t] >> 4) & 1u) ? (hint[t] & 1u) : 0u);
+			u8* rec = blob + where[firstId + t];
+			rec[0] = (u8)fl; rec[1] = 0; rec[2] = 0; rec[3] = 0;
+		}
 	}
 }
 
@@ -655,7 +730,7 @@ __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, co
 __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, int n, int xs, int y, int z, uint4 d)
 {
 #pragma unroll
-	for (int l = 1; l < PYRAMID_LEVELS; ++l) {
+	for (int l = 1; l < 4; ++l) {
 		const PyramidLevel& P = pyr[l];
 		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
 		i8* at = P.data + pyramid_offset(P, xs >> l, y >> l, z >> l); // 8 / 4 / 2 lattice samples: inside one brick row
@@ -669,6 +744,16 @@ __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, i
 		} else {
 			*(u16*)at = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
 		}
+		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
+	}
+	// levels >= 4: at most one lattice sample per segment (its first voxel), on one row in 256 - a loop that is not unrolled
+	// (k_rebrick is a copy kernel: the registers of three more unrolled levels cost it a wave per SIMD)
+	if ((y | z) & 15) return;
+#pragma unroll 1
+	for (int l = 4; l < PYRAMID_LEVELS; ++l) {
+		const PyramidLevel& P = pyr[l];
+		if (!P.data || ((y | z) & ((1 << l) - 1))) break;
+		if (!(xs & ((1 << l) - 1))) P.data[pyramid_offset(P, xs >> l, y >> l, z >> l)] = (i8)(d.x & 0xFFu);
 		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
 	}
 }
@@ -702,7 +787,7 @@ __device__ __forceinline__ void lattice_rows_of(const MirrorState& X, int n, int
 		if (zFar) xplane_write_segment(X.xp, n, xs, y, n, d);
 		if (yFar && zFar) xplane_write_segment(X.xp, n, xs, n, n, d);
 	}
-	if (!X.pyr[1].data && !X.pyr[2].data && !X.pyr[3].data) return;
+	if (!X.pyr[1].data) return; // (the copies of the coarser levels exist where this one does)
 	if (!((y | z) & 1)) pyramid_write_segment(X.pyr, n, xs, y, z, d);
 	if (yFar && !(z & 1)) pyramid_write_segment(X.pyr, n, xs, n, z, d);
 	if (zFar && !(y & 1)) pyramid_write_segment(X.pyr, n, xs, y, n, d);
@@ -2329,7 +2414,7 @@ __device__ __forceinline__ void list_write_pass(const ExecParamsDev& p, const Li
 			static_assert(sizeof(BlockRecord) == 128 && offsetof(ListedBlock, rec) == 0, "a record is eight 16-byte pieces at the head of a listed block");
 #pragma unroll
 			for (u32 q = 0; q < 8; ++q) { // (list entries are 156 bytes apart: dword stores)
-				const uint4 v = load16_through(L.records + slot, q * 16u);
+				const uint4 v = load16_through(L.records, (u32)slot * (u32)sizeof(BlockRecord) + q * 16u); // (the base is the level's, uniform: it travels in scalar registers)
 				u32* dst = (u32*)&out.rec + q * 4u;
 				dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
 			}
@@ -3096,7 +3181,7 @@ struct Backend {
 	void run_encode_grid(const GridView& g, u32* meta, const uint64_t* where, u8* blob)
 	{
 		const u32 nb = (u32)g.n / 16;
-		hipLaunchKernelGGL(k_encode_grid, dim3(nb * nb * nb), dim3(WG), 0, stream, g, meta, (const unsigned long long*)where, blob);
+		hipLaunchKernelGGL(k_encode_grid, dim3(((nb + 7u) / 8u) * nb * nb), dim3(WG), 0, stream, g, meta, (const unsigned long long*)where, blob);
 		check(hipGetLastError(), "k_encode_grid launch");
 	}
 	void run_heightmap(const GridView& g, const i8* map, u8* flags)
