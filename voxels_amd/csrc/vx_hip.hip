@@ -65,6 +65,7 @@ struct ExecParamsDev {
 constexpr int WG = 256;
 constexpr int REG_CAP_SMALL = LARGE_THRESHOLD; // LDS capacity class of the regular pass that covers ordinary surfaces
 constexpr int REG_CAP_MID = 1536;               // second class of the table-driven passes (dense surfaces: three workgroups per CU instead of one in the 4096-cell class)
+constexpr int REG_CAP_BIG = 4096;               // third class of the table-driven passes: every block (two workgroups per CU; round 4 left blocks beyond 1536 cells to the general pass at one workgroup per CU)
 
 // ------------------------------------------------------------------------------------------------------
 // workgroup helpers
@@ -2941,7 +2942,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -2978,6 +2979,7 @@ struct Backend {
 		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
 		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
+		tune.bigClass = env_u32("VX_BIG_CLASS", 1); // 0: blocks beyond REG_CAP_MID cells through the general pass, as until round 4 (A/B measurements)
 		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1); // 0: incremental runs as the chain of launches with work lists (A/B measurements, tests of that path)
 		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
 		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
@@ -3015,6 +3017,7 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Small), "hipFuncSetAttribute(k_regular0 small, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, f0Small), "hipFuncSetAttribute(k_regular0_fast)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>))), "hipFuncSetAttribute(k_regular0_fast mid)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular0_fast<REG_CAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>))), "hipFuncSetAttribute(k_regular0_fast big)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular0<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, r0Large), "hipFuncSetAttribute(k_regular0 large, handed on)")) {
 			err = lastError;
 			return false;
@@ -3023,6 +3026,7 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular<REG_CAP_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regSmall), "hipFuncSetAttribute(k_regular small, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>))), "hipFuncSetAttribute(k_regular1_fast)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>))), "hipFuncSetAttribute(k_regular1_fast mid)")
+		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>))), "hipFuncSetAttribute(k_regular1_fast big)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
@@ -3413,9 +3417,13 @@ struct Backend {
 				if (spread) { (void)hipStreamWaitEvent(sideC, evClassified, 0); spreadC = true; }
 				if (!level0Done) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_SMALL>), dim3(gridS), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_SMALL>), on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_MID>), dim3(std::min<u32>(cap, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_MID>), upper, dev(p), (u32)REG_CAP_SMALL);
+				// the third class (blocks beyond REG_CAP_MID cells), table-driven as well: behind the second on its stream; what the
+				// three classes hand on (zero samples) is complete when all of them are done
+				const u32 ldsB = F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>), gridB = std::min<u32>(cap, (u32)cus * 4);
+				if (largeClass && tune.bigClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_BIG>), dim3(gridB), dim3(WG), ldsB, upper, dev(p), (u32)REG_CAP_MID);
 				if (spread) {
 					(void)hipEventRecord(evMidC, sideC);
-					hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, sideC, dev(p), (u32)REG_CAP_MID);
+					if (!tune.bigClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, sideC, dev(p), (u32)REG_CAP_MID);
 					(void)hipEventRecord(evSideC, sideC);
 					(void)hipStreamWaitEvent(on, evMidC, 0);
 				}
@@ -3423,7 +3431,7 @@ struct Backend {
 				if (!tailPending) hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(tailWgs[0]), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
-					if (!spread) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
+					if (!spread && !tune.bigClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
 				}
 			} else {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 0>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
@@ -3453,9 +3461,10 @@ struct Backend {
 				if (spread) { (void)hipStreamWaitEvent(sideD, evMaterial, 0); spreadD = true; }
 				if (!upperDone) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
 				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), upper, dev(p), fastEnd, (u32)REG_CAP_SMALL);
+				if (largeClass && tune.bigClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_BIG>, dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>), upper, dev(p), fastEnd, (u32)REG_CAP_MID);
 				if (spread) {
 					(void)hipEventRecord(evMidD, sideD);
-					hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, sideD, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
+					if (!tune.bigClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, sideD, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
 					(void)hipEventRecord(evSideD, sideD);
 					(void)hipStreamWaitEvent(on, evMidD, 0);
 				}
@@ -3463,7 +3472,7 @@ struct Backend {
 				if (!tailPending) hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(tailWgs[1]), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
-					if (!spread) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
+					if (!spread && !tune.bigClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
 				}
 				generalBegin = fastEnd;
 			}
@@ -3530,7 +3539,8 @@ struct Backend {
 	bool dirty_fused_applies(const P& p, u32 levels, bool largeExpected) const
 	{
 		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
-		return tune.dirtyFused && tune.upper && tune.fast0 && tune.fast1 && !tune.forceWide && !largeExpected && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+		(void)largeExpected; // (blocks beyond the first capacity class: two launches more, see run_dirty_fused)
+		return tune.dirtyFused && tune.upper && tune.fast0 && tune.fast1 && !tune.forceWide && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	struct DirtyLaunch {
 		u32 lo[MAX_LEVELS][3], hi[MAX_LEVELS][3], start[MAX_LEVELS + 1];
@@ -3539,8 +3549,11 @@ struct Backend {
 		u32* roleTicket; u32* slowDone;
 		BlockRecord* hostRecs; u32* hostHeader; u32 headerWords, publishedWord;
 	};
+	// largeExpected: blocks with more non-trivial cells than the first capacity class holds are left alone by k_main<true>; the
+	// 4096-cell class of the general pass takes them from the work lists, in two launches of its own in front of the tail
+	// (launched only when the run before met such blocks; a run that meets one unannounced says so in its header and is repeated)
 	template <typename P>
-	void run_dirty_fused(const P& p, u32 levels, const DirtyLaunch& q)
+	void run_dirty_fused(const P& p, u32 levels, const DirtyLaunch& q, bool largeExpected)
 	{
 		DirtyPlan d;
 		memset(&d, 0, sizeof(d));
@@ -3566,6 +3579,13 @@ struct Backend {
 		}
 		hipLaunchKernelGGL(k_main<true>, dim3(std::max<u32>(1u, std::min<u32>(items, slots))), dim3(WG), UP_TAB_LDS + MAIN_STATE_LDS, stream, dev(p), plan);
 		check(hipGetLastError(), "k_main (incremental) launch");
+		if (largeExpected) {
+			const u32 ldsL0 = R0_TAB_LDS + sizeof(Reg0State<4096>), ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
+			hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus))), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+			const u32 upper = q.start[levels] - q.start[1];
+			if (upper) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
+			check(hipGetLastError(), "large-class launches (incremental)");
+		}
 		DirtyTailPlan t;
 		memset(&t, 0, sizeof(t));
 		// a general workgroup per block that could be handed on (zero samples on a carved surface are not rare: the ball brush puts
