@@ -370,6 +370,44 @@ def test_hip_carve_modify_matches_reference_fixture(poly, port):
     assert np.array_equal(poly.stats(), gold.stats)
 
 
+def test_hip_fast_flag_protocol_equals_the_conservative_one(port):
+    """k_main's workgroups hand material caches, bitmaps and cell counts to each other through write-through stores, relaxed
+    flags and write-through loads (no fences).  libvoxels_hip_conservative.so is the same source with release / acquire
+    fences around every flag (-DVX_CONSERVATIVE_SYNC): both libraries on the same grids - full runs with every level, the
+    bench's 4 levels, an incremental run - must produce the same bytes, and one of them is checked against the oracle."""
+    from voxels_amd import Polygonizer, digest, synth
+    from voxels_amd.binding import HipLibrary
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voxels_amd", "csrc", "libvoxels_hip_conservative.so")
+    assert os.path.exists(path), "libvoxels_hip_conservative.so missing (run __graft_entry__.build())"
+    slow = Polygonizer(device=0, library=HipLibrary(path))
+    fast = Polygonizer(device=0)
+    for q in (slow, fast):
+        q.set_materials(vxo.default_lut())
+    try:
+        for n, seed, levels in ((256, 5, 0), (512, 1337, 4), (128, 9, 0)):
+            got = []
+            for q in (slow, fast):
+                q.create_terrain(n, seed)
+                for _ in range(3):  # (repeated: the flags of one run must not be taken for the next one's)
+                    q.execute(levels)
+                got.append(digest.surface_digest(q.all_levels()))
+            assert digest.digests_equal(got[0], got[1]), "n=%d: fast and conservative flag protocols disagree" % n
+            if n == 256:
+                d, m, b = synth.terrain(n, seed=seed)
+                ref = port.execute(port.grid_from_dense(d, m, b)).all_levels()
+                ok, msg = fields.surface_equal(slow.all_levels(), ref, nrm_tol=NRM_TOL)
+                assert ok, msg
+        # an incremental run on both (k_main<true>: the same flags, a subset of the blocks)
+        got = []
+        for q in (slow, fast):
+            mn, mx = q.inject_ball((60.0, 64.0, 70.0), (24.0, 24.0, 24.0), 11.0, 2)
+            q.execute_dirty(mn, mx)
+            got.append(digest.surface_digest(q.all_levels()))
+        assert digest.digests_equal(got[0], got[1]), "incremental run: fast and conservative flag protocols disagree"
+    finally:
+        slow.close(); fast.close()
+
+
 def test_hip_incremental_runs_as_chain_of_launches(port):
     """Incremental runs are three launches by default (k_dirty_head | k_main<true> | k_dirty_tail); the chain of launches
     with work lists remains for surfaces with blocks beyond the first capacity class.  The same chain of edits through a

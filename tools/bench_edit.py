@@ -54,7 +54,10 @@ def main():
     # steady state (BASELINE config 5): a chain of r = 20 carves along the surface, per call wall time and device time - on the
     # three-launch path (k_dirty_head | k_main<true> | k_dirty_tail) and, in a second context, on the chain of launches
     steady = {}
-    for label, env in (("fused", None), ("chain", "0")):
+    # (ball centres: lattice points put exact zero samples wherever x^2 + y^2 + z^2 = r^2 has integer solutions - blocks with a zero
+    # sample take the general pass, 40-60 us each, in the run's last kernel; an application's brush positions are arbitrary
+    # floats, so both kinds are timed: "frac" = centres off the lattice, "int" = the lattice-point worst case)
+    for label, env, frac in (("fused", None, (0.37, 0.61, 0.23)), ("fused, lattice-point centres", None, (0.0, 0.0, 0.0)), ("chain", "0", (0.37, 0.61, 0.23))):
         if env is not None:
             os.environ["VX_DIRTY_FUSED"] = env
         w = Polygonizer()
@@ -63,21 +66,21 @@ def main():
         w.upload(*pre, oracle.grid_from_dense(*pre).block_flags())
         w.execute(0)
         calls, devs, blocks = [], [], 0
-        for k in range(12):
-            pk = (pos[0] + 23.0 * (k % 4) - 30.0, pos[1] + 19.0 * (k // 4) - 20.0, pos[2] + 2.0 * (k % 3))
+        for k in range(16):
+            pk = (pos[0] + 23.0 * (k % 4) - 30.0 + frac[0], pos[1] + 19.0 * (k // 4) - 20.0 + frac[1], pos[2] + 2.0 * (k % 3) + frac[2])
             a, bq = w.inject_ball(pk, ext, r, 2)
             t = time.perf_counter(); got = w.execute_dirty(a, bq); dt = time.perf_counter() - t
             if k >= 2:
                 calls.append(dt * 1e3); devs.append(w.info.device_ms); blocks += got.size
-        steady[label] = (float(np.mean(calls)), float(np.min(calls)), float(np.mean(devs)), blocks / len(calls), w)
+        steady[label] = (float(np.mean(calls)), float(np.median(calls)), float(np.min(calls)), float(np.mean(devs)), blocks / len(calls), w, float(np.max(calls)))
     from voxels_amd import digest
-    da, db = digest.surface_digest(steady["fused"][4].all_levels()), digest.surface_digest(steady["chain"][4].all_levels())
+    da, db = digest.surface_digest(steady["fused"][5].all_levels()), digest.surface_digest(steady["chain"][5].all_levels())
     assert digest.digests_equal(da, db), "the two incremental paths disagree"
     print("grid %d^3, IT_Subtract ball r=%g, extents %s: %d blocks changed, %d blocks rebuilt" % (n, r, ext, bids.size, ids.size))
-    for label in ("fused", "chain"):
-        m, lo, dv, nb, _ = steady[label]
-        print("  steady state, %s path: vx_polygonize_dirty %.4f ms per call (best %.4f), device %.4f ms, %.0f blocks rebuilt per call" % (label, m, lo, dv, nb))
-    print("  surfaces after the 12 edits: equal on both paths (digest %016x)" % int(da[1]))
+    for label in ("fused", "fused, lattice-point centres", "chain"):
+        m, med, lo, dv, nb, _, hi = steady[label]
+        print("  steady state, %s: vx_polygonize_dirty %.4f ms per call (median %.4f, best %.4f, worst %.4f), device %.4f ms, %.0f blocks rebuilt per call" % (label, m, med, lo, hi, dv, nb))
+    print("  surfaces after the 16 edits: equal on both paths (digest %016x)" % int(da[1]))
     print("  device edit (vx_grid_inject_ball, incl. BF_Empty refresh): %7.3f ms" % (t_dev * 1e3))
     print("  incremental polygonization (vx_polygonize_dirty)          : %7.3f ms (device %.3f ms)" % (t_poly * 1e3, dev1))
     print("  second edit (r=12): device edit %.3f ms, vx_polygonize_dirty %.3f ms (device %.3f ms), %d blocks rebuilt" % (t_dev2 * 1e3, t_poly2 * 1e3, dev2, idsb.size))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A chain of sphere carves with incremental runs on a resident terrain (BASELINE config 5 shape), for kernel traces and
-timings: python tools/edit_run.py [n=512] [levels=0] [edits=8].  Prints per-call wall and device time."""
+timings: python tools/edit_run.py [n=512] [levels=0] [edits=8] [frac=0.37].  Prints per-call wall and device time."""
 import os
 import sys
 import time
@@ -18,6 +18,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     levels = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     edits = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    frac = float(sys.argv[4]) if len(sys.argv) > 4 else 0.37  # ball centres off the lattice (0 = lattice points: exact zero samples on the ball)
     p = Polygonizer(device=0)
     p.set_materials(synth.default_lut())
     p.create_terrain(n, 1337)
@@ -27,7 +28,7 @@ def main():
     zs = float(np.argmax(col >= 0)) if (col >= 0).any() else n * 0.5  # a point on the surface
     calls, devs, blocks = [], [], []
     for k in range(edits):
-        pos = (n / 2.0 + 23.0 * (k % 4) - 30.0, n / 2.0 + 19.0 * (k // 4) - 20.0, zs + 2.0 * (k % 3))
+        pos = (n / 2.0 + 23.0 * (k % 4) - 30.0 + frac, n / 2.0 + 19.0 * (k // 4) - 20.0 + frac * 1.65, zs + 2.0 * (k % 3) + frac * 0.62)
         mn, mx = p.inject_ball(pos, (44.0, 44.0, 44.0), 20.0, 2)
         t = time.perf_counter()
         got = p.execute_dirty(mn, mx)

@@ -118,6 +118,18 @@ def build_hip_casedump(force=False):
     return out
 
 
+def build_hip_conservative(force=False):
+    """Test build of the HIP library whose in-kernel dependency flags use release / acquire fences instead of write-through
+    stores and loads (-DVX_CONSERVATIVE_SYNC, vx_hip.hip): tests/test_gpu_parity.py compares it with the product library."""
+    out = os.path.join(CSRC, "libvoxels_hip_conservative.so")
+    srcs = [os.path.join(CSRC, f) for f in ("vx_hip.hip", "vx_regular0.inl", "vx_fast0.inl", "vx_fast1.inl", "vx_main.inl", "vx_host.inl", "tv_block.h", "tv_core.h", "tv_fast0.h", "tv_fast1.h", "tv_tables.inc")]
+    if not force and not _newer(out, srcs):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc] + HIP_FLAGS + ["-DVX_CONSERVATIVE_SYNC", "-o", out, os.path.join(CSRC, "vx_hip.hip")], cwd=CSRC)
+    return out
+
+
 def build_synth(force=False):
     """Host-side synthetic input generator (include/voxels_synth.h)."""
     out = os.path.join(CSRC, "libvoxels_synth.so")

@@ -169,11 +169,22 @@ __device__ __forceinline__ void store16_through(void* uniformBase, u32 byteOffse
 	v4u32 x = { v.x, v.y, v.z, v.w };
 	__builtin_amdgcn_raw_buffer_store_b128(x, rsrc, (int)byteOffset, 0, /* aux: sc1 */ 16);
 }
+// -DVX_CONSERVATIVE_SYNC (libvoxels_hip_conservative.so, a test build of the same sources): the textbook form of the same
+// protocol - every producer wave releases at agent scope before the barrier, the flag is a release store, the poll an acquire
+// load, and every consumer wave acquires behind the barrier - so that nothing rests on which stores and loads were written
+// as write-through ones.  tests/test_gpu_parity.py runs both libraries on the same grids and compares every byte: a payload
+// access the fast protocol forgot to route past the caches shows as a difference there (or in the stress runs).
 __device__ __forceinline__ void publish_done_through(unsigned long long* flag, u32 epoch, u32 payload)
 {
+#if defined(VX_CONSERVATIVE_SYNC)
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) __hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
 	__syncthreads();
 	if (threadIdx.x == 0) __hip_atomic_store(flag, ((unsigned long long)epoch << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 enum { WAIT_SPINS = 1u << 17 }; // x ~1 us per poll: a tenth of a second, against runs of a millisecond
@@ -183,7 +194,11 @@ enum { WAIT_SPINS = 1u << 17 }; // x ~1 us per poll: a tenth of a second, agains
 __device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epoch, u32* giveUp)
 {
 	for (u32 spins = 0;; ++spins) {
+#if defined(VX_CONSERVATIVE_SYNC)
+		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#else
 		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 		if ((u32)(v >> 32) == epoch) return (u32)v;
 		if (spins > (u32)WAIT_SPINS || ((spins & 255u) == 255u && __hip_atomic_load(giveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { atomicOr(giveUp, 1u); return 0u; }
 		__builtin_amdgcn_s_sleep(4);
@@ -198,6 +213,9 @@ __device__ __forceinline__ void acquire_and_meet(bool polled)
 {
 	(void)polled;
 	__syncthreads();
+#if defined(VX_CONSERVATIVE_SYNC)
+	__threadfence(); // every wave that is about to read what the producers published
+#endif
 }
 
 __device__ __forceinline__ uint4 load16_through(const void* uniformBase, u32 byteOffset)

@@ -103,6 +103,10 @@ struct vx_ctx {
 	// pools
 	void *dVerts = nullptr, *dIdx = nullptr;
 	u32 vertCap = 0, idxCap = 0;
+	void *dVertsSpare = nullptr, *dIdxSpare = nullptr; // vx_compact_pools: the pair the live meshes are packed into (kept; swaps roles with the pools)
+	u32 spareVertCap = 0, spareIdxCap = 0;
+	void* dSeg = nullptr;                              // ... and its copy list
+	size_t segCap = 0;
 	// results
 	u32 levelsRun = 0;
 	bool haveSurface = false;
@@ -713,6 +717,7 @@ void vx_ctx_destroy(vx_ctx* c)
 	free_bricks(c);
 	free_level_tables(c);
 	c->be.free(c->dVerts); c->be.free(c->dIdx);
+	c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare); c->be.free(c->dSeg);
 	c->be.free(c->dTables); c->be.free(c->dLut); c->be.free(c->headerSet[0]); c->be.free(c->headerSet[1]);
 	c->be.free(c->dDirty); c->be.free(c->dWork); c->be.free(c->dGather);
 	c->be.free_pinned(c->hRecs);
@@ -1617,22 +1622,39 @@ int vx_compact_pools(vx_ctx* c)
 			for (int f = 0; f < 6; ++f) { moveV(e.rec.tvOff[f], e.rec.tvCount[f]); moveI(e.rec.tiOff[f], e.rec.tiCount[f]); }
 		}
 	}
-	const u32 capV = std::max<u32>(nv + nv / 8 + 1024, 1u << 16), capI = std::max<u32>(ni + ni / 8 + 4096, 1u << 18);
-	void* newV = c->be.alloc((size_t)capV * sizeof(PolyVertex));
-	void* newI = c->be.alloc((size_t)capI * 4);
-	void* dSeg = c->be.alloc((segV.size() + segI.size() + 4) * 4);
-	bool ok = newV && newI && dSeg;
+	// The live meshes move into a second pair of pools, which the context keeps from then on (the pools swap roles at every
+	// compaction): allocating and freeing pool-sized device buffers cost 15-55 ms per compaction - every eight or so edits
+	// of BASELINE config 5 - against 0.3 ms for the copy itself.  The spare pair has the pools' own capacity.
+	if (c->spareVertCap < c->vertCap || c->spareIdxCap < c->idxCap) {
+		c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
+		c->dVertsSpare = c->be.alloc((size_t)c->vertCap * sizeof(PolyVertex));
+		c->dIdxSpare = c->be.alloc((size_t)c->idxCap * 4);
+		c->spareVertCap = c->dVertsSpare ? c->vertCap : 0; c->spareIdxCap = c->dIdxSpare ? c->idxCap : 0;
+		if (!c->dVertsSpare || !c->dIdxSpare) {
+			c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
+			c->dVertsSpare = c->dIdxSpare = nullptr; c->spareVertCap = c->spareIdxCap = 0;
+			return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed");
+		}
+	}
+	const size_t segWords = segV.size() + segI.size() + 4;
+	if (segWords * 4 > c->segCap) {
+		c->be.free(c->dSeg);
+		c->segCap = segWords * 4 + segWords;
+		c->dSeg = c->be.alloc(c->segCap);
+		if (!c->dSeg) { c->segCap = 0; return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed"); }
+	}
+	void* dSeg = c->dSeg;
+	bool ok = true;
 	if (ok && !segV.empty()) ok = c->be.h2d(dSeg, segV.data(), segV.size() * 4);
 	if (ok && !segI.empty()) ok = c->be.h2d((u32*)dSeg + segV.size(), segI.data(), segI.size() * 4);
 	if (ok) {
-		c->be.run_copy_segments((const u32*)dSeg, (u32)(segV.size() / 3), c->dVerts, newV, (u32)sizeof(PolyVertex));
-		c->be.run_copy_segments((const u32*)dSeg + segV.size(), (u32)(segI.size() / 3), c->dIdx, newI, 4u);
+		c->be.run_copy_segments((const u32*)dSeg, (u32)(segV.size() / 3), c->dVerts, c->dVertsSpare, (u32)sizeof(PolyVertex));
+		c->be.run_copy_segments((const u32*)dSeg + segV.size(), (u32)(segI.size() / 3), c->dIdx, c->dIdxSpare, 4u);
 		ok = c->be.sync_ok();
 	}
-	c->be.free(dSeg);
-	if (!ok) { c->be.free(newV); c->be.free(newI); return fail(c, VX_ERR_DEVICE, "vx_compact_pools: device copy failed: " + c->be.error()); }
-	c->be.free(c->dVerts); c->be.free(c->dIdx);
-	c->dVerts = newV; c->dIdx = newI; c->vertCap = capV; c->idxCap = capI;
+	if (!ok) return fail(c, VX_ERR_DEVICE, "vx_compact_pools: device copy failed: " + c->be.error());
+	std::swap(c->dVerts, c->dVertsSpare); std::swap(c->dIdx, c->dIdxSpare);
+	std::swap(c->vertCap, c->spareVertCap); std::swap(c->idxCap, c->spareIdxCap);
 	c->deviceLists = false;
 	c->poolVerts = nv; c->poolIdx = ni;
 	c->poolLineage = next_lineage(); // host copies describe the old layout
