@@ -11,6 +11,14 @@
 // one vertex and one lane = one triangle (three indices).  5 barriers.
 namespace {
 
+#if defined(VX_F0_PROFILE)
+// tools builds: where a level-0 block's time goes inside f0_walk (cycles / 64 as thread 0 sees them, summed over all blocks)
+__device__ unsigned long long g_f0prof[12];
+#define F0_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_f0prof[i], (now_ - f0Tick) >> 6); f0Tick = now_; } while (0)
+#else
+#define F0_TICK(i) do { } while (0)
+#endif
+
 constexpr u32 F0_TAB_FIXED = TAB_F0_BYTES - TAB_F0_CASE;   // case rows | triangle rows | edge infos | direction masks
 constexpr u32 F0_TAB_LDS = F0_TAB_FIXED + 2048;            // + the per-case vertex rows widened to 8 bytes
 
@@ -240,16 +248,22 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 	if (have) f0_request<SELF>(g, L, cur, pf);
 	it += stride;
 	bool haveNext = have && f0_next<CAP, REMAP, SELF>(p, L, total, lo, stride, limit, it, f0_peek<REMAP>(p, L, total, limit, it), nxt);
+#if defined(VX_F0_PROFILE)
+	unsigned long long f0Tick = __builtin_readcyclecounter();
+#endif
 	while (have) {
 		const u32 candIt = it + stride;
 		R0Candidate cand;
+		F0_TICK(0); // (between blocks: next-item bookkeeping)
 		__syncthreads(); // the previous block is done with the LDS state (and the tables are staged)
+		F0_TICK(1);
 		{
 			const u32 z = f0_deposit<SELF>(st, L, cur, pf);
 			if (__ballot(z != 0) && (tid & 63) == 0) zeroFlag[parity] = 1;
 			if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
 		}
 		__syncthreads();
+		F0_TICK(2); // deposit (waits for the prefetched loads) + barrier
 		const bool clean = r0_uniform(zeroFlag[parity]) == 0;
 		parity ^= 1u;
 		bool requested = false;
@@ -264,6 +278,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				if (cells > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u); // (the host repeats the run with the upper classes)
 			}
 			mine = cells != 0 && cells <= (u32)CAP;
+			F0_TICK(3); // own bitmap + barrier
 		}
 		if (mine && clean) {
 			// ---- popcount prefix of the bitmap (every wave computes all of it: no exchange), compact cell list ----------
@@ -294,6 +309,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				}
 			}
 			__syncthreads();
+			F0_TICK(4); // prefix + compact list + barrier
 
 			// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
 			const u32 nt = r0_uniform(st.wordPrefix[128]);
@@ -318,6 +334,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				if (lane == 0) st.waveTot[wave] = carry;
 			}
 			__syncthreads();
+			F0_TICK(5); // cells + barrier
 			{
 				u32 waveBase = 0, tot = 0;
 #pragma unroll
@@ -343,10 +360,11 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				}
 			}
 			__syncthreads();
+			F0_TICK(6); // bases + reservation + descriptors + barrier
 
 			const u32 vTotalU = r0_uniform(st.vTotal), tTotalU = r0_uniform(st.tTotal);
-			const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
 			const int ox = (int)(cur.bx * 16), oy = (int)(cur.by * 16), oz = (int)(cur.bz * 16);
+			const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
 			// Vertices and indices leave in ONE loop, and the next block's inputs are requested inside its first trip (a loop
 			// with stores that is entered while loads are in flight makes the compiler drain the memory queue in front of it).
 			if (room) {
@@ -391,6 +409,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 					}
 				}
 			}
+			F0_TICK(7); // vertices + triangles (+ the next block's requests)
 			if (tid == 0) {
 				BlockRecord& r = L.records[cur.slot];
 				r.coordId = cur.coord;
@@ -403,6 +422,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				if (!room) atomicOr(&p.P.cursors[CUR_OVF], 1u);
 				wgStats[0] += nt;
 			}
+			F0_TICK(8); // record
 		} else if (mine && tid == 0) {
 			// a zero sample: the general pass takes the block
 			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;

@@ -1527,6 +1527,18 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		for (int i = 0; i < 7; ++i) fprintf(stderr, "[main profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
 	}
 #endif
+#if defined(VX_F0_PROFILE)
+	{
+		static const char* names[9] = { "between blocks", "top barrier", "deposit + barrier", "own bitmap + barrier", "prefix + list + barrier", "cells + barrier", "bases + reserve + describe + barrier", "vertices + triangles", "record" };
+		unsigned long long v[12], sum = 0;
+		if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_f0prof), sizeof(v)) == hipSuccess) {
+			for (int i = 0; i < 9; ++i) sum += v[i];
+			for (int i = 0; i < 9; ++i) fprintf(stderr, "[f0 profile] %-36s %12llu x64 cycles  %5.1f %%\n", names[i], v[i], 100.0 * (double)v[i] / (double)(sum ? sum : 1));
+			memset(v, 0, sizeof(v));
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(g_f0prof), v, sizeof(v));
+		}
+	}
+#endif
 #if defined(VX_CLS_PROFILE)
 	{
 		static const char* names[5] = { "class bytes + init", "loads + sign masks", "classification", "slot allocation (+ ancestors)", "bitmap stores" };
