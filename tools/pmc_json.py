@@ -44,7 +44,7 @@ def main():
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) of "
                      "`%s`; summaries committed as profiles/%s_pmc_*.txt" % (command, label),
            "units": "FETCH_SIZE/WRITE_SIZE are KiB, summed over the dispatches of a kernel and divided by the number of polygonizations (k_main, k_tail: by their own dispatches)",
-           "correction": "calibrated on known access patterns (tools/pmc_calib.hip, profiles/%s_pmc_calibration.txt): on gfx950 FETCH_SIZE "
+           "correction": "calibrated on known access patterns (tools/pmc_calib.hip, profiles/r02a_pmc_calibration.txt): on gfx950 FETCH_SIZE "
                          "reports exactly half of the bytes of the 128-byte lines a kernel pulls in, for every access width tried (16 / 8 / 4 / 1 bytes "
                          "per lane, contiguous or strided up to one byte per line) - every kernel's FETCH_SIZE is doubled; WRITE_SIZE equals the bytes "
                          "written (16-byte, 4-byte and 48-byte-record stores) and is taken as reported." % label}

@@ -317,29 +317,9 @@ struct DeviceState
 	vx_ctx* Ctx = nullptr;        // the primary context: the whole grid, every level, the caches a Modification continues from
 	uint64_t ResidentGridUid = 0; // VoxelGrid::Uid of the grid mirrored in HBM (0 = none; never compare addresses: they get reused)
 	uint64_t ResidentGeneration = 0;
-	// Helper contexts, one per further device (VOXELS_DEVICES = N; on a box with fewer devices they share them): each holds a
-	// slab of rows of the grid, polygonizes the levels whose blocks fit the slab and delivers those meshes over its own link
-	// - of a 1024^3 Execute 10 of 18 ms are the meshes on their way to the host.
-	std::vector<vx_ctx*> Helpers;
-
 	~DeviceState()
 	{
-		for (vx_ctx* h : Helpers) if (h) vx_ctx_destroy(h);
 		if (Ctx) vx_ctx_destroy(Ctx);
-	}
-
-	// helper contexts for slabs of n / count rows (created on first use, kept); false: the grid is not cut that way
-	bool EnsureHelpers(unsigned n, unsigned count)
-	{
-		if (count < 2 || n < 16 * count || (n / 16) % count) return false; // (every helper needs at least one block layer)
-		int devices = 0;
-		if (vx_device_count(&devices) != VX_OK || devices < 1) return false;
-		while (Helpers.size() < count) {
-			vx_ctx* h = nullptr;
-			if (vx_ctx_create((int)(Helpers.size() % (size_t)devices), &h) != VX_OK) return false;
-			Helpers.push_back(h);
-		}
-		return true;
 	}
 
 	// InitializeVoxels brings one context up ahead of time (HIP runtime, code objects, the context's constant tables: ~0.3 s that
@@ -419,6 +399,31 @@ class TransVoxelImpl
 {
 public:
 	std::shared_ptr<DeviceState> Device; // where this Polygonizer's full runs happen
+	// Helper contexts, one per further device (VOXELS_DEVICES = N; on a box with fewer devices they share them): each holds a
+	// slab of rows of the grid, polygonizes the levels whose blocks fit the slab and delivers those meshes over its own link
+	// - of a 1024^3 Execute 10 of 16 ms are the meshes on their way to the host.  They belong to the Polygonizer, not to
+	// the device state of one surface: what a helper produced lives on in host arenas the surface owns, so the next
+	// Execute reuses the same N contexts however many older surfaces are still alive.
+	std::vector<vx_ctx*> Helpers;
+
+	~TransVoxelImpl()
+	{
+		for (vx_ctx* h : Helpers) if (h) vx_ctx_destroy(h);
+	}
+
+	// helper contexts for slabs of n / count rows (created on first use, kept); false: the grid is not cut that way
+	bool EnsureHelpers(unsigned n, unsigned count)
+	{
+		if (count < 2 || n < 16 * count || (n / 16) % count) return false; // (every helper needs at least one block layer)
+		int devices = 0;
+		if (vx_device_count(&devices) != VX_OK || devices < 1) return false;
+		while (Helpers.size() < count) {
+			vx_ctx* h = nullptr;
+			if (vx_ctx_create((int)(Helpers.size() % (size_t)devices), &h) != VX_OK) return false;
+			Helpers.push_back(h);
+		}
+		return true;
+	}
 
 	static void FillStats(vx_ctx* ctx, PolygonizationStatistics& st)
 	{
@@ -505,7 +510,7 @@ public:
 		std::vector<std::thread>& threads = helpers.threads;
 		threads.reserve(devices);
 		for (unsigned i = 0; i < devices; ++i)
-			threads.emplace_back(&TransVoxelImpl::RunHelper, Device->Helpers[i], (const VoxelGrid*)g, (const uint8_t*)flags.data(), (const uint8_t*)lut, (const uint8_t*)valid, i * rows, (i + 1) * rows, helperLevels, &res[i]);
+			threads.emplace_back(&TransVoxelImpl::RunHelper, Helpers[i], (const VoxelGrid*)g, (const uint8_t*)flags.data(), (const uint8_t*)lut, (const uint8_t*)valid, i * rows, (i + 1) * rows, helperLevels, &res[i]);
 		// the primary, on the calling thread
 		vx_ctx* ctx = Device->Ctx;
 		vx_exec_info info;
@@ -533,7 +538,7 @@ public:
 		}
 		helpers.join();
 		for (unsigned i = 0; i < devices; ++i) { s->ShardMeshes.push_back(res[i].Meshes); ok = ok && res[i].Ok; } // (the surface owns the copies from here on)
-		if (!ok) { Log(LS_Error, vx_last_error(ctx)); for (vx_ctx* h : Device->Helpers) if (h && *vx_last_error(h)) Log(LS_Error, vx_last_error(h)); return nullptr; }
+		if (!ok) { Log(LS_Error, vx_last_error(ctx)); for (vx_ctx* h : Helpers) if (h && *vx_last_error(h)) Log(LS_Error, vx_last_error(h)); return nullptr; }
 		// the finer levels: every helper's blocks, merged by id (ids number the blocks of the whole grid: = GetBlockForLevel order)
 		for (unsigned l = 0; l < helperLevels && l < info.levels; ++l) {
 			struct Ref { unsigned id, helper, k; };
@@ -592,7 +597,7 @@ public:
 			if (!Device || Device.use_count() > 1) Device = DeviceState::Create();
 			if (!Device) return nullptr;
 			const unsigned devices = RequestedDevices();
-			if (devices > 1 && Device->EnsureHelpers(g->Size(), devices)) {
+			if (devices > 1 && EnsureHelpers(g->Size(), devices)) {
 				PolygonSurface* r = ExecuteOnDevices(g, materials, devices);
 				lap("Execute on several devices");
 				return r;
