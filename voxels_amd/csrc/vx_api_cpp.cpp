@@ -678,6 +678,24 @@ extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage lo
 	if (!getenv("VOXELS_NO_PREWARM")) {
 		std::shared_ptr<Voxels::DeviceState> d = Voxels::DeviceState::Create();
 		if (d) {
+			// the kernels are loaded on first use, a few milliseconds each: one small synthetic grid through every call an
+			// Execute makes (terrain on the device -> polygonize -> write as a file -> expand the file -> polygonize -> meshes
+			// to the host) pays that here as well
+			{
+				vx_exec_info info;
+				vx_host_meshes hm = { nullptr, nullptr, 0, 0, nullptr };
+				uint64_t size = 0;
+				uint8_t lut[256 * 6], valid[256];
+				memset(lut, 0, sizeof(lut)); memset(valid, 1, sizeof(valid));
+				bool ok = vx_grid_create_terrain(d->Ctx, 64, 1) == VX_OK && vx_material_lut(d->Ctx, lut, valid) == VX_OK && vx_polygonize(d->Ctx, 0, &info) == VX_OK;
+				std::vector<char> file;
+				if (ok && vx_grid_pack(d->Ctx, nullptr, 0, &size) == VX_OK) {
+					file.resize((size_t)size);
+					ok = vx_grid_pack(d->Ctx, file.data(), size, &size) == VX_OK && vx_grid_upload_packed(d->Ctx, file.data(), size) == VX_OK && vx_polygonize(d->Ctx, 0, &info) == VX_OK;
+				}
+				if (ok && vx_host_meshes_acquire(d->Ctx, &hm) == VX_OK) vx_host_meshes_release(hm.arena);
+				(void)vx_grid_invalidate(d->Ctx); // (whatever the application uploads next replaces this grid; nothing of it is kept)
+			}
 			const char* mb = getenv("VOXELS_PREWARM_MB");
 			const uint64_t bytes = mb ? (uint64_t)atoll(mb) << 20 : 0;
 			if (bytes) (void)vx_host_meshes_reserve(d->Ctx, bytes * 5 / 6 / sizeof(Voxels::PolygonVertex), bytes / 6 / 4);

@@ -2515,7 +2515,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		}
 	}
 	__syncthreads();
-	list_write_pass(p, plan, t.levels, pub, role - general, t.listWgs, true);
+	// (records and counts written by the general workgroups of this very launch are read past the caches; when nothing was handed
+	// on, everything the list pass reads comes from earlier launches)
+	list_write_pass(p, plan, t.levels, pub, role - general, t.listWgs, handedOn);
 	if (t.next.header) {
 		const u32 lanes = t.listWgs * WG;
 		for (u32 i = (role - general) * WG + threadIdx.x; i * 4u < t.next.start[MAX_LEVELS] || i < t.next.listWgs; i += lanes) {
