@@ -1741,7 +1741,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	for (u32 L = 0; L < MAX_LEVELS; ++L) prevActive[L] = c->hdr[L];
 	u32 retries = 0;
 	float ms = 0.f;
-	std::vector<BlockRecord> recs(total);
+	std::vector<BlockRecord> recsChain;       // (the chain's records are downloaded into this; the three-launch path reads the page-locked landing buffer in place)
+	const BlockRecord* recs = nullptr;
+	bool recordsInListOrder = false;          // the three-launch path: a level's records follow the order of its box's coordinates
 	// Three launches where the table-driven passes apply (k_dirty_head | k_main<true> | k_dirty_tail, vx_hip.hip): the box goes
 	// out as launch arguments, records and header come back through page-locked memory written by the last kernel.  A run
 	// that meets a block beyond the first capacity class says so in its header and is repeated as the chain of launches.
@@ -1803,7 +1805,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			if (c->hdr[HDR_LARGE] && !c->dirtyLargeHint) { c->dirtyLargeHint = true; continue; } // a block beyond the first capacity class, unannounced: once more, with that class launched
 			c->dirtyLargeHint = c->hdr[HDR_LARGE] != 0;
 			const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
-			if (!overflow) { if (total) memcpy(recs.data(), c->hRecs, (size_t)total * sizeof(BlockRecord)); break; }
+			if (!overflow) { recs = c->hRecs; recordsInListOrder = true; break; }
 			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 			// (appended blocks fill the pools' slack edit after edit: growing by half keeps overflows - a repeated run, a copy of
 			// the pools and an allocation, ~1 ms - rare; vx_compact_pools gives dead ranges back)
@@ -1839,7 +1841,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		if (!c->be.d2h(c->hdr, c->dHeader, HDR_WORDS * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
 		const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 		if (!overflow) {
-			if (total && !c->be.d2h(recs.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
+			recsChain.resize(total);
+			if (total && !c->be.d2h(recsChain.data(), c->dGather, (size_t)total * sizeof(BlockRecord))) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: record download failed");
+			recs = recsChain.data();
 			break;
 		}
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
@@ -1852,16 +1856,27 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
 		const u32 nWork = c->hdr[HDR_WORK + L];
-		// gathered records are in work-list (arbitrary) order: index them by block coordinate
+		// The three-launch path lists a level's active slots in the order of the box's coordinates (k_dirty_head), which is the
+		// order of `coords`: one walk over both.  The chain appends to its work lists with atomics (arbitrary order): its
+		// records are indexed by block coordinate first.
 		std::vector<std::pair<u32, u32> > byCoord;
-		byCoord.reserve(nWork);
-		for (u32 k = 0; k < nWork; ++k) byCoord.push_back(std::make_pair(recs[start[L] + k].coordId, start[L] + k));
-		std::sort(byCoord.begin(), byCoord.end());
+		if (!recordsInListOrder) {
+			byCoord.reserve(nWork);
+			for (u32 k = 0; k < nWork; ++k) byCoord.push_back(std::make_pair(recs[start[L] + k].coordId, start[L] + k));
+			std::sort(byCoord.begin(), byCoord.end());
+		}
+		u32 w = 0;
 		for (u32 k = 0; k < cnt[L]; ++k) {
 			const u32 coord = coords[start[L] + k];
-			auto it = std::lower_bound(byCoord.begin(), byCoord.end(), std::make_pair(coord, 0u));
-			if (it == byCoord.end() || it->first != coord) continue; // no surface in this block
-			const BlockRecord& r = recs[it->second];
+			const BlockRecord* rp = nullptr;
+			if (recordsInListOrder) {
+				if (w < nWork && recs[start[L] + w].coordId == coord) rp = &recs[start[L] + w++];
+			} else {
+				auto it = std::lower_bound(byCoord.begin(), byCoord.end(), std::make_pair(coord, 0u));
+				if (it != byCoord.end() && it->first == coord) rp = &recs[it->second];
+			}
+			if (!rp) continue; // no surface in this block
+			const BlockRecord& r = *rp;
 			if (!r.vCount) continue;
 			EmittedBlock e;
 			e.rec = r;
@@ -1869,6 +1884,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			block_corners(d, coord, e.minc, e.maxc);
 			fresh[L].push_back(std::move(e));
 		}
+		if (recordsInListOrder && w != nWork) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's records do not follow its work lists (internal error)");
 		if (L) trivialBlocks += cnt[L];
 	}
 	// the lists change in place, now that nothing can fail any more: the dropped blocks leave (everything behind the first of
