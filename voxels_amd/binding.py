@@ -351,6 +351,12 @@ class Polygonizer:
         self.info = info
         return ids[:cnt.value].copy()
 
+    def debug_header(self, count=352):
+        """vx_debug_header: the device copy of the run's header words (diagnostics)"""
+        out = np.zeros(count, np.uint32)
+        self._check(self._lib.vx_debug_header(self._h, _ptr(out), int(count)), "vx_debug_header")
+        return out
+
     def level(self, lvl, with_data=True):
         nb = C.c_uint32()
         tot = np.zeros(4, np.uint64)

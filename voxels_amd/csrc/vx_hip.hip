@@ -1374,20 +1374,24 @@ struct MatLds {
 // dynamically indexed arrays — an entry's count is compared in order of first appearance, first maximum wins
 __device__ __forceinline__ u32 vote8(const u32 e[8])
 {
-	u32 bestCnt = 0, bestId = 0, bestBl = 0;
+	// (the blend sum is formed for the winning id alone, behind the counting: the 64 comparisons of the counting carry one
+	// accumulation instead of two - a material block votes on every cell of its six boundary layers, ~1 700 votes, and this
+	// function was an eighth of k_main's vector instructions)
+	u32 ids[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) ids[i] = e[i] & 0xFFu;
+	u32 bestCnt = 0, bestId = 0;
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		const u32 id = e[i] & 0xFFu;
-		u32 cnt = 0, bl = 0;
+		u32 cnt = 0;
 #pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			const bool same = (e[j] & 0xFFu) == id;
-			cnt += same ? 1u : 0u;
-			bl += same ? (e[j] >> 8) : 0u;
-		}
-		if (id != EMPTY_MATERIAL && cnt > bestCnt) { bestCnt = cnt; bestId = id; bestBl = bl; }
+		for (int j = 0; j < 8; ++j) cnt += ids[j] == ids[i] ? 1u : 0u;
+		if (ids[i] != EMPTY_MATERIAL && cnt > bestCnt) { bestCnt = cnt; bestId = ids[i]; }
 	}
 	if (!bestCnt) return EMPTY_MATINFO;
+	u32 bestBl = 0;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) bestBl += ids[j] == bestId ? (e[j] >> 8) : 0u;
 	// bl <= 8 * 255, cnt <= 8: the quotient is an integer or at least 1/8 away from one, fp32 division is exact enough
 	const u32 avg = (u32)((float)bestBl / (float)bestCnt);
 	return bestId | ((avg & 0xFFu) << 8);
@@ -1475,27 +1479,40 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		static_assert(sizeof(st.voteList) >= 1089 * 4 + 1092, "row masks of the children on top of the vote list");
 		u16* piece = (u16*)st.voteList;                 // [row * 2 + h]
 		u8* farBit = (u8*)st.voteList + 1089 * 4;       // [row]
-		u32 ex = 0;
-		size_t resident = 0;
+		// Addresses relative to the first child's brick, in 32 bits (k_main runs on mirrors below 4 GiB): the brick index is
+		// linear in the block coordinates and brick_local's bit fields are disjoint per axis, so a row's offset is
+		// ((Z >> 4) * bricks per plane + (Y >> 4) * bricks per row + h) << 12 | local(Y & 15, Z & 15) - a dozen instructions
+		// where fifteen calls of brick_offset with their clamps cost a hundred each (1 500 per lane and block: a tenth of
+		// k_main's vector instructions at 1024^3).
+		const u32 nbU = (u32)n >> 4, planeBricks = (u32)g.bRowsY * nbU;
+		const size_t origin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
+		u32 ex = 0, residentRel = 0;
 #pragma unroll
-		for (int c = 7; c >= 0; --c) if (st.childSlot[c] >= 0) { ex |= 1u << c; resident = brick_base(g, (int)(bx * 2) + (c & 1), (int)(by * 2) + ((c >> 1) & 1), (int)(bz * 2) + (c >> 2)); }
+		for (int c = 7; c >= 0; --c) if (st.childSlot[c] >= 0) { ex |= 1u << c; residentRel = (((u32)(c >> 2) * planeBricks + (u32)((c >> 1) & 1) * nbU + (u32)(c & 1)) << 12); }
 		if (tid < 8) st.childSkip[tid] = st.childSlot[tid] >= 0 ? (u32)C.skip[st.childSlot[tid]] : 1u;
-		const auto needed = [&](int Y, int Z, int h) {
+		const u32 exPair = (ex | (ex >> 1)) & 0x55u;
+		const auto needed = [&](int Y, int Z) {
+			// (the second piece of a row also holds sample 16 of the first child column: x is never partitioned)
 			const u32 sel = ((Y <= 16 ? 0x11u : 0u) | (Y >= 16 ? 0x44u : 0u)) & ((Z <= 16 ? 0x0Fu : 0u) | (Z >= 16 ? 0xF0u : 0u));
-			(void)h; // (the second piece of a row also holds sample 16 of the first child column: x is never partitioned)
-			return (((ex | (ex >> 1)) & 0x55u) & sel) != 0u;
+			return (exPair & sel) != 0u;
 		};
-		const int X0 = (int)(bx * 32), Y0 = (int)(by * 32), Z0 = (int)(bz * 32);
+		const int yMax = n - 1 - (int)(by * 32), zMax = n - 1 - (int)(bz * 32); // (>= 31: the clamp binds on row / plane 32 of the grid's last blocks)
+		const auto rowRel = [&](int Y, int Z) {
+			const u32 yc = (u32)min(Y, yMax), zc = (u32)min(Z, zMax);
+			return ((__umul24(zc >> 4, planeBricks) + __umul24(yc >> 4, nbU)) << 12) | (((zc & 15u) >> 1) << 9) | (((yc & 15u) >> 2) << 7) | ((zc & 1u) << 6) | ((yc & 3u) << 4);
+		};
+		const i8* base = g.bDist + origin;
+		// piece u = (Z * 33 + Y) * 2 + h, u < 2178: Z = u / 66 (exact as (u * 993) >> 16 below 2560)
 #pragma unroll 1
 		for (int batch = 0; batch < 2; ++batch) {
 			uint4 d[5];
 #pragma unroll
 			for (int q = 0; q < 5; ++q) {
-				const int u = min(tid + (batch * 5 + q) * WG, 2177);
-				const int h = u & 1, row = u >> 1, Y = row % 33, Z = row / 33;
-				size_t off = resident;
-				if (needed(Y, Z, h)) off = brick_offset(g, min(X0 + h * 16, n - 16), min(Y0 + Y, n - 1), min(Z0 + Z, n - 1));
-				d[q] = *(const uint4*)(g.bDist + off);
+				const u32 u = (u32)min(tid + (batch * 5 + q) * WG, 2177);
+				const u32 Z = (u * 993u) >> 16, rem = u - Z * 66u, Y = rem >> 1, h = rem & 1u;
+				u32 off = residentRel;
+				if (needed((int)Y, (int)Z)) off = rowRel((int)Y, (int)Z) + (h << 12);
+				d[q] = *(const uint4*)(base + off);
 			}
 #pragma unroll
 			for (int q = 0; q < 5; ++q) {
@@ -1504,13 +1521,18 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 			}
 		}
 		{
+			// the sample behind the second piece: x = min(X0 + 32, n - 1) - the first byte of the third brick along x, or, at the
+			// grid's far side, the last byte of the second
+			const bool lastX = (int)(bx * 32) + 32 > n - 1;
+			const u32 farRel = lastX ? ((1u << 12) | 15u) : (2u << 12);
 			i8 f[5];
 #pragma unroll
 			for (int q = 0; q < 5; ++q) {
-				const int row = min(tid + q * WG, 1088), Y = row % 33, Z = row / 33;
-				size_t off = resident;
-				if (needed(Y, Z, 1)) off = brick_offset(g, min(X0 + 32, n - 1), min(Y0 + Y, n - 1), min(Z0 + Z, n - 1));
-				f[q] = g.bDist[off];
+				const u32 row = (u32)min(tid + q * WG, 1088);
+				const u32 Z = (row * 1986u) >> 16, Y = row - Z * 33u; // (row / 33, exact below 1280)
+				u32 off = residentRel;
+				if (needed((int)Y, (int)Z)) off = rowRel((int)Y, (int)Z) + farRel;
+				f[q] = base[off];
 			}
 #pragma unroll
 			for (int q = 0; q < 5; ++q) { const int row = tid + q * WG; if (row < 1089) farBit[row] = (u8)(((u32)(f[q] >> 7)) & 1u); }
@@ -2492,7 +2514,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 	__shared__ u32 roleSh[2];
 	const u32 general = t.wgs0 + t.wgs1;
 	if (threadIdx.x == 0) {
-		const u32 handed = TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1);
+		const u32 handed = TV_LOAD_THROUGH(p.G.slowCount) + TV_LOAD_THROUGH(p.G.slowCount + 1); // (blocks handed on, both passes)
 		roleSh[0] = handed;
 		roleSh[1] = handed ? atomicAdd(t.roleTicket, 1u) : blockIdx.x;
 	}
@@ -2508,10 +2530,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		return;
 	}
 	if (threadIdx.x == 0 && handedOn) {
+		// Patience in proportion to the work handed on: the general workgroups were sized by the run before (two per pass when
+		// it handed on nothing), and a grid whose every surface block holds a zero sample - a height map's - can leave them
+		// thousands of blocks at 50-100 us each.  (A fixed bound of 2^17 polls gave up on exactly that run now and then.)
+		const u32 patience = (u32)WAIT_SPINS + (r0_uniform(roleSh[0]) / max(general, 1u) + 1u) * 4096u;
 		u32 spins = 0;
 		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
 			__builtin_amdgcn_s_sleep(4);
-			if (++spins > (u32)WAIT_SPINS) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
+			if (++spins > patience) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
 		}
 	}
 	__syncthreads();
@@ -2717,11 +2743,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3))) void k_
 		return;
 	}
 	const u32 gw = ticket - general;
-	if (threadIdx.x == 0 && (TV_LOAD_THROUGH(p.G.slowCount) | TV_LOAD_THROUGH(p.G.slowCount + 1)) != 0u) {
-		u32 spins = 0;
-		while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
-			__builtin_amdgcn_s_sleep(4);
-			if (++spins > (u32)WAIT_SPINS) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
+	if (threadIdx.x == 0) {
+		const u32 handed = TV_LOAD_THROUGH(p.G.slowCount) + TV_LOAD_THROUGH(p.G.slowCount + 1);
+		if (handed) {
+			const u32 patience = (u32)WAIT_SPINS + (handed / max(general, 1u) + 1u) * 4096u; // (in proportion to the work handed on, see k_tail)
+			u32 spins = 0;
+			while (__hip_atomic_load(t.slowDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < general) {
+				__builtin_amdgcn_s_sleep(4);
+				if (++spins > patience) { atomicOr(p.G.giveUp, 1u); break; } // (the host fails the run)
+			}
 		}
 	}
 	__syncthreads();

@@ -1394,6 +1394,9 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		if (stale) c->be.begin_timing();
 		if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize: brick mirror allocation failed: " + c->be.error());
 		if (stale) mirrorMs = c->be.end_timing_ms(); // (waits for the copy: only a run on a changed grid pays this)
+		// (a changed grid: what the run before handed to the general passes says nothing about this one - they are launched at
+		// full width once, ~10 us, instead of leaving thousands of zero-sample blocks of, say, a height map to two workgroups)
+		if (stale) c->be.slowHint[0] = c->be.slowHint[1] = ~0u;
 	}
 	const u32 levels = (num_levels == 0 || num_levels > c->refLevels) ? c->refLevels : num_levels;
 	const u32 slabPlanes = c->zEnd - c->zBegin, slabRows = c->yEnd - c->yBegin;
