@@ -255,6 +255,15 @@ def test_emu_repeated_edits_vs_port(emu, port):
     assert addr in [a.verts.ctypes.data for a in again]
     for a in again:
         fields.check_host_meshes(p, a)
+        a.release()
+    # an arena reserved ahead of time (InitializeVoxels with VOXELS_PREWARM_MB does this) is the one the next acquire of a
+    # fitting size is handed: no page-locking inside the call
+    p._lib.vx_host_meshes_trim()
+    p.reserve_host_meshes(int(p.info.total_verts) + 1000, int(p.info.total_indices) + 1000)
+    first = p.host_meshes()
+    assert first.verts.size == int(p.info.total_verts) and first.indices.size == int(p.info.total_indices)
+    fields.check_host_meshes(p, first)
+    first.release()
 
 
 def test_emu_transition_face_batches(emu, port):

@@ -127,6 +127,7 @@ class HipLibrary:
         lib.vx_host_meshes_release.restype = None
         lib.vx_host_meshes_trim.argtypes = []
         lib.vx_host_meshes_trim.restype = None
+        lib.vx_host_meshes_reserve.argtypes = [vp, C.c_uint64, C.c_uint64]
         lib.vx_stats.argtypes = [vp, vp]
         lib.vx_selftest.argtypes = [vp, vp]
         lib.vx_stage_layout.argtypes = [vp, C.POINTER(C.c_int)]
@@ -372,6 +373,10 @@ class Polygonizer:
         self._check(self._lib.vx_download_level(self._h, lvl, _ptr(infos), _ptr(verts), _ptr(idx), _ptr(tverts), _ptr(tidx)),
                     "vx_download_level")
         return Level(infos, verts, idx, tverts, tidx)
+
+    def reserve_host_meshes(self, n_verts, n_indices):
+        """vx_host_meshes_reserve: page-lock an arena of that size ahead of time (it waits in the recycling list)."""
+        self._check(self._lib.vx_host_meshes_reserve(self._h, int(n_verts), int(n_indices)), "vx_host_meshes_reserve")
 
     def host_meshes(self, previous=None):
         """vx_host_meshes_acquire: both pools on the host (page-locked, one DMA), as numpy views.  Block k of level l owns
