@@ -47,7 +47,7 @@ def main():
            "correction": "calibrated on known access patterns (tools/pmc_calib.hip, profiles/r02a_pmc_calibration.txt): on gfx950 FETCH_SIZE "
                          "reports exactly half of the bytes of the 128-byte lines a kernel pulls in, for every access width tried (16 / 8 / 4 / 1 bytes "
                          "per lane, contiguous or strided up to one byte per line) - every kernel's FETCH_SIZE is doubled; WRITE_SIZE equals the bytes "
-                         "written (16-byte, 4-byte and 48-byte-record stores) and is taken as reported." % label}
+                         "written (16-byte, 4-byte and 48-byte-record stores) and is taken as reported."}
     fetch, ex1 = parse(d + "/pass1.txt")
     fk = {k: v.get("FETCH_SIZE", 0.0) / max(own_calls.get(k, ex1), 1) for k, v in fetch.items()}
     write, ex2 = parse(d + "/pass2.txt")
