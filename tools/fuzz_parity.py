@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP path against the oracle (not part of the test suite; run on the GPU box):
 terrains, full-range noise, zero-heavy fields, sparse bubbles and flat slabs with random materials, sizes 32..128,
-every level; with a third argument `edits`: random chains of device edits + incremental runs.
+every level; with a third argument `edits`: random chains of device edits + incremental runs (VX_FUZZ_CHAIN = edits per
+chain, default 5; VX_FUZZ_N = grid size).
 Usage: python tools/fuzz_parity.py [seconds] [first_seed] [edits]"""
 import os
 import sys
@@ -49,13 +50,13 @@ def fuzz_edits(oracle, p, budget, seed):
     t0, chains, edits = time.time(), 0, 0
     while time.time() - t0 < budget:
         rng = np.random.RandomState(seed)
-        n = int(rng.choice([32, 64, 64]))
+        n = int(os.environ["VX_FUZZ_N"]) if os.environ.get("VX_FUZZ_N") else int(rng.choice([32, 64, 64]))
         d, m, b = make_field(int(rng.choice([0, 1, 2])), n, seed)
         g = oracle.grid_from_dense(d, m, b)
         s = oracle.execute(g)
         p.upload_packed(g.pack())
         p.execute()
-        for _ in range(5):
+        for _ in range(int(os.environ.get("VX_FUZZ_CHAIN", "5"))):  # (long chains: pool growth, compaction, the capacity classes coming and going)
             pos = tuple(float(x) for x in rng.uniform(-4, n + 4, 3).round(rng.choice([0, 1, 2])))
             ext = tuple(float(x) for x in rng.uniform(3, 26, 3).round(rng.choice([0, 1])))
             if rng.rand() < 0.7:

@@ -2992,7 +2992,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1, spreadUpper = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -3029,6 +3029,7 @@ struct Backend {
 		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
 		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
+		tune.spreadUpper = env_u32("VX_SPREAD_UPPER", 1); // 0: the upper capacity classes of the levels >= 1 behind the first class on the main stream instead of behind the transition pass (A/B measurements)
 		tune.bigClass = env_u32("VX_BIG_CLASS", 1); // 0: blocks beyond REG_CAP_MID cells through the general pass, as until round 4 (A/B measurements)
 		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1); // 0: incremental runs as the chain of launches with work lists (A/B measurements, tests of that path)
 		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
@@ -3504,7 +3505,7 @@ struct Backend {
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
 				// (as on level 0: the upper classes beside the first one when the run is overlapped, i.e. when this is the main
 				// stream of run_overlapped_tail - on side stream B, behind the transition pass)
-				const bool spread = largeClass && overlappedTail && on == stream && !upperDone;
+				const bool spread = tune.spreadUpper && largeClass && overlappedTail && on == stream && !upperDone;
 				hipStream_t sideD = sideB;
 				hipStream_t upper = spread ? sideD : on;
 				const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
