@@ -838,6 +838,32 @@ def test_hip_create_heightmap(poly, port, n):
 
 
 @pytest.mark.gpu
+def test_hip_zero_sample_grid_behind_a_clean_one(port):
+    """A height map's surface blocks all hold exact zeros: the table-driven passes hand every one of them to the general
+    pass.  Behind a run that handed on nothing (which sizes the general workgroups of the next run at two per pass) the list
+    workgroups of k_tail once gave up waiting for them ("a dependency wait ... timed out"): their patience is in proportion
+    to the work handed on now, and a changed grid launches the general passes at full width."""
+    from voxels_amd import Polygonizer
+    q = Polygonizer(device=0)
+    q.set_materials(vxo.default_lut())
+    try:
+        q.create_terrain(256, 7)
+        for _ in range(2):
+            q.execute()   # nothing handed on: the hint for the next run is zero
+        n = 256
+        base = fields.smooth_noise(n, 5, scale=n // 4, amp=0.2 * n, octaves=3)[0]
+        hm = np.clip(np.round(base) + (n // 2 - 127), -128, 127).astype(np.int8)
+        g = port.grid_from_heightmap(n, hm)
+        q.create_heightmap(hm)
+        for _ in range(2):
+            q.execute()
+            ok, msg = fields.surface_equal(q.all_levels(), port.execute(g).all_levels(), nrm_tol=NRM_TOL)
+            assert ok, msg
+    finally:
+        q.close()
+
+
+@pytest.mark.gpu
 def test_hip_device_only_pipeline_512(poly, port):
     """Everything the widened path offers, chained on a grid that never exists on the host in dense form: height-map
     constructor -> polygonize -> write file -> ball edit -> incremental polygonize -> compact -> write file; against the
