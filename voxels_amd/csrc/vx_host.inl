@@ -1685,6 +1685,10 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (!c->haveSurface) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: run vx_polygonize first");
 	if (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n) return fail(c, VX_ERR_INVALID, "vx_polygonize_dirty: not supported on slabs");
 	const u32 levels = c->levelsRun;
+	auto tNow = []() { return std::chrono::steady_clock::now(); };
+	auto tUs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
+	const auto t0 = tNow(); // (VX_HOST_TIMING: where the call's host time goes)
+	auto t1 = t0, t2 = t0, t3 = t0, t4 = t0;
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: brick mirror allocation failed: " + c->be.error());
 	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;
@@ -1744,6 +1748,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	for (u32 L = 0; L < MAX_LEVELS; ++L) prevActive[L] = c->hdr[L];
 	u32 retries = 0;
 	float ms = 0.f;
+	t1 = tNow();
 	std::vector<BlockRecord> recsChain;       // (the chain's records are downloaded into this; the three-launch path reads the page-locked landing buffer in place)
 	const BlockRecord* recs = nullptr;
 	bool recordsInListOrder = false;          // the three-launch path: a level's records follow the order of its box's coordinates
@@ -1800,7 +1805,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			c->be.begin_timing();
 			c->be.run_dirty_fused(p, levels, q, c->dirtyLargeHint);
 			c->be.end_timing_record();
+			t2 = tNow();
 			if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
+			t3 = tNow();
 			ms = c->be.elapsed_ms();
 			if (c->hdrPinned[HDR_PUBLISHED] == 0) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's header did not arrive (internal error)");
 			memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
@@ -1900,6 +1907,8 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			return e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2]; }), list.end());
 		list.insert(list.end(), fresh[L].begin(), fresh[L].end());
 	}
+	t4 = tNow();
+	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] lists + box %.0f us, enqueue %.0f us, wait %.0f us, records + lists %.0f us, device %.0f us\n", tUs(t0, t1), tUs(t1, t2), tUs(t2, t3), tUs(t3, t4), ms * 1e3);
 	c->nextId = nextId;
 	c->stats[0] = total;
 	c->stats[2] = c->hdr[HDR_STATS + 0];
