@@ -66,6 +66,7 @@ typedef struct vx_exec_info {
 	float mirror_ms;            /* device time this call spent bringing the library's mirrors of the grid up to date (brick
 	                               order, lattice copies, sign summaries: the one place where all n^3 samples are read) —
 	                               0 when the grid did not change since the last run; not part of device_ms */
+	uint32_t first_meshed_level; /* 0 for an ordinary run; vx_polygonize_from: the first level whose meshes the run produced */
 } vx_exec_info;
 
 /* ---- context ------------------------------------------------------------------------------------------- */
@@ -190,6 +191,13 @@ int vx_material_lut(vx_ctx* ctx, const uint8_t* lut /*256*6*/, const uint8_t* va
 /* num_levels = 0: all log2(n/16)+1 levels like the reference; otherwise only levels 0..num_levels-1 (the
  * "last level has no transitions" rule still uses the reference's level count). */
 int vx_polygonize(vx_ctx* ctx, uint32_t num_levels, vx_exec_info* info);
+/* The same run without the meshes of the levels below first_meshed_level - for a caller that gets those from other devices
+ * (libVoxels.so with VOXELS_DEVICES = N: helper contexts polygonize the finer levels slab by slab) but needs everything a later
+ * Modification continues from in THIS context: the slot maps, non-trivial / consistency bitmaps and material caches of every level
+ * (the reference keeps them in the PolygonMap, src/TransVoxelImpl.h:81-133; a Modification reads the caches of blocks it does not
+ * rebuild, :753-838).  Levels below first_meshed_level list no blocks and count nothing into the statistics; info->first_meshed_level
+ * says what the run really did (0 where the partial form is not available - dense surfaces, stage timing: every level was meshed). */
+int vx_polygonize_from(vx_ctx* ctx, uint32_t num_levels, uint32_t first_meshed_level, vx_exec_info* info);
 /* Incremental re-polygonization of a dirty box (src/TransVoxelImpl.cpp:429-465); corners in OUTPUT (Y-up)
  * coordinates as Grid::InjectSurface returns them.  Returns the new block ids. */
 int vx_polygonize_dirty(vx_ctx* ctx, const float min_corner[3], const float max_corner[3], vx_exec_info* info,

@@ -163,6 +163,8 @@ struct Backend {
 	template <typename P> void run_overlapped_tail(const P&, u32) {}
 	template <typename P> bool single_stream(const P&, u32) const { return false; } // (HIP backend: one launch behind the classification)
 	template <typename P> void run_main_staged(const P&, u32) {}
+	u32 emitFrom = 0; // (HIP backend: partial runs; the emulation always meshes every level)
+	template <typename P> bool partial_applies(const P&, u32) const { return false; }
 	// (HIP backend: incremental runs as three launches; the emulation walks the chain with work lists)
 	template <typename P> bool dirty_fused_applies(const P&, u32, bool) const { return false; }
 	struct DirtyLaunch {

@@ -408,6 +408,65 @@ def test_hip_fast_flag_protocol_equals_the_conservative_one(port):
         slow.close(); fast.close()
 
 
+def test_hip_partial_run_keeps_every_cache(port):
+    """vx_polygonize_from (what libVoxels.so's primary context runs when helper devices mesh the finer levels): no meshes below
+    the first meshed level, the levels from it up byte for byte those of a full run, statistics that add up with those of the
+    levels left out - and every cache a Modification continues from: the same edit after a partial and after a full run
+    rebuilds the same blocks with the same bytes, against the oracle."""
+    from voxels_amd import Polygonizer, synth
+    n, first = 256, 2
+    full, part = Polygonizer(device=0), Polygonizer(device=0)
+    try:
+        for q in (full, part):
+            q.set_materials(vxo.default_lut())
+            q.create_terrain(n, 11)
+        full.execute()
+        info = part.execute_from(0, first)
+        assert info.first_meshed_level == first and info.levels == full.info.levels
+        a, b = full.all_levels(), part.all_levels()
+        for l in range(first):
+            assert len(b[l].infos) == 0, "level %d lists blocks" % l
+        ok, msg = fields.surface_equal(b[first:], a[first:], nrm_tol=0.0)
+        assert ok, msg
+        low = Polygonizer(device=0)
+        low.set_materials(vxo.default_lut()); low.create_terrain(n, 11); low.execute(first)
+        assert np.array_equal(part.stats() + low.stats(), full.stats())
+        low.close()
+        # the same carve on both, and on the oracle
+        d, m, bl = synth.terrain(n, seed=11)
+        g = port.grid_from_dense(d, m, bl)
+        s = port.execute(g)
+        col = d[:, n // 2, n // 2]
+        zs = float(np.argmax(col >= 0)) if (col >= 0).any() else n / 2.0
+        for pos, ext, r in (((n / 2.0, n / 2.0, zs), (30.0, 30.0, 30.0), 13.0), ((n / 2.0 + 21.5, n / 2.0 - 9.25, zs + 2.0), (24.0, 24.0, 24.0), 9.0)):
+            mn, mx = g.inject_ball(pos, ext, r, 2)
+            ref_ids = port.execute_modify(g, s, mn, mx)
+            got = []
+            for q in (full, part):
+                a0, b0 = q.inject_ball(pos, ext, r, 2)
+                got.append(q.execute_dirty(a0, b0))
+                assert np.array_equal(q.stats(), s.stats())
+            assert np.array_equal(got[0], ref_ids) and np.array_equal(got[1], ref_ids)
+            ok, msg = fields.surface_equal(full.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+            assert ok, msg
+            # the partial context lists, below its first meshed level, exactly the rebuilt blocks - with the bytes the full one has for them
+            fa, pa = full.all_levels(), part.all_levels()
+            ok, msg = fields.surface_equal(pa[first:], fa[first:], nrm_tol=0.0)
+            assert ok, msg
+            for l in range(first):
+                ids_full = {int(i): k for k, i in enumerate(fa[l].infos["id"])}
+                vo = np.concatenate([[0], np.cumsum(fa[l].infos["n_verts"])]); io = np.concatenate([[0], np.cumsum(fa[l].infos["n_idx"])])
+                pv = np.concatenate([[0], np.cumsum(pa[l].infos["n_verts"])]); pi = np.concatenate([[0], np.cumsum(pa[l].infos["n_idx"])])
+                assert len(pa[l].infos) > 0
+                for k, bid in enumerate(pa[l].infos["id"]):
+                    j = ids_full[int(bid)]
+                    assert pa[l].infos[k] == fa[l].infos[j]
+                    assert np.array_equal(pa[l].verts[pv[k]:pv[k + 1]], fa[l].verts[vo[j]:vo[j + 1]]), "level %d block %d" % (l, bid)
+                    assert np.array_equal(pa[l].idx[pi[k]:pi[k + 1]], fa[l].idx[io[j]:io[j + 1]])
+    finally:
+        full.close(); part.close()
+
+
 def test_hip_incremental_runs_as_chain_of_launches(port):
     """Incremental runs are three launches by default (k_dirty_head | k_main<true> | k_dirty_tail); the chain of launches
     with work lists remains for surfaces with blocks beyond the first capacity class.  The same chain of edits through a

@@ -59,7 +59,7 @@ class ExecInfo(C.Structure):
     _fields_ = [("levels", C.c_uint32), ("retries", C.c_uint32), ("device_ms", C.c_float),
                 ("total_verts", C.c_uint64), ("total_indices", C.c_uint64),
                 ("active_blocks", C.c_uint32 * 8), ("algorithmic_bytes", C.c_uint64),
-                ("blocks_read", C.c_uint32), ("mirror_ms", C.c_float)]
+                ("blocks_read", C.c_uint32), ("mirror_ms", C.c_float), ("first_meshed_level", C.c_uint32)]
 
 
 def hip_library_path():
@@ -119,6 +119,7 @@ class HipLibrary:
         lib.vx_grid_invalidate.argtypes = [vp]
         lib.vx_material_lut.argtypes = [vp, vp, vp]
         lib.vx_polygonize.argtypes = [vp, u32, C.POINTER(ExecInfo)]
+        lib.vx_polygonize_from.argtypes = [vp, u32, u32, C.POINTER(ExecInfo)]
         lib.vx_polygonize_dirty.argtypes = [vp, vp, vp, C.POINTER(ExecInfo), vp, u32, C.POINTER(u32)]
         lib.vx_level_counts.argtypes = [vp, u32, C.POINTER(u32), vp]
         lib.vx_download_level.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -333,6 +334,14 @@ class Polygonizer:
     def execute(self, num_levels=0):
         info = ExecInfo()
         self._check(self._lib.vx_polygonize(self._h, int(num_levels), C.byref(info)), "vx_polygonize")
+        self.info = info
+        return info
+
+    def execute_from(self, num_levels, first_meshed_level):
+        """vx_polygonize_from: caches and bitmaps of every level, meshes only from first_meshed_level up (info.first_meshed_level
+        tells what the run really did)."""
+        info = ExecInfo()
+        self._check(self._lib.vx_polygonize_from(self._h, int(num_levels), int(first_meshed_level), C.byref(info)), "vx_polygonize_from")
         self.info = info
         return info
 

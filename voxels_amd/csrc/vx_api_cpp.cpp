@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,6 +204,12 @@ struct SurfaceImpl : public PolygonSurface
 	std::vector<vx_host_meshes> ShardMeshes;
 	struct CoarseLevel { std::vector<PolygonVertex> V, TV; std::vector<unsigned> I, TI; };
 	std::vector<CoarseLevel> Coarse;
+	// Levels [0, HelperLevels) of such a surface were meshed by the helpers ONLY (the primary ran vx_polygonize_from: caches and
+	// bitmaps of every level, meshes from HelperLevels up).  HelperBlocks[l] = the helper-made blocks of level l that no
+	// Modification has replaced yet (views into ShardMeshes, which then stay with the surface); a Modification drops the ones
+	// inside its box and appends what the primary rebuilt.
+	unsigned HelperLevels = 0;
+	std::vector<std::vector<BlockImpl> > HelperBlocks;
 	PolygonizationStatistics Stats;
 	unsigned GridSize = 0;
 	std::shared_ptr<DeviceState> Device; // the context whose device caches describe this surface: kept alive by the surface, usable by any Polygonizer (Modification)
@@ -447,6 +454,7 @@ public:
 		vx_host_meshes Meshes = { nullptr, nullptr, 0, 0, nullptr };
 		std::vector<std::vector<vx_block_info> > Infos;
 		std::vector<std::vector<vx_block_ranges> > Ranges;
+		uint32_t Stats[20] = {};
 	};
 	static void RunHelper(vx_ctx* ctx, const VoxelGrid* g, const uint8_t* flags, const uint8_t* lut, const uint8_t* valid, unsigned y0, unsigned y1, unsigned levels, HelperResult* out)
 	{
@@ -455,6 +463,7 @@ public:
 		if (vx_material_lut(ctx, lut, valid) != VX_OK) return;
 		if (vx_polygonize(ctx, levels, &info) != VX_OK) return;
 		if (vx_host_meshes_acquire(ctx, &out->Meshes) != VX_OK) return;
+		if (vx_stats(ctx, out->Stats) != VX_OK) return;
 		out->Infos.resize(levels); out->Ranges.resize(levels);
 		for (unsigned l = 0; l < levels; ++l) {
 			uint32_t nb = 0;
@@ -514,7 +523,10 @@ public:
 		// the primary, on the calling thread
 		vx_ctx* ctx = Device->Ctx;
 		vx_exec_info info;
-		bool ok = Device->SyncGrid(*g) && vx_material_lut(ctx, lut, valid) == VX_OK && vx_polygonize(ctx, 0, &info) == VX_OK;
+		// (the primary leaves the meshes of the levels the helpers cover to them: caches, bitmaps and slot maps of every level -
+		// what a later Modification continues from - and the meshes of the coarser levels; info.first_meshed_level says whether
+		// the run could be partial - it cannot for dense surfaces - or meshed everything as until round 4)
+		bool ok = Device->SyncGrid(*g) && vx_material_lut(ctx, lut, valid) == VX_OK && vx_polygonize_from(ctx, 0, helperLevels, &info) == VX_OK;
 		std::unique_ptr<SurfaceImpl> s(new SurfaceImpl);
 		s->GridSize = n;
 		s->Device = Device;
@@ -537,6 +549,16 @@ public:
 			FillStats(ctx, s->Stats);
 		}
 		helpers.join();
+		if (ok && info.first_meshed_level) {
+			// the statistics of the levels the primary did not mesh are the helpers' (every counter adds up over slabs and levels)
+			bool all = true;
+			for (unsigned i = 0; i < devices; ++i) all = all && res[i].Ok;
+			if (all) for (unsigned i = 0; i < devices; ++i) {
+				const uint32_t* h = res[i].Stats;
+				s->Stats.BlocksCalculated += h[0]; s->Stats.TrivialCells += h[1]; s->Stats.NonTrivialCells += h[2]; s->Stats.DegenerateTrianglesRemoved += h[3];
+				for (int k = 0; k < 16; ++k) s->Stats.PerCaseCellsCount[k] += h[4 + k];
+			}
+		}
 		for (unsigned i = 0; i < devices; ++i) { s->ShardMeshes.push_back(res[i].Meshes); ok = ok && res[i].Ok; } // (the surface owns the copies from here on)
 		if (!ok) { Log(LS_Error, vx_last_error(ctx)); for (vx_ctx* h : Helpers) if (h && *vx_last_error(h)) Log(LS_Error, vx_last_error(h)); return nullptr; }
 		// the finer levels: every helper's blocks, merged by id (ids number the blocks of the whole grid: = GetBlockForLevel order)
@@ -551,6 +573,10 @@ public:
 				const Ref& r = order[q];
 				FillBlock(out[q], res[r.helper].Infos[l][r.k], res[r.helper].Ranges[l][r.k], (const PolygonVertex*)res[r.helper].Meshes.verts, res[r.helper].Meshes.indices);
 			}
+		}
+		if (info.first_meshed_level) {
+			s->HelperLevels = std::min<unsigned>(info.first_meshed_level, helperLevels);
+			s->HelperBlocks.assign(s->Levels.begin(), s->Levels.begin() + std::min<size_t>(s->HelperLevels, s->Levels.size()));
 		}
 		// the coarser levels: compact arrays in block order (vx_download_level's layout)
 		for (unsigned l = helperLevels; l < info.levels; ++l) {
@@ -645,9 +671,33 @@ public:
 		if (rc != VX_OK) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
 		mod->ModifiedBlocks.insert(mod->ModifiedBlocks.end(), ids.begin(), ids.begin() + count);
 		if (!FetchSurface(ctx, std::min<unsigned>(info.levels, (unsigned)s->Levels.size()), *s)) { Log(LS_Error, vx_last_error(ctx)); return nullptr; }
-		// (a surface made by several devices continues on its primary context, which holds every level and every cache: all views
-		// now point into the primary's copy, the helpers' copies can go)
-		s->ReleaseShardCopies();
+		if (s->HelperLevels) {
+			// The finer levels of this surface were meshed by helper devices only: the primary's lists hold just what Modifications
+			// rebuilt.  A level is then the helper-made blocks that no Modification has replaced - minus the ones whose minimal
+			// corner lies in this one's box (src/TransVoxelImpl.cpp:433-450: touched blocks plus one ring, per level) - followed by
+			// the primary's blocks, which is the order the reference's vector ends up in (:443-464: erase in place, append).
+			for (unsigned l = 0; l < s->HelperLevels && l < s->Levels.size(); ++l) {
+				const float bm = (float)(16u << l), ext = (float)s->GridSize;
+				float lo[3], hi[3];
+				for (int k = 0; k < 3; ++k) {
+					lo[k] = std::floor(mn[k] / bm - 1.0f) * bm; hi[k] = std::floor(mx[k] / bm + 2.0f) * bm;
+					lo[k] = std::min(std::max(lo[k], 0.f), ext); hi[k] = std::min(std::max(hi[k], 0.f), ext);
+				}
+				std::vector<BlockImpl>& kept = s->HelperBlocks[l];
+				kept.erase(std::remove_if(kept.begin(), kept.end(), [&](const BlockImpl& b) {
+					return b.MinCorner.x >= lo[0] && b.MinCorner.y >= lo[1] && b.MinCorner.z >= lo[2] && b.MinCorner.x < hi[0] && b.MinCorner.y < hi[1] && b.MinCorner.z < hi[2]; }), kept.end());
+				std::vector<BlockImpl> merged;
+				merged.reserve(kept.size() + s->Levels[l].size());
+				merged.insert(merged.end(), kept.begin(), kept.end());
+				merged.insert(merged.end(), s->Levels[l].begin(), s->Levels[l].end());
+				s->Levels[l].swap(merged);
+			}
+			s->Coarse.clear(); // (the coarser levels' views point into the primary's page-locked copy now)
+		} else {
+			// (a surface made by several devices whose primary meshed everything continues on that context, which holds every
+			// level and every cache: all views now point into the primary's copy, the helpers' copies can go)
+			s->ReleaseShardCopies();
+		}
 		FillStats(ctx, s->Stats);
 		return s;
 	}

@@ -1399,13 +1399,17 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 
 // One block of one level >= 1.  GATED (k_main): the children's caches come from other workgroups of the same launch - waited
 // for right in front of the vote, the only phase that reads them - and the block's own completion is published.
-template <bool GATED>
+template <bool GATED, bool PARTIAL = false>
 // selfChild (level 1): the children's consistency bitmaps are not read but formed here, from the children's own samples -
 // the run has no classification pass (k_run_head<allocate>), and the level-0 blocks that form their bitmaps themselves run
 // beside this block, in no order.
 // boxLo / boxHi (incremental runs inside k_main): only the children inside this box of block coordinates are part of the run and
 // publish; the others' caches are what earlier launches left.
-__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid, const bool selfChild = false, const u32* boxLo = nullptr, const u32* boxHi = nullptr)
+// PARTIAL (vx_polygonize_from, emitFrom >= 1: no level-0 walk, no meshes below emitFrom): a level-1 block also writes what the
+// walks of its level-0 children would have left - bitmap, consistency bits, cell count, an empty record - and every block of a
+// level below emitFrom its own empty record (all seven meshes): the caches are complete for a later Modification, the lists
+// hold nothing of these levels.
+__device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32 slot, MatLds& st, const int tid, const bool selfChild = false, const u32* boxLo = nullptr, const u32* boxHi = nullptr, const u32 emitFrom = 0u)
 {
 	const LevelDesc& L = p.levels[level];
 	const LevelDesc& C = p.levels[level - 1];
@@ -1583,6 +1587,29 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
 	}
 	__syncthreads();
+	if (PARTIAL && level == 1u && selfChild) {
+		// (what f0_self_bits / f0_next<SELF> leave behind a level-0 block: here for all eight children at once)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int w = tid + q * WG, c = w >> 7, cs = st.childSlot[c];
+			if (cs >= 0) {
+				const u32 bits = st.childBits[c][w & 127];
+				C.ntBits[(size_t)cs * 128 + (w & 127)] = bits;
+				C.consBits[(size_t)cs * 128 + (w & 127)] = bits;
+			}
+		}
+		if (tid < 8 && st.childSlot[tid] >= 0) {
+			u32 cells = 0;
+			for (int w = 0; w < 128; ++w) cells += (u32)__popc(st.childBits[tid][w]);
+			C.ntCount[st.childSlot[tid]] = (u16)cells;
+			reg_write_empty_record(C, (u32)st.childSlot[tid]);
+		}
+	}
+	if (PARTIAL && level < emitFrom && tid == 0) {
+		reg_write_empty_record(L, slot);
+		BlockRecord& r = L.records[slot];
+		for (int f = 0; f < 6; ++f) { r.tvOff[f] = r.tvCount[f] = r.tiOff[f] = r.tiCount[f] = 0; }
+	}
 	if (THROUGH && tid < 32) store16_through(L.ntBits + (size_t)slot * 128, (u32)tid * 16u, ((const uint4*)st.ntRow)[tid]); // the bitmap, 16 bytes per lane
 	// ---- selection: cells that need an entry (non-trivial, or visited by the transition pass) and have
 	//      any child entry to vote on.  All eight children of a cell live in one child block. -----------
@@ -3083,7 +3110,8 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition, wide)")
 		    || !check(hipFuncSetAttribute((const void*)k_main<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main)")
-		    || !check(hipFuncSetAttribute((const void*)k_main<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main, incremental)")) {
+		    || !check(hipFuncSetAttribute((const void*)k_main<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main, incremental)")
+		    || !check(hipFuncSetAttribute((const void*)k_main<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UP_TAB_LDS + MAIN_STATE_LDS)), "hipFuncSetAttribute(k_main, partial)")) {
 			err = lastError;
 			return false;
 		}
@@ -3562,10 +3590,16 @@ struct Backend {
 	}
 	template <typename P>
 	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0 && tune.selfHead; }
+	// Partial runs (vx_polygonize_from): the levels below emitFrom get caches and bitmaps but no meshes.  Only the single-stream
+	// form offers it (partial_applies); the host asks before it launches and tells its caller what the run really did.
+	u32 emitFrom = 0;
+	template <typename P>
+	bool partial_applies(const P& p, u32 levels) const { return single_stream(p, levels) && !stageOn; }
 	template <typename P>
 	void run_main(const P& p, u32 levels, bool withLevel0)
 	{
 		MainPlan plan;
+		memset(&plan, 0, sizeof(plan));
 		plan.levels = levels;
 		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
 		plan.level0 = withLevel0 ? 1u : 0u;
@@ -3579,7 +3613,12 @@ struct Backend {
 		// number is correct - a workgroup that finds the queues empty leaves - but every workgroup costs a dequeue)
 		u32 grid = (u32)std::min<unsigned long long>(items, (unsigned long long)cus * (withLevel0 ? tune.mainWgsPerCu : tune.upWgsPerCu));
 		if (!withLevel0 && upperItemsHint) grid = std::max<u32>(std::min<u32>(grid, upperItemsHint), std::min<u32>(grid, (u32)cus));
-		launch_with_event(k_main<false>, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
+		if (emitFrom && withLevel0) {
+			// (no level-0 queue: the persistent workgroups are the upper queue's)
+			plan.level0 = 0u; plan.upperNum = plan.upperDen = 1u; plan.emitFrom = emitFrom;
+			launch_with_event(k_main<false, true>, dim3(grid), UP_TAB_LDS + MAIN_STATE_LDS, dev(p), plan);
+		} else
+			launch_with_event(k_main<false>, dim3(grid), UP_TAB_LDS + (withLevel0 ? MAIN_STATE_LDS : UP_STATE_LDS), dev(p), plan);
 		check(hipGetLastError(), "k_main launch");
 	}
 

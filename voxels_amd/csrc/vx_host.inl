@@ -1383,7 +1383,9 @@ int vx_material_lut(vx_ctx* c, const uint8_t* lut, const uint8_t* valid)
 	return c->be.h2d(c->dLut, img.data(), img.size()) ? VX_OK : fail(c, VX_ERR_DEVICE, "vx_material_lut: copy failed");
 }
 
-int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
+int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info) { return vx_polygonize_from(c, num_levels, 0, info); }
+
+int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_level, vx_exec_info* info)
 {
 	VX_ENTER(c);
 	if (!c || !c->n || !c->dDist) return fail(c, VX_ERR_INVALID, "vx_polygonize: no grid resident (call vx_grid_upload / vx_grid_attach first)");
@@ -1414,7 +1416,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		const char* ei = getenv("VX_POOL_INDICES");
 		if (!ensure_pools(c, std::max<u32>(std::max(1u << 16, area * 6), ev ? (u32)atoll(ev) : 0u), std::max<u32>(std::max(1u << 18, area * 24), ei ? (u32)atoll(ei) : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
 	}
-	u32 retries = 0;
+	u32 retries = 0, emitFrom = 0;
 	float ms = 0.f;
 	const bool hostTiming = c->hostTiming;
 	c->be.largeClass = c->largeHint;
@@ -1434,6 +1436,9 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		c->otherSetClean = false;
 		ExecParams p;
 		fill_params(c, p, levels);
+		// a partial run (first_meshed_level > 0) exists on the single-stream path only; anything else meshes every level and says so
+		emitFrom = (first_meshed_level && c->be.partial_applies(p, levels)) ? std::min<u32>(first_meshed_level, levels) : 0u;
+		c->be.emitFrom = emitFrom;
 		c->be.begin_timing();
 		c->be.stage_mark(0);
 		c->be.tailDone = (u32*)c->dHeader + HDR_PUBLISHED + 1; // (k_tail's count of finished general workgroups)
@@ -1498,6 +1503,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: output pools keep overflowing");
 		if (!ensure_pools(c, usedV + usedV / 8 + 1024, usedI + usedI / 8 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize: cannot grow output pools");
 	}
+	c->be.emitFrom = 0;
 	c->largeHint = c->hdr[HDR_LARGE] != 0;
 	{
 		// what the next run of this context can expect on the levels >= 1 (sizes the launch of k_main): a material item per
@@ -1519,6 +1525,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		const LevelDesc& d = c->lv[L];
 		const u32 owned = d.cnt * (d.yb1 - d.yb0) * (d.zb1 - d.zb0);
 		idBase += d.cnt * d.cnt * d.cnt;
+		if (L < emitFrom) continue; // (a partial run: the statistics are those of the levels it meshed)
 		blocksCalculated += owned;
 		trivial += BLOCK_CELLS * (L == 0 ? c->hdr[HDR_STATS + 2] : owned);
 	}
@@ -1596,6 +1603,7 @@ int vx_polygonize(vx_ctx* c, uint32_t num_levels, vx_exec_info* info)
 		info->algorithmic_bytes = (uint64_t)c->n * slabRows * slabPlanes + 2ull * 4096 * c->hdr[0] + 48ull * c->poolVerts + 4ull * c->poolIdx;
 		info->blocks_read = c->hdr[HDR_LARGE + 1];
 		info->mirror_ms = mirrorMs;
+		info->first_meshed_level = emitFrom;
 	}
 	return VX_OK;
 }

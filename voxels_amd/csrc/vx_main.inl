@@ -47,13 +47,20 @@ struct MainPlan {
 	// (Globals::workItems / workCount, written by k_dirty_head); a material block only waits for the children that are part of
 	// this run - those inside the dirty box of their level ([boxLo, boxHi) in block coordinates x, y, z)
 	u32 boxLo[MAX_LEVELS][3], boxHi[MAX_LEVELS][3];
+	// partial runs (k_main<false, true>, vx_polygonize_from): the levels below emitFrom keep their caches and bitmaps up to date
+	// but produce no meshes (another device produces those, libVoxels.so with VOXELS_DEVICES): no level-0 queue, regular and
+	// transition items only for the levels >= emitFrom
+	u32 emitFrom;
 };
 
 // DIRTY: the incremental run's form (TransVoxelRun::Execute with a Modification, src/TransVoxelImpl.cpp:429-465): the same two
 // queues over the work lists k_dirty_head wrote - level-0 blocks with the bitmaps the head formed (no SELF), material blocks
 // that keep the old cache contents where the reference does (mat_block: defineAll), and the levels beyond the lattice copies
 // handed to the general pass of the run's last kernel through Globals::slowItems[1].
-template <bool DIRTY>
+// PARTIAL: the levels below plan.emitFrom are somebody else's to mesh (the helper devices of a multi-device Execute): their
+// material blocks run as always - the caches a later Modification continues from - and the level-1 material blocks also
+// write the bitmaps of their level-0 children, which no level-0 walk forms in such a run.
+template <bool DIRTY, bool PARTIAL = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_main(ExecParamsDev p, MainPlan plan)
 {
 	u8* tab = smem;
@@ -76,12 +83,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		matEnd[l] = r0_uniform(run);
 	}
 	const u32 matTotal = matEnd[MAX_LEVELS - 1];
-	u32 regTotal = 0, trTotal = 0;
+	u32 regTotal = 0, trTotal = 0, skipItems = 0; // (PARTIAL: the blocks of the levels 1 .. emitFrom - 1 lead both segments and are left out)
 #pragma unroll
 	for (u32 l = 1; l < MAX_LEVELS; ++l) {
 		if (l < plan.fastEnd) regTotal = matEnd[l];
 		if (l < plan.levels && p.levels[l].hasTransitions) trTotal = matEnd[l];
+		if (PARTIAL && l + 1u == plan.emitFrom) skipItems = matEnd[l];
 	}
+	if (PARTIAL) { regTotal = max(regTotal, skipItems) - skipItems; trTotal = max(trTotal, skipItems) - skipItems; }
 	const u32 upperTotal = matTotal + regTotal + trTotal;
 	const u32 total0 = plan.level0 ? r0_uniform(DIRTY ? p.G.workCount[0] : p.G.slotCounts[0]) : 0u;
 
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		if (item >= upperTotal) { upperLeft = false; continue; }
 		// item -> (kind, level, slot): the position inside its segment, looked up in the level boundaries
 		const bool isMat = item < matTotal, isReg = !isMat && item < matTotal + regTotal;
-		const u32 f = isMat ? item : (isReg ? item - matTotal : item - matTotal - regTotal);
+		const u32 f = isMat ? item : ((isReg ? item - matTotal : item - matTotal - regTotal) + (PARTIAL ? skipItems : 0u));
 		u32 level = 1, base = 0;
 #pragma unroll
 		for (u32 l = 1; l + 1 < MAX_LEVELS; ++l) if (f >= matEnd[l]) { level = l + 1; base = matEnd[l]; }
@@ -139,7 +148,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 				mat_block<true>(p, level, slot, *(MatLds*)state, tid, false, plan.boxLo[level - 1u], plan.boxHi[level - 1u]);
 				// a level without a lattice copy has no table-driven regular pass: the general pass of the run's last kernel takes the block
 				if (level >= plan.fastEnd && tid0 == 0) p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
-			} else
+			} else if (PARTIAL)
+				mat_block<true, true>(p, level, slot, *(MatLds*)state, tid, true, nullptr, nullptr, plan.emitFrom);
+			else
 				mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
 			MAIN_TICK(3);
 			continue;
