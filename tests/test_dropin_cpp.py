@@ -66,6 +66,33 @@ def test_same_application_same_bytes_on_several_devices(tmp_path, n, devices, va
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,devices,variant", [(128, 2, ""), (128, 4, "B"), (64, 2, "")])
+def test_several_devices_split_the_levels(tmp_path, n, devices, variant):
+    """A gentler surface (DROPIN_GENTLE: no block beyond the first capacity class), where the primary context of a multi-device
+    Execute really leaves the finer levels to the helpers (vx_polygonize_from: VOXELS_TRACE says from which level it meshed):
+    the surface is then helper-made blocks below that level and the primary's above, a Modification drops the helper-made
+    blocks inside its box and appends the primary's - and the dump is still the reference binary's, byte for byte."""
+    from voxels_amd import build
+    build.build_cpp_api()
+    build.build_dropin_tests()
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/dropin_ref not built (needs /root/reference at build time)")
+    a, b = str(tmp_path / "ours.bin"), str(tmp_path / "ref.bin")
+    extra = [variant] if variant else []
+    env = dict(os.environ, DROPIN_GENTLE="1")
+    out = subprocess.run([OURS, str(n), a] + extra, env=dict(env, VOXELS_DEVICES=str(devices), VOXELS_TRACE="1"), timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-500:]
+    meshed = [int(l.split("meshed from level")[1].split()[0]) for l in out.stderr.splitlines() if "meshed from level" in l]
+    assert meshed and min(meshed) >= 1, "the primary meshed every level itself: %s" % out.stderr[-800:]
+    subprocess.check_call([REF, str(n), b] + extra, env=env, timeout=300)
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert len(da) == len(db), (len(da), len(db))
+    if da != db:
+        first = next(i for i in range(len(da)) if da[i] != db[i])
+        raise AssertionError("dumps differ at byte %d of %d" % (first, len(da)))
+
+
+@pytest.mark.gpu
 def test_device_mirror_tracks_grids_and_edits():
     """a Polygonizer reused on a new grid at a recycled address must upload it; two Polygonizers on one grid
     must both see an edit (tests/cpp/mirror_test.cpp)."""

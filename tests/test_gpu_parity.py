@@ -455,8 +455,9 @@ def test_hip_partial_run_keeps_every_cache(port):
             assert ok, msg
             for l in range(first):
                 ids_full = {int(i): k for k, i in enumerate(fa[l].infos["id"])}
-                vo = np.concatenate([[0], np.cumsum(fa[l].infos["n_verts"])]); io = np.concatenate([[0], np.cumsum(fa[l].infos["n_idx"])])
-                pv = np.concatenate([[0], np.cumsum(pa[l].infos["n_verts"])]); pi = np.concatenate([[0], np.cumsum(pa[l].infos["n_idx"])])
+                starts = lambda counts: np.concatenate([[0], np.cumsum(counts.astype(np.int64))]).astype(np.int64)
+                vo, io = starts(fa[l].infos["n_verts"]), starts(fa[l].infos["n_idx"])
+                pv, pi = starts(pa[l].infos["n_verts"]), starts(pa[l].infos["n_idx"])
                 assert len(pa[l].infos) > 0
                 for k, bid in enumerate(pa[l].infos["id"]):
                     j = ids_full[int(bid)]

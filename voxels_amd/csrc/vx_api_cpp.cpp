@@ -574,6 +574,7 @@ public:
 				FillBlock(out[q], res[r.helper].Infos[l][r.k], res[r.helper].Ranges[l][r.k], (const PolygonVertex*)res[r.helper].Meshes.verts, res[r.helper].Meshes.indices);
 			}
 		}
+		if (getenv("VOXELS_TRACE")) fprintf(stderr, "[Voxels] %u devices: helpers mesh the levels below %u, the primary meshed from level %u (device %.3f ms)\n", devices, helperLevels, info.first_meshed_level, info.device_ms);
 		if (info.first_meshed_level) {
 			s->HelperLevels = std::min<unsigned>(info.first_meshed_level, helperLevels);
 			s->HelperBlocks.assign(s->Levels.begin(), s->Levels.begin() + std::min<size_t>(s->HelperLevels, s->Levels.size()));

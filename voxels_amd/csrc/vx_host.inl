@@ -1419,7 +1419,9 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 	u32 retries = 0, emitFrom = 0;
 	float ms = 0.f;
 	const bool hostTiming = c->hostTiming;
-	c->be.largeClass = c->largeHint;
+	// (a partial run exists on the single-stream path only: it is tried first whatever the run before - of another grid,
+	// perhaps - met; blocks beyond the first capacity class repeat the run as the chain, with every level meshed)
+	c->be.largeClass = first_meshed_level ? false : c->largeHint;
 	auto tNow = []() { return std::chrono::steady_clock::now(); };
 	auto tUs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
 	const auto t0 = tNow();
