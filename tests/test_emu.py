@@ -266,6 +266,19 @@ def test_emu_repeated_edits_vs_port(emu, port):
     first.release()
 
 
+def test_emu_polygonize_from_falls_back_to_a_full_run(emu, port):
+    """vx_polygonize_from on a backend without the partial form (the emulation; on the GPU: dense surfaces, stage timing):
+    every level is meshed and the call says so - callers (libVoxels.so's multi-device Execute) rely on that answer."""
+    gold = Golden("terrain32_mat")
+    p = make_poly(emu)
+    p.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    info = p.execute_from(0, 1)
+    assert info.first_meshed_level == 0
+    ok, msg = fields.surface_equal(p.all_levels(), gold.levels)
+    assert ok, msg
+    assert np.array_equal(p.stats(), gold.stats)
+
+
 def test_emu_transition_face_batches(emu, port):
     """White noise at 64^3: every level-1 block has three neighbour faces whose 3 x 256 transition cells are all
     non-trivial — more than the 512-cell transition state holds, so the faces go through in several batches."""
