@@ -193,3 +193,28 @@ def check_host_meshes(poly, hm):
                 assert np.array_equal(hm.verts[r["tv_off"][k][f]:r["tv_off"][k][f] + nv], lev.tverts[otv:otv + nv]), (l, k, f)
                 assert np.array_equal(hm.indices[r["ti_off"][k][f]:r["ti_off"][k][f] + ni], lev.tidx[oti:oti + ni]), (l, k, f)
                 otv += nv; oti += ni
+
+
+def listed_blocks_equal_by_id(part, full):
+    """Every block `part` (a Level) lists is listed by `full` under the same id with the same bytes (regular mesh, transition
+    meshes, corners, counts).  Returns (ok, message).  For surfaces that hold a subset of a level's blocks - the levels a
+    partial run (vx_polygonize_from) did not mesh list only what later Modifications rebuilt."""
+    def starts(counts):
+        return np.concatenate([[0], np.cumsum(counts.astype(np.int64))]).astype(np.int64)
+    where = {int(i): k for k, i in enumerate(full.infos["id"])}
+    fv, fi = starts(full.infos["n_verts"]), starts(full.infos["n_idx"])
+    ftv, fti = starts(full.infos["n_tverts"].sum(axis=1)), starts(full.infos["n_tidx"].sum(axis=1))
+    pv, pi = starts(part.infos["n_verts"]), starts(part.infos["n_idx"])
+    ptv, pti = starts(part.infos["n_tverts"].sum(axis=1)), starts(part.infos["n_tidx"].sum(axis=1))
+    for k, bid in enumerate(part.infos["id"]):
+        j = where.get(int(bid))
+        if j is None:
+            return False, "block id %d is not in the full surface" % bid
+        if part.infos[k] != full.infos[j]:
+            return False, "block %d: infos differ" % bid
+        for name, a, ao, b, bo in (("verts", part.verts, pv, full.verts, fv), ("idx", part.idx, pi, full.idx, fi),
+                                   ("tverts", part.tverts, ptv, full.tverts, ftv), ("tidx", part.tidx, pti, full.tidx, fti)):
+            if not np.array_equal(a[ao[k]:ao[k + 1]], b[bo[j]:bo[j + 1]]):
+                return False, "block %d: %s differ" % (bid, name)
+    return True, "ok"
+

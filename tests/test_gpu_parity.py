@@ -454,16 +454,9 @@ def test_hip_partial_run_keeps_every_cache(port):
             ok, msg = fields.surface_equal(pa[first:], fa[first:], nrm_tol=0.0)
             assert ok, msg
             for l in range(first):
-                ids_full = {int(i): k for k, i in enumerate(fa[l].infos["id"])}
-                starts = lambda counts: np.concatenate([[0], np.cumsum(counts.astype(np.int64))]).astype(np.int64)
-                vo, io = starts(fa[l].infos["n_verts"]), starts(fa[l].infos["n_idx"])
-                pv, pi = starts(pa[l].infos["n_verts"]), starts(pa[l].infos["n_idx"])
                 assert len(pa[l].infos) > 0
-                for k, bid in enumerate(pa[l].infos["id"]):
-                    j = ids_full[int(bid)]
-                    assert pa[l].infos[k] == fa[l].infos[j]
-                    assert np.array_equal(pa[l].verts[pv[k]:pv[k + 1]], fa[l].verts[vo[j]:vo[j + 1]]), "level %d block %d" % (l, bid)
-                    assert np.array_equal(pa[l].idx[pi[k]:pi[k + 1]], fa[l].idx[io[j]:io[j + 1]])
+                ok, msg = fields.listed_blocks_equal_by_id(pa[l], fa[l])
+                assert ok, "level %d: %s" % (l, msg)
     finally:
         full.close(); part.close()
 

@@ -102,7 +102,7 @@ def main():
     p.set_materials(vxo.default_lut())
     if len(sys.argv) > 3 and sys.argv[3] == "edits":
         return fuzz_edits(oracle, p, budget, seed)
-    t0, runs = time.time(), 0
+    t0, runs, partial = time.time(), 0, 0
     while time.time() - t0 < budget:
         kind, n = seed % 5, [32, 64, 64, 128][(seed // 5) % 4]
         d, m, b = make_field(kind, n, seed)
@@ -118,9 +118,37 @@ def main():
         if not np.array_equal(p.pack(), g.pack()):
             print("PACK MISMATCH seed %d" % seed)
             sys.exit(1)
+        if seed % 3 == 0 and len(s.all_levels()) > 1 and not os.environ.get("VX_FUZZ_EMU"):
+            # a partial run (vx_polygonize_from): the levels from `first` up as in the full run, nothing below - and, behind an
+            # edit, exactly the rebuilt blocks below, with the oracle's bytes (the caches the partial run left are complete)
+            rng = np.random.RandomState(seed)
+            ref = s.all_levels()
+            first = int(rng.randint(1, len(ref) + 1))
+            info = p.execute_from(0, first)
+            if info.first_meshed_level:
+                got = p.all_levels()
+                ok, msg = fields.surface_equal(got[first:], ref[first:], nrm_tol=0.0)
+                if not ok or any(len(got[l].infos) for l in range(first)):
+                    print("PARTIAL RUN MISMATCH seed %d first %d: %s" % (seed, first, msg))
+                    sys.exit(1)
+                pos = tuple(float(x) for x in rng.uniform(4, n - 4, 3).round(1))
+                args = (pos, (18.0, 18.0, 18.0), float(rng.uniform(3, 8)), int(rng.randint(0, 3)))
+                mn, mx = g.inject_ball(*args)
+                p.inject_ball(*args)
+                ref_ids = oracle.execute_modify(g, s, mn, mx)
+                ids = p.execute_dirty(mn, mx)
+                got, ref = p.all_levels(), s.all_levels()
+                ok, msg = fields.surface_equal(got[first:], ref[first:], nrm_tol=0.0)
+                for l in range(first):
+                    if ok:
+                        ok, msg = fields.listed_blocks_equal_by_id(got[l], ref[l])
+                if not (ok and np.array_equal(ids, ref_ids) and np.array_equal(p.stats(), s.stats())):
+                    print("PARTIAL RUN + EDIT MISMATCH seed %d first %d: %s" % (seed, first, msg))
+                    sys.exit(1)
+                partial += 1
         runs += 1
         seed += 1
-    print("fuzz ok: %d grids, seeds up to %d, normals compared bitwise" % (runs, seed - 1))
+    print("fuzz ok: %d grids (%d of them also as a partial run + an edit), seeds up to %d, normals compared bitwise" % (runs, partial, seed - 1))
 
 
 if __name__ == "__main__":
