@@ -487,10 +487,11 @@ public:
 		}
 	}
 
-	// A full Execute on several devices.  The primary context polygonizes the whole grid as always (it keeps the caches a
-	// later Modification continues from, gives the statistics, and the few blocks of the levels coarser than a slab, which read
-	// voxels of every slab); the meshes of the finer levels - nearly all bytes of the result - are produced a second time by
-	// the helpers, each for its slab, and travel to the host over the helpers' own links, side by side.
+	// A full Execute on several devices.  The primary context holds the whole grid and runs from the first level the helpers
+	// do not cover (vx_polygonize_from): it builds the caches of every level - what a later Modification continues from - and
+	// meshes the few blocks of the levels coarser than a slab, which read voxels of every slab.  The meshes of the finer
+	// levels - nearly all bytes of the result - are the helpers', each for its slab, and travel to the host over the helpers'
+	// own links, side by side.  (A dense surface makes the primary mesh everything, as until round 4: info.first_meshed_level.)
 	PolygonSurface* ExecuteOnDevices(VoxelGrid* g, const MaterialMap* materials, unsigned devices)
 	{
 		const unsigned n = g->Size(), rows = n / devices;
