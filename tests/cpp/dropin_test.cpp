@@ -158,6 +158,26 @@ int main(int argc, char** argv)
 	Dump(f, surface);
 	mod->Destroy();
 
+	// DROPIN_EDITS=k: k further edits of the same surface - overlapping the first and each other, adding and carving in turn,
+	// updated by either Polygonizer in turn (blocks rebuilt twice, blocks dropped again, lists that keep growing)
+	const int further = getenv("DROPIN_EDITS") ? atoi(getenv("DROPIN_EDITS")) : 0;
+	for (int e = 0; e < further; ++e) {
+		Ball brush; brush.r = n * (0.06f + 0.02f * (float)(e % 3));
+		const float3 at(n * (0.42f + 0.09f * (float)e), n * (0.47f - 0.03f * (float)(e % 2)), n * (0.55f - 0.06f * (float)e));
+		const float3pair touched = grid->InjectSurface(at, float3(n * 0.2f, n * 0.2f, n * 0.2f), &brush, (e & 1) ? IT_Subtract : IT_Add);
+		Put(f, &touched, sizeof(touched));
+		Modification* m2 = Modification::Create();
+		m2->Map = surface;
+		m2->MinCornerModified = touched.first;
+		m2->MaxCornerModified = touched.second;
+		if (((e & 1) ? polyB : poly).Execute(*grid, &mats, m2) != surface) { fprintf(stderr, "Modification %d did not update the surface in place\n", e + 2); return 6; }
+		unsigned c2 = 0;
+		const unsigned* ids2 = m2->GetModifiedBlocks(&c2);
+		PutU(f, c2); Put(f, ids2, size_t(c2) * 4);
+		Dump(f, surface);
+		m2->Destroy();
+	}
+
 	// material edit, block accessors, save/load round trip, fresh full polygonization of the loaded grid
 	grid->InjectMaterial(float3(n * 0.4f, n * 0.5f, n * 0.5f), float3(n * 0.25f, n * 0.25f, n * 0.25f), 5, true);
 	std::vector<char> dist(4096);

@@ -93,6 +93,31 @@ def test_several_devices_split_the_levels(tmp_path, n, devices, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,devices,gentle", [(64, 1, False), (128, 1, True), (128, 2, True), (128, 4, False)])
+def test_a_surface_edited_again_and_again(tmp_path, n, devices, gentle):
+    """DROPIN_EDITS=4: four more Modifications of the same surface behind the first - overlapping boxes, adding and carving in
+    turn, the two Polygonizers in turn.  On several devices with the gentle surface the finer levels are helper-made blocks
+    that shrink edit by edit while the primary's rebuilt blocks are dropped and appended again (the reference's vector order,
+    src/TransVoxelImpl.cpp:443-464, :1274-1293)."""
+    from voxels_amd import build
+    build.build_cpp_api()
+    build.build_dropin_tests()
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/dropin_ref not built (needs /root/reference at build time)")
+    a, b = str(tmp_path / "ours.bin"), str(tmp_path / "ref.bin")
+    env = dict(os.environ, DROPIN_EDITS="4")
+    if gentle:
+        env["DROPIN_GENTLE"] = "1"
+    subprocess.check_call([OURS, str(n), a], env=dict(env, VOXELS_DEVICES=str(devices)), timeout=300)
+    subprocess.check_call([REF, str(n), b], env=env, timeout=300)
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert len(da) == len(db), (len(da), len(db))
+    if da != db:
+        first = next(i for i in range(len(da)) if da[i] != db[i])
+        raise AssertionError("dumps differ at byte %d of %d" % (first, len(da)))
+
+
+@pytest.mark.gpu
 def test_device_mirror_tracks_grids_and_edits():
     """a Polygonizer reused on a new grid at a recycled address must upload it; two Polygonizers on one grid
     must both see an edit (tests/cpp/mirror_test.cpp)."""
