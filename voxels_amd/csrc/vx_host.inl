@@ -1624,6 +1624,25 @@ void live_totals(const vx_ctx* c, uint64_t& verts, uint64_t& idx)
 	}
 }
 
+// the second pair of pools vx_compact_pools packs into: at least `needV` vertices / `needI` indices, allocated with the pools'
+// own capacity when that is more
+bool ensure_spare_pools(vx_ctx* c, uint64_t needV, uint64_t needI)
+{
+	if (c->dVertsSpare && c->dIdxSpare && c->spareVertCap >= needV && c->spareIdxCap >= needI) return true;
+	const uint64_t capV = std::max<uint64_t>(needV, c->vertCap), capI = std::max<uint64_t>(needI, c->idxCap);
+	if (capV > 0xFFFFFFFFull || capI > 0xFFFFFFFFull) return false;
+	c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
+	c->dVertsSpare = c->be.alloc((size_t)capV * sizeof(PolyVertex));
+	c->dIdxSpare = c->be.alloc((size_t)capI * 4);
+	if (!c->dVertsSpare || !c->dIdxSpare) {
+		c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
+		c->dVertsSpare = c->dIdxSpare = nullptr; c->spareVertCap = c->spareIdxCap = 0;
+		return false;
+	}
+	c->spareVertCap = (u32)capV; c->spareIdxCap = (u32)capI;
+	return true;
+}
+
 } // namespace
 
 int vx_compact_pools(vx_ctx* c)
@@ -1649,18 +1668,10 @@ int vx_compact_pools(vx_ctx* c)
 	}
 	// The live meshes move into a second pair of pools, which the context keeps from then on (the pools swap roles at every
 	// compaction): allocating and freeing pool-sized device buffers cost 15-55 ms per compaction - every eight or so edits
-	// of BASELINE config 5 - against 0.3 ms for the copy itself.  The spare pair has the pools' own capacity.
-	if (c->spareVertCap < c->vertCap || c->spareIdxCap < c->idxCap) {
-		c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
-		c->dVertsSpare = c->be.alloc((size_t)c->vertCap * sizeof(PolyVertex));
-		c->dIdxSpare = c->be.alloc((size_t)c->idxCap * 4);
-		c->spareVertCap = c->dVertsSpare ? c->vertCap : 0; c->spareIdxCap = c->dIdxSpare ? c->idxCap : 0;
-		if (!c->dVertsSpare || !c->dIdxSpare) {
-			c->be.free(c->dVertsSpare); c->be.free(c->dIdxSpare);
-			c->dVertsSpare = c->dIdxSpare = nullptr; c->spareVertCap = c->spareIdxCap = 0;
-			return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed");
-		}
-	}
+	// of BASELINE config 5 - against 0.3 ms for the copy itself.
+	// It has to hold the live meshes and room for the next edits' blocks; the first incremental run of a surface allocates it
+	// with the pools' capacity (ensure_spare_pools), so that no edit in a sequence pays for the allocation.
+	if (!ensure_spare_pools(c, (uint64_t)nv + nv / 2 + (1u << 16), (uint64_t)ni + ni / 2 + (1u << 18))) return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed");
 	const size_t segWords = segV.size() + segI.size() + 4;
 	if (segWords * 4 > c->segCap) {
 		c->be.free(c->dSeg);
@@ -1702,13 +1713,21 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
 	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: brick mirror allocation failed: " + c->be.error());
 	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;
-	// once more than half of the pools is dead they are packed first
+	// once more than half of the pools is dead they are packed first (into the spare pair, which the first incremental run of
+	// a context allocates: 15-55 ms that would otherwise hit whichever edit triggers the first compaction; a failure here is
+	// not an error - vx_compact_pools asks again when it needs the pair)
+	if (!c->dVertsSpare) {
+		(void)ensure_spare_pools(c, 0, 0);
+		if (c->hostTiming) fprintf(stderr, "[vx host, dirty] spare pools allocated: %.0f us\n", tUs(t0, tNow()));
+	}
 	{
 		uint64_t liveV, liveI;
 		live_totals(c, liveV, liveI);
 		if ((uint64_t)c->poolVerts > 2 * liveV + (1u << 16) || (uint64_t)c->poolIdx > 2 * liveI + (1u << 18)) {
+			const auto tc = tNow();
 			const int rc = vx_compact_pools(c);
 			if (rc != VX_OK) return rc;
+			if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools packed: %.0f us\n", tUs(tc, tNow()));
 		}
 	}
 	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
@@ -1829,7 +1848,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 			// (appended blocks fill the pools' slack edit after edit: growing by half keeps overflows - a repeated run, a copy of
 			// the pools and an allocation, ~1 ms - rare; vx_compact_pools gives dead ranges back)
+			const auto tg = tNow();
 			if (!grow_pools_keeping(c, usedV + usedV / 2 + 1024, usedI + usedI / 2 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+			if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools grown: %.0f us\n", tUs(tg, tNow()));
 			continue;
 		}
 		if (!uploaded && total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
