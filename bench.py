@@ -56,6 +56,21 @@ def mem_available_gb():
     return 0.0
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time per scheduler period the container may use (cgroup v2 cpu.max / v1 cfs_quota_us), None without a quota."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(n, seed, levels=4):
     """The unmodified reference (oracle/_ref) — or the port when _ref is absent — on the host cores: the SAME grid as the
     GPU run when the host has the memory for it (else a sub-world), all cores, plus a one-thread figure on a bounded
@@ -68,7 +83,11 @@ def cpu_baseline(n, seed, levels=4):
     oracle = vxo.load_ref() or vxo.load_port()
     if oracle is None:
         return None
-    cores = os.cpu_count() or 1
+    host_cpus = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    # threads: the CPUs this process may actually use - its affinity mask, and the container's CPU bandwidth quota when there is
+    # one (more threads than the quota pays for only get the whole process put to sleep until the scheduler's period ends)
+    cores = max(1, min(host_cpus, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus, int(np.ceil(quota)) if quota else host_cpus))
     big = n if (mem_available_gb() >= 40 and cores >= 16) else (512 if cores >= 16 else 256)
 
     counts = {}
@@ -95,7 +114,8 @@ def cpu_baseline(n, seed, levels=4):
     t_all = run(big, cores, 2, count=(big == n))
     t_one = run(256, 1, 1)
     ref_digest = counts.pop("_digest", None)
-    return {"_digest": ref_digest, "value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": oracle.kind, "counts": counts or None,
+    return {"_digest": ref_digest, "value": round(big ** 3 / t_all / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "host_cpus": host_cpus,
+            "cpu_quota_cores": quota, "kind": oracle.kind, "counts": counts or None,
             "one_thread": {"value": round(256 ** 3 / t_one / 1e6, 3), "unit": "Mvoxels/s", "cores": 1,
                            "sample": "256^3 sub-world of the same seeded terrain, all 5 reference LOD levels, 1 run of %.1f s" % t_one},
             "sample": "%s of the same seeded terrain, all %d reference LOD levels (the reference cannot limit levels; the GPU "
@@ -547,7 +567,10 @@ def main():
             ep.create_terrain(en, seed)
             ei0 = ep.execute(0)
             ep.level(0, with_data=False)  # (the host copy of the block lists: fetched once after a full run)
-            col = synth.terrain(en, 0, en, seed, materials=False)[0][:, en // 2, en // 2]
+            # (the surface's height from the resident grid: generating the grid on the host a second time would be a burst of
+            # host threads right in front of the timed calls - in a container with a CPU quota that burst gets every thread of the
+            # process put to sleep for the rest of a 100 ms period, profiles/r05_edit_stalls.txt)
+            col = ep.column(en, en // 2, en // 2)
             zs = float(np.argmax(col >= 0)) if (col >= 0).any() else en * 0.5
             calls, devs, rebuilt, edit_ms, bytes_alg = [], [], [], [], []
             pv, pi = int(ei0.total_verts), int(ei0.total_indices)

@@ -33,6 +33,7 @@ struct Backend {
 	bool d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	void sync() {}
 	bool sync_ok() { return true; }
+	float idle_before_ms() { return -1.f; }
 	bool d2h_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool d2h_side(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool h2d_async(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
@@ -78,6 +79,12 @@ struct Backend {
 				src += sz;
 			}
 		}
+	}
+	void run_box_ids(u32* out, const u32 first[3], const u32 count[3], u32 nb)
+	{
+		u32 i = 0;
+		for (u32 z = 0; z < count[2]; ++z) for (u32 y = 0; y < count[1]; ++y) for (u32 x = 0; x < count[0]; ++x)
+			out[i++] = ((first[2] + z) * nb + first[1] + y) * nb + first[0] + x;
 	}
 	void run_edit(const GridView& g, u8* flags, const u32* ids, u32 count, const EditParams& e)
 	{

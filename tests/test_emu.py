@@ -552,6 +552,8 @@ def test_emu_caves_style_matches_host_generator_and_oracle(emu):
     host = make_poly(emu)
     host.upload(d, m, b, synth.block_empty_flags(d))
     assert np.array_equal(dev.pack(), host.pack())
+    # (Polygonizer.column: a voxel column of the resident grid, what bench.py and the tools find the surface height with)
+    assert np.array_equal(dev.column(n, 37, 21), d[:, 21, 37]) and np.array_equal(dev.column(n, 0, 63), d[:, 63, 0])
     port = vxo.load_port()
     s = port.execute(port.grid_from_dense(d, m, b))
     dev.execute()

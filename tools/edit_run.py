@@ -24,7 +24,7 @@ def main():
     p.create_terrain(n, 1337)
     p.execute(levels)
     p.level(0, with_data=False)  # (the host copy of the block lists: fetched once after a full run)
-    col = synth.terrain(n, 0, n, 1337, materials=False)[0][:, n // 2, n // 2]
+    col = p.column(n, n // 2, n // 2)
     zs = float(np.argmax(col >= 0)) if (col >= 0).any() else n * 0.5  # a point on the surface
     calls, devs, blocks = [], [], []
     for k in range(edits):

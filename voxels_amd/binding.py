@@ -227,6 +227,12 @@ class Polygonizer:
         self._check(self._lib.vx_grid_read_block(self._h, int(block_id), _ptr(d), _ptr(m), _ptr(b), _ptr(f)), "vx_grid_read_block")
         return d, m, b, int(f[0])
 
+    def column(self, n, x, y):
+        """The n distance samples of the voxel column (x, y) of the resident grid (all z), read block by block: what tools use
+        to find the surface without generating the grid on the host a second time."""
+        nb = n // 16
+        return np.concatenate([self.read_block((bz * nb + y // 16) * nb + x // 16)[0][:, y % 16, x % 16] for bz in range(nb)])
+
     def inject_ball(self, pos, ext, radius, inj_type):
         """Grid::InjectSurface with the analytic ball brush, on the device; returns the modified box (output order)."""
         pos = np.ascontiguousarray(pos, np.float32); ext = np.ascontiguousarray(ext, np.float32)

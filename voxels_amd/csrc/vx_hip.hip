@@ -451,6 +451,15 @@ __global__ __launch_bounds__(WG) void k_edit(GridView g, const u32* ids, EditPar
 	}
 }
 
+// The ids of a box of blocks (an edit's touched blocks, run_edit of vx_host.inl), z-major: id = (z * nb + y) * nb + x.
+__global__ __launch_bounds__(WG) void k_box_ids(u32* out, u32 x0, u32 y0, u32 z0, u32 nx, u32 ny, u32 total, u32 nb)
+{
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	if (i >= total) return;
+	const u32 x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
+	out[i] = (z * nb + y) * nb + x;
+}
+
 // BF_Empty by the codec's rule (edit_block_empty of tv_block.h walks the block serially), one workgroup per block.
 // A run starts where the value changes and every 255 voxels inside a constant stretch; the RLE stays "effective"
 // while it has at most 2048 runs; empty <=> effective and every sample has strictly the sign of the first.
@@ -3012,6 +3021,8 @@ struct Backend {
 	hipStream_t copyStream[4] = { nullptr, nullptr, nullptr, nullptr }; // d2h_bulk
 	hipEvent_t evCopy = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t evPrevEnd = nullptr; // the end of the previous timed run (idle_before_ms: diagnostics, VX_HOST_TIMING)
+	bool havePrevEnd = false;
 	hipEvent_t stageEv[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; // [8]: between the level-0 and the level >= 1 regular pass
 	bool stageOn = false, stageValid = false;
 	std::string lastError;
@@ -3121,6 +3132,7 @@ struct Backend {
 	{
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
+		if (evPrevEnd) (void)hipEventDestroy(evPrevEnd);
 		for (int i = 0; i < 9; ++i) if (stageEv[i]) (void)hipEventDestroy(stageEv[i]);
 		for (hipStream_t& cs : copyStream) if (cs) { (void)hipStreamDestroy(cs); cs = nullptr; }
 		if (evCopy) (void)hipEventDestroy(evCopy);
@@ -3175,6 +3187,8 @@ struct Backend {
 		    && check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	void sync() { (void)hipStreamSynchronize(stream); }
+	// (Polling the stream with hipStreamQuery instead was tried against the sporadic 80-95 ms stalls of DESIGN section 9: they also
+	// hit kernel launches and event records, with and without polling, and polling costs 5-10 us per call.)
 	bool sync_ok() { return check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 	bool d2h_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)"); }
 	bool h2d_async(void* d, const void* s, size_t bytes) { return check(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)"); } // (page-locked source)
@@ -3249,7 +3263,7 @@ struct Backend {
 	float end_timing_ms()
 	{
 		(void)hipEventRecord(ev1, stream);
-		if (hipEventSynchronize(ev1) != hipSuccess) return -1.f;
+		if (!sync_ok()) return -1.f; // (ev1 is the last entry of the stream)
 		float ms = 0.f;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
 		return ms;
@@ -3297,6 +3311,12 @@ struct Backend {
 		hipLaunchKernelGGL(k_scatter_blocks, dim3(count), dim3(WG), 0, stream, ids, n, sd, sm, sb, dist, mat, blend);
 		check(hipGetLastError(), "k_scatter_blocks launch");
 	}
+	void run_box_ids(u32* out, const u32 first[3], const u32 count[3], u32 nb)
+	{
+		const u32 total = count[0] * count[1] * count[2];
+		hipLaunchKernelGGL(k_box_ids, dim3((total + WG - 1) / WG), dim3(WG), 0, stream, out, first[0], first[1], first[2], count[0], count[1], total, nb);
+		check(hipGetLastError(), "k_box_ids launch");
+	}
 	void run_edit(const GridView& g, u8* flags, const u32* ids, u32 count, const EditParams& e)
 	{
 		hipLaunchKernelGGL(k_edit, dim3(count), dim3(WG), 0, stream, g, ids, e);
@@ -3304,6 +3324,18 @@ struct Backend {
 		check(hipGetLastError(), "k_edit launch");
 	}
 	void end_timing_record() { (void)hipEventRecord(ev1, stream); }
+	// Diagnostics (VX_HOST_TIMING): how long the stream sat idle on the DEVICE's clock between the end of the previous timed run
+	// and the start of this one - to be called after this run was waited for; then marks this run's end for the next call.  A
+	// host wait that is much longer than the kernels took is either a late wake-up of the host (idle time as always) or a late
+	// start on the device (the idle time holds the delay).  -1: no previous run.
+	float idle_before_ms()
+	{
+		float ms = -1.f;
+		if (!evPrevEnd && hipEventCreate(&evPrevEnd) != hipSuccess) return ms;
+		if (havePrevEnd && hipEventElapsedTime(&ms, evPrevEnd, ev0) != hipSuccess) ms = -1.f;
+		havePrevEnd = hipEventRecord(evPrevEnd, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+		return ms;
+	}
 	float elapsed_ms() // after the stream was synchronised
 	{
 		float ms = 0.f;

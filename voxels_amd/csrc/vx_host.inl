@@ -1301,18 +1301,25 @@ namespace {
 
 // blocks the reference refreshes for an edit at pos +- ext (VoxelGrid.cpp:341-366: the test uses the FULL extents on
 // both sides, twice the edited box) and the box it reports (:477-487, output order)
-void edit_touched_blocks(u32 n, const float pos[3], const float ext[3], std::vector<u32>& out)
+// The blocks an edit touches (Grid::InjectSurface / InjectMaterial walk every block and test its box against the brush's,
+// src/VoxelGrid.cpp): the test is one comparison pair per axis and monotone in the block's coordinate, so the touched blocks
+// are a box of blocks - first[k] .. first[k] + count[k] - 1 per axis (internal axes), found with 3 * nb tests instead of nb^3.
+// The float expressions are the reference's, per axis.
+bool edit_touched_box(u32 n, const float pos[3], const float ext[3], u32 first[3], u32 count[3])
 {
 	const u32 nb = n / 16;
-	for (u32 z = 0; z < nb; ++z) for (u32 y = 0; y < nb; ++y) for (u32 x = 0; x < nb; ++x) {
-		const float bmin[3] = { (float)(x * 16), (float)(y * 16), (float)(z * 16) };
-		bool hit = true;
-		for (int k = 0; k < 3; ++k) {
-			const float bmax = (bmin[k] + 8.f) + 8.f;
-			if (pos[k] - ext[k] > bmax || bmin[k] > pos[k] + ext[k]) hit = false;
+	for (int k = 0; k < 3; ++k) {
+		u32 lo = nb, hi = 0, hits = 0;
+		for (u32 b = 0; b < nb; ++b) {
+			const float bmin = (float)(b * 16), bmax = (bmin + 8.f) + 8.f;
+			if (pos[k] - ext[k] > bmax || bmin > pos[k] + ext[k]) continue;
+			lo = std::min(lo, b); hi = b; ++hits;
 		}
-		if (hit) out.push_back((z * nb + y) * nb + x);
+		if (!hits) return false;
+		if (hi - lo + 1 != hits) return false; // (cannot happen: the test is monotone; nothing is edited rather than the wrong blocks)
+		first[k] = lo; count[k] = hits;
 	}
+	return true;
 }
 
 void edit_modified_box(u32 n, const float pos[3], const float ext[3], float outMin[3], float outMax[3])
@@ -1328,24 +1335,23 @@ int run_edit(vx_ctx* c, const char* what, const float pos[3], const float ext[3]
 {
 	if (!c || !pos || !ext || !outMin || !outMax) return fail(c, VX_ERR_INVALID, std::string(what) + ": null argument");
 	if (!c->ownsGrid || !c->n || (c->zBegin != 0 || c->zEnd != c->n || c->yBegin != 0 || c->yEnd != c->n)) return fail(c, VX_ERR_INVALID, std::string(what) + ": needs a whole grid owned by the context (vx_grid_upload / vx_grid_upload_packed)");
-	std::vector<u32> touched;
-	edit_touched_blocks(c->n, pos, ext, touched);
+	u32 first[3], count[3];
 	edit_modified_box(c->n, pos, ext, outMin, outMax);
-	if (touched.empty()) return VX_OK;
-	if (touched.size() * 4 > c->scratchCap) {
+	if (!edit_touched_box(c->n, pos, ext, first, count)) return VX_OK;
+	const size_t touched = (size_t)count[0] * count[1] * count[2];
+	if (touched * 4 > c->scratchCap) {
 		c->be.free(c->dScratch);
-		c->scratchCap = touched.size() * 4 + 4096;
+		c->scratchCap = touched * 4 + 4096;
 		c->dScratch = c->be.alloc(c->scratchCap);
 		if (!c->dScratch) { c->scratchCap = 0; return fail(c, VX_ERR_DEVICE, std::string(what) + ": allocation failed"); }
 	}
-	void* dIds = c->dScratch;
-	bool ok = c->be.h2d(dIds, touched.data(), touched.size() * 4);
-	if (ok) {
-		c->be.run_edit(resident_view(c), (u8*)c->dFlags, (const u32*)dIds, (u32)touched.size(), e);
-		rebrick_blocks(c, (const u32*)dIds, (u32)touched.size());
-		ok = c->be.sync_ok();
-	}
-	return ok ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device edit failed: " + c->be.error());
+	// the box's block ids are written on the device (z-major like the reference's walk): nothing is uploaded, the call's one
+	// wait is the edit's completion (the brush's box the caller gets back does not depend on it)
+	u32* dIds = (u32*)c->dScratch;
+	c->be.run_box_ids(dIds, first, count, c->n / 16);
+	c->be.run_edit(resident_view(c), (u8*)c->dFlags, dIds, (u32)touched, e);
+	rebrick_blocks(c, dIds, (u32)touched);
+	return c->be.sync_ok() ? VX_OK : fail(c, VX_ERR_DEVICE, std::string(what) + ": device edit failed: " + c->be.error());
 }
 
 } // namespace
@@ -1698,6 +1704,33 @@ int vx_compact_pools(vx_ctx* c)
 	return VX_OK;
 }
 
+// An incremental run found the pools too small (its cursors ended at usedV / usedI; nothing it wrote is referenced yet).  When a
+// third of what the pools hold is dead, packing them (into the spare pair: no allocation) makes the room; otherwise, or if that
+// is still not enough, they grow to one and a half times what the run needs.
+static int make_room_for_edit(vx_ctx* c, u32 usedV, u32 usedI)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const u32 addedV = usedV > c->poolVerts ? usedV - c->poolVerts : 0, addedI = usedI > c->poolIdx ? usedI - c->poolIdx : 0;
+	uint64_t liveV, liveI;
+	live_totals(c, liveV, liveI);
+	bool packed = false;
+	if ((uint64_t)c->poolVerts * 2 > liveV * 3 || (uint64_t)c->poolIdx * 2 > liveI * 3) {
+		const int rc = vx_compact_pools(c);
+		if (rc != VX_OK) return rc;
+		packed = true;
+	}
+	const uint64_t needV = (uint64_t)c->poolVerts + addedV, needI = (uint64_t)c->poolIdx + addedI;
+	bool grown = false;
+	if (needV > c->vertCap || needI > c->idxCap) {
+		const uint64_t wantV = needV + needV / 2 + 1024, wantI = needI + needI / 2 + 4096;
+		if (wantV > 0xFFFFFFFFull || wantI > 0xFFFFFFFFull || !grow_pools_keeping(c, (u32)wantV, (u32)wantI)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+		grown = true;
+	}
+	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools%s%s: %.0f us\n", packed ? " packed" : "", grown ? " grown" : "",
+	                           (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() * 1e-3);
+	return VX_OK;
+}
+
 int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_corner[3], vx_exec_info* info,
                         uint32_t* modified_ids, uint32_t cap, uint32_t* count)
 {
@@ -1716,9 +1749,16 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	// once more than half of the pools is dead they are packed first (into the spare pair, which the first incremental run of
 	// a context allocates: 15-55 ms that would otherwise hit whichever edit triggers the first compaction; a failure here is
 	// not an error - vx_compact_pools asks again when it needs the pair)
+	// The same call gives the pools room for twice what is alive: appended blocks then fill them up to the point where they
+	// are packed, and a sequence of edits allocates nothing (an allocation of this size can take tens of milliseconds when
+	// the driver has to reclaim memory first; pools that still overflow - the surface grew - grow by half, as before).
 	if (!c->dVertsSpare) {
+		uint64_t liveV, liveI;
+		live_totals(c, liveV, liveI);
+		const uint64_t wantV = 2 * liveV + (1u << 17), wantI = 2 * liveI + (1u << 19);
+		if (wantV <= 0xFFFFFFFFull && wantI <= 0xFFFFFFFFull) (void)grow_pools_keeping(c, (u32)wantV, (u32)wantI);
 		(void)ensure_spare_pools(c, 0, 0);
-		if (c->hostTiming) fprintf(stderr, "[vx host, dirty] spare pools allocated: %.0f us\n", tUs(t0, tNow()));
+		if (c->hostTiming) fprintf(stderr, "[vx host, dirty] room for edits (pools for twice the live meshes, spare pair): %.0f us\n", tUs(t0, tNow()));
 	}
 	{
 		uint64_t liveV, liveI;
@@ -1848,9 +1888,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
 			// (appended blocks fill the pools' slack edit after edit: growing by half keeps overflows - a repeated run, a copy of
 			// the pools and an allocation, ~1 ms - rare; vx_compact_pools gives dead ranges back)
-			const auto tg = tNow();
-			if (!grow_pools_keeping(c, usedV + usedV / 2 + 1024, usedI + usedI / 2 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
-			if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools grown: %.0f us\n", tUs(tg, tNow()));
+			{ const int rc = make_room_for_edit(c, usedV, usedI); if (rc != VX_OK) return rc; }
 			continue;
 		}
 		if (!uploaded && total && !c->be.h2d(c->dDirty, coords.data(), (size_t)total * 4)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: upload failed");
@@ -1888,7 +1926,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			break;
 		}
 		if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
-		if (!grow_pools_keeping(c, usedV + usedV / 2 + 1024, usedI + usedI / 2 + 4096)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
+		{ const int rc = make_room_for_edit(c, usedV, usedI); if (rc != VX_OK) return rc; }
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
@@ -1939,7 +1977,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		list.insert(list.end(), fresh[L].begin(), fresh[L].end());
 	}
 	t4 = tNow();
-	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] lists + box %.0f us, enqueue %.0f us, wait %.0f us, records + lists %.0f us, device %.0f us\n", tUs(t0, t1), tUs(t1, t2), tUs(t2, t3), tUs(t3, t4), ms * 1e3);
+	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] lists + box %.0f us, enqueue %.0f us, wait %.0f us, records + lists %.0f us, device %.0f us, stream idle before the run %.0f us\n", tUs(t0, t1), tUs(t1, t2), tUs(t2, t3), tUs(t3, t4), ms * 1e3, (double)c->be.idle_before_ms() * 1e3);
 	c->nextId = nextId;
 	c->stats[0] = total;
 	c->stats[2] = c->hdr[HDR_STATS + 0];
