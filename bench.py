@@ -73,7 +73,8 @@ def cpu_quota_cores():
 
 def cpu_baseline(n, seed, levels=4):
     """The unmodified reference (oracle/_ref) — or the port when _ref is absent — on the host cores: the SAME grid as the
-    GPU run when the host has the memory for it (else a sub-world), all cores, plus a one-thread figure on a bounded
+    GPU run when the host has the memory for it (else a sub-world), one thread per CPU the process may use (affinity mask,
+    container quota), plus a one-thread figure on a bounded
     sub-world.  The reference cannot limit LOD levels: it always produces log2(n/16)+1 of them (stated in `sample`).
     Reported baseline only; never part of the product path.  When the grid is the GPU run's, the first `levels` levels of
     what the reference produced are digested (voxels_amd/digest.py: every byte of every mesh, ids, corners, counts) so that
