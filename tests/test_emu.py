@@ -416,6 +416,41 @@ def check_device_edits(p, port, n, seed, surface_tol=0.0):
         assert np.array_equal(p.stats(), s.stats())
 
 
+def test_emu_edit_sequence_with_tight_pools(emu, port, monkeypatch):
+    """VX_POOL_SLACK=64: every pool rule meets its limit within a few edits - the first full run grows its pools, the first
+    incremental run makes room, later ones do not fit and pack the pools (a third dead) or grow them, and a call that finds more
+    than half dead packs first.  Every step: the oracle's ids, statistics and surface; the host copy follows each new layout."""
+    monkeypatch.setenv("VX_POOL_SLACK", "64")
+    n = 64
+    f = fields.terrain_field(n, 21)
+    m, b = fields.materials_for(n, 21)
+    g = port.grid_from_float(f, m, b)
+    s = port.execute(g)
+    p = make_poly(emu)
+    p.upload_packed(g.pack())
+    info = p.execute()
+    assert info.retries >= 1  # (64 vertices of pool for a surface of thousands)
+    ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+    assert ok, msg
+    rng = np.random.RandomState(5)
+    sizes = []
+    for k in range(24):
+        pos = tuple(float(x) for x in rng.uniform(14, n - 14, 3).round(2))
+        args = (pos, (16.0, 16.0, 16.0), float(rng.uniform(3, 7)), 2 if k % 3 else 0)
+        mn, mx = g.inject_ball(*args)
+        mn2, mx2 = p.inject_ball(*args)
+        assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2)
+        ref_ids = port.execute_modify(g, s, mn, mx)
+        got = p.execute_dirty(mn, mx)
+        assert np.array_equal(got, ref_ids), k
+        ok, msg = fields.surface_equal(p.all_levels(), s.all_levels())
+        assert ok, "edit %d: %s" % (k, msg)
+        assert np.array_equal(p.stats(), s.stats())
+        sizes.append(int(p.info.total_verts))
+    assert any(b < a for a, b in zip(sizes, sizes[1:])), "the pools were never packed: %s" % sizes
+    assert np.array_equal(p.pack(), g.pack())
+
+
 def test_emu_device_edits(emu, port):
     check_device_edits(make_poly(emu), port, 64, 23)
 

@@ -494,6 +494,46 @@ def test_hip_incremental_runs_as_chain_of_launches(port):
     q.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_hip_edit_sequence_with_tight_pools(port, fused):
+    """VX_POOL_SLACK=64 (tests/test_emu.py has the same sequence on the emulation): full runs that grow their pools, incremental
+    runs that do not fit - repeated behind packing or growing the pools, with the slots and cache blocks the failed attempt
+    already claimed - and packing in front of a run; both incremental paths.  Every step against the oracle."""
+    from voxels_amd import Polygonizer, synth
+    n = 64
+    os.environ["VX_POOL_SLACK"] = "64"
+    os.environ["VX_DIRTY_FUSED"] = fused
+    try:
+        q = Polygonizer(device=0)
+    finally:
+        del os.environ["VX_POOL_SLACK"], os.environ["VX_DIRTY_FUSED"]
+    try:
+        q.set_materials(vxo.default_lut())
+        d0, m0, b0 = synth.terrain(n, seed=21)
+        g = port.grid_from_dense(d0, m0, b0)
+        s = port.execute(g)
+        q.upload_packed(g.pack())
+        assert q.execute().retries >= 1
+        rng = np.random.RandomState(5)
+        sizes = []
+        for k in range(24):
+            pos = tuple(float(x) for x in rng.uniform(14, n - 14, 3).round(2))
+            args = (pos, (16.0, 16.0, 16.0), float(rng.uniform(3, 7)), 2 if k % 3 else 0)
+            mn, mx = g.inject_ball(*args)
+            q.inject_ball(*args)
+            ref_ids = port.execute_modify(g, s, mn, mx)
+            got = q.execute_dirty(mn, mx)
+            assert np.array_equal(got, ref_ids), k
+            ok, msg = fields.surface_equal(q.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
+            assert ok, "edit %d: %s" % (k, msg)
+            assert np.array_equal(q.stats(), s.stats())
+            sizes.append(int(q.info.total_verts))
+        assert any(b < a for a, b in zip(sizes, sizes[1:])), "the pools were never packed: %s" % sizes
+        assert np.array_equal(q.pack(), g.pack())
+    finally:
+        q.close()
+
+
 @pytest.mark.parametrize("n", [64, 256])
 def test_hip_repeated_edits_vs_port(poly, port, n):
     """Chained edits with incremental runs: device-resident caches persist like the reference's PolygonMap caches."""

@@ -128,6 +128,7 @@ struct vx_ctx {
 	bool largeHint = true;      // launch the 4096-cell capacity class of the regular pass (unknown before the first run)
 	bool stagedMain = false;    // the last run with stage timing used the single-stream form (vx_stage_layout)
 	u32 runEpoch = 0;           // tag of the current full run in LevelDesc::matDone (Globals::epoch)
+	u32 poolSlack = 1u << 16;   // VX_POOL_SLACK (read once at context creation; tests): the vertices of headroom the pool rules add - smallest pool, packing threshold, room for edits (indices: four times as many)
 	bool hostTiming = false;    // VX_HOST_TIMING (read once at context creation): print where a vx_polygonize call spends host time
 };
 
@@ -689,6 +690,7 @@ int vx_ctx_create(int device_index, vx_ctx** out)
 	std::string e;
 	if (!c->be.init(device_index, e)) { delete c; return VX_ERR_DEVICE; }
 	c->hostTiming = getenv("VX_HOST_TIMING") != nullptr;
+	if (const char* e = getenv("VX_POOL_SLACK")) c->poolSlack = std::max<u32>(64u, (u32)atoll(e));
 	std::vector<u8> img;
 	build_table_image(img);
 	c->dTables = c->be.alloc(TAB_F0_BYTES);
@@ -1420,7 +1422,7 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 		const u32 area = c->n * c->n;
 		const char* ev = getenv("VX_POOL_VERTS"); // (experiments: pools large enough for any layout from the start)
 		const char* ei = getenv("VX_POOL_INDICES");
-		if (!ensure_pools(c, std::max<u32>(std::max(1u << 16, area * 6), ev ? (u32)atoll(ev) : 0u), std::max<u32>(std::max(1u << 18, area * 24), ei ? (u32)atoll(ei) : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
+		if (!ensure_pools(c, std::max<u32>(std::max(c->poolSlack, c->poolSlack == (1u << 16) ? area * 6 : 0u), ev ? (u32)atoll(ev) : 0u), std::max<u32>(std::max(c->poolSlack * 4u, c->poolSlack == (1u << 16) ? area * 24 : 0u), ei ? (u32)atoll(ei) : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
 	}
 	u32 retries = 0, emitFrom = 0;
 	float ms = 0.f;
@@ -1677,7 +1679,7 @@ int vx_compact_pools(vx_ctx* c)
 	// of BASELINE config 5 - against 0.3 ms for the copy itself.
 	// It has to hold the live meshes and room for the next edits' blocks; the first incremental run of a surface allocates it
 	// with the pools' capacity (ensure_spare_pools), so that no edit in a sequence pays for the allocation.
-	if (!ensure_spare_pools(c, (uint64_t)nv + nv / 2 + (1u << 16), (uint64_t)ni + ni / 2 + (1u << 18))) return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed");
+	if (!ensure_spare_pools(c, (uint64_t)nv + nv / 2 + c->poolSlack, (uint64_t)ni + ni / 2 + 4ull * c->poolSlack)) return fail(c, VX_ERR_DEVICE, "vx_compact_pools: allocation failed");
 	const size_t segWords = segV.size() + segI.size() + 4;
 	if (segWords * 4 > c->segCap) {
 		c->be.free(c->dSeg);
@@ -1726,7 +1728,7 @@ static int make_room_for_edit(vx_ctx* c, u32 usedV, u32 usedI)
 		if (wantV > 0xFFFFFFFFull || wantI > 0xFFFFFFFFull || !grow_pools_keeping(c, (u32)wantV, (u32)wantI)) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: cannot grow output pools");
 		grown = true;
 	}
-	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools%s%s: %.0f us\n", packed ? " packed" : "", grown ? " grown" : "",
+	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] the run did not fit: pools%s%s: %.0f us\n", packed ? " packed" : "", grown ? " grown" : "",
 	                           (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() * 1e-3);
 	return VX_OK;
 }
@@ -1755,7 +1757,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	if (!c->dVertsSpare) {
 		uint64_t liveV, liveI;
 		live_totals(c, liveV, liveI);
-		const uint64_t wantV = 2 * liveV + (1u << 17), wantI = 2 * liveI + (1u << 19);
+		const uint64_t wantV = 2 * liveV + 2ull * c->poolSlack, wantI = 2 * liveI + 8ull * c->poolSlack;
 		if (wantV <= 0xFFFFFFFFull && wantI <= 0xFFFFFFFFull) (void)grow_pools_keeping(c, (u32)wantV, (u32)wantI);
 		(void)ensure_spare_pools(c, 0, 0);
 		if (c->hostTiming) fprintf(stderr, "[vx host, dirty] room for edits (pools for twice the live meshes, spare pair): %.0f us\n", tUs(t0, tNow()));
@@ -1763,11 +1765,11 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	{
 		uint64_t liveV, liveI;
 		live_totals(c, liveV, liveI);
-		if ((uint64_t)c->poolVerts > 2 * liveV + (1u << 16) || (uint64_t)c->poolIdx > 2 * liveI + (1u << 18)) {
+		if ((uint64_t)c->poolVerts > 2 * liveV + c->poolSlack || (uint64_t)c->poolIdx > 2 * liveI + 4ull * c->poolSlack) {
 			const auto tc = tNow();
 			const int rc = vx_compact_pools(c);
 			if (rc != VX_OK) return rc;
-			if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools packed: %.0f us\n", tUs(tc, tNow()));
+			if (c->hostTiming) fprintf(stderr, "[vx host, dirty] pools packed (more than half dead): %.0f us\n", tUs(tc, tNow()));
 		}
 	}
 	// ---- block lists (everything in output, Y-up, coordinates like the reference) ----------------------------
