@@ -460,4 +460,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
 }
 
+// The capacity classes above the first over the level-0 work list of an incremental run (Globals::workItems[0]), behind
+// k_main<true>, which leaves blocks beyond its class alone: bitmaps and cell counts are k_dirty_head's.  A block with a zero
+// sample goes to k_regular0<4096, 2> through Globals::slowItems[0].
+template <int CAP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_dirty_regular0_fast(ExecParamsDev p, u32 lo)
+{
+	if (*p.G.largeBlocks == 0) return; // nothing beyond the first class (uniform over the grid)
+	typedef Fast0State<CAP> ST;
+	u8* tab = smem;
+	ST& st = *(ST*)(smem + F0_TAB_LDS);
+	__shared__ u32 wgStats[20];
+	__shared__ u32 zeroFlag[2];
+
+	const LevelDesc& L = p.levels[0];
+	(void)L;
+	const u32 total = r0_uniform(p.G.workCount[0]);
+	if (blockIdx.x >= total) return;
+	const int tid = (int)threadIdx.x;
+	if (tid < 20) wgStats[tid] = 0;
+	if (tid < 2) zeroFlag[tid] = 0;
+	const F0Tables T = f0_stage_tables(tab, p.tables);
+
+	u32 parity = 0;
+	f0_walk<CAP, false>(p, T, st, wgStats, zeroFlag, parity, total, lo, blockIdx.x, gridDim.x, total, tid);
+	__syncthreads();
+	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+}
+
 } // namespace

@@ -295,4 +295,43 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_
 	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
 }
 
+// The same blocks' work over the work lists of an incremental run (Globals::workItems, levels 1 .. levelEnd - 1): the capacity
+// classes above the first behind k_main<true>, which leaves blocks beyond its class alone.  Bitmaps, cache blocks and cell
+// counts are what k_main<true>'s material blocks wrote in the launch before.  What a block hands on (a zero lattice sample, a
+// chain that ends on a voxel) goes to k_regular<4096, 2> through Globals::slowItems[1] like everywhere.
+template <int CAP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5))) void k_dirty_regular1_fast(ExecParamsDev p, u32 levelEnd, u32 lo)
+{
+	if (*p.G.largeBlocks == 0) return; // nothing beyond the first class (uniform over the grid)
+	typedef Fast1State<CAP> ST;
+	u8* tab = smem;
+	ST& st = *(ST*)(smem + F0_TAB_LDS);
+	__shared__ u32 wgStats[20];
+	__shared__ u32 zeroFlag[2];
+	__shared__ WorkList wl;
+
+	const int tid = (int)threadIdx.x;
+	if (tid < 20) wgStats[tid] = 0;
+	if (tid < 2) zeroFlag[tid] = 0;
+	if (tid == 0) {
+		u32 run = 0;
+		for (u32 l = 0; l <= MAX_LEVELS; ++l) { wl.start[l] = run; if (l >= 1 && l < levelEnd) run += p.G.workCount[l]; }
+	}
+	const F0Tables T = f0_stage_tables(tab, p.tables); // visible after the first barrier of the item loop
+	__syncthreads();
+	const u32 total = r0_uniform(wl.start[MAX_LEVELS]);
+	const GridView& g = p.G.grid;
+	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
+	u32 parity = 0;
+	for (u32 it = blockIdx.x; it < total; it += gridDim.x) {
+		u32 level, idx;
+		decode_item(wl, levelEnd, it, level, idx);
+		const u32 slot = p.G.workItems[level][idx];
+		const LevelDesc& L = p.levels[level];
+		f1_block<CAP, false>(p, T, smp, st, wgStats, zeroFlag, parity, r0_uniform(level), r0_uniform(slot), r0_uniform(L.slotCoord[slot]), r0_uniform((u32)L.ntCount[slot]), lo, tid);
+	}
+	__syncthreads();
+	if (tid < 20 && wgStats[tid]) atomicAdd(&p.G.stats[tid], wgStats[tid]);
+}
+
 } // namespace

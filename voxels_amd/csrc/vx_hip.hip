@@ -3116,6 +3116,8 @@ struct Backend {
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>))), "hipFuncSetAttribute(k_regular1_fast)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>))), "hipFuncSetAttribute(k_regular1_fast mid)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular1_fast<REG_CAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>))), "hipFuncSetAttribute(k_regular1_fast big)")
+		    || !check(hipFuncSetAttribute((const void*)k_dirty_regular0_fast<REG_CAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>))), "hipFuncSetAttribute(k_dirty_regular0_fast big)")
+		    || !check(hipFuncSetAttribute((const void*)k_dirty_regular1_fast<REG_CAP_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>))), "hipFuncSetAttribute(k_dirty_regular1_fast big)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large, handed on)")
 		    || !check(hipFuncSetAttribute((const void*)k_regular<4096, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, regLarge), "hipFuncSetAttribute(k_regular large)")
 		    || !check(hipFuncSetAttribute((const void*)k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, trLds), "hipFuncSetAttribute(k_transition)")
@@ -3703,9 +3705,22 @@ struct Backend {
 		check(hipGetLastError(), "k_main (incremental) launch");
 		if (largeExpected) {
 			const u32 ldsL0 = R0_TAB_LDS + sizeof(Reg0State<4096>), ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
-			hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus))), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
 			const u32 upper = q.start[levels] - q.start[1];
-			if (upper) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
+			const u32 grid0 = std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus));
+			if (tune.bigClass) {
+				// blocks beyond k_main's capacity class: table-driven like everywhere else (a general block of this size takes 45 us
+				// where a table-driven one takes a third); the general pass only sees what those hand on
+				hipLaunchKernelGGL(k_dirty_regular0_fast<REG_CAP_BIG>, dim3(std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus * 2))), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>), stream, dev(p), (u32)REG_CAP_SMALL);
+				hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+				if (upper) {
+					hipLaunchKernelGGL(k_dirty_regular1_fast<REG_CAP_BIG>, dim3(std::min<u32>(upper, (u32)cus * 2)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>), stream, dev(p), plan.fastEnd, (u32)REG_CAP_SMALL);
+					// (also the blocks of a level without a lattice copy: k_main<true> hands every one of them on)
+					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
+				}
+			} else {
+				hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+				if (upper) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
+			}
 			check(hipGetLastError(), "large-class launches (incremental)");
 		}
 		DirtyTailPlan t;
