@@ -181,7 +181,7 @@ struct Backend {
 		u32* roleTicket; u32* slowDone;
 		BlockRecord* hostRecs; u32* hostHeader; u32 headerWords, publishedWord;
 	};
-	template <typename P> void run_dirty_fused(const P&, u32, const DirtyLaunch&, bool) {}
+	template <typename P> void run_dirty_fused(const P&, u32, const DirtyLaunch&, bool, bool) {}
 	void stage_enable(bool) {}
 	void stage_mark(int) {}
 	// halo messages: the same piece descriptors, moved with memcpy; no communicator (multi-process CPU runs exchange

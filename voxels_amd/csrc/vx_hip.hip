@@ -2718,7 +2718,8 @@ __global__ __launch_bounds__(WG) void k_dirty_head(ExecParamsDev p, DirtyPlan d)
 	if (tid == 0) {
 		p.P.cursors[CUR_V] = d.poolVerts; p.P.cursors[CUR_I] = d.poolIdx;
 		p.G.stats[2] = sh[3] & 0xFFFFu;
-		*p.G.largeBlocks = sh[3] >> 16;
+		*p.G.largeBlocks = sh[3] >> 16;     // (the material blocks of k_main<true> add the levels above)
+		p.G.largeBlocks[2] = sh[3] >> 16;   // level 0 alone: the host announces the two kinds apart (run_dirty_fused)
 	}
 	// the work lists: a wave per level (levels beyond the fourth: a second turn), 64 coordinates of the level's box per step, four
 	// steps' slots requested together; the list keeps the box's coordinate order
@@ -3677,7 +3678,7 @@ struct Backend {
 	// 4096-cell class of the general pass takes them from the work lists, in two launches of its own in front of the tail
 	// (launched only when the run before met such blocks; a run that meets one unannounced says so in its header and is repeated)
 	template <typename P>
-	void run_dirty_fused(const P& p, u32 levels, const DirtyLaunch& q, bool largeExpected)
+	void run_dirty_fused(const P& p, u32 levels, const DirtyLaunch& q, bool large0Expected, bool largeUpperExpected)
 	{
 		DirtyPlan d;
 		memset(&d, 0, sizeof(d));
@@ -3703,22 +3704,26 @@ struct Backend {
 		}
 		hipLaunchKernelGGL(k_main<true>, dim3(std::max<u32>(1u, std::min<u32>(items, slots))), dim3(WG), UP_TAB_LDS + MAIN_STATE_LDS, stream, dev(p), plan);
 		check(hipGetLastError(), "k_main (incremental) launch");
-		if (largeExpected) {
+		if (large0Expected || largeUpperExpected) {
+			// (level 0 and the levels above it are announced apart: the coarse levels of a terrain hold such blocks where level 0
+			// has none, and each pair of launches costs ~10 us even when it finds nothing)
 			const u32 ldsL0 = R0_TAB_LDS + sizeof(Reg0State<4096>), ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
-			const u32 upper = q.start[levels] - q.start[1];
+			const u32 upper = largeUpperExpected ? q.start[levels] - q.start[1] : 0u;
 			const u32 grid0 = std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus));
 			if (tune.bigClass) {
 				// blocks beyond k_main's capacity class: table-driven like everywhere else (a general block of this size takes 45 us
 				// where a table-driven one takes a third); the general pass only sees what those hand on
-				hipLaunchKernelGGL(k_dirty_regular0_fast<REG_CAP_BIG>, dim3(std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus * 2))), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>), stream, dev(p), (u32)REG_CAP_SMALL);
-				hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+				if (large0Expected) {
+					hipLaunchKernelGGL(k_dirty_regular0_fast<REG_CAP_BIG>, dim3(std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus * 2))), dim3(WG), F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>), stream, dev(p), (u32)REG_CAP_SMALL);
+					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+				}
 				if (upper) {
 					hipLaunchKernelGGL(k_dirty_regular1_fast<REG_CAP_BIG>, dim3(std::min<u32>(upper, (u32)cus * 2)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>), stream, dev(p), plan.fastEnd, (u32)REG_CAP_SMALL);
 					// (also the blocks of a level without a lattice copy: k_main<true> hands every one of them on)
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
 				}
 			} else {
-				hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
+				if (large0Expected) hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
 				if (upper) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
 			}
 			check(hipGetLastError(), "large-class launches (incremental)");

@@ -94,7 +94,8 @@ struct vx_ctx {
 	u32 dirtyCap = 0;
 	void* dDirtyTicket = nullptr; // incremental runs as three launches: k_dirty_head's count of finished workgroups over all its launches
 	u32 dirtyTickets = 0;         // ... and what the host knows it to be
-	bool dirtyLargeHint = false;  // the last incremental run met blocks beyond the first capacity class (their launches are made)
+	bool dirtyLargeHint = false;  // the last incremental run met blocks beyond the first capacity class on the levels >= 1 (their launches are made)
+	bool dirtyLarge0Hint = false; // ... on level 0
 	// level tables
 	u32 tablesN = 0, tablesZb0 = 0, tablesZb1 = 0, tablesYb0 = 0, tablesYb1 = 0;
 	u32 refLevels = 0;
@@ -1830,7 +1831,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	{
 		ExecParams p0;
 		fill_params(c, p0, levels);
-		fused = total && cnt[0] && c->be.dirty_fused_applies(p0, levels, c->dirtyLargeHint);
+		fused = total && cnt[0] && c->be.dirty_fused_applies(p0, levels, c->dirtyLargeHint || c->dirtyLarge0Hint);
 	}
 	if (fused) {
 		if (!c->dDirtyTicket) {
@@ -1874,7 +1875,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			q.hostRecs = c->hRecs; q.hostHeader = c->hdrPinned; q.headerWords = HDR_WORDS; q.publishedWord = HDR_PUBLISHED;
 			c->hdrPinned[HDR_PUBLISHED] = 0;
 			c->be.begin_timing();
-			c->be.run_dirty_fused(p, levels, q, c->dirtyLargeHint);
+			c->be.run_dirty_fused(p, levels, q, c->dirtyLarge0Hint, c->dirtyLargeHint);
 			c->be.end_timing_record();
 			t2 = tNow();
 			if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
@@ -1883,8 +1884,15 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			if (c->hdrPinned[HDR_PUBLISHED] == 0) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's header did not arrive (internal error)");
 			memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
 			if (c->hdr[HDR_GIVEUP]) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: a dependency wait inside the run timed out (internal error)");
-			if (c->hdr[HDR_LARGE] && !c->dirtyLargeHint) { c->dirtyLargeHint = true; continue; } // a block beyond the first capacity class, unannounced: once more, with that class launched
-			c->dirtyLargeHint = c->hdr[HDR_LARGE] != 0;
+			{
+				// blocks beyond the first capacity class, on level 0 (counted by k_dirty_head) and above it: unannounced, the run is
+				// repeated once with their launches made
+				const u32 large0 = c->hdr[HDR_LARGE + 2], largeUpper = c->hdr[HDR_LARGE] > large0 ? c->hdr[HDR_LARGE] - large0 : 0u;
+				const bool missed = (large0 && !c->dirtyLarge0Hint) || (largeUpper && !c->dirtyLargeHint);
+				c->dirtyLarge0Hint = large0 != 0 || (missed && c->dirtyLarge0Hint);
+				c->dirtyLargeHint = largeUpper != 0 || (missed && c->dirtyLargeHint);
+				if (missed) continue;
+			}
 			const u32 usedV = c->hdr[HDR_CURSORS], usedI = c->hdr[HDR_CURSORS + CUR_I], overflow = c->hdr[HDR_CURSORS + CUR_OVF];
 			if (!overflow) { recs = c->hRecs; recordsInListOrder = true; break; }
 			if (++retries > 3) return fail(c, VX_ERR_OVERFLOW, "vx_polygonize_dirty: output pools keep overflowing");
