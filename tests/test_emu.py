@@ -455,6 +455,36 @@ def test_emu_device_edits(emu, port):
     check_device_edits(make_poly(emu), port, 64, 23)
 
 
+def test_emu_brushes_anywhere_touch_the_reference_s_blocks(emu, port):
+    """vx_grid_inject_ball / vx_grid_inject_material find the touched blocks as a box (three per-axis scans instead of the
+    reference's walk over every block, src/VoxelGrid.cpp:388-584): brushes inside, across the grid's sides, outside it, of zero
+    extent, on block boundaries - the grid afterwards is the reference's, byte for byte, and so is the box handed back."""
+    n = 48
+    rng = np.random.RandomState(77)
+    f = fields.terrain_field(n, 3)
+    m, b = fields.materials_for(n, 3)
+    g = port.grid_from_float(f, m, b)
+    p = make_poly(emu)
+    p.upload_packed(g.pack())
+    cases = [((16.0, 16.0, 16.0), (16.0, 16.0, 16.0), 5.0), ((0.0, 0.0, 0.0), (10.0, 10.0, 10.0), 6.0), ((float(n), float(n), float(n)), (8.0, 8.0, 8.0), 5.0),
+             ((24.0, 24.0, 24.0), (0.0, 0.0, 0.0), 3.0), ((-30.0, 20.0, 20.0), (10.0, 10.0, 10.0), 4.0), ((20.0, 200.0, 20.0), (12.0, 12.0, 12.0), 4.0),
+             ((31.999, 32.0, 32.001), (0.001, 16.0, 15.999), 7.0), ((47.5, 0.5, 23.0), (3.0, 3.0, 40.0), 9.0)]
+    for _ in range(40):
+        pos = tuple(float(x) for x in rng.uniform(-10, n + 10, 3).round(3))
+        ext = tuple(float(x) for x in rng.choice([0.5, 3.0, 8.0, 17.0, 40.0], 3))
+        cases.append((pos, ext, float(rng.uniform(1, 12))))
+    for k, (pos, ext, r) in enumerate(cases):
+        t = (2, 0, 1)[k % 3]
+        mn, mx = g.inject_ball(pos, ext, r, t)
+        mn2, mx2 = p.inject_ball(pos, ext, r, t)
+        assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2), (k, pos, ext)
+        if k % 4 == 3:
+            a = g.inject_material(pos, ext, 7 + k % 5, k % 8 < 4)
+            c = p.inject_material(pos, ext, 7 + k % 5, k % 8 < 4)
+            assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), (k, pos, ext)
+        assert np.array_equal(p.pack(), g.pack()), "brush %d at %s, extent %s" % (k, pos, ext)
+
+
 def check_compaction(p, port, n):
     """Pools after a chain of edits hold dead ranges; vx_compact_pools packs the live meshes into fresh pools without
     changing anything a caller can download, and further incremental runs keep working."""
