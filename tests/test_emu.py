@@ -455,16 +455,16 @@ def test_emu_device_edits(emu, port):
     check_device_edits(make_poly(emu), port, 64, 23)
 
 
-def test_emu_brushes_anywhere_touch_the_reference_s_blocks(emu, port):
+def check_brushes_anywhere(p, port):
     """vx_grid_inject_ball / vx_grid_inject_material find the touched blocks as a box (three per-axis scans instead of the
-    reference's walk over every block, src/VoxelGrid.cpp:388-584): brushes inside, across the grid's sides, outside it, of zero
-    extent, on block boundaries - the grid afterwards is the reference's, byte for byte, and so is the box handed back."""
+    reference's walk over every block, src/VoxelGrid.cpp:388-584; the ids are written by k_box_ids): brushes inside, across the
+    grid's sides, outside it, of zero extent, on block boundaries - the grid afterwards is the reference's, byte for byte, and
+    so is the box handed back."""
     n = 48
     rng = np.random.RandomState(77)
     f = fields.terrain_field(n, 3)
     m, b = fields.materials_for(n, 3)
     g = port.grid_from_float(f, m, b)
-    p = make_poly(emu)
     p.upload_packed(g.pack())
     cases = [((16.0, 16.0, 16.0), (16.0, 16.0, 16.0), 5.0), ((0.0, 0.0, 0.0), (10.0, 10.0, 10.0), 6.0), ((float(n), float(n), float(n)), (8.0, 8.0, 8.0), 5.0),
              ((24.0, 24.0, 24.0), (0.0, 0.0, 0.0), 3.0), ((-30.0, 20.0, 20.0), (10.0, 10.0, 10.0), 4.0), ((20.0, 200.0, 20.0), (12.0, 12.0, 12.0), 4.0),
@@ -483,6 +483,10 @@ def test_emu_brushes_anywhere_touch_the_reference_s_blocks(emu, port):
             c = p.inject_material(pos, ext, 7 + k % 5, k % 8 < 4)
             assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), (k, pos, ext)
         assert np.array_equal(p.pack(), g.pack()), "brush %d at %s, extent %s" % (k, pos, ext)
+
+
+def test_emu_brushes_anywhere_touch_the_reference_s_blocks(emu, port):
+    check_brushes_anywhere(make_poly(emu), port)
 
 
 def check_compaction(p, port, n):

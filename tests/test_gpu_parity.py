@@ -908,6 +908,14 @@ def test_hip_device_edits(poly, port, n):
 
 
 @pytest.mark.gpu
+def test_hip_brushes_anywhere_touch_the_reference_s_blocks(poly, port):
+    """Brushes inside, across and outside the grid (tests/test_emu.py has the same list on the emulation): the touched blocks'
+    ids are written on the device (k_box_ids), the grid afterwards is the reference's byte for byte."""
+    from test_emu import check_brushes_anywhere
+    check_brushes_anywhere(poly, port)
+
+
+@pytest.mark.gpu
 def test_hip_pool_compaction(poly, port):
     """vx_compact_pools after incremental runs: live meshes packed on the device, downloads unchanged."""
     from test_emu import check_compaction
