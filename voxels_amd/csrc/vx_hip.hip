@@ -1490,13 +1490,11 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		// on top of the vote list (written after the bitmaps are complete).  A piece only some absent child would read is
 		// not resident on a rank that owns a slab of the grid: it is read from a resident address instead and masked.
 		static_assert(sizeof(st.voteList) >= 1089 * 4 + 1092, "row masks of the children on top of the vote list");
-		u16* piece = (u16*)st.voteList;                 // [row * 2 + h]
-		u8* farBit = (u8*)st.voteList + 1089 * 4;       // [row]
+		u32* rowW = (u32*)st.voteList;                  // [row]: sign bits of the samples 0..31
+		u8* farBit = (u8*)st.voteList + 1089 * 4;       // [row]: sign bit of sample 32
 		// Addresses relative to the first child's brick, in 32 bits (k_main runs on mirrors below 4 GiB): the brick index is
 		// linear in the block coordinates and brick_local's bit fields are disjoint per axis, so a row's offset is
-		// ((Z >> 4) * bricks per plane + (Y >> 4) * bricks per row + h) << 12 | local(Y & 15, Z & 15) - a dozen instructions
-		// where fifteen calls of brick_offset with their clamps cost a hundred each (1 500 per lane and block: a tenth of
-		// k_main's vector instructions at 1024^3).
+		// ((Z >> 4) * bricks per plane + (Y >> 4) * bricks per row + h) << 12 | local(Y & 15, Z & 15).
 		const u32 nbU = (u32)n >> 4, planeBricks = (u32)g.bRowsY * nbU;
 		const size_t origin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
 		u32 ex = 0, residentRel = 0;
@@ -1504,51 +1502,58 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		for (int c = 7; c >= 0; --c) if (st.childSlot[c] >= 0) { ex |= 1u << c; residentRel = (((u32)(c >> 2) * planeBricks + (u32)((c >> 1) & 1) * nbU + (u32)(c & 1)) << 12); }
 		if (tid < 8) st.childSkip[tid] = st.childSlot[tid] >= 0 ? (u32)C.skip[st.childSlot[tid]] : 1u;
 		const u32 exPair = (ex | (ex >> 1)) & 0x55u;
-		const auto needed = [&](int Y, int Z) {
+		const auto needed = [&](u32 Y, u32 Z) {
 			// (the second piece of a row also holds sample 16 of the first child column: x is never partitioned)
-			const u32 sel = ((Y <= 16 ? 0x11u : 0u) | (Y >= 16 ? 0x44u : 0u)) & ((Z <= 16 ? 0x0Fu : 0u) | (Z >= 16 ? 0xF0u : 0u));
+			const u32 sel = ((Y <= 16u ? 0x11u : 0u) | (Y >= 16u ? 0x44u : 0u)) & ((Z <= 16u ? 0x0Fu : 0u) | (Z >= 16u ? 0xF0u : 0u));
 			return (exPair & sel) != 0u;
 		};
-		const int yMax = n - 1 - (int)(by * 32), zMax = n - 1 - (int)(bz * 32); // (>= 31: the clamp binds on row / plane 32 of the grid's last blocks)
-		const auto rowRel = [&](int Y, int Z) {
-			const u32 yc = (u32)min(Y, yMax), zc = (u32)min(Z, zMax);
+		const u32 yMax = (u32)(n - 1 - (int)(by * 32)), zMax = (u32)(n - 1 - (int)(bz * 32)); // (>= 31: the clamp binds on row / plane 32 of the grid's last blocks)
+		const auto rowRel = [&](u32 Y, u32 Z) {
+			const u32 yc = min(Y, yMax), zc = min(Z, zMax);
 			return ((__umul24(zc >> 4, planeBricks) + __umul24(yc >> 4, nbU)) << 12) | (((zc & 15u) >> 1) << 9) | (((yc & 15u) >> 2) << 7) | ((zc & 1u) << 6) | ((yc & 3u) << 4);
 		};
 		const i8* base = g.bDist + origin;
-		// piece u = (Z * 33 + Y) * 2 + h, u < 2178: Z = u / 66 (exact as (u * 993) >> 16 below 2560)
-#pragma unroll 1
+		// the sample behind the second piece: x = min(X0 + 32, n - 1) - the first byte of the third brick along x, or, at the
+		// grid's far side, the last byte of the second
+		const bool lastX = (int)(bx * 32) + 32 > n - 1;
+		const u32 farRel = lastX ? ((1u << 12) | 15u) : (2u << 12);
+		// the sign bits of four bytes as a nibble: the bits 7, 15, 23, 31 times (1 + 2^7 + 2^14 + 2^21) meet in the bits 28..31 (no two
+		// partial products share a bit, nothing carries)
+		const auto sign4 = [](u32 d) { return ((d & 0x80808080u) * 0x00204081u) >> 28; };
+		const auto sign16 = [&](uint4 d) { return sign4(d.x) | (sign4(d.y) << 4) | (sign4(d.z) << 8) | (sign4(d.w) << 12); };
+		// A lane takes the rows tid, tid + 256, ... (row = Z * 33 + Y; 256 = 7 * 33 + 25: the next row is 7 planes and 25 rows
+		// on) and reads BOTH pieces and the far sample of each: three loads per row from one offset, all of a batch in flight
+		// before the first mask is formed.  (Round 6: the pieces used to be dealt out one by one, 2 178 of them with an address
+		// of their own each, and the consumer below picked its half per lane - together a fifth of a material block's vector
+		// instructions at 1024^3.)
+		u32 Z = ((u32)tid * 1986u) >> 16, Y = (u32)tid - Z * 33u; // (tid / 33, exact below 1280)
+#pragma unroll
 		for (int batch = 0; batch < 2; ++batch) {
-			uint4 d[5];
+			const int rows = batch ? 2 : 3;
+			uint4 a[3], b[3];
+			i8 f[3];
+			u32 rowIdx[3];
 #pragma unroll
-			for (int q = 0; q < 5; ++q) {
-				const u32 u = (u32)min(tid + (batch * 5 + q) * WG, 2177);
-				const u32 Z = (u * 993u) >> 16, rem = u - Z * 66u, Y = rem >> 1, h = rem & 1u;
-				u32 off = residentRel;
-				if (needed((int)Y, (int)Z)) off = rowRel((int)Y, (int)Z) + (h << 12);
-				d[q] = *(const uint4*)(base + off);
+			for (int q = 0; q < 3; ++q) {
+				if (q < rows) {
+					const u32 r = Z * 33u + Y;
+					rowIdx[q] = r;
+					u32 off = residentRel, offB = residentRel, offF = residentRel;
+					if (r <= 1088u && needed(Y, Z)) { off = rowRel(Y, Z); offB = off + (1u << 12); offF = off + farRel; }
+					a[q] = *(const uint4*)(base + off);
+					b[q] = *(const uint4*)(base + offB);
+					f[q] = base[offF];
+					Y += 25u; Z += 7u;
+					if (Y >= 33u) { Y -= 33u; Z += 1u; }
+				}
 			}
 #pragma unroll
-			for (int q = 0; q < 5; ++q) {
-				const int u = tid + (batch * 5 + q) * WG;
-				if (u < 2178) piece[u] = (u16)(sign_nibble(d[q].x) | (sign_nibble(d[q].y) << 4) | (sign_nibble(d[q].z) << 8) | (sign_nibble(d[q].w) << 12));
+			for (int q = 0; q < 3; ++q) {
+				if (q < rows && rowIdx[q] <= 1088u) {
+					rowW[rowIdx[q]] = sign16(a[q]) | (sign16(b[q]) << 16);
+					farBit[rowIdx[q]] = (u8)(((u32)(f[q] >> 7)) & 1u);
+				}
 			}
-		}
-		{
-			// the sample behind the second piece: x = min(X0 + 32, n - 1) - the first byte of the third brick along x, or, at the
-			// grid's far side, the last byte of the second
-			const bool lastX = (int)(bx * 32) + 32 > n - 1;
-			const u32 farRel = lastX ? ((1u << 12) | 15u) : (2u << 12);
-			i8 f[5];
-#pragma unroll
-			for (int q = 0; q < 5; ++q) {
-				const u32 row = (u32)min(tid + q * WG, 1088);
-				const u32 Z = (row * 1986u) >> 16, Y = row - Z * 33u; // (row / 33, exact below 1280)
-				u32 off = residentRel;
-				if (needed((int)Y, (int)Z)) off = rowRel((int)Y, (int)Z) + farRel;
-				f[q] = base[off];
-			}
-#pragma unroll
-			for (int q = 0; q < 5; ++q) { const int row = tid + q * WG; if (row < 1089) farBit[row] = (u8)(((u32)(f[q] >> 7)) & 1u); }
 		}
 	} else if (level == 1) {
 #pragma unroll
@@ -1570,26 +1575,27 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		if (nt) atomicAdd(&st.ntTotal, (u32)__popc(nt));
 	}
 	if (level == 1 && selfChild) {
-		const u32* pair = (const u32*)st.voteList;       // both pieces of a row: bit 16 = the first sample of the second piece
+		const u32* rowW = (const u32*)st.voteList;
 		const u8* farBit = (const u8*)st.voteList + 1089 * 4;
 		const bool lastHalf = (int)(bx * 32) + 16 >= n; // the grid ends behind the first child column: sample 16 = sample 15
+		// cell row (Y, Z) of the 32 x 32 child cell rows: both x halves from the same four sample rows (AND / OR over the rows
+		// first, the halves cut out of the results)
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			const int c = tid + q * WG;                   // (x half, cell row Y, cell plane Z) of the 32 x 32 x 2 child cell rows
-			const int h = c & 1, Y = (c >> 1) & 31, Z = c >> 6;
-			const int r00 = Z * 33 + Y;
-			u32 m[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int r = r00 + (k & 1) + (k >> 1) * 33;
-				const u32 w = pair[r];
-				m[k] = h ? ((w >> 16) | ((u32)farBit[r] << 16)) : (lastHalf ? ((w & 0xFFFFu) | ((w & 0x8000u) << 1)) : (w & 0x1FFFFu));
-			}
-			const u32 A = m[0] & m[1] & m[2] & m[3], O = m[0] | m[1] | m[2] | m[3];
-			u32 bits = ((O | (O >> 1)) & ~(A & (A >> 1))) & 0xFFFFu;
-			const int cb = h | ((Y >> 4) << 1) | ((Z >> 4) << 2);
-			if (st.childSkip[cb]) bits = 0;                // (absent children count as skipped)
-			((u16*)st.childBits[cb])[((Z & 15) << 4) | (Y & 15)] = (u16)bits;
+		for (int q = 0; q < 4; ++q) {
+			const int Yc = tid & 31, Zc = (tid >> 5) + q * 8;
+			const int r00 = Zc * 33 + Yc;
+			const u32 w0 = rowW[r00], w1 = rowW[r00 + 1], w2 = rowW[r00 + 33], w3 = rowW[r00 + 34];
+			const u32 f0 = farBit[r00], f1 = farBit[r00 + 1], f2 = farBit[r00 + 33], f3 = farBit[r00 + 34];
+			const u32 A = w0 & w1 & w2 & w3, O = w0 | w1 | w2 | w3, Af = f0 & f1 & f2 & f3, Of = f0 | f1 | f2 | f3;
+			const u32 A0 = lastHalf ? ((A & 0xFFFFu) | ((A & 0x8000u) << 1)) : (A & 0x1FFFFu), O0 = lastHalf ? ((O & 0xFFFFu) | ((O & 0x8000u) << 1)) : (O & 0x1FFFFu);
+			const u32 A1 = (A >> 16) | (Af << 16), O1 = (O >> 16) | (Of << 16);
+			u32 bits0 = ((O0 | (O0 >> 1)) & ~(A0 & (A0 >> 1))) & 0xFFFFu, bits1 = ((O1 | (O1 >> 1)) & ~(A1 & (A1 >> 1))) & 0xFFFFu;
+			const int cb = ((Yc >> 4) << 1) | ((q >> 1) << 2);
+			if (st.childSkip[cb]) bits0 = 0;              // (absent children count as skipped)
+			if (st.childSkip[cb | 1]) bits1 = 0;
+			const int at = ((Zc & 15) << 4) | (Yc & 15);
+			((u16*)st.childBits[cb])[at] = (u16)bits0;
+			((u16*)st.childBits[cb | 1])[at] = (u16)bits1;
 		}
 	} else if (level == 1) {
 #pragma unroll
@@ -3031,7 +3037,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1, spreadUpper = 1; } tune;
+	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainHeads = 1, mainGranule = 32, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1, spreadUpper = 1; } tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -3075,6 +3081,8 @@ struct Backend {
 		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
 		tune.mainBatch = std::max<u32>(1, env_u32("VX_MAIN_BATCH", 2));
 		tune.mainUpperNum = env_u32("VX_MAIN_UPPER_NUM", 1);
+		tune.mainHeads = env_u32("VX_MAIN_HEADS", 1) >= 8 ? 8u : 1u; // 8: one level-0 queue head per XCD (round 6: fewer L2 misses, no faster - profiles/r06_xcd_heads.txt)
+		tune.mainGranule = std::max<u32>(1, env_u32("VX_MAIN_GRANULE", 32));
 		tune.mainUpperDen = std::max<u32>(1, env_u32("VX_MAIN_UPPER_DEN", 4));
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -3639,6 +3647,7 @@ struct Backend {
 		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
 		plan.level0 = withLevel0 ? 1u : 0u;
 		plan.batch = tune.mainBatch;
+		plan.heads = tune.mainHeads; plan.granule = ((tune.mainGranule + plan.batch - 1u) / plan.batch) * plan.batch;
 		plan.upperNum = withLevel0 ? tune.mainUpperNum : 1u; plan.upperDen = withLevel0 ? tune.mainUpperDen : 1u;
 		unsigned long long items = 0; // at most: one material item per block, one regular, one transition
 		for (u32 l = 1; l < levels; ++l) items += (unsigned long long)p.levels[l].cap * (1u + (l < plan.fastEnd ? 1u : 0u) + (p.levels[l].hasTransitions ? 1u : 0u));
@@ -3694,6 +3703,7 @@ struct Backend {
 		plan.level0 = 1u;
 		const u32 slots = (u32)cus * tune.mainWgsPerCu;
 		plan.batch = q.start[1] > 2u * slots ? tune.mainBatch : 1u; // (few blocks: every one its own workgroup)
+		plan.heads = 1u; plan.granule = plan.batch; // (a work list of a few hundred entries: one head)
 		plan.upperNum = tune.mainUpperNum; plan.upperDen = tune.mainUpperDen;
 		memcpy(plan.boxLo, q.lo, sizeof(plan.boxLo)); memcpy(plan.boxHi, q.hi, sizeof(plan.boxHi));
 		u32 items = q.start[1], upperVol = 0;

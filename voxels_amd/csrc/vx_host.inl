@@ -46,7 +46,7 @@ typedef ListedBlock EmittedBlock;
 
 // largest grid edge: 2048 = 8 LOD levels (MAX_LEVELS) and 32-bit element offsets inside a block neighbourhood
 enum { VX_MAX_GRID = 2048 };
-enum { HDR_WORDS = 352, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_PUBLISHED = 289 /* workgroups of the list pass that are done */, HDR_L0HEAD = 320, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
+enum { HDR_WORDS = 576, HDR_LISTS = 8, HDR_CURSORS = 32, HDR_STATS = 128, HDR_WORK = 160, HDR_LARGE = 176, HDR_SLOW = 224, HDR_UPPER = 256, HDR_GIVEUP = 288, HDR_PUBLISHED = 289 /* workgroups of the list pass that are done */, HDR_L0HEAD = 320 /* eight heads, one line each: k_main's level-0 queue per XCD */, HDR_PARTIALS = 32768 }; // counters spread over 128-byte lines
 
 } // namespace
 

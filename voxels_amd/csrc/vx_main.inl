@@ -36,12 +36,28 @@ constexpr u32 UP_STATE_LDS = sizeof(TrState) > sizeof(Fast1State<REG_CAP_SMALL>)
 constexpr u32 MAIN_STATE_LDS = sizeof(Fast0State<REG_CAP_SMALL>) > UP_STATE_LDS ? sizeof(Fast0State<REG_CAP_SMALL>) : UP_STATE_LDS;
 static_assert((UP_TAB_LDS & 15u) == 0, "the state behind the tables stays 16-byte aligned");
 
+// HW_REG_XCC_ID (register 20, bits 3:0 on gfx942 / gfx950): the XCD a wave runs on.  s_getreg immediate = (size - 1) << 11 | offset << 6 | id
+__device__ __forceinline__ u32 xcc_id()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+#else
+	return 0u;
+#endif
+}
+
 struct MainPlan {
 	u32 levels;     // levels of the run: material items for 1 .. levels - 1
 	u32 fastEnd;    // regular items for the levels 1 .. fastEnd - 1 (the levels with a lattice copy)
 	u32 level0;     // 1: the level-0 queue is part of the launch (its LDS then holds a Fast0State), and no classification pass ran
 	                // (k_run_head<allocate>): level-0 blocks and level-1 material blocks form the bitmaps they need
 	u32 batch;      // level-0 slots per dequeue
+	u32 heads;      // 1: one head for all workgroups; 8: one head per XCD - the slot range is dealt out in granules of `granule`
+	                // consecutive slots (the blocks of one 8 x 8 x 4 box of k_run_head follow each other: spatial neighbours) round
+	                // robin over the heads, a workgroup pulls from its own XCD's head (the halo lines neighbouring blocks share
+	                // then meet in ONE 4 MiB L2) and moves on to the next head when that is exhausted.  Speed only: any
+	                // workgroup may pull from any head.
+	u32 granule;    // a multiple of `batch`
 	u32 upperNum, upperDen; // workgroups with blockIdx % upperDen < upperNum prefer the upper queue
 	// incremental runs (k_main<true>, vx_polygonize_dirty): the queues hand out the entries of the levels' work lists
 	// (Globals::workItems / workCount, written by k_dirty_head); a material block only waits for the children that are part of
@@ -102,6 +118,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	u32 parity = 0, quietParity = 0, parity0 = 0;
 	bool upperLeft = upperTotal != 0, level0Left = total0 != 0; // (this workgroup's knowledge: a queue is empty once a dequeue came back beyond its end)
 	const bool preferUpper = (blockIdx.x % plan.upperDen) < plan.upperNum;
+	// the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0): which level-0 head it pulls from first
+	u32 head0 = plan.heads > 1u ? (xcc_id() & (plan.heads - 1u)) : 0u;
+	u32 headsLeft = plan.heads;
 
 #if defined(VX_MAIN_PROFILE)
 	// tools builds: where the workgroups' time goes, by role (cycles as thread 0 sees them; header words behind the large-block counter)
@@ -119,10 +138,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		const bool takeUpper = upperLeft && (preferUpper || !level0Left);
 		if (!takeUpper) {
 			// ---- a batch of consecutive level-0 slots -----------------------------------------------------------------
-			if (tid0 == 0) sh.nextItem = atomicAdd(p.G.level0Head, plan.batch);
+			if (tid0 == 0) sh.nextItem = atomicAdd(p.G.level0Head + head0 * 32u, plan.batch);
 			__syncthreads();
-			const u32 first = r0_uniform(sh.nextItem);
-			if (first >= total0) { level0Left = false; continue; }
+			u32 first = r0_uniform(sh.nextItem);
+			if (plan.heads > 1u) first = ((first / plan.granule) * plan.heads + head0) * plan.granule + first % plan.granule; // head h owns the granules h, h + heads, ...
+			if (first >= total0) {
+				// this head is exhausted (its positions only grow): on to the next one, if any is left
+				head0 = (head0 + 1u) & (plan.heads - 1u);
+				if (--headsLeft == 0u) level0Left = false;
+				continue;
+			}
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (visible after the walk's first barrier)
 			MAIN_TICK(1);
 			f0_walk<REG_CAP_SMALL, false, !DIRTY>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
@@ -151,7 +176,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			} else if (PARTIAL)
 				mat_block<true, true>(p, level, slot, *(MatLds*)state, tid, true, nullptr, nullptr, plan.emitFrom);
 			else
+#if defined(VX_ABL_NOSELFCHILD)
+				mat_block<true>(p, level, slot, *(MatLds*)state, tid, false); // (ablation: timing only, wrong results)
+#else
 				mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
+#endif
 			MAIN_TICK(3);
 			continue;
 		}
