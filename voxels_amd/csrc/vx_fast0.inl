@@ -89,6 +89,7 @@ __device__ __forceinline__ void f0_request(const GridView& g, const LevelDesc& L
 {
 	const int tid = f0_opaque_tid();
 	const int n = g.n, cnt = (int)L.cnt;
+	if (VX_ABL & 4096) { pf.d[0] = pf.d[1] = pf.m[0] = pf.m[1] = pf.b[0] = pf.b[1] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x81818181u); pf.dl[0] = pf.dl[1] = pf.dr[0] = pf.dr[1] = pf.mf[0] = pf.mf[1] = pf.bf[0] = pf.bf[1] = 0x01010101u; pf.bits = 0; return; }
 	// every lane loads (indices clamped into range): a conditional load with a default value makes the compiler wait for
 	// the data right behind the load, and these requests must stay in flight
 	if (!SELF) pf.bits = L.ntBits[(size_t)b.slot * 128 + (tid & 127)];
@@ -383,7 +384,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 						if (!requested) { if (haveNext) f0_request<SELF>(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
 #if !defined(VX_WAVE_STORE)
-						if (j < vEnd) {
+						if (j < vEnd && !(VX_ABL & 1)) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
 							const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
 							f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), vOut + j);
@@ -400,7 +401,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 							wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
 						}
 #endif
-						if (j < tEnd) {
+						if (j < tEnd && !(VX_ABL & 2)) {
 							u32 ids[3];
 							f0_triangle(st, T, j, ids);
 							u32* o3 = iOut + j * 3u; // 12 bytes per lane, consecutive lanes consecutive triangles

@@ -113,6 +113,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	__syncthreads();
 	const bool clean = r0_uniform(zeroFlag[parity]) == 0;
 	parity ^= 1u;
+	if (VX_ABL & 8192) return;
 	if (!clean) {
 		if (tid == 0) p.G.slowItems[1][atomicAdd(&p.G.slowCount[1], 1u)] = (level << 24) | slot;
 		return;
@@ -210,7 +211,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 			for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
 				const u32 j = base + (u32)tid;
 #if !defined(VX_WAVE_STORE)
-				if (j < vEnd) {
+				if (j < vEnd && !(VX_ABL & 32)) {
 					const u32 desc = st.vdesc[j];
 					const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
 					if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
@@ -227,7 +228,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 					wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
 				}
 #endif
-				if (j < tEnd) {
+				if (j < tEnd && !(VX_ABL & 64)) {
 					u32 ids[3];
 					f0_triangle(st, T, j, ids);
 					u32* o3 = iOut + j * 3u;

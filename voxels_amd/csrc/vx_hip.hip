@@ -62,6 +62,12 @@ struct ExecParamsDev {
 	const u8* tables;
 };
 
+// tools builds (tools/ab_build.py x=-DVX_ABL=<bits>): parts of the work switched off to see what they cost in time and
+// instructions (tools/exp/r06_ablate.sh); the results of such a build are wrong by construction.  0 in the product.
+#if !defined(VX_ABL)
+#define VX_ABL 0
+#endif
+
 constexpr int WG = 256;
 constexpr int REG_CAP_SMALL = LARGE_THRESHOLD; // LDS capacity class of the regular pass that covers ordinary surfaces
 constexpr int REG_CAP_MID = 1536;               // second class of the table-driven passes (dense surfaces: three workgroups per CU instead of one in the 4096-cell class)
@@ -1698,7 +1704,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	//      conditional (a load with a default value is waited for on the spot) — the children of a cell are always
 	//      inside the grid; entries the consistency bits rule out are masked after the fact. ----------------------------
 	{
-		const int nVote = (int)st.voteCount;
+		const int nVote = (VX_ABL & 16) ? 0 : (int)st.voteCount;
 		// the children's materials come from the brick mirrors: the 2 x 2 x 2 child blocks are 8 consecutive-in-x pairs of
 		// 4 KB bricks, a cell's 8 children sit in 2 lines per field (4 in the dense fields)
 		const size_t childOrigin = brick_base(g, (int)(bx * 2), (int)(by * 2), (int)(bz * 2));
@@ -2264,6 +2270,7 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 	TRB_TICK(2);
 	tr_phase_classify(st, tid, WG);
 	__syncthreads();
+	if (VX_ABL & 2048) { for (int w = tid; w < 48; w += WG) st.ntAll[w] = 0; __syncthreads(); }
 	TRB_TICK(3);
 	for (int f0 = 0; f0 < 6;) {
 		const int f1 = tr_batch_end(st, f0); // uniform
@@ -2312,10 +2319,10 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 					tr_phase_describe(st, chunk, tid, WG);
 					__syncthreads();
 				}
-				tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
+				if (!(VX_ABL & 512)) tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
 			}
 			TRB_TICK(9);
-			for (u32 chunk = 0; chunk < st.iTotal; chunk += VDESC_CAP) {
+			for (u32 chunk = 0; chunk < ((VX_ABL & 1024) ? 0u : st.iTotal); chunk += VDESC_CAP) {
 				__syncthreads();
 				tr_phase_stage_indices(st, T, chunk, tid, WG);
 				__syncthreads();

@@ -107,8 +107,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 		if (PARTIAL && l + 1u == plan.emitFrom) skipItems = matEnd[l];
 	}
 	if (PARTIAL) { regTotal = max(regTotal, skipItems) - skipItems; trTotal = max(trTotal, skipItems) - skipItems; }
+	if (VX_ABL & 4) trTotal = 0;
+	if (VX_ABL & 8) regTotal = 0;
 	const u32 upperTotal = matTotal + regTotal + trTotal;
-	const u32 total0 = plan.level0 ? r0_uniform(DIRTY ? p.G.workCount[0] : p.G.slotCounts[0]) : 0u;
+	const u32 total0 = (plan.level0 && !(VX_ABL & 128)) ? r0_uniform(DIRTY ? p.G.workCount[0] : p.G.slotCounts[0]) : 0u;
 
 	const GridView& g = p.G.grid;
 	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
@@ -176,11 +178,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 			} else if (PARTIAL)
 				mat_block<true, true>(p, level, slot, *(MatLds*)state, tid, true, nullptr, nullptr, plan.emitFrom);
 			else
-#if defined(VX_ABL_NOSELFCHILD)
-				mat_block<true>(p, level, slot, *(MatLds*)state, tid, false); // (ablation: timing only, wrong results)
-#else
-				mat_block<true>(p, level, slot, *(MatLds*)state, tid, plan.level0 != 0u);
-#endif
+				mat_block<true>(p, level, slot, *(MatLds*)state, tid, (VX_ABL & 256) ? false : plan.level0 != 0u);
 			MAIN_TICK(3);
 			continue;
 		}
