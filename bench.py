@@ -374,7 +374,7 @@ def main():
     stage_names = ["k_reset+k_run_head", "-", "--", "k_main", "k_after_level0", "k_after_upper", "---", "k_lists"]
     stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage) if not k.startswith("-")}
     single_stream = poly.stage_layout() == 1
-    if not single_stream:  # (a configuration without k_main: the chain of launches, VX_UPPER=0 / VX_MAIN_LEVEL0=0)
+    if not single_stream:  # (a configuration without k_main: the chain of launches, VX_UPPER=0)
         stage_names = ["reset", "k_classify", "k_hierarchy", "k_material", "k_regular0", "k_regular", "k_transition", "k_lists"]
         stage_ms = {k: round(float(v), 4) for k, v in zip(stage_names, stage)}
         alg = {"k_classify": float(4096 * blocks_read),

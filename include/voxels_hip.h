@@ -133,6 +133,12 @@ int vx_grid_upload_slab_y(vx_ctx* ctx, uint32_t n, uint32_t y_begin, uint32_t y_
  * memory the library does not own).  The mirrors are rebuilt by the next polygonization; the emptiness flags stay the
  * caller's business, as with vx_grid_attach. */
 int vx_grid_invalidate(vx_ctx* ctx);
+/* Forget what earlier runs of this context learned about ITS surfaces - which capacity classes to launch, how many blocks the
+ * general passes take over, how many upper-queue items a run has: the next run starts from the conservative defaults of a new
+ * context (all capacity classes launched).  For a context that is handed to another owner with another grid (libVoxels.so:
+ * the context InitializeVoxels warmed up on a toy terrain, adopted by the application's first Polygonizer).  No reference
+ * counterpart: the reference keeps no state between Execute calls beyond the PolygonSurface itself. */
+int vx_ctx_forget_hints(vx_ctx* ctx);
 /* ---- generation on the device ------------------------------------------------------------------------------------------
  * Grid::Create(w, h, d, ..., VoxelSurface*) samples an application callback on the host (src/VoxelGrid.cpp:79-132) and
  * quantises the samples (:37-50).  For the benchmark's synthetic surface (include/voxels_synth.h, vxs_terrain) the same

@@ -103,6 +103,7 @@ static void Dump(FILE* f, const PolygonSurface* s)
 	const PolygonizationStatistics* st = s->GetStatistics();
 	Put(f, st, sizeof(*st));
 	PutU(f, s->GetCacheSizeBytes());
+	PutU(f, s->GetPolygonDataSizeBytes()); // (incl. the reference's quirk: the transition meshes count as 12 vector objects per block, src/TransVoxelImpl.cpp:222-235)
 }
 
 static void LogSink(LogSeverity sev, const char* msg) { if (sev >= LS_Error) fprintf(stderr, "[voxels] %s\n", msg); }

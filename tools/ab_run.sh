@@ -2,7 +2,7 @@
 # A/B or ablation timing of variant libraries (tools/ab_build.py) on the bench workload, one kernel at a time.
 # Usage (GPU box): bash tools/ab_run.sh <outdir> <name>[:ENV=VALUE[:ENV=VALUE..]] ...
 #   name = "base" (the product library) or a variant built into tools/ab/<name>.so; the part behind the first ':' is
-#   exported for that run (e.g. base:VX_TR_GRID=1024).  Prints the serialised stage times of every run.
+#   exported for that run (e.g. base:VX_UPPER=0).  Prints the serialised stage times of every run.
 cd "$GRAFT_REPO_ROOT"
 out=$1; shift; mkdir -p "$out"
 for spec in "$@"; do

@@ -1,4 +1,5 @@
-"""Time of the one-step mesh download (vx_host_meshes_acquire) for different cuts of the copy.
+"""Time of the one-step mesh download (vx_host_meshes_acquire: one copy stream, 32 MB pieces - the cut is fixed since round 6,
+profiles/r03_d2h_time.txt has the sweep that settled it).
 usage: python tools/d2h_time.py [n=1024] [levels=4]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -16,8 +17,7 @@ p.set_materials(lut)
 p.execute(levels)
 mb = (p.info.total_verts * 48 + p.info.total_indices * 4) / 1e6
 print("pools: %.1f MB" % mb)
-for lanes, piece in ((1, 32), (2, 32), (2, 8), (4, 32), (4, 8), (2, 128), (3, 16)):
-    os.environ["VX_D2H_STREAMS"], os.environ["VX_D2H_PIECE_MB"] = str(lanes), str(piece)
+for lanes, piece in ((1, 32),):
     best = 1e9
     for r in range(4):
         p.execute(levels)

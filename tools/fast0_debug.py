@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the level-0 regular pass on the GPU: the table-driven pass for zero-free blocks (VX_FAST0=1, default) against
-the general pass (VX_FAST0=0) on the same grids, block by block and field by field — where do they differ?
+"""A/B of the level-0 regular pass on the GPU: the table-driven pass for zero-free blocks (VX_FAST=3, default) against
+the general pass (VX_FAST=0) on the same grids, block by block and field by field — where do they differ?
 Usage: python tools/fast0_debug.py [n ...]"""
 import os
 import sys
@@ -15,8 +15,7 @@ from voxels_amd import Polygonizer, synth  # noqa: E402
 
 
 def run(fast, d, m, b, flags, levels):
-    os.environ["VX_FAST0"] = "1" if fast else "0"
-    os.environ["VX_FAST1"] = "1" if fast else "0"
+    os.environ["VX_FAST"] = "3" if fast else "0"
     p = Polygonizer()
     p.set_materials(vxo.default_lut())
     p.upload(d, m, b, flags)

@@ -23,7 +23,6 @@ cp $d/tle/timeline_edit_fused.txt profiles/${l}_timeline_edit_fused.txt
 head -20 $d/tle/timeline_edit_chain.txt > profiles/${l}_timeline_edit_chain.txt
 (grep -v amdgpu $d/tle/edit_fused.txt | tail -3; echo "--- VX_DIRTY_FUSED=0"; grep -v amdgpu $d/tle/edit_chain.txt | tail -3) > profiles/${l}_edit_times.txt
 cp $d/bench_edit.txt profiles/${l}_bench_edit.txt
-if [ -f $d/pmc_wave/pass1.txt ]; then (echo "# -DVX_WAVE_STORE: WRITE_SIZE of the bench command's launches, and step times of that build / the product build, alternating"; grep -E "k_main|k_tail|k_run_head" $d/pmc_wave/pass1.txt | cut -c1-150; cat $d/wave_times.txt) > profiles/${l}_wave_store.txt; fi
 python tools/pmc_json.py $d/pmc 1024 4 1 $l profiles/pmc_latest.json
 python tools/pmc_json.py $d/pmc_caves 1024 4 1 ${l}_caves profiles/pmc_caves_latest.json "python tools/caves_run.py 1024 4 3"
 ls profiles | grep "^${l}_"

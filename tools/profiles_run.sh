@@ -19,11 +19,6 @@ timeout 300 bash tools/timeline_slab.sh $out/tlslab 8 3 > $out/tlslab.log 2>&1
 timeout 300 bash tools/timeline_caves.sh $out/tlc > $out/tlc.log 2>&1
 timeout 400 bash tools/timeline_edit.sh $out/tle 512 0 > $out/tle.log 2>&1
 timeout 400 python tools/bench_edit.py 512 2>&1 | grep -v amdgpu.ids > $out/bench_edit.txt
-# the wave-wide record stores (-DVX_WAVE_STORE, tools/ab/wave.so when built): bytes written and time of the same launches
-if [ -f tools/ab/wave.so ]; then
-  VOXELS_HIP_LIBRARY=tools/ab/wave.so timeout 300 bash tools/pmc_run.sh $out/pmc_wave "WRITE_SIZE" > $out/pmc_wave.log 2>&1
-  (VOXELS_HIP_LIBRARY=tools/ab/wave.so QT_WORKLOADS=1024 python tools/quick_times.py -; QT_WORKLOADS=1024 python tools/quick_times.py -; VOXELS_HIP_LIBRARY=tools/ab/wave.so QT_WORKLOADS=1024 python tools/quick_times.py -; QT_WORKLOADS=1024 python tools/quick_times.py -) 2>&1 | grep -v amdgpu.ids > $out/wave_times.txt
-fi
 timeout 600 python tools/slab_time.py y > $out/slab_time_y.txt 2>&1
 timeout 300 python tools/quick_times.py > $out/quick_times.txt 2>&1
 timeout 300 python tools/stress_runs.py 40000 4000 2>&1 | grep -v amdgpu.ids > $out/stress.txt

@@ -117,6 +117,7 @@ class HipLibrary:
         lib.vx_grid_attach.argtypes = [vp, u32, u32, u32, vp, i32, vp, vp, i32, vp]
         lib.vx_grid_update_blocks.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         lib.vx_grid_invalidate.argtypes = [vp]
+        lib.vx_ctx_forget_hints.argtypes = [vp]
         lib.vx_material_lut.argtypes = [vp, vp, vp]
         lib.vx_polygonize.argtypes = [vp, u32, C.POINTER(ExecInfo)]
         lib.vx_polygonize_from.argtypes = [vp, u32, u32, C.POINTER(ExecInfo)]
@@ -324,6 +325,11 @@ class Polygonizer:
         """The attached tensors were rewritten in place by the caller: the library's mirrors of them are rebuilt by the
         next execute().  Without this call (or a new attach) a run after an in-place edit polygonizes the OLD contents."""
         self._check(self._lib.vx_grid_invalidate(self._h), "vx_grid_invalidate")
+
+    def forget_hints(self):
+        """What earlier runs taught this context about its surfaces (capacity classes, launch sizes) is forgotten: the next run
+        starts from a new context's conservative defaults (vx_ctx_forget_hints)."""
+        self._check(self._lib.vx_ctx_forget_hints(self._h), "vx_ctx_forget_hints")
 
     def update_blocks(self, block_ids, dist, mat, blend, empty_flags):
         block_ids = np.ascontiguousarray(block_ids, np.uint32)

@@ -697,10 +697,7 @@ struct FetchedMaterials {
 };
 
 enum { EMIT_BATCH = 4 };     // vertices per lane whose fetches are in flight together
-#if !defined(VX_LOD_BATCH)
-#define VX_LOD_BATCH 4
-#endif
-enum { LOD_BATCH = VX_LOD_BATCH }; // ... whose LOD chains advance in lockstep (levels >= 1)
+enum { LOD_BATCH = 4 };      // ... whose LOD chains advance in lockstep (levels >= 1)
 
 // mat_at() for the corners of a level-0 block's cells: one base address per block, 32-bit offsets per corner.
 // The only clamp that can bite is the far corner layer of the last block of an axis.

@@ -238,7 +238,7 @@ TV_HD void normalize_fix_zero(float v[3])
 // keep normalize_fix_zero.
 TV_HD void normalize_gradient(float v[3])
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VX_EXACT_NORMALS_ONLY)
+#if defined(__HIP_DEVICE_COMPILE__)
 	const float len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
 	if (!(len2 > 0.f)) { v[0] = v[1] = v[2] = 0.f; return; } // integer components: the length is 0 or at least 1
 	const float r = __builtin_amdgcn_rsqf(len2), s = len2 * r, h = 0.5f * r;
@@ -478,18 +478,11 @@ TV_HD void pack_vertex_row(const RawVertex& r, unsigned long long row, PolyVerte
 #endif
 }
 
-// Where a packed vertex goes: to its record in memory (three 16-byte stores of the lane), or - device only - into the
-// lane's registers, from where a whole wave's records leave together as whole lines (wave_store_records, vx_hip.hip)
+// Where a packed vertex goes: to its record in memory (three 16-byte stores of the lane)
 struct VertexToMemory {
 	PolyVertex* out;
 	TV_HD void operator()(const RawVertex& r, unsigned long long row) const { pack_vertex_row(r, row, out); }
 };
-#if defined(__HIPCC__)
-struct VertexToRegs {
-	VertexRegs* regs;
-	__device__ __forceinline__ void operator()(const RawVertex& r, unsigned long long row) const { pack_vertex_regs(r, row, *regs); }
-};
-#endif
 
 TV_HD void pack_vertex(const RawVertex& r, const u8* lut, PolyVertex* out) { pack_vertex_row(r, lut_row(lut, r.mat), out); }
 

@@ -340,10 +340,15 @@ struct DeviceState
 			std::lock_guard<std::mutex> g(PrewarmLock());
 			if (Prewarmed()) { std::shared_ptr<DeviceState> d; d.swap(Prewarmed()); return d; }
 		}
+		return CreateFresh(LS_CriticalError);
+	}
+	// (severity: what a failure is worth to the caller - an Execute cannot go on without a device; InitializeVoxels' warm-up can)
+	static std::shared_ptr<DeviceState> CreateFresh(LogSeverity severity)
+	{
 		std::shared_ptr<DeviceState> d(new DeviceState);
 		if (vx_ctx_create(0, &d->Ctx) != VX_OK) {
 			d->Ctx = nullptr;
-			Log(LS_CriticalError, "Voxels: no usable HIP device (libvoxels_hip has no CPU fallback)");
+			Log(severity, "Voxels: no usable HIP device (libvoxels_hip has no CPU fallback)");
 			return nullptr;
 		}
 		return d;
@@ -728,7 +733,9 @@ extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage lo
 	// code objects ~0.25 s, page-locking the first mesh arena ~0.13 s).  VOXELS_NO_PREWARM=1 skips the context,
 	// VOXELS_PREWARM_MB=<n> also page-locks an arena for n MB of meshes (vertices : indices as 5 : 1 by bytes).
 	if (!getenv("VOXELS_NO_PREWARM")) {
-		std::shared_ptr<Voxels::DeviceState> d = Voxels::DeviceState::Create();
+		// (a host without a usable device still initialises - IE_Ok like the reference - and is told so as a warning, not as
+		// an error; the first Execute reports the missing device as the error it then is)
+		std::shared_ptr<Voxels::DeviceState> d = Voxels::DeviceState::CreateFresh(Voxels::LS_Warning);
 		if (d) {
 			// the kernels are loaded on first use, a few milliseconds each: one small synthetic grid through every call an
 			// Execute makes (terrain on the device -> polygonize -> write as a file -> expand the file -> polygonize -> meshes
@@ -747,6 +754,8 @@ extern "C" Voxels::InitError InitializeVoxels(int version, Voxels::LogMessage lo
 				}
 				if (ok && vx_host_meshes_acquire(d->Ctx, &hm) == VX_OK) vx_host_meshes_release(hm.arena);
 				(void)vx_grid_invalidate(d->Ctx); // (whatever the application uploads next replaces this grid; nothing of it is kept)
+				(void)vx_ctx_forget_hints(d->Ctx); // (... nor what the toy terrain taught the context about capacity classes: the application's first grid may be dense)
+				if (!ok) Voxels::Log(Voxels::LS_Warning, "Voxels: the warm-up run of InitializeVoxels failed (the first Execute pays the one-time costs instead)");
 			}
 			const char* mb = getenv("VOXELS_PREWARM_MB");
 			const uint64_t bytes = mb ? (uint64_t)atoll(mb) << 20 : 0;

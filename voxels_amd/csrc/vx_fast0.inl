@@ -39,9 +39,6 @@ __device__ __forceinline__ F0Tables f0_stage_tables(u8* lds, const u8* image) { 
 // inclusive scan over the wave with DPP row shifts and row broadcasts (gfx9): no LDS traffic, six dependent adds
 __device__ __forceinline__ u32 wave_inclusive_scan_dpp(u32 v)
 {
-#if defined(VX_SCAN_SHFL)
-	return wave_inclusive_scan(v);
-#else
 	int x = (int)v;
 	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
 	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
@@ -50,7 +47,6 @@ __device__ __forceinline__ u32 wave_inclusive_scan_dpp(u32 v)
 	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
 	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
 	return (u32)x;
-#endif
 }
 
 __device__ __forceinline__ u32 f0_has_zero_byte(u32 v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
@@ -383,24 +379,11 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 					for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
 						if (!requested) { if (haveNext) f0_request<SELF>(g, L, nxt, pf); cand = f0_peek<REMAP>(p, L, total, limit, candIt); requested = true; }
 						const u32 j = base + (u32)tid;
-#if !defined(VX_WAVE_STORE)
 						if (j < vEnd && !(VX_ABL & 1)) {
 							const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
 							const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
 							f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), vOut + j);
 						}
-#else
-						const u32 jw = r0_uniform(base + ((u32)tid & ~63u)); // the wave's first vertex: its 64 records leave as whole lines
-						if (jw < vEnd) {
-							VertexRegs vr;
-							if (j < vEnd) {
-								const u32 desc = st.vdesc[j], c = desc & 0xFFFu;
-								const u32 cellId = st.matId[(c >> 8) * F0_MPLANE + ((c >> 4) & 15u) * F0_MROW + (c & 15u)];
-								f0_vertex(st, T, desc, ox, oy, oz, K::lut_row_waterfall(p.G.lut, cellId), VertexToRegs{ &vr });
-							}
-							wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
-						}
-#endif
 						if (j < tEnd && !(VX_ABL & 2)) {
 							u32 ids[3];
 							f0_triangle(st, T, j, ids);

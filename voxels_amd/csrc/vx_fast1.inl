@@ -210,24 +210,11 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 			u32* iOut = p.P.idx + r0_uniform(st.iOff) + ct * 3u;
 			for (u32 base = 0; base < vEnd || base < tEnd; base += WG) {
 				const u32 j = base + (u32)tid;
-#if !defined(VX_WAVE_STORE)
 				if (j < vEnd && !(VX_ABL & 32)) {
 					const u32 desc = st.vdesc[j];
 					const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
 					if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, vOut + j)) notInterior = 1;
 				}
-#else
-				const u32 jw = r0_uniform(base + ((u32)tid & ~63u)); // the wave's first vertex: its 64 records leave as whole lines
-				if (jw < vEnd) {
-					VertexRegs vr;
-					if (j < vEnd) {
-						const u32 desc = st.vdesc[j];
-						const unsigned long long lut = K::lut_row_waterfall(p.G.lut, (u32)st.cacheId[desc & 0xFFFu]);
-						if (!f1_vertex(st, T, smp, L.cache + (size_t)slot * BLOCK_CELLS, desc, (int)level, ox, oy, oz, lut, VertexToRegs{ &vr })) notInterior = 1;
-					}
-					wave_store_records(vOut + jw, min(vEnd - jw, 64u), vr);
-				}
-#endif
 				if (j < tEnd && !(VX_ABL & 64)) {
 					u32 ids[3];
 					f0_triangle(st, T, j, ids);

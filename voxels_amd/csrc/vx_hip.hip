@@ -120,44 +120,8 @@ __device__ u32 block_exclusive_scan_u16(u16* a, u32 n, u32* scratch)
 // what one address sustains — so the number of round trips matters more than the bytes.
 __device__ __forceinline__ void reserve_both(u32* cursors, u32 verts, u32 indices, u32& vOff, u32& iOff)
 {
-#if defined(VX_SEPARATE_RESERVE)
-	vOff = atomicAdd(&cursors[CUR_V], verts);
-	iOff = atomicAdd(&cursors[CUR_I], indices);
-#else
 	const unsigned long long r = atomicAdd((unsigned long long*)cursors, (unsigned long long)verts | ((unsigned long long)indices << 32));
 	vOff = (u32)r; iOff = (u32)(r >> 32);
-#endif
-}
-
-// ---- a wave's vertex records as whole lines ------------------------------------------------------------------------------
-// One lane = one vertex leaves 64 records of 48 bytes per wave: as three 16-byte stores per lane every store instruction
-// touches all 24 lines of the wave's 3 KB with a third of each (partial writes that the streaming path does not merge:
-// WRITE_SIZE was 1.26 x the mesh bytes).  Here the 192 pieces of 16 bytes are first dealt to the lanes in address order -
-// piece q = 3 * lane + part goes to lane q & 63 for store q >> 6; as 3 is coprime to 64 every part is ONE ds_permute_b32 per
-// dword (a lane-to-lane move through the LDS crossbar, no LDS memory), twelve in all, and a lane picks the part (lane + store) % 3
-// of what arrived - so that each of the three stores writes 1 KB of consecutive addresses.
-// All 64 lanes of the wave must call (lanes at and behind `count` pass anything); `first` = record of lane 0, `count` >= 1.
-__device__ __forceinline__ void wave_store_records(PolyVertex* first, u32 count, const VertexRegs& r)
-{
-	const u32 lane = (u32)threadIdx.x & 63u;
-	const int to0 = (int)(((3u * lane) & 63u) << 2), to1 = (int)(((3u * lane + 1u) & 63u) << 2), to2 = (int)(((3u * lane + 2u) & 63u) << 2);
-	const u32 m = lane % 3u;
-	typedef u32 __attribute__((ext_vector_type(4))) v4u;
-	v4u s0, s1, s2;
-#pragma unroll
-	for (int d = 0; d < 4; ++d) {
-		const u32 t0 = (u32)__builtin_amdgcn_ds_permute(to0, (int)r.w[d]);
-		const u32 t1 = (u32)__builtin_amdgcn_ds_permute(to1, (int)r.w[4 + d]);
-		const u32 t2 = (u32)__builtin_amdgcn_ds_permute(to2, (int)r.w[8 + d]);
-		s0[d] = m == 0u ? t0 : (m == 1u ? t1 : t2);
-		s1[d] = m == 0u ? t1 : (m == 1u ? t2 : t0);
-		s2[d] = m == 0u ? t2 : (m == 1u ? t0 : t1);
-	}
-	v4u* dst = (v4u*)first + lane;
-	const u32 pieces = count * 3u;
-	if (lane < pieces) TV_STREAM_STORE(dst, s0);
-	if (lane + 64u < pieces) TV_STREAM_STORE(dst + 64, s1);
-	if (lane + 128u < pieces) TV_STREAM_STORE(dst + 128, s2);
 }
 
 // ---- dependencies between workgroups of ONE launch (k_main): LevelDesc::matDone ----------------------------------------
@@ -2722,17 +2686,17 @@ __global__ __launch_bounds__(WG) void k_dirty_head(ExecParamsDev p, DirtyPlan d)
 	u32 notSkipped = 0, large = 0;
 	for (u32 i = (u32)tid; i < d.start[1]; i += WG) { const u32 v = TV_LOAD_THROUGH(d.info + i); notSkipped += v & 1u; large += (v >> 1) & 1u; }
 	{
-		u32 v = notSkipped | (large << 16);
+		// (two sums in words of their own: a dirty box of a 1024^3 grid can hold more than 65 535 blocks)
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
-		if ((tid & 63) == 0) atomicAdd(&sh[3], v);
+		for (int o = 32; o > 0; o >>= 1) { notSkipped += (u32)__shfl_xor((int)notSkipped, o, 64); large += (u32)__shfl_xor((int)large, o, 64); }
+		if ((tid & 63) == 0) { atomicAdd(&sh[3], notSkipped); atomicAdd(&sh[4], large); }
 	}
 	__syncthreads();
 	if (tid == 0) {
 		p.P.cursors[CUR_V] = d.poolVerts; p.P.cursors[CUR_I] = d.poolIdx;
-		p.G.stats[2] = sh[3] & 0xFFFFu;
-		*p.G.largeBlocks = sh[3] >> 16;     // (the material blocks of k_main<true> add the levels above)
-		p.G.largeBlocks[2] = sh[3] >> 16;   // level 0 alone: the host announces the two kinds apart (run_dirty_fused)
+		p.G.stats[2] = sh[3];
+		*p.G.largeBlocks = sh[4];     // (the material blocks of k_main<true> add the levels above)
+		p.G.largeBlocks[2] = sh[4];   // level 0 alone: the host announces the two kinds apart (run_dirty_fused)
 	}
 	// the work lists: a wave per level (levels beyond the fourth: a second turn), 64 coordinates of the level's box per step, four
 	// steps' slots requested together; the list keeps the box's coordinate order
@@ -3044,7 +3008,21 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	struct Tuning { u32 classifyRowGroup = 4, matGrid = 0, regWgsPerCu = 20, f1WgsPerCu = 20, trGrid = 0, fast0 = 1, fast1 = 1, forceWide = 0, foldBlocks = 65536, upper = 1, upWgsPerCu = 5, mainLevel0 = 1, mainWgsPerCu = 4, mainBatch = 2, mainHeads = 1, mainGranule = 32, mainUpperNum = 1, mainUpperDen = 4, selfHead = 1, publishHeader = 1, tail = 1, tailCleans = 1, dirtyFused = 1, bigClass = 1, spreadUpper = 1; } tune;
+	// Runtime knobs (read once per context).  Eight in all with VX_POOL_SLACK and VX_HOST_TIMING (vx_host.inl); each selects a path
+	// that production runs reach through their data - dense surfaces, grids beyond 1024^3, blocks with zero samples - so that the
+	// tests can drive those paths on small fixtures (tests/test_gpu_parity.py::test_hip_runtime_knobs_select_equivalent_paths).
+	struct Tuning {
+		u32 fast = 3;        // VX_FAST: bit 0 = table-driven pass on level 0, bit 1 = on the levels >= 1 (0: every block through the general passes)
+		u32 forceWide = 0;   // VX_FORCE_WIDE=1: the 64-bit-offset kernel variants (grids beyond 1024^3) on small grids too
+		u32 upper = 1;       // VX_UPPER=0: the chain of launches (what dense surfaces run) instead of k_main
+		u32 selfHead = 1;    // VX_SELF_HEAD=0: a classification pass (k_classify, k_hierarchy) instead of k_run_head handing out the slots
+		u32 dirtyFused = 1;  // VX_DIRTY_FUSED=0: incremental runs as the chain of launches with work lists
+		u32 mainHeads = 1;   // VX_MAIN_HEADS=8: one level-0 queue head per XCD (round 6: fewer L2 misses, no faster - profiles/r06_xcd_heads.txt)
+		// fixed since round 6 (were environment variables while they were being measured; profiles/HISTORY.md has the sweeps)
+		static constexpr u32 classifyRowGroup = 4, regWgsPerCu = 20, f1WgsPerCu = 20, foldBlocks = 65536, upWgsPerCu = 5, mainWgsPerCu = 4, mainBatch = 2, mainGranule = 32, mainUpperNum = 1, mainUpperDen = 4;
+		bool fast0() const { return (fast & 1u) != 0; }
+		bool fast1() const { return (fast & 2u) != 0; }
+	} tune;
 	static u32 env_u32(const char* name, u32 fallback) { const char* v = getenv(name); return v ? (u32)atoi(v) : fallback; }
 
 	bool check(hipError_t e, const char* what)
@@ -3066,31 +3044,12 @@ struct Backend {
 		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { err = "no HIP device"; return false; }
 		if (!check(hipSetDevice(device), "hipSetDevice")) { err = lastError; return false; }
 		this->device = device;
-		tune.classifyRowGroup = env_u32("VX_CLASSIFY_ROWGROUP", 4);
-		tune.matGrid = env_u32("VX_MAT_GRID", 0);
-		tune.regWgsPerCu = std::max<u32>(1, env_u32("VX_REG_WGS_PER_CU", 20));
-		tune.f1WgsPerCu = std::max<u32>(1, env_u32("VX_F1_WGS_PER_CU", 20));
-		tune.trGrid = env_u32("VX_TR_GRID", 0) & ~7u;
-		tune.fast0 = env_u32("VX_FAST0", 1); // 0: every level-0 block through the general pass (A/B measurements)
-		tune.fast1 = env_u32("VX_FAST1", 1); // the same for the levels >= 1
-		tune.foldBlocks = env_u32("VX_FOLD_BLOCKS", 65536); // level-0 blocks up to which k_classify also activates the ancestors
-		tune.forceWide = env_u32("VX_FORCE_WIDE", 0); // run the 64-bit-offset variants on small grids too (tests)
-		tune.upper = env_u32("VX_UPPER", 1);           // 0: the levels >= 1 as the chain of launches k_main replaces (A/B measurements)
-		tune.upWgsPerCu = std::max<u32>(1, env_u32("VX_UP_WGS_PER_CU", 5)); // k_main without the level-0 queue (VX_MAIN_LEVEL0=0)
-		tune.tailCleans = env_u32("VX_TAIL_CLEANS", 1); // 0: every run starts with k_reset (A/B measurements)
-		tune.tail = env_u32("VX_TAIL", 1); // 0: the general passes behind k_main and the list pass as launches of their own (A/B measurements)
-		tune.publishHeader = env_u32("VX_PUBLISH_HEADER", 1); // 0: the header is copied behind the run (A/B measurements)
-		tune.selfHead = env_u32("VX_SELF_HEAD", 1); // 0: a classification pass (k_classify, k_hierarchy) and the level-0 pass as launches of their own (A/B measurements)
-		tune.spreadUpper = env_u32("VX_SPREAD_UPPER", 1); // 0: the upper capacity classes of the levels >= 1 behind the first class on the main stream instead of behind the transition pass (A/B measurements)
-		tune.bigClass = env_u32("VX_BIG_CLASS", 1); // 0: blocks beyond REG_CAP_MID cells through the general pass, as until round 4 (A/B measurements)
-		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1); // 0: incremental runs as the chain of launches with work lists (A/B measurements, tests of that path)
-		tune.mainLevel0 = env_u32("VX_MAIN_LEVEL0", 1); // 0: the level-0 pass as a launch of its own on a second stream (A/B measurements)
-		tune.mainWgsPerCu = std::max<u32>(1, env_u32("VX_MAIN_WGS_PER_CU", 4));
-		tune.mainBatch = std::max<u32>(1, env_u32("VX_MAIN_BATCH", 2));
-		tune.mainUpperNum = env_u32("VX_MAIN_UPPER_NUM", 1);
-		tune.mainHeads = env_u32("VX_MAIN_HEADS", 1) >= 8 ? 8u : 1u; // 8: one level-0 queue head per XCD (round 6: fewer L2 misses, no faster - profiles/r06_xcd_heads.txt)
-		tune.mainGranule = std::max<u32>(1, env_u32("VX_MAIN_GRANULE", 32));
-		tune.mainUpperDen = std::max<u32>(1, env_u32("VX_MAIN_UPPER_DEN", 4));
+		tune.fast = env_u32("VX_FAST", 3);
+		tune.forceWide = env_u32("VX_FORCE_WIDE", 0);
+		tune.upper = env_u32("VX_UPPER", 1);
+		tune.selfHead = env_u32("VX_SELF_HEAD", 1);
+		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1);
+		tune.mainHeads = env_u32("VX_MAIN_HEADS", 1) >= 8 ? 8u : 1u;
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -3230,8 +3189,8 @@ struct Backend {
 	// 57 GB/s, 2-4 streams 53-56 GB/s - the link is the limit, so one stream is the default.
 	bool d2h_bulk(void* const* dst, const void* const* src, const size_t* bytes, int count)
 	{
-		const u32 lanes = std::min<u32>(4, std::max<u32>(1, env_u32("VX_D2H_STREAMS", 1)));
-		const size_t piece = (size_t)std::max<u32>(1, env_u32("VX_D2H_PIECE_MB", 32)) << 20;
+		const u32 lanes = 1; // (more copy streams were measured and bought nothing: one engine saturates the link, profiles/r03_d2h_time.txt)
+		const size_t piece = (size_t)32 << 20;
 		size_t total = 0;
 		for (int i = 0; i < count; ++i) total += bytes[i];
 		if (!total) return true;
@@ -3515,7 +3474,7 @@ struct Backend {
 	{
 		const u32 cap = p.levels[level].cap;
 		if (!cap) return;
-		const u32 grid = std::min<u32>(cap, tune.matGrid ? tune.matGrid : (u32)cus * 8);
+		const u32 grid = std::min<u32>(cap, (u32)cus * 8);
 		launch_with_event(k_material, dim3(grid), 0u, dev(p), level);
 		check(hipGetLastError(), "k_material launch");
 	}
@@ -3533,7 +3492,7 @@ struct Backend {
 			if (p.G.dirty) {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 1>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
-			} else if (tune.fast0) {
+			} else if (tune.fast0()) {
 				// blocks without a zero sample: the table-driven pass; the others are handed on through Globals::slowItems
 				// (dense surfaces: a second table-driven class up to REG_CAP_MID cells; beyond that, and for what either class
 				// hands on, the general pass in its two classes)
@@ -3549,10 +3508,9 @@ struct Backend {
 				// the third class (blocks beyond REG_CAP_MID cells), table-driven as well: behind the second on its stream; what the
 				// three classes hand on (zero samples) is complete when all of them are done
 				const u32 ldsB = F0_TAB_LDS + sizeof(Fast0State<REG_CAP_BIG>), gridB = std::min<u32>(cap, (u32)cus * 4);
-				if (largeClass && tune.bigClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_BIG>), dim3(gridB), dim3(WG), ldsB, upper, dev(p), (u32)REG_CAP_MID);
+				if (largeClass) hipLaunchKernelGGL((k_regular0_fast<REG_CAP_BIG>), dim3(gridB), dim3(WG), ldsB, upper, dev(p), (u32)REG_CAP_MID);
 				if (spread) {
 					(void)hipEventRecord(evMidC, sideC);
-					if (!tune.bigClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, sideC, dev(p), (u32)REG_CAP_MID);
 					(void)hipEventRecord(evSideC, sideC);
 					(void)hipStreamWaitEvent(on, evMidC, 0);
 				}
@@ -3560,7 +3518,6 @@ struct Backend {
 				if (!tailPending) hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 2>), dim3(tailWgs[0]), dim3(WG), ldsS, on, dev(p), 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular0<4096, 2>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_SMALL);
-					if (!spread && !tune.bigClass) hipLaunchKernelGGL((k_regular0<4096, 0>), dim3(gridL), dim3(WG), ldsL, on, dev(p), (u32)REG_CAP_MID);
 				}
 			} else {
 				hipLaunchKernelGGL((k_regular0<REG_CAP_SMALL, 0>), dim3(gridS), dim3(WG), ldsS, on, dev(p), 0u);
@@ -3578,22 +3535,21 @@ struct Backend {
 			// (Globals::slowItems[1]) and the coarser levels go through the general pass.  (32-bit voxel offsets: mirrors < 4 GiB.)
 			const u32 fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
 			const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
-			if (!p.G.dirty && tune.fast1 && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
+			if (!p.G.dirty && tune.fast1() && levelBegin == 1 && fastEnd > 1 && mirrorsSmall && p.G.pyr[1].data) {
 				u32 capFast = 0;
 				for (u32 l = 1; l < fastEnd; ++l) capFast += p.levels[l].cap;
 				// (as on level 0: the upper classes beside the first one when the run is overlapped, i.e. when this is the main
 				// stream of run_overlapped_tail - on side stream B, behind the transition pass)
-				const bool spread = tune.spreadUpper && largeClass && overlappedTail && on == stream && !upperDone;
+				const bool spread = largeClass && overlappedTail && on == stream && !upperDone;
 				hipStream_t sideD = sideB;
 				hipStream_t upper = spread ? sideD : on;
 				const u32 ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
 				if (spread) { (void)hipStreamWaitEvent(sideD, evMaterial, 0); spreadD = true; }
 				if (!upperDone) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_SMALL>, dim3(std::min<u32>(capFast, (u32)cus * tune.f1WgsPerCu)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_SMALL>), on, dev(p), fastEnd, 0u);
 				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_MID>, dim3(std::min<u32>(capFast, (u32)cus * 12)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_MID>), upper, dev(p), fastEnd, (u32)REG_CAP_SMALL);
-				if (largeClass && tune.bigClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_BIG>, dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>), upper, dev(p), fastEnd, (u32)REG_CAP_MID);
+				if (largeClass) hipLaunchKernelGGL(k_regular1_fast<REG_CAP_BIG>, dim3(std::min<u32>(capFast, (u32)cus * 4)), dim3(WG), F0_TAB_LDS + sizeof(Fast1State<REG_CAP_BIG>), upper, dev(p), fastEnd, (u32)REG_CAP_MID);
 				if (spread) {
 					(void)hipEventRecord(evMidD, sideD);
-					if (!tune.bigClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, sideD, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
 					(void)hipEventRecord(evSideD, sideD);
 					(void)hipStreamWaitEvent(on, evMidD, 0);
 				}
@@ -3601,7 +3557,6 @@ struct Backend {
 				if (!tailPending) hipLaunchKernelGGL((k_regular<REG_CAP_SMALL, 2>), dim3(tailWgs[1]), dim3(WG), ldsS, on, dev(p), 1u, levels, 0u);
 				if (largeClass) {
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
-					if (!spread && !tune.bigClass) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(capFast, (u32)cus)), dim3(WG), ldsL, on, dev(p), 1u, fastEnd, (u32)REG_CAP_MID);
 				}
 				generalBegin = fastEnd;
 			}
@@ -3636,10 +3591,10 @@ struct Backend {
 		// (dense surfaces - blocks beyond the first capacity class are expected - keep the chain of launches on five streams: the
 		// upper classes run at one to three workgroups per CU for hundreds of microseconds and belong BESIDE the rest; behind
 		// k_main they made the second bench workload 3.9 ms per step against 3.5)
-		return tune.upper && tune.fast1 && !tune.forceWide && !largeClass && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+		return tune.upper && tune.fast1() && !tune.forceWide && !largeClass && !p.G.dirty && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	template <typename P>
-	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0 && tune.mainLevel0 && tune.selfHead; }
+	bool single_stream(const P& p, u32 levels) const { return main_applies(p, levels) && tune.fast0() && tune.selfHead; }
 	// Partial runs (vx_polygonize_from): the levels below emitFrom get caches and bitmaps but no meshes.  Only the single-stream
 	// form offers it (partial_applies); the host asks before it launches and tells its caller what the run really did.
 	u32 emitFrom = 0;
@@ -3681,7 +3636,7 @@ struct Backend {
 	{
 		const bool mirrorsSmall = (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n * (unsigned long long)p.G.grid.n < (1ull << 32);
 		(void)largeExpected; // (blocks beyond the first capacity class: two launches more, see run_dirty_fused)
-		return tune.dirtyFused && tune.upper && tune.fast0 && tune.fast1 && !tune.forceWide && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
+		return tune.dirtyFused && tune.upper && tune.fast0() && tune.fast1() && !tune.forceWide && levels > 1 && mirrorsSmall && p.G.pyr[1].data != nullptr;
 	}
 	struct DirtyLaunch {
 		u32 lo[MAX_LEVELS][3], hi[MAX_LEVELS][3], start[MAX_LEVELS + 1];
@@ -3727,7 +3682,7 @@ struct Backend {
 			const u32 ldsL0 = R0_TAB_LDS + sizeof(Reg0State<4096>), ldsL = REG_TAB_LDS + sizeof(RegStateT<4096>);
 			const u32 upper = largeUpperExpected ? q.start[levels] - q.start[1] : 0u;
 			const u32 grid0 = std::max<u32>(1u, std::min<u32>(q.start[1], (u32)cus));
-			if (tune.bigClass) {
+			{
 				// blocks beyond k_main's capacity class: table-driven like everywhere else (a general block of this size takes 45 us
 				// where a table-driven one takes a third); the general pass only sees what those hand on
 				if (large0Expected) {
@@ -3739,9 +3694,6 @@ struct Backend {
 					// (also the blocks of a level without a lattice copy: k_main<true> hands every one of them on)
 					hipLaunchKernelGGL((k_regular<4096, 2>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
 				}
-			} else {
-				if (large0Expected) hipLaunchKernelGGL((k_regular0<4096, 1>), dim3(grid0), dim3(WG), ldsL0, stream, dev(p), (u32)REG_CAP_SMALL);
-				if (upper) hipLaunchKernelGGL((k_regular<4096, 0>), dim3(std::min<u32>(upper, (u32)cus)), dim3(WG), ldsL, stream, dev(p), 1u, levels, (u32)REG_CAP_SMALL);
 			}
 			check(hipGetLastError(), "large-class launches (incremental)");
 		}
@@ -3796,7 +3748,7 @@ struct Backend {
 			run_main(p, levels, true);
 			upperDone = level0Done = true;
 			tailWgs[0] = tailWgs[1] = 0;
-			tailPending = tune.tail && tailDone && p.levels[0].listCounts;
+			tailPending = tailDone && p.levels[0].listCounts;
 			launch_regular(p, 0, levels, stream);
 			upperDone = level0Done = false;
 			overlappedTail = false;
@@ -3922,7 +3874,6 @@ struct Backend {
 	HeaderPublish publish = {};
 	bool lists_publish_header(u32* hostDst, const u32* devHeader, u32 words, u32* doneCounter)
 	{
-		if (!tune.publishHeader) return false;
 		publish.host = hostDst; publish.dev = devHeader; publish.words = words; publish.done = doneCounter;
 		return true;
 	}
@@ -3940,7 +3891,7 @@ struct Backend {
 			TailPlan t;
 			t.wgs0 = tailWgs[0]; t.wgs1 = tailWgs[1]; t.listWgs = wgs; t.levels = levels; t.slowDone = tailDone; t.roleTicket = tailDone + 1;
 			t.next = nextReset;
-			if (!wgs || !tune.tailCleans) t.next.header = nullptr;
+			if (!wgs) t.next.header = nullptr;
 			tailCleaned = t.next.header != nullptr;
 			nextReset.header = nullptr;
 			const u32 lds = std::max<u32>(R0_TAB_LDS + sizeof(Reg0State<REG_CAP_SMALL>), REG_TAB_LDS + sizeof(RegStateT<REG_CAP_SMALL>));
@@ -3963,7 +3914,7 @@ struct Backend {
 		if (!cap) return;
 		// five resident workgroups per CU, each striding over its items (measured at 1024^3: 1280 workgroups 0.107 ms,
 		// 1024: 0.117, 1536: 0.126, one workgroup per block: 0.109 - a workgroup's start costs about as much as its planes)
-		const u32 grid = std::min<u32>(cap, tune.trGrid ? tune.trGrid : (u32)cus * 5);
+		const u32 grid = std::min<u32>(cap, (u32)cus * 5);
 		const bool wide = (size_t)p.G.grid.n * p.G.grid.n * p.G.grid.n >= ((size_t)1 << 32) || tune.forceWide;
 		if (wide) hipLaunchKernelGGL(k_transition<true>, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);
 		else hipLaunchKernelGGL(k_transition<false>, dim3(grid), dim3(WG), TR_TAB_LDS + sizeof(TrState), stream, dev(p), levels);

@@ -94,6 +94,7 @@ struct vx_ctx {
 	u32 dirtyCap = 0;
 	void* dDirtyTicket = nullptr; // incremental runs as three launches: k_dirty_head's count of finished workgroups over all its launches
 	u32 dirtyTickets = 0;         // ... and what the host knows it to be
+	bool editRoomFailed = false;  // the first incremental run's reservation (pools for twice the live meshes, spare pair) failed: not retried per edit
 	bool dirtyLargeHint = false;  // the last incremental run met blocks beyond the first capacity class on the levels >= 1 (their launches are made)
 	bool dirtyLarge0Hint = false; // ... on level 0
 	// level tables
@@ -1087,6 +1088,18 @@ int vx_grid_invalidate(vx_ctx* c)
 	return VX_OK;
 }
 
+int vx_ctx_forget_hints(vx_ctx* c)
+{
+	VX_ENTER(c);
+	if (!c) return VX_ERR_INVALID;
+	c->largeHint = true;
+	c->dirtyLargeHint = c->dirtyLarge0Hint = false;
+	c->editRoomFailed = false;
+	c->be.upperItemsHint = 0;
+	c->be.slowHint[0] = c->be.slowHint[1] = ~0u;
+	return VX_OK;
+}
+
 namespace {
 
 // The four halo messages of an attached slab (see include/voxels_hip.h): which layers of which field go where.
@@ -1421,9 +1434,7 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 	if (!c->vertCap) {
 		// first guess: ~3 vertices and ~12 indices per surface voxel column; grown on demand (exact need is known after a run)
 		const u32 area = c->n * c->n;
-		const char* ev = getenv("VX_POOL_VERTS"); // (experiments: pools large enough for any layout from the start)
-		const char* ei = getenv("VX_POOL_INDICES");
-		if (!ensure_pools(c, std::max<u32>(std::max(c->poolSlack, c->poolSlack == (1u << 16) ? area * 6 : 0u), ev ? (u32)atoll(ev) : 0u), std::max<u32>(std::max(c->poolSlack * 4u, c->poolSlack == (1u << 16) ? area * 24 : 0u), ei ? (u32)atoll(ei) : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
+		if (!ensure_pools(c, std::max(c->poolSlack, c->poolSlack == (1u << 16) ? area * 6 : 0u), std::max(c->poolSlack * 4u, c->poolSlack == (1u << 16) ? area * 24 : 0u))) return fail(c, VX_ERR_DEVICE, "vx_polygonize: pool allocation failed");
 	}
 	u32 retries = 0, emitFrom = 0;
 	float ms = 0.f;
@@ -1528,6 +1539,7 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I];
 	c->poolLineage = next_lineage(); // the pools were rewritten
 	c->haveSurface = true;
+	c->editRoomFailed = false; // (a new surface: its first incremental run asks for room again)
 	c->listsReady = false; // the host copy of the block lists is fetched on first access
 	c->deviceLists = true;
 	u32 idBase = 0;
@@ -1755,12 +1767,16 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	// The same call gives the pools room for twice what is alive: appended blocks then fill them up to the point where they
 	// are packed, and a sequence of edits allocates nothing (an allocation of this size can take tens of milliseconds when
 	// the driver has to reclaim memory first; pools that still overflow - the surface grew - grow by half, as before).
-	if (!c->dVertsSpare) {
+	if (!c->dVertsSpare && !c->editRoomFailed) {
 		uint64_t liveV, liveI;
 		live_totals(c, liveV, liveI);
 		const uint64_t wantV = 2 * liveV + 2ull * c->poolSlack, wantI = 2 * liveI + 8ull * c->poolSlack;
-		if (wantV <= 0xFFFFFFFFull && wantI <= 0xFFFFFFFFull) (void)grow_pools_keeping(c, (u32)wantV, (u32)wantI);
-		(void)ensure_spare_pools(c, 0, 0);
+		bool got = true;
+		if (wantV <= 0xFFFFFFFFull && wantI <= 0xFFFFFFFFull) got = grow_pools_keeping(c, (u32)wantV, (u32)wantI);
+		got = ensure_spare_pools(c, 0, 0) && got;
+		//  a reservation the device could not give is not asked for again by every later edit - each attempt is a
+		// large allocation that can take tens of milliseconds; vx_compact_pools asks when it needs the pair, a full run starts over
+		if (!got) { c->editRoomFailed = true; if (c->hostTiming) fprintf(stderr, "[vx host, dirty] room for edits could not be reserved (not asked for again before the next full run)\n"); }
 		if (c->hostTiming) fprintf(stderr, "[vx host, dirty] room for edits (pools for twice the live meshes, spare pair): %.0f us\n", tUs(t0, tNow()));
 	}
 	{
@@ -1878,12 +1894,18 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			c->be.run_dirty_fused(p, levels, q, c->dirtyLarge0Hint, c->dirtyLargeHint);
 			c->be.end_timing_record();
 			t2 = tNow();
-			if (!c->be.sync_ok()) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + c->be.error());
+			//  a run that failed may not have counted all its workgroups into the device's ticket: the host's count and
+			// the device's start over together, or no later run would ever elect its last workgroup
+			auto ticketLost = [&]() {
+				if (c->dDirtyTicket && !c->be.fill(c->dDirtyTicket, 0, 64)) { c->be.free(c->dDirtyTicket); c->dDirtyTicket = nullptr; }
+				c->dirtyTickets = 0;
+			};
+			if (!c->be.sync_ok()) { const std::string why = c->be.error(); ticketLost(); return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: device run failed: " + why); }
 			t3 = tNow();
 			ms = c->be.elapsed_ms();
-			if (c->hdrPinned[HDR_PUBLISHED] == 0) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's header did not arrive (internal error)");
+			if (c->hdrPinned[HDR_PUBLISHED] == 0) { ticketLost(); (void)c->be.sync_ok(); return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's header did not arrive (internal error)"); }
 			memcpy(c->hdr, c->hdrPinned, HDR_WORDS * 4);
-			if (c->hdr[HDR_GIVEUP]) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: a dependency wait inside the run timed out (internal error)");
+			if (c->hdr[HDR_GIVEUP]) { ticketLost(); (void)c->be.sync_ok(); return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: a dependency wait inside the run timed out (internal error)"); }
 			{
 				// blocks beyond the first capacity class, on level 0 (counted by k_dirty_head) and above it: unannounced, the run is
 				// repeated once with their launches made
@@ -1939,8 +1961,6 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		{ const int rc = make_room_for_edit(c, usedV, usedI); if (rc != VX_OK) return rc; }
 	}
 	// ---- new blocks, appended in list order (TransVoxelImpl.cpp:1274-1293) -------------------------------------
-	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
-	c->deviceLists = false;
 	u32 trivialBlocks = c->hdr[HDR_STATS + 2];
 	for (u32 L = 0; L < levels; ++L) {
 		const LevelDesc& d = c->lv[L];
@@ -1949,7 +1969,9 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		// order of `coords`: one walk over both.  The chain appends to its work lists with atomics (arbitrary order): its
 		// records are indexed by block coordinate first.
 		std::vector<std::pair<u32, u32> > byCoord;
-		if (!recordsInListOrder) {
+		bool inOrder = recordsInListOrder;
+	again:
+		if (!inOrder) {
 			byCoord.reserve(nWork);
 			for (u32 k = 0; k < nWork; ++k) byCoord.push_back(std::make_pair(recs[start[L] + k].coordId, start[L] + k));
 			std::sort(byCoord.begin(), byCoord.end());
@@ -1958,7 +1980,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		for (u32 k = 0; k < cnt[L]; ++k) {
 			const u32 coord = coords[start[L] + k];
 			const BlockRecord* rp = nullptr;
-			if (recordsInListOrder) {
+			if (inOrder) {
 				if (w < nWork && recs[start[L] + w].coordId == coord) rp = &recs[start[L] + w++];
 			} else {
 				auto it = std::lower_bound(byCoord.begin(), byCoord.end(), std::make_pair(coord, 0u));
@@ -1973,9 +1995,13 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			block_corners(d, coord, e.minc, e.maxc);
 			fresh[L].push_back(std::move(e));
 		}
-		if (recordsInListOrder && w != nWork) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: the run's records do not follow its work lists (internal error)");
+		//  records that do not follow the box's coordinate order are looked up by coordinate, like the chain's: nothing
+		// of the context has been committed yet, and nothing fails here
+		if (inOrder && w != nWork) { inOrder = false; fresh[L].clear(); goto again; }
 		if (L) trivialBlocks += cnt[L];
 	}
+	c->poolVerts = c->hdr[HDR_CURSORS]; c->poolIdx = c->hdr[HDR_CURSORS + CUR_I]; // from here on nothing can fail
+	c->deviceLists = false;
 	// the lists change in place, now that nothing can fail any more: the dropped blocks leave (everything behind the first of
 	// them moves up, nothing is copied in front of it), the rebuilt ones are appended (:1274-1293)
 	for (u32 L = 0; L < levels; ++L) {
