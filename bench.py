@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-isolated", action="store_true", help="skip the second context that times the parts of k_main as launches of their own (profiling runs: only the product path's kernels in the trace)")
     ap.add_argument("--require-c-abi-transport", action="store_true", help="N > 1 only: fail if the C-ABI RCCL communicator (vx_comm_init) cannot be brought up.  Default: the halo then moves through torch.distributed (RCCL as well) and the line says so in config.halo_transport / config.c_abi_rccl_error - such a line is no evidence for vx_halo_exchange, but the timed steps do not contain the exchange unless --halo-every-step")
     ap.add_argument("--allow-torch-transport", action="store_true", help=argparse.SUPPRESS)  # (the default since round 5; kept so that old command lines still parse)
+    ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_dry_run.py: the script's own control flow (rank bookkeeping, collectives, transports, self-check, the JSON line) on CPU - gloo instead of RCCL, whatever library VOXELS_HIP_LIBRARY names instead of the HIP one.  Its numbers mean nothing and the line says so.
     ap.add_argument("--halo-every-step", action="store_true", help="N > 1 only: exchange the slab halo inside every timed step (as after an edit) instead of once before the steps")
     return ap.parse_args()
 
@@ -164,13 +165,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run_cpu
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     dist_pkg = None
     if world > 1:
         import torch.distributed as dist_pkg
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist_pkg.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist_pkg.init_process_group("gloo")
+        else:
+            dist_pkg.init_process_group("nccl", device_id=dev)
+
+    def device_sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     n, levels, seed = args.n, args.levels, 1337
     coarse = 16 << (levels - 1)
@@ -183,8 +193,9 @@ def main():
     #      tensors with the halo layers the path reads) and exchange halos through the C ABI over RCCL. -------------------
     axis = args.slab_axis if world > 1 else "z"
     poly = Polygonizer(device=local_rank)
-    assert poly.backend == "hip:gfx950"
-    poly.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert dry or poly.backend == "hip:gfx950"
+    if not dry:
+        poly.set_stream(torch.cuda.current_stream().cuda_stream)
     poly.set_materials(synth.default_lut())
     t_gen = time.perf_counter()
     slab = None
@@ -196,7 +207,15 @@ def main():
         from voxels_amd.slab import SlabBuffers
         slab = SlabBuffers(torch, n, rank, world, dev, axis=axis)
         slab.attach(poly)
-        poly.fill_terrain(seed)
+        if dry:
+            # (no generator on the device: the host generator's bytes, which vx_grid_fill_terrain reproduces - tests/)
+            d, m, b = synth.terrain(n, seed=seed)
+            sl = (slice(slab.z0, slab.z1),) if axis == "z" else (slice(None), slice(slab.z0, slab.z1))
+            slab.fill_own(np.ascontiguousarray(d[sl]), np.ascontiguousarray(m[sl]), np.ascontiguousarray(b[sl]),
+                          synth.block_empty_flags(d[sl]) if axis == "z" else synth.block_empty_flags(d))
+            slab.attach(poly)
+        else:
+            poly.fill_terrain(seed)
         # The exchange runs through the C ABI (vx_comm_init / vx_halo_exchange: RCCL bound by the library itself).  Every rank
         # walks through the SAME sequence of collectives whatever fails where: rank 0 broadcasts a status byte + the id
         # (zeros when it could not make one), all ranks agree (MIN) before anybody enters ncclCommInitRank, and agree again
@@ -231,7 +250,7 @@ def main():
             comm_error = why or "another rank failed"
             sys.stderr.write("rank %d: C-ABI RCCL communicator unavailable (%s): torch.distributed moves the halo, the line says so\n" % (rank, comm_error))
             halo_transport = "torch-distributed"
-    torch.cuda.synchronize()
+    device_sync()
     t_gen = time.perf_counter() - t_gen
 
     def halo_exchange():
@@ -247,7 +266,7 @@ def main():
                 slab.attach(poly)
 
     halo_exchange()
-    torch.cuda.synchronize()
+    device_sync()
 
     if args.serialize:
         poly.set_stage_timing(True)
@@ -262,7 +281,7 @@ def main():
     def barrier():
         if world > 1:
             dist_pkg.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(args.warmup):
         info = step()
@@ -274,6 +293,8 @@ def main():
         run_dev_ms += info.device_ms
     barrier()
     run_dev_ms /= max(args.steps, 1)
+    if dry:
+        run_dev_ms = run_dev_ms or 1.0  # (the emulation reports no device time)
     elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -311,14 +332,39 @@ def main():
         tsum = torch.from_numpy(digest.pack(mine)).to(dev)
         dist_pkg.all_reduce(tsum, op=dist_pkg.ReduceOp.SUM)
         summed = digest.unpack(tsum.cpu().numpy(), mine[0].shape[0])  # (the levels the run produced: fewer than requested on small grids)
+        # The levels whose block is larger than a slab (1024^3 on 8 ranks: 4, 5, 6) - the reference always produces
+        # log2(n / 16) + 1 - come from rank 0: the ranks' own layers gathered once (CoarseLevels, voxels_amd/slab.py: every rank
+        # walks through the same collectives), a partial run over them.  Only when the slabs ran every level they can.
+        from voxels_amd.slab import CoarseLevels, sharded_levels
+        coarse_info = None
+        all_levels_run = mine[0].shape[0] == sharded_levels(n, world)
+
+        def make_coarse_poly():
+            q = Polygonizer(device=local_rank)
+            q.set_materials(synth.default_lut())
+            return q
+        t_coarse = time.perf_counter()
+        coarse = CoarseLevels(slab, dist_pkg, make_coarse_poly) if all_levels_run else None
         verdict = torch.zeros(1, dtype=torch.int32, device=dev)
         if rank == 0:
             # (whatever happens here, rank 0 reaches the broadcast below: the other ranks are waiting in it)
             try:
+                upper = coarse.execute() if coarse is not None else []
+                device_sync()
+                t_coarse = time.perf_counter() - t_coarse
+                if upper:
+                    summed = digest.join(summed, digest.surface_digest(upper, first_level=coarse.first))
+                    coarse_info = {"levels": [coarse.first, coarse.levels], "gather_and_run_ms": round(t_coarse * 1e3, 2), "device_ms": round(float(coarse.info.device_ms), 4),
+                                   "first_meshed_level": int(coarse.info.first_meshed_level),
+                                   "note": "levels whose block is larger than a slab, on rank 0 from the gathered fields (vx_polygonize_from); outside the timed steps"}
                 whole_poly = Polygonizer(device=local_rank)
                 whole_poly.set_materials(synth.default_lut())
-                whole_poly.create_terrain(n, seed)
-                whole_poly.execute(levels)
+                if dry:
+                    d, m, b = synth.terrain(n, seed=seed)
+                    whole_poly.upload(d, m, b, synth.block_empty_flags(d))
+                else:
+                    whole_poly.create_terrain(n, seed)
+                whole_poly.execute(0 if upper else levels)
                 ref = digest.surface_digest(whole_poly.all_levels())
                 whole_poly.close()
                 equal = digest.digests_equal(summed, ref)
@@ -328,10 +374,12 @@ def main():
                                            "whole-grid run is what tests/ and parity_vs_reference compare with the oracle)",
                                    "totals_per_level_blocks_verts_indices_tverts_tindices": summed[0].tolist(),
                                    "hash": "%016x" % int(summed[1]), "reference": "whole-grid run of the same library on rank 0's GPU",
-                                   "reference_totals": ref[0].tolist(), "reference_hash": "%016x" % int(ref[1])}
+                                   "reference_totals": ref[0].tolist(), "reference_hash": "%016x" % int(ref[1]), "coarse_levels": coarse_info}
             except Exception as e:  # noqa: BLE001
                 verdict[0] = 0
                 multi_gpu_check = {"result": "ERROR", "error": str(e)[-300:]}
+        if coarse is not None:
+            coarse.close()
         dist_pkg.broadcast(verdict, 0)
         if int(verdict.item()) != 1:
             if rank == 0:
@@ -342,16 +390,21 @@ def main():
     # ---- per-kernel device timing (HIP events on the stream the kernels run on).  With stage timing enabled the
     #      library serialises its streams so that every kernel's duration is its own; the timed steps above ran the
     #      normal, overlapped pipeline (level-0 regular pass and transition pass beside the material chain). ----
-    poly.set_stage_timing(True)
+    if not dry:
+        poly.set_stage_timing(True)
     stage = np.zeros(8, np.float64)
     reps = 5
     dev_ms = 0.0
     for _ in range(reps):
         info = poly.execute(levels)
-        stage += poly.stage_times()
+        if not dry:
+            stage += poly.stage_times()
         dev_ms += info.device_ms
     stage /= reps
     dev_ms /= reps
+    if dry:
+        stage[:] = 1.0  # (no stage timing on CPU: placeholders, the line is marked dry_run)
+        dev_ms = dev_ms or 1.0
     if not args.serialize:
         poly.set_stage_timing(False)
     per_level = []
@@ -454,10 +507,10 @@ def main():
     def timed(fn, reps=3):
         best = None
         for _ in range(reps):
-            torch.cuda.synchronize()
+            device_sync()
             t = time.perf_counter()
             fn()
-            torch.cuda.synchronize()
+            device_sync()
             dt = (time.perf_counter() - t) * 1e3
             best = dt if best is None else min(best, dt)
         return round(best, 3)
@@ -501,13 +554,13 @@ def main():
         best = None
         for _ in range(3):
             poly.invalidate()
-            torch.cuda.synchronize()
+            device_sync()
             t = time.perf_counter()
             ci = poly.execute(levels)
-            torch.cuda.synchronize()
+            device_sync()
             wall = (time.perf_counter() - t) * 1e3
             if best is None or wall < best[0]:
-                best = (wall, float(ci.mirror_ms), float(ci.device_ms))
+                best = (wall, float(ci.mirror_ms) or (1.0 if dry else 0.0), float(ci.device_ms))
         vox = n * n * planes
         mirror_bytes = 6 * vox + sum(vox >> (3 * l) for l in range(1, 4))  # three fields read + written, lattice copies of levels 1..3 written
         cold = {"cold_execute_ms": round(best[0], 4), "mirror_build_ms": round(best[1], 4), "device_ms_after_mirrors": round(best[2], 4),
@@ -531,18 +584,18 @@ def main():
             other.create_terrain(n, seed + 1)
             for _ in range(3):
                 poly.execute(levels); oi = other.execute(levels)
-            torch.cuda.synchronize()
+            device_sync()
             k = max(10, min(args.steps, 50))
             ta = time.perf_counter()
             for _ in range(k):
                 poly.execute(levels); other.execute(levels)
-            torch.cuda.synchronize()
+            device_sync()
             alt_ms = (time.perf_counter() - ta) / (2 * k) * 1e3
             # the second grid alone, back to back (its surface differs a little from the headline grid's: the pair's expected mean)
             tb = time.perf_counter()
             for _ in range(k):
                 other.execute(levels)
-            torch.cuda.synchronize()
+            device_sync()
             other_ms = (time.perf_counter() - tb) / k * 1e3
             other.close()
             expected = 0.5 * (ms_per_step + other_ms)
@@ -577,8 +630,8 @@ def main():
             pv, pi = int(ei0.total_verts), int(ei0.total_indices)
             for k in range(14):
                 pos = (en / 2.0 + 23.0 * (k % 4) - 30.0 + 0.37, en / 2.0 + 19.0 * (k // 4) - 20.0 + 0.61, zs + 2.0 * (k % 3) + 0.23)
-                torch.cuda.synchronize()
-                t = time.perf_counter(); mn, mx = ep.inject_ball(pos, (44.0, 44.0, 44.0), 20.0, 2); torch.cuda.synchronize(); te = time.perf_counter() - t
+                device_sync()
+                t = time.perf_counter(); mn, mx = ep.inject_ball(pos, (44.0, 44.0, 44.0), 20.0, 2); device_sync(); te = time.perf_counter() - t
                 t = time.perf_counter(); got = ep.execute_dirty(mn, mx); dt = time.perf_counter() - t
                 nv, ni = int(ep.info.total_verts), int(ep.info.total_indices)
                 if k >= 2:
@@ -611,12 +664,12 @@ def main():
         poly.create_terrain(n, seed, 1)
         for _ in range(2):
             xi = poly.execute(levels)
-        torch.cuda.synchronize()
+        device_sync()
         t = time.perf_counter()
         k = 10
         for _ in range(k):
             xi = poly.execute(levels)
-        torch.cuda.synchronize()
+        device_sync()
         ms = (time.perf_counter() - t) / k * 1e3
         tot = np.zeros(4, np.uint64)
         lvl0 = None
@@ -682,6 +735,7 @@ def main():
             "vs_baseline": None,
             "dtype": "i8",
             "data": "synthetic",
+            "dry_run": bool(dry),  # (true only for tests/test_bench_dry_run.py: the script's control flow on CPU, numbers meaningless)
             "config": {"workload": "%d^3 procedural noise terrain (seed %d), materials, LOD levels 0..%d with transition cells, "
                                    "%s-slab sharded over %d GPU(s)" % (n, seed, levels - 1, axis, world),
                        "grid": n, "levels": levels, "parallelism": "%sslab%d" % (axis, world),

@@ -40,12 +40,21 @@ def main():
     p.set_materials(vxo.default_lut())
     slab.attach(p)
     p.execute(levels)
-    save(out_dir, rank, p)
+    # the levels whose block is larger than a slab: on rank 0, from the gathered fields (voxels_amd/slab.py CoarseLevels)
+    from voxels_amd.slab import CoarseLevels
+
+    def make():
+        q = Polygonizer(library=emu_library())
+        q.set_materials(vxo.default_lut())
+        return q
+    coarse = CoarseLevels(slab, dist, make)
+    save(out_dir, rank, p, coarse.execute(), coarse.first)
+    coarse.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def save(out_dir, rank, p):
+def save(out_dir, rank, p, coarse=None, coarse_first=0):
     """the rank's levels + the digest of the whole sharded run as bench.py --gpus N forms it: every rank's digest
     (voxels_amd/digest.py), packed and summed with all_reduce"""
     from voxels_amd import digest
@@ -53,7 +62,12 @@ def save(out_dir, rank, p):
     packed = torch.from_numpy(digest.pack(digest.surface_digest(all_levels)))
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     out = {"stats": p.stats(), "digest_sum": packed.numpy()}
-    for li, lv in enumerate(all_levels):
+    named = list(enumerate(all_levels)) + [(coarse_first + i, lv) for i, lv in enumerate(coarse or [])]
+    out["coarse_first"], out["coarse_count"] = coarse_first, len(coarse or [])
+    if coarse:
+        # what bench.py --gpus N compares: the ranks' summed digest joined with rank 0's digest of the coarse levels
+        out["digest_all"] = digest.pack(digest.join(digest.unpack(packed.numpy(), len(all_levels)), digest.surface_digest(coarse, first_level=coarse_first)))
+    for li, lv in named:
         out["L%d_infos" % li] = lv.infos
         out["L%d_verts" % li] = lv.verts
         out["L%d_idx" % li] = lv.idx
@@ -85,7 +99,15 @@ def main_rccl(out_dir, n, levels, axis, rank, world):
     p.invalidate()                         # the attached tensors were rewritten behind the library's back
     p.halo_exchange()
     p.execute(levels)
-    save(out_dir, rank, p)
+    from voxels_amd.slab import CoarseLevels
+
+    def make():
+        q = Polygonizer(device=local)
+        q.set_materials(synth.default_lut())
+        return q
+    coarse = CoarseLevels(slab, dist, make)  # (the gather moves device tensors over gloo: staged through the host by torch)
+    save(out_dir, rank, p, coarse.execute(), coarse.first)
+    coarse.close()
     dist.barrier()
     dist.destroy_process_group()
 

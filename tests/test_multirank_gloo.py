@@ -31,12 +31,16 @@ def test_two_ranks_equal_one(tmp_path, axis, port):
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mr_worker.py"), str(tmp_path), str(n), str(levels), axis], env=e))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    parts, stats, digest_sums = [], np.zeros(20, np.uint64), []
+    parts, stats, digest_sums, coarse, digest_all = [], np.zeros(20, np.uint64), [], [], None
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         digest_sums.append(z["digest_sum"])
         parts.append([Level(z["L%d_infos" % l], z["L%d_verts" % l], z["L%d_idx" % l], z["L%d_tverts" % l], z["L%d_tidx" % l]) for l in range(levels)])
         stats += z["stats"]
+        if int(z["coarse_count"]):
+            assert r == 0 and int(z["coarse_first"]) == levels
+            coarse = [Level(z["L%d_infos" % l], z["L%d_verts" % l], z["L%d_idx" % l], z["L%d_tverts" % l], z["L%d_tidx" % l]) for l in range(levels, levels + int(z["coarse_count"]))]
+            digest_all = z["digest_all"]
     d, m, b = synth.terrain(n, seed=5)
     whole = Polygonizer(library=emu_library())
     whole.set_materials(vxo.default_lut())
@@ -55,3 +59,10 @@ def test_two_ranks_equal_one(tmp_path, axis, port):
     for ds in digest_sums:
         assert digest.digests_equal(digest.unpack(ds, levels), digest.surface_digest(ref)), "all-reduced digest vs oracle"
     assert np.array_equal(stats.astype(np.uint32), whole.stats())
+    # EVERY level the reference produces: the slabs' levels 0..2 and, from rank 0's CoarseLevels (the
+    # gathered fields, vx_polygonize_from), level 3 - whose one block spans both slabs - against the oracle's whole surface
+    ref_all = oracle.execute(oracle.grid_from_dense(d, m, b)).all_levels()
+    assert len(ref_all) == levels + 1 and len(coarse) == 1
+    ok, msg = fields.surface_equal(merged + coarse, ref_all)
+    assert ok, "2 ranks + coarse levels vs oracle: " + msg
+    assert digest.digests_equal(digest.unpack(digest_all, levels + 1), digest.surface_digest(ref_all)), "digest of all levels vs oracle"

@@ -49,9 +49,10 @@ def _vertex_words(verts, with_normals):
     return np.ascontiguousarray(keep).view(np.uint64).reshape(-1), 5
 
 
-def surface_digest(levels, with_normals=True):
-    """levels: list of Level (voxels_amd.binding.Level or the oracle's).  Returns (totals int64[len(levels), 5], hash uint64):
-    totals = blocks, vertices, indices, transition vertices, transition indices per level."""
+def surface_digest(levels, with_normals=True, first_level=0):
+    """levels: list of Level (voxels_amd.binding.Level or the oracle's), the first of which is LOD level `first_level` (a block's
+    value depends on its level).  Returns (totals int64[len(levels), 5], hash uint64): totals = blocks, vertices, indices,
+    transition vertices, transition indices per level."""
     totals = np.zeros((len(levels), 5), np.int64)
     total_hash = np.uint64(0)
     with np.errstate(over="ignore"):
@@ -60,7 +61,7 @@ def surface_digest(levels, with_normals=True):
             totals[li] = (len(inf), len(lv.verts), len(lv.idx), len(lv.tverts), len(lv.tidx))
             if len(inf) == 0:
                 continue
-            key = _mix(inf["id"].astype(np.uint64) * _M1 + np.uint64(li + 1))
+            key = _mix(inf["id"].astype(np.uint64) * _M1 + np.uint64(first_level + li + 1))
             h = key.copy()
             vw, per = _vertex_words(lv.verts, with_normals)
             h += _mix(_stream_sums(vw, inf["n_verts"], per) + np.uint64(11)) * np.uint64(3)
@@ -85,6 +86,13 @@ def combine(parts):
         for p in parts:
             h = h + np.uint64(p[1])
     return totals, np.uint64(h)
+
+
+def join(fine, coarse):
+    """The digest of the levels [0, k) and the digest of the levels [k, ...) (surface_digest(..., first_level=k)) as the digest
+    of all of them: what a sharded run's slabs and the rank that takes the coarse levels produce together."""
+    with np.errstate(over="ignore"):
+        return np.concatenate([fine[0], coarse[0]]), np.uint64(np.uint64(fine[1]) + np.uint64(coarse[1]))
 
 
 def digests_equal(a, b):

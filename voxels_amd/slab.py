@@ -1,4 +1,5 @@
-"""Z-slab sharding of the voxel grid over the ranks of one node and the halo exchange the path needs.
+"""Slab sharding of the voxel grid over the ranks of one node, the halo exchange the path needs, and the coarse levels a
+sharded run leaves to one rank (CoarseLevels).
 
 Blocks of every LOD level are owned by exactly one rank when the slab thickness is a multiple of the coarsest
 block size (16 << (levels-1)).  Beyond its own planes [z0, z1) a rank reads:
@@ -125,6 +126,107 @@ class SlabBuffers:
         else:
             poly.attach_y(self.n, self.z0, self.z1, self.dist.data_ptr(), self.z0 - 1, self.planes + 3, self.mat.data_ptr(),
                           self.blend.data_ptr(), self.z0, self.planes + 1, self.flags.data_ptr())
+
+
+def sharded_levels(n, world):
+    """How many levels a sharded run of `world` slabs produces itself: those whose block (16 << level voxels) fits the slab,
+    so that every block has one owner.  The reference always produces log2(n / 16) + 1 (src/TransVoxelImpl.cpp:490-492); the
+    rest are coarse_levels()'s."""
+    planes, k = n // world, 0
+    while (16 << k) <= planes and (16 << k) <= n:
+        k += 1
+    return k
+
+
+def all_levels_count(n):
+    k = 1
+    while (16 << k) <= n:
+        k += 1
+    return k
+
+
+def gather_whole_fields(slab, dist_pkg, dst=0):
+    """Every rank's OWN layers of the three fields, joined on rank `dst` into whole-grid tensors [n, n, n] (None on the other
+    ranks), and the BF_Empty flags of all blocks (every rank contributes the flags it owns; the others are zero until a
+    halo exchange fills the neighbours' in).  One gather per field, no host copy."""
+    t, p, w, r = slab.torch, slab.planes, slab.world, slab.rank
+    dim = 0 if slab.axis == "z" else 1
+    out = []
+    for own in (slab._d(1, p + 1), slab._m(slab.mat, 0, p), slab._m(slab.blend, 0, p)):
+        own = own.contiguous()
+        chunks = [t.empty_like(own) for _ in range(w)] if r == dst else None
+        dist_pkg.gather(own, chunks, dst=dst)
+        out.append(t.cat(chunks, dim=dim).contiguous() if r == dst else None)
+        del chunks
+    flags = slab.flags.clone()
+    dist_pkg.all_reduce(flags, op=dist_pkg.ReduceOp.MAX)
+    return out[0], out[1], out[2], flags
+
+
+class CoarseLevels:
+    """The levels a sharded run cannot produce slab by slab - those whose block is larger than a slab (1024^3 on 8 ranks:
+    levels 4..6) - on ONE rank, so that a sharded run yields every level the reference does (last sentence).
+
+    What such a level reads is not a coarse lattice alone: every vertex walks its LOD chain down to the level-0 edge that
+    holds the crossing (FindBestVertexInLODChain, src/TransVoxelImpl.cpp:1484-1509) and takes its normals and materials
+    from the level-0 voxels around that edge (:1239-1246, :1698-1703), its cell materials are votes over the caches of
+    the level below (:753-838), and the transition cells of level L read the level L-1 lattice - so the 64^3-strided
+    sample set SURVEY names is not enough; the crossings can lie anywhere.  The rank therefore gathers the owned layers of
+    the three fields once per grid change (3 B per voxel over the links: 384 MB per sending rank at 1024^3 / 8, a few
+    milliseconds over xGMI; never part of a timed step of an unchanged grid), attaches them to a context of its own and
+    runs vx_polygonize_from(first level = sharded_levels): slot maps, bitmaps and material caches of every level, meshes of
+    the coarse ones only (0.15 ms at 1024^3).  Costs that rank 6 B per voxel of device memory (fields + mirrors)."""
+
+    def __init__(self, slab, dist_pkg, make_polygonizer, dst=0):
+        self.slab, self.dst = slab, dst
+        self.first = sharded_levels(slab.n, slab.world)
+        self.levels = all_levels_count(slab.n)
+        self.poly = None
+        self.fields = None
+        if self.first >= self.levels:
+            return  # (a single slab, or slabs as thick as the grid's coarsest block: nothing is missing)
+        d, m, b, flags = gather_whole_fields(slab, dist_pkg, dst)
+        if slab.rank == dst:
+            self.fields = (d, m, b, flags)  # (attached memory: must outlive the context)
+            self.poly = make_polygonizer()
+            self.poly.attach(slab.n, 0, slab.n, d.data_ptr(), 0, m.data_ptr(), b.data_ptr(), 0, flags.data_ptr())
+
+    @classmethod
+    def from_slabs(cls, slabs, make_polygonizer):
+        """The same for all slabs of a grid held by ONE process (several contexts on one device: tests, tools): the whole-grid
+        tensors are joined from the slabs' own layers directly."""
+        t, first = slabs[0].torch, slabs[0]
+        self = cls.__new__(cls)
+        self.slab, self.dst = first, first.rank
+        self.first, self.levels = sharded_levels(first.n, first.world), all_levels_count(first.n)
+        self.poly = self.fields = None
+        if self.first >= self.levels:
+            return self
+        p, dim = first.planes, 0 if first.axis == "z" else 1
+        d = t.cat([x._d(1, p + 1) for x in slabs], dim=dim).contiguous()
+        m = t.cat([x._m(x.mat, 0, p) for x in slabs], dim=dim).contiguous()
+        b = t.cat([x._m(x.blend, 0, p) for x in slabs], dim=dim).contiguous()
+        flags = slabs[0].flags.clone()
+        for x in slabs[1:]:
+            flags = t.maximum(flags, x.flags)
+        self.fields = (d, m, b, flags)
+        self.poly = make_polygonizer()
+        self.poly.attach(first.n, 0, first.n, d.data_ptr(), 0, m.data_ptr(), b.data_ptr(), 0, flags.data_ptr())
+        return self
+
+    def execute(self):
+        """-> the Level list of the coarse levels [first, levels) on rank dst (empty list where nothing is missing), None elsewhere"""
+        if self.first >= self.levels:
+            return [] if self.slab.rank == self.dst else None
+        if self.poly is None:
+            return None
+        self.info = self.poly.execute_from(0, self.first)
+        return self.poly.all_levels()[self.first:]
+
+    def close(self):
+        if self.poly is not None:
+            self.poly.close()
+        self.poly = self.fields = None
 
 
 def merge_rank_levels(per_rank_levels):
