@@ -415,6 +415,7 @@ struct Backend {
 					st->wordPrefix[48] = (u16)exclusive_scan(st->wordPrefix, 48);
 					st->vTotal = st->iTotal = st->vOff = st->iOff = 0;
 					if (st->wordPrefix[48]) {
+						tr_phase_cells_of(*st, 0, 1);
 						tr_phase_list(*st, T, L, b, 0, 1);
 						tr_phase_count(*st, T, 0, 1);
 						st->vTotal = exclusive_scan(st->vbase, st->wordPrefix[48]);

@@ -1101,15 +1101,48 @@ TV_HD void tr_cell_values(const TrState& st, int f, int row, int col, i8 v9[9])
 		for (int i = 0; i < 3; ++i) v9[j * 3 + i] = p[j * TR_PROW + i];
 }
 
+// sign bits of one staged plane row (33 samples): bits 0..16 = samples 0..16 (returned), `hi` = samples 16..32
+TV_HD u32 tr_row_signs(const i8* row, u32& hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	// (rows are 16-byte aligned: TR_PROW = 48).  The sign bits of four bytes as a nibble: the bits 7, 15, 23, 31 times
+	// (1 + 2^7 + 2^14 + 2^21) meet in the bits 28..31 - no two partial products share a bit, nothing carries
+	const uint4 a = *(const uint4*)row, b = *(const uint4*)(row + 16);
+	const auto s4 = [](u32 d) { return ((d & 0x80808080u) * 0x00204081u) >> 28; };
+	const u32 lo16 = s4(a.x) | (s4(a.y) << 4) | (s4(a.z) << 8) | (s4(a.w) << 12), hi16 = s4(b.x) | (s4(b.y) << 4) | (s4(b.z) << 8) | (s4(b.w) << 12);
+#else
+	u32 lo16 = 0, hi16 = 0;
+	for (int i = 0; i < 16; ++i) { lo16 |= ((u32)(row[i] >> 7) & 1u) << i; hi16 |= ((u32)(row[16 + i] >> 7) & 1u) << i; }
+#endif
+	hi = hi16 | (((u32)(row[32] >> 7) & 1u) << 16);
+	return lo16 | ((hi16 & 1u) << 16);
+}
+
+// non-trivial transition cells among the 8 cells whose 3 x 3 samples lie in the bits 2c .. 2c + 2 of three rows: A = AND of the
+// rows' sign masks, O = their OR (17 bits each).  A cell is trivial iff its nine samples agree in sign (case code 0 or 511, :1923).
+TV_HD u32 tr_cells8(u32 A, u32 O)
+{
+	const u32 all = A & (A >> 1) & (A >> 2), any = O | (O >> 1) | (O >> 2);
+	u32 x = any & ~all & 0x5555u;                       // bit 2c: cell c
+	x = (x | (x >> 1)) & 0x3333u; x = (x | (x >> 2)) & 0x0F0Fu; x = (x | (x >> 4)) & 0x00FFu;
+	return x;
+}
+
+// One lane per (face, cell row): the 16 cells of the row from the sign masks of its three sample rows, bit-parallel (round 6:
+// one lane per cell with nine byte reads and a case code each was a tenth of a transition block's vector instructions).
 TV_HD void tr_phase_classify(TrState& st, int tid, int nth)
 {
-	for (int c = tid; c < TR_CELLS; c += nth) {
-		const int f = c >> 8;
-		if (!((st.faceOn >> f) & 1u)) continue;
-		i8 v9[9];
-		tr_cell_values(st, f, (c >> 4) & 15, c & 15, v9);
-		const u32 code = tr_case_code(v9);
-		if (code != 0 && code != 511) TV_ATOMIC_OR(&st.ntAll[c >> 5], 1u << (c & 31));
+	for (int cr = tid; cr < 96; cr += nth) {
+		const int f = cr >> 4, row = cr & 15;
+		u32 bits = 0;
+		if ((st.faceOn >> f) & 1u) {
+			const i8* p = st.plane[f] + (row * 2) * TR_PROW;
+			u32 h0, h1, h2;
+			const u32 l0 = tr_row_signs(p, h0), l1 = tr_row_signs(p + TR_PROW, h1), l2 = tr_row_signs(p + 2 * TR_PROW, h2);
+			bits = tr_cells8(l0 & l1 & l2, l0 | l1 | l2) | (tr_cells8(h0 & h1 & h2, h0 | h1 | h2) << 8);
+		}
+		// cell c = f << 8 | row << 4 | col is bit c & 31 of word c >> 5: the row's 16 cells are one half-word
+		((u16*)st.ntAll)[cr] = (u16)bits;
 	}
 }
 
@@ -1119,17 +1152,35 @@ TV_HD void tr_low_local(const FaceGeom& fg, int row, int col, int local[3])
 	face_scatter(fg, col, row, fg.positive ? 15 : 0, local);
 }
 
-// preMat: TrState::faceMat filled by the caller (per transition cell), or nullptr: the entries are fetched here
+// compact -> cell id of the batch's non-trivial transition cells (behind the scan of the batch's word counts): one lane per
+// (face, cell row) half-word of the working bitmap
+TV_HD void tr_phase_cells_of(TrState& st, int tid, int nth)
+{
+	for (int cr = tid; cr < 96; cr += nth) {
+		u32 bits = ((const u16*)st.ntBits)[cr];
+		if (!bits) continue;
+		u32 k = st.wordPrefix[cr >> 1];
+		if (cr & 1) k += (u32)TV_POPC(st.ntBits[cr >> 1] & 0xFFFFu);
+		while (bits) {
+			const u32 col = (u32)__builtin_ctz(bits);
+			bits &= bits - 1;
+			st.cellOf[k++] = (u16)(((u32)cr << 4) | col);
+		}
+	}
+}
+
+// preMat: TrState::faceMat filled by the caller (per transition cell), or nullptr: the entries are fetched here.
+// One lane per COMPACT cell (tr_phase_cells_of ran, a barrier passed): until round 6 every lane walked six of the 1 536 cells
+// and skipped the trivial ones - with a few non-trivial cells in every wave the whole body ran for nearly every group of 64.
 TV_HD void tr_phase_list(TrState& st, const Tables& T, const LevelDesc& L, const RegBlockCtx& b, int tid, int nth, const u16* preMat = nullptr)
 {
-	for (int c = tid; c < TR_CELLS; c += nth) {
-		if (!bit_get(st.ntBits, (u32)c)) continue;
-		const u32 k = bit_rank(st.ntBits, st.wordPrefix, (u32)c);
+	const int nt = st.wordPrefix[48];
+	for (int k = tid; k < nt; k += nth) {
+		const int c = st.cellOf[k];
 		const int f = c >> 8, row = (c >> 4) & 15, col = c & 15;
 		i8 v9[9], v[13];
 		tr_cell_values(st, f, row, col, v9);
 		tr_expand_values(v9, v);
-		st.cellOf[k] = (u16)c;
 		const u32 code = tr_case_code(v9);
 #if defined(VX_CASE_DUMP)
 		L.trCaseDump[(size_t)b.slot * TR_CELLS + (u32)c] = (u16)code;

@@ -24,16 +24,22 @@ struct BrickSamplerT {
 	u32 nb, rowsY;     // blocks per row, resident block rows per block plane
 	int yb0, zb0;      // first resident block row / plane
 	typedef OFF Off;
-	__device__ __forceinline__ Off tx(int x) const { x = max(0, min(x, last)); return ((Off)((u32)x >> 4) << 12) | ((u32)x & 15u); }
+	// (brick_local's bit fields as sums: x + 4080 * (x >> 4) = (x >> 4) << 12 | (x & 15); with y & 15 = 4a + b the tile bits are
+	// 128 a + 16 b = 16 * ((y & 15) + (y & 12)); with z & 15 = 2a + b they are 512 a + 64 b = 64 * ((z & 15) + 3 * (z & 14)) - a multiply-add
+	// where the shifts, masks and ORs of the literal form cost three to four instructions more per term, and a vertex of a
+	// level >= 1 forms fifteen to twenty terms)
+	__device__ __forceinline__ Off tx(int x) const { x = max(0, min(x, last)); return (Off)x + (Off)__umul24((u32)x >> 4, 4080u); }
 	__device__ __forceinline__ Off ty(int y) const
 	{
 		y = max(0, min(y, last));
-		return ((Off)__umul24((u32)((y >> 4) - yb0), nb) << 12) | ((((u32)y >> 2) & 3u) << 7) | (((u32)y & 3u) << 4);
+		const u32 l = (u32)y & 15u;
+		return ((Off)__umul24((u32)((y >> 4) - yb0), nb) << 12) + ((l + (l & 12u)) << 4);
 	}
 	__device__ __forceinline__ Off tz(int z) const
 	{
 		z = max(0, min(z, last));
-		return ((Off)__umul24(__umul24((u32)((z >> 4) - zb0), rowsY), nb) << 12) | ((((u32)z >> 1) & 7u) << 9) | (((u32)z & 1u) << 6);
+		const u32 l = (u32)z & 15u;
+		return ((Off)__umul24(__umul24((u32)((z >> 4) - zb0), rowsY), nb) << 12) + ((l + 3u * (l & 14u)) << 6);
 	}
 	__device__ __forceinline__ int dist(Off o) const { return bDist[o]; }
 	__device__ __forceinline__ u32 mat(Off o, int, int, int) const { return (u32)bMat[o] | ((u32)bBlend[o] << 8); }

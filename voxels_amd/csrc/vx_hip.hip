@@ -1376,6 +1376,28 @@ __device__ __forceinline__ u32 vote8(const u32 e[8])
 	return bestId | ((avg & 0xFFu) << 8);
 }
 
+// The same vote where it is usually trivial: on a terrain nearly every voted cell has children of ONE material (or none), so the
+// 64 comparisons of the general count are spent on finding out that there is nothing to decide.  Every lane looks for its first
+// entry and whether all its other entries carry that id or none; if that holds for every voting lane of the wave (`active`: the
+// others pass anything) the winner is that id, its count the entries that carry it, its blend their mean - what vote8 computes
+// for such a lane, with a third of the instructions.  One wave-uniform branch; a wave with a mixed lane takes the general vote.
+__device__ __forceinline__ u32 vote8_mostly_uniform(const u32 e[8], bool active)
+{
+	u32 first = EMPTY_MATERIAL;
+#pragma unroll
+	for (int i = 7; i >= 0; --i) first = (e[i] & 0xFFu) != (u32)EMPTY_MATERIAL ? (e[i] & 0xFFu) : first;
+	bool simple = true;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) simple = simple && ((e[i] & 0xFFu) == first || (e[i] & 0xFFu) == (u32)EMPTY_MATERIAL);
+	if (__ballot(active && !simple) != 0ull) return vote8(e);
+	u32 cnt = 0, bl = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { const bool mine = (e[i] & 0xFFu) == first; cnt += mine ? 1u : 0u; bl += mine ? (e[i] >> 8) : 0u; }
+	if (first == (u32)EMPTY_MATERIAL) return EMPTY_MATINFO;
+	const u32 avg = (u32)((float)bl / (float)cnt);
+	return first | ((avg & 0xFFu) << 8);
+}
+
 // One block of one level >= 1.  GATED (k_main): the children's caches come from other workgroups of the same launch - waited
 // for right in front of the vote, the only phase that reads them - and the block's own completion is published.
 template <bool GATED, bool PARTIAL = false>
@@ -1706,7 +1728,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 						const u32 entry = ((mat2[v][i >> 1] >> sh) & 0xFFu) | (((bl2[v][i >> 1] >> sh) & 0xFFu) << 8);
 						e[i] = ((st.childBits[cb][local >> 5] >> (local & 31u)) & 1u) ? entry : (u32)EMPTY_MATINFO;
 					}
-					const u32 entry = vote8(e);
+					const u32 entry = vote8_mostly_uniform(e, true);
 					if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
 				}
 			}
@@ -1731,7 +1753,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 					u32 e[8];
 #pragma unroll
 					for (int i = 0; i < 8; ++i) e[i] = (pair[v][i >> 1] >> ((u32)(i & 1) * 16u)) & 0xFFFFu;
-					const u32 entry = vote8(e);
+					const u32 entry = vote8_mostly_uniform(e, true);
 					if (defineAll || entry != (u32)EMPTY_MATINFO) st.out[c] = (u16)entry;
 				}
 			}
@@ -2249,12 +2271,14 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 		__syncthreads();
 		TRB_TICK(4);
 		if (st.wordPrefix[48] != 0) {
+			tr_phase_cells_of(st, tid, WG); // (the compact list needs no material: formed in front of the wait, one barrier for both)
 			if (GATED && !matReady) {
 				// the block's material cache (tr_phase_list reads the cells behind the faces) comes from another workgroup of this launch
 				if (tid == 0) (void)wait_done(L.matDone + b.slot, p.G.epoch, p.G.giveUp);
 				acquire_and_meet(tid < 64);
 				matReady = true;
-			}
+			} else
+				__syncthreads();
 			TRB_TICK(5);
 			tr_phase_list(st, T, L, b, tid, WG, preMat ? st.faceMat : nullptr);
 			__syncthreads();
