@@ -66,7 +66,7 @@ def test_hip_matches_reference_fixture(poly, name):
 
 
 @pytest.mark.parametrize("knob,value", [("VX_FAST", "0"), ("VX_FAST", "1"), ("VX_FAST", "2"), ("VX_UPPER", "0"), ("VX_SELF_HEAD", "0"),
-                                         ("VX_FORCE_WIDE", "1"), ("VX_MAIN_HEADS", "8"), ("VX_DIRTY_FUSED", "0"), ("VX_HOST_TIMING", "1"), ("VX_POOL_SLACK", "64")])
+                                         ("VX_FORCE_WIDE", "1"), ("VX_DIRTY_FUSED", "0"), ("VX_HOST_TIMING", "1"), ("VX_POOL_SLACK", "64")])
 def test_hip_runtime_knobs_select_equivalent_paths(knob, value):
     """Every runtime knob the library still reads (INTEGRATION.md lists them; the numeric tuning knobs of the earlier rounds are
     constants now) selects a path production runs reach through their data.  Each one, on fixtures with materials and on a

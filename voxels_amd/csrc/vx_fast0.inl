@@ -345,7 +345,8 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 				// last lane makes them: its wave owns the tail of the compact list and is the first to run out of cells.
 				if (tid == WG - 1) {
 					st.vTotal = vTotal; st.tTotal = tTotal;
-					reserve_both(p.P.cursors, vTotal, tTotal * 3u, st.vOff, st.iOff);
+					if (VX_ABL & 32768) { st.vOff = (cur.slot * 701u) % (p.P.vertCap - 4096u); st.iOff = (cur.slot * 4001u) % (p.P.idxCap - 16384u); } // (tools: what the returning atomic costs)
+					else reserve_both(p.P.cursors, vTotal, tTotal * 3u, st.vOff, st.iOff);
 				}
 				for (u32 k0 = kBeg; k0 < kEnd; k0 += 64u) {
 					const u32 k = k0 + lane;

@@ -64,6 +64,9 @@ struct ExecParamsDev {
 
 // tools builds (tools/ab_build.py x=-DVX_ABL=<bits>): parts of the work switched off to see what they cost in time and
 // instructions (tools/exp/r06_ablate.sh); the results of such a build are wrong by construction.  0 in the product.
+#if !defined(VX_MAIN_WAVES)
+#define VX_MAIN_WAVES 4   // waves per SIMD k_main is compiled for (4: 128 VGPRs)
+#endif
 #if !defined(VX_ABL)
 #define VX_ABL 0
 #endif
@@ -793,8 +796,8 @@ __device__ __forceinline__ void lattice_rows_of(const MirrorState& X, int n, int
 }
 
 // k_rebrick: dense fields -> mirrors (tv_core.h GridView).  Box mode (ids == nullptr): a workgroup copies the 8
-// x-neighbour blocks that share the 128-byte lines of their voxel rows, 8 consecutive lanes per line; list mode: one
-// block per workgroup, one voxel row per lane.  Only rows that are resident in the dense fields are copied (a slab's halo
+// x-neighbour blocks that share the 128-byte lines of their voxel rows, 8 consecutive lanes per line read and one whole
+// 128-byte tile per brick written by a wave's store; list mode: one block per workgroup, one voxel row per lane.  Only rows that are resident in the dense fields are copied (a slab's halo
 // block layers hold a few planes / rows each).
 struct RebrickRanges { int dz0, dz1, dy0, dy1, mz0, mz1, my0, my1; };
 
@@ -839,7 +842,10 @@ __device__ __forceinline__ u16 block_sign_word(u32 collected)
 	return (u16)w;
 }
 
-__global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
+#if !defined(VX_RB_WAVES)
+#define VX_RB_WAVES 4
+#endif
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES))) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
 {
 	__shared__ u32 blockSigns[8];
 	const int nb = g.n >> 4, tid = (int)threadIdx.x;
@@ -857,12 +863,50 @@ __global__ __launch_bounds__(WG) void k_rebrick(GridView g, RebrickRanges r, Mir
 	const int gx = (int)blockIdx.x % groups, by = yb0 + ((int)blockIdx.x / groups) % ybCount, bz = zb0 + (int)blockIdx.x / (groups * ybCount);
 	const int bx = gx * 8 + (tid & 7);
 	u32 signs = 0;
-	if (bx < nb) {
+	// A wave takes one 128-byte tile of each of its 8 bricks per trip: rows y = 4 w .. 4 w + 3 of the planes z = 2 it, 2 it + 1
+	// (brick_local: the tile's 8 pieces in lane order), so every store instruction writes 8 whole lines.
+	const int sub = tid >> 3, ry = ((sub >> 3) << 2) | (sub & 3), rz = (sub >> 2) & 1;
+	const int gy = by * 16 + ry, gz0 = bz * 16 + rz;
+	// (uniform) the rule: every row of these blocks is resident in all three dense fields and owned by this rank, and none is the
+	// grid's last row or plane (whose samples are also the lattices' clamped far entries) - a slab's halo block layers and the
+	// grid's far block layers take the general row by row form below
+	const bool whole = by * 16 >= r.dy0 && by * 16 + 16 <= r.dy1 && bz * 16 >= r.dz0 && bz * 16 + 16 <= r.dz1
+	                && by * 16 >= r.my0 && by * 16 + 16 <= r.my1 && bz * 16 >= r.mz0 && bz * 16 + 16 <= r.mz1
+	                && by * 16 >= X.yBegin && by * 16 + 15 <= X.yEnd && bz * 16 >= X.zBegin && bz * 16 + 15 <= X.zEnd
+	                && by + 1 < nb && bz + 1 < nb;
+	if (bx < nb && whole) {
+		// all requests of a field are in flight before the first piece is stored (a load behind a range test is waited for on the spot)
+		const size_t dst = brick_base(g, bx, by, bz) + brick_local(0u, (u32)ry, (u32)rz);
+		const size_t srcD = dist_offset(g, bx * 16, gy, gz0), stepD = (size_t)2 * g.pitchY * g.n;
+		const size_t srcM = mat_offset(g, bx * 16, gy, gz0), stepM = (size_t)2 * g.pitchYMat * g.n;
+		uint4 d[8];
+#pragma unroll
+		for (int it = 0; it < 8; ++it) d[it] = *(const uint4*)(g.mat + srcM + it * stepM);
+#pragma unroll
+		for (int it = 0; it < 8; ++it) *(uint4*)(const_cast<u8*>(g.bMat) + dst + (it << 9)) = d[it];
+#pragma unroll
+		for (int it = 0; it < 8; ++it) d[it] = *(const uint4*)(g.blend + srcM + it * stepM);
+#pragma unroll
+		for (int it = 0; it < 8; ++it) *(uint4*)(const_cast<u8*>(g.bBlend) + dst + (it << 9)) = d[it];
+#pragma unroll
+		for (int it = 0; it < 8; ++it) d[it] = *(const uint4*)(g.dist + srcD + it * stepD);
+		const bool y0 = ry == 0;
+		const bool planes = X.xp[0].data || X.xp[1].data || X.xp[2].data, lattices = X.pyr[1].data != nullptr && !((ry | rz) & 1);
 #pragma unroll
 		for (int it = 0; it < 8; ++it) {
-			const int row = it * 32 + (tid >> 3);
-			signs |= rebrick_row(g, r, X, bx, by * 16 + (row & 15), bz * 16 + (row >> 4));
+			*(uint4*)(const_cast<i8*>(g.bDist) + dst + (it << 9)) = d[it];
+			const u32 any = (d[it].x | d[it].y | d[it].z | d[it].w) & 0x80808080u, all = (d[it].x & d[it].y & d[it].z & d[it].w) & 0x80808080u;
+			const u32 pair = (any ? 2u : 0u) | (all != 0x80808080u ? 1u : 0u) | ((d[it].x & 0x80u) ? 8u : 4u); // fields 0 and 1 of this row
+			const bool z0 = it == 0 && rz == 0;
+			signs |= pair | (y0 ? pair << 4 : 0u) | (z0 ? pair << 8 : 0u) | (y0 && z0 ? pair << 12 : 0u);
+			// the lattice samples of the row (one row in four carries any; no far entries along y and z in here)
+			if (planes) xplane_write_segment(X.xp, g.n, bx * 16, gy, gz0 + 2 * it, d[it]);
+			if (lattices) pyramid_write_segment(X.pyr, g.n, bx * 16, gy, gz0 + 2 * it, d[it]);
 		}
+		atomicOr(&blockSigns[tid & 7], signs);
+	} else if (bx < nb) {
+#pragma unroll 1
+		for (int it = 0; it < 8; ++it) signs |= rebrick_row(g, r, X, bx, gy, gz0 + 2 * it);
 		atomicOr(&blockSigns[tid & 7], signs);
 	}
 	__syncthreads();
@@ -3032,7 +3076,7 @@ struct Backend {
 	int device = 0;
 	bool ok = true;
 	// launch geometry knobs, read from the environment once when the context is created (tuning aids)
-	// Runtime knobs (read once per context).  Eight in all with VX_POOL_SLACK and VX_HOST_TIMING (vx_host.inl); each selects a path
+	// Runtime knobs (read once per context).  Seven in all with VX_POOL_SLACK and VX_HOST_TIMING (vx_host.inl); each selects a path
 	// that production runs reach through their data - dense surfaces, grids beyond 1024^3, blocks with zero samples - so that the
 	// tests can drive those paths on small fixtures (tests/test_gpu_parity.py::test_hip_runtime_knobs_select_equivalent_paths).
 	struct Tuning {
@@ -3041,9 +3085,8 @@ struct Backend {
 		u32 upper = 1;       // VX_UPPER=0: the chain of launches (what dense surfaces run) instead of k_main
 		u32 selfHead = 1;    // VX_SELF_HEAD=0: a classification pass (k_classify, k_hierarchy) instead of k_run_head handing out the slots
 		u32 dirtyFused = 1;  // VX_DIRTY_FUSED=0: incremental runs as the chain of launches with work lists
-		u32 mainHeads = 1;   // VX_MAIN_HEADS=8: one level-0 queue head per XCD (round 6: fewer L2 misses, no faster - profiles/r06_xcd_heads.txt)
 		// fixed since round 6 (were environment variables while they were being measured; profiles/HISTORY.md has the sweeps)
-		static constexpr u32 classifyRowGroup = 4, regWgsPerCu = 20, f1WgsPerCu = 20, foldBlocks = 65536, upWgsPerCu = 5, mainWgsPerCu = 4, mainBatch = 2, mainGranule = 32, mainUpperNum = 1, mainUpperDen = 4;
+		static constexpr u32 classifyRowGroup = 4, regWgsPerCu = 20, f1WgsPerCu = 20, foldBlocks = 65536, upWgsPerCu = 5, mainWgsPerCu = 4, mainBatch = 2, mainUpperNum = 1, mainUpperDen = 4;
 		bool fast0() const { return (fast & 1u) != 0; }
 		bool fast1() const { return (fast & 2u) != 0; }
 	} tune;
@@ -3073,7 +3116,6 @@ struct Backend {
 		tune.upper = env_u32("VX_UPPER", 1);
 		tune.selfHead = env_u32("VX_SELF_HEAD", 1);
 		tune.dirtyFused = env_u32("VX_DIRTY_FUSED", 1);
-		tune.mainHeads = env_u32("VX_MAIN_HEADS", 1) >= 8 ? 8u : 1u;
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
 		if (!check(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking), "hipStreamCreate")) { err = lastError; return false; }
@@ -3633,7 +3675,6 @@ struct Backend {
 		plan.fastEnd = std::min<u32>(levels, PYRAMID_LEVELS);
 		plan.level0 = withLevel0 ? 1u : 0u;
 		plan.batch = tune.mainBatch;
-		plan.heads = tune.mainHeads; plan.granule = ((tune.mainGranule + plan.batch - 1u) / plan.batch) * plan.batch;
 		plan.upperNum = withLevel0 ? tune.mainUpperNum : 1u; plan.upperDen = withLevel0 ? tune.mainUpperDen : 1u;
 		unsigned long long items = 0; // at most: one material item per block, one regular, one transition
 		for (u32 l = 1; l < levels; ++l) items += (unsigned long long)p.levels[l].cap * (1u + (l < plan.fastEnd ? 1u : 0u) + (p.levels[l].hasTransitions ? 1u : 0u));
@@ -3689,7 +3730,6 @@ struct Backend {
 		plan.level0 = 1u;
 		const u32 slots = (u32)cus * tune.mainWgsPerCu;
 		plan.batch = q.start[1] > 2u * slots ? tune.mainBatch : 1u; // (few blocks: every one its own workgroup)
-		plan.heads = 1u; plan.granule = plan.batch; // (a work list of a few hundred entries: one head)
 		plan.upperNum = tune.mainUpperNum; plan.upperDen = tune.mainUpperDen;
 		memcpy(plan.boxLo, q.lo, sizeof(plan.boxLo)); memcpy(plan.boxHi, q.hi, sizeof(plan.boxHi));
 		u32 items = q.start[1], upperVol = 0;

@@ -36,28 +36,13 @@ constexpr u32 UP_STATE_LDS = sizeof(TrState) > sizeof(Fast1State<REG_CAP_SMALL>)
 constexpr u32 MAIN_STATE_LDS = sizeof(Fast0State<REG_CAP_SMALL>) > UP_STATE_LDS ? sizeof(Fast0State<REG_CAP_SMALL>) : UP_STATE_LDS;
 static_assert((UP_TAB_LDS & 15u) == 0, "the state behind the tables stays 16-byte aligned");
 
-// HW_REG_XCC_ID (register 20, bits 3:0 on gfx942 / gfx950): the XCD a wave runs on.  s_getreg immediate = (size - 1) << 11 | offset << 6 | id
-__device__ __forceinline__ u32 xcc_id()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	return (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-#else
-	return 0u;
-#endif
-}
-
 struct MainPlan {
 	u32 levels;     // levels of the run: material items for 1 .. levels - 1
 	u32 fastEnd;    // regular items for the levels 1 .. fastEnd - 1 (the levels with a lattice copy)
 	u32 level0;     // 1: the level-0 queue is part of the launch (its LDS then holds a Fast0State), and no classification pass ran
 	                // (k_run_head<allocate>): level-0 blocks and level-1 material blocks form the bitmaps they need
-	u32 batch;      // level-0 slots per dequeue
-	u32 heads;      // 1: one head for all workgroups; 8: one head per XCD - the slot range is dealt out in granules of `granule`
-	                // consecutive slots (the blocks of one 8 x 8 x 4 box of k_run_head follow each other: spatial neighbours) round
-	                // robin over the heads, a workgroup pulls from its own XCD's head (the halo lines neighbouring blocks share
-	                // then meet in ONE 4 MiB L2) and moves on to the next head when that is exhausted.  Speed only: any
-	                // workgroup may pull from any head.
-	u32 granule;    // a multiple of `batch`
+	u32 batch;      // level-0 slots per dequeue (one head for the chip: a head per XCD over spatial granules - round 6,
+	                // profiles/r06_xcd_heads.txt - fetched 9 % fewer lines and was no faster)
 	u32 upperNum, upperDen; // workgroups with blockIdx % upperDen < upperNum prefer the upper queue
 	// incremental runs (k_main<true>, vx_polygonize_dirty): the queues hand out the entries of the levels' work lists
 	// (Globals::workItems / workCount, written by k_dirty_head); a material block only waits for the children that are part of
@@ -77,12 +62,12 @@ struct MainPlan {
 // material blocks run as always - the caches a later Modification continues from - and the level-1 material blocks also
 // write the bitmaps of their level-0 children, which no level-0 walk forms in such a run.
 template <bool DIRTY, bool PARTIAL = false>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_main(ExecParamsDev p, MainPlan plan)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVES))) void k_main(ExecParamsDev p, MainPlan plan)
 {
 	u8* tab = smem;
 	u8* state = smem + UP_TAB_LDS;
 	// (one 16-byte aligned block of statics in front of the dynamic region: its base stays aligned for the 16-byte LDS accesses)
-	__shared__ __attribute__((aligned(16))) struct { u32 wgStats[20]; u32 scanScratch[8]; u32 zeroFlag[2]; u32 quietFaces[2]; u32 zeroFlag0[2]; u32 nextItem; u32 pad[1]; } sh;
+	__shared__ __attribute__((aligned(16))) struct { u32 wgStats[20]; u32 scanScratch[8]; u32 zeroFlag[2]; u32 quietFaces[2]; u32 zeroFlag0[2]; u32 nextItem[2]; } sh;
 	static_assert(sizeof(sh) % 16 == 0, "static LDS in front of the dynamic region");
 	u32* const wgStats = sh.wgStats; u32* const scanScratch = sh.scanScratch; u32* const zeroFlag = sh.zeroFlag; u32* const quietFaces = sh.quietFaces;
 
@@ -120,9 +105,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 	u32 parity = 0, quietParity = 0, parity0 = 0;
 	bool upperLeft = upperTotal != 0, level0Left = total0 != 0; // (this workgroup's knowledge: a queue is empty once a dequeue came back beyond its end)
 	const bool preferUpper = (blockIdx.x % plan.upperDen) < plan.upperNum;
-	// the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0): which level-0 head it pulls from first
-	u32 head0 = plan.heads > 1u ? (xcc_id() & (plan.heads - 1u)) : 0u;
-	u32 headsLeft = plan.heads;
+	// One barrier per item says both "the previous item is done with the LDS state" and "the ticket is there": the ticket travels
+	// through sh.nextItem[item parity].  (Round 6: drawing the next ticket one item ahead - the returning atomic's 2 us round trip
+	// behind the item instead of in front of it - was 2.5 % SLOWER for either queue: the answer comes back in order with the
+	// item's first loads and is waited for with them, and a held upper item delays whoever depends on it.)
+	u32 turn = 0;
 
 #if defined(VX_MAIN_PROFILE)
 	// tools builds: where the workgroups' time goes, by role (cycles as thread 0 sees them; header words behind the large-block counter)
@@ -133,33 +120,25 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #define MAIN_TICK(i) do { } while (0)
 #endif
 	while (upperLeft || level0Left) {
-		__syncthreads(); // the previous item is done (with the LDS state, and with `nextItem`)
-		MAIN_TICK(0);
 		int tid = tid0;
 		asm volatile("" : "+v"(tid)); // (per item: what a lane derives from its index alone is not hoisted out of the loop and kept in registers)
 		const bool takeUpper = upperLeft && (preferUpper || !level0Left);
+		turn ^= 1u;
+		if (tid0 == 0) sh.nextItem[turn] = takeUpper ? atomicAdd(p.G.upperHead, 1u) : atomicAdd(p.G.level0Head, plan.batch);
+		__syncthreads(); // the previous item is done (with the LDS state), and the ticket is there
+		MAIN_TICK(0);
 		if (!takeUpper) {
 			// ---- a batch of consecutive level-0 slots -----------------------------------------------------------------
-			if (tid0 == 0) sh.nextItem = atomicAdd(p.G.level0Head + head0 * 32u, plan.batch);
-			__syncthreads();
-			u32 first = r0_uniform(sh.nextItem);
-			if (plan.heads > 1u) first = ((first / plan.granule) * plan.heads + head0) * plan.granule + first % plan.granule; // head h owns the granules h, h + heads, ...
-			if (first >= total0) {
-				// this head is exhausted (its positions only grow): on to the next one, if any is left
-				head0 = (head0 + 1u) & (plan.heads - 1u);
-				if (--headsLeft == 0u) level0Left = false;
-				continue;
-			}
+			const u32 first = r0_uniform(sh.nextItem[turn]);
+			if (first >= total0) { level0Left = false; continue; }
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (visible after the walk's first barrier)
 			MAIN_TICK(1);
 			f0_walk<REG_CAP_SMALL, false, !DIRTY>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
 			MAIN_TICK(2);
 			continue;
 		}
-		// ---- one item of the upper queue (one returning atomic per item; a few thousand items per run) ------------------------
-		if (tid0 == 0) sh.nextItem = atomicAdd(p.G.upperHead, 1u);
-		__syncthreads();
-		const u32 item = r0_uniform(sh.nextItem);
+		// ---- one item of the upper queue (a few thousand items per run) ---------------------------------------------------
+		const u32 item = r0_uniform(sh.nextItem[turn]);
 		MAIN_TICK(1);
 		if (item >= upperTotal) { upperLeft = false; continue; }
 		// item -> (kind, level, slot): the position inside its segment, looked up in the level boundaries
