@@ -728,10 +728,11 @@ __global__ __launch_bounds__(WG) void k_scatter_blocks(const u32* ids, u32 n, co
 // One 16-voxel segment [xs, xs + 16) of the voxel row (y,z): its samples on the level-L lattice go to the level's copy.  y and z may be the first row beyond the grid (y == n: the loaded data then is the
 // clamped row n - 1, and y >> L is exactly the index of the level's clamped far entry); the voxel n - 1 of a row is also
 // stored as the far entry of its lattice row.
+template <int FIRST = 1, bool FAR_X = true>
 __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, int n, int xs, int y, int z, uint4 d)
 {
 #pragma unroll
-	for (int l = 1; l < 4; ++l) {
+	for (int l = FIRST; l < 4; ++l) {
 		const PyramidLevel& P = pyr[l];
 		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
 		i8* at = P.data + pyramid_offset(P, xs >> l, y >> l, z >> l); // 8 / 4 / 2 lattice samples: inside one brick row
@@ -745,7 +746,7 @@ __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, i
 		} else {
 			*(u16*)at = (u16)((d.x & 0xFFu) | ((d.z & 0xFFu) << 8));
 		}
-		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
+		if (FAR_X && xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
 	}
 	// levels >= 4: at most one lattice sample per segment (its first voxel), on one row in 256 - a loop that is not unrolled
 	// (k_rebrick is a copy kernel: the registers of three more unrolled levels cost it a wave per SIMD)
@@ -755,7 +756,7 @@ __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, i
 		const PyramidLevel& P = pyr[l];
 		if (!P.data || ((y | z) & ((1 << l) - 1))) break;
 		if (!(xs & ((1 << l) - 1))) P.data[pyramid_offset(P, xs >> l, y >> l, z >> l)] = (i8)(d.x & 0xFFu);
-		if (xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
+		if (FAR_X && xs + 16 == n) P.data[pyramid_offset(P, n >> l, y >> l, z >> l)] = (i8)(d.w >> 24);
 	}
 }
 
@@ -767,14 +768,26 @@ __device__ __forceinline__ void pyramid_write_segment(const PyramidLevel* pyr, i
 
 // The same segment for the x-plane copies (XPlanes, tv_block.h): its first voxel if the segment starts on a plane
 // X = 32 k of a lattice, its last voxel (n - 1) as the clamped far plane.  y / z may be n like above.
+template <int FIRST = 0, bool FAR_X = true>
 __device__ __forceinline__ void xplane_write_segment(const XPlanes* xp, int n, int xs, int y, int z, uint4 d)
 {
 #pragma unroll
-	for (int l = 0; l < XPLANE_LEVELS; ++l) {
+	for (int l = FIRST; l < XPLANE_LEVELS; ++l) {
 		const XPlanes& P = xp[l];
 		if (!P.data || ((y | z) & ((1 << l) - 1))) continue;
 		if (!(xs & ((32 << l) - 1))) P.data[xplane_offset(P, (u32)(xs >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)(d.x & 0xFFu);
-		if (xs + 16 == n) P.data[xplane_offset(P, (u32)(n >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)(d.w >> 24);
+		if (FAR_X && xs + 16 == n) P.data[xplane_offset(P, (u32)(n >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)(d.w >> 24);
+	}
+}
+
+// the clamped far entries along x of every lattice copy and x-plane copy that row (y, z) belongs to: the row's last voxel (n - 1)
+__device__ __forceinline__ void lattice_far_x(const MirrorState& X, int n, int y, int z, u32 last)
+{
+#pragma unroll 1
+	for (int l = 0; l < PYRAMID_LEVELS; ++l) {
+		if ((y | z) & ((1 << l) - 1)) break;
+		if (l >= 1 && X.pyr[l].data) X.pyr[l].data[pyramid_offset(X.pyr[l], n >> l, y >> l, z >> l)] = (i8)last;
+		if (l < XPLANE_LEVELS && X.xp[l].data) X.xp[l].data[xplane_offset(X.xp[l], (u32)(n >> l) >> 5, (u32)(z >> l), (u32)(y >> l))] = (i8)last;
 	}
 }
 
@@ -848,6 +861,17 @@ __device__ __forceinline__ u16 block_sign_word(u32 collected)
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES))) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
 {
 	__shared__ u32 blockSigns[8];
+	// what the workgroup's rows contribute to the finest lattice copies and x-plane copies, collected here and written in whole
+	// 16-byte rows behind the copy (as stores of their own they were 8-, 4- and 1-byte pieces by a quarter of the lanes: more
+	// store instructions than the copy itself, 8 % of its time)
+	__shared__ __attribute__((aligned(16))) struct {
+		u8 p1[8][8][64];  // level-1 lattice: [Z1][Y1][X1] of the 64 x 8 x 8 samples under the 8 blocks
+		u8 p2[4][4][32];  // level-2 lattice
+		u8 x0[4][16][16]; // level-0 x planes X = 32 k: [k][z][y]
+		u8 x1[2][8][8];   // level-1 x planes
+		u8 p3[2][2][16];  // level-3 lattice
+		u8 x2[4][4];      // level-2 x plane (one per 8 blocks)
+	} lat;
 	const int nb = g.n >> 4, tid = (int)threadIdx.x;
 	if (tid < 8) blockSigns[tid] = 0;
 	__syncthreads();
@@ -861,20 +885,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES)
 	}
 	const int groups = (nb + 7) >> 3;
 	const int gx = (int)blockIdx.x % groups, by = yb0 + ((int)blockIdx.x / groups) % ybCount, bz = zb0 + (int)blockIdx.x / (groups * ybCount);
-	const int bx = gx * 8 + (tid & 7);
+	const int bxl = tid & 7, bx = gx * 8 + bxl;
 	u32 signs = 0;
 	// A wave takes one 128-byte tile of each of its 8 bricks per trip: rows y = 4 w .. 4 w + 3 of the planes z = 2 it, 2 it + 1
 	// (brick_local: the tile's 8 pieces in lane order), so every store instruction writes 8 whole lines.
 	const int sub = tid >> 3, ry = ((sub >> 3) << 2) | (sub & 3), rz = (sub >> 2) & 1;
 	const int gy = by * 16 + ry, gz0 = bz * 16 + rz;
-	// (uniform) the rule: every row of these blocks is resident in all three dense fields and owned by this rank, and none is the
-	// grid's last row or plane (whose samples are also the lattices' clamped far entries) - a slab's halo block layers and the
-	// grid's far block layers take the general row by row form below
-	const bool whole = by * 16 >= r.dy0 && by * 16 + 16 <= r.dy1 && bz * 16 >= r.dz0 && bz * 16 + 16 <= r.dz1
+	// (uniform) the rule: all 8 blocks exist, every row of theirs is resident in all three dense fields and owned by this rank, and
+	// none is the grid's last row or plane (whose samples are also the lattices' clamped far entries) - a slab's halo block
+	// layers, the grid's far block layers and grids narrower than 8 blocks take the general row by row form below
+	const bool whole = gx * 8 + 8 <= nb
+	                && by * 16 >= r.dy0 && by * 16 + 16 <= r.dy1 && bz * 16 >= r.dz0 && bz * 16 + 16 <= r.dz1
 	                && by * 16 >= r.my0 && by * 16 + 16 <= r.my1 && bz * 16 >= r.mz0 && bz * 16 + 16 <= r.mz1
 	                && by * 16 >= X.yBegin && by * 16 + 15 <= X.yEnd && bz * 16 >= X.zBegin && bz * 16 + 15 <= X.zEnd
 	                && by + 1 < nb && bz + 1 < nb;
-	if (bx < nb && whole) {
+	if (whole) {
 		// all requests of a field are in flight before the first piece is stored (a load behind a range test is waited for on the spot)
 		const size_t dst = brick_base(g, bx, by, bz) + brick_local(0u, (u32)ry, (u32)rz);
 		const size_t srcD = dist_offset(g, bx * 16, gy, gz0), stepD = (size_t)2 * g.pitchY * g.n;
@@ -891,7 +916,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES)
 #pragma unroll
 		for (int it = 0; it < 8; ++it) d[it] = *(const uint4*)(g.dist + srcD + it * stepD);
 		const bool y0 = ry == 0;
-		const bool planes = X.xp[0].data || X.xp[1].data || X.xp[2].data, lattices = X.pyr[1].data != nullptr && !((ry | rz) & 1);
+		const bool planes = X.xp[0].data || X.xp[1].data || X.xp[2].data, lattices = X.pyr[1].data != nullptr;
+		const bool even = !((ry | rz) & 1), fourth = !((ry & 3) | rz);   // this lane's rows with even it / it a multiple of 2 lie on the level-1 / level-2 lattice
 #pragma unroll
 		for (int it = 0; it < 8; ++it) {
 			*(uint4*)(const_cast<i8*>(g.bDist) + dst + (it << 9)) = d[it];
@@ -900,16 +926,52 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES)
 			const bool z0 = it == 0 && rz == 0;
 			signs |= pair | (y0 ? pair << 4 : 0u) | (z0 ? pair << 8 : 0u) | (y0 && z0 ? pair << 12 : 0u);
 			// the lattice samples of the row (one row in four carries any; no far entries along y and z in here)
-			if (planes) xplane_write_segment(X.xp, g.n, bx * 16, gy, gz0 + 2 * it, d[it]);
-			if (lattices) pyramid_write_segment(X.pyr, g.n, bx * 16, gy, gz0 + 2 * it, d[it]);
+			if (planes) {
+				if (!(bxl & 1)) lat.x0[bxl >> 1][2 * it + rz][ry] = (u8)d[it].x;
+				if (!(bxl & 3) && even) lat.x1[bxl >> 2][it][ry >> 1] = (u8)d[it].x;
+				if (!bxl && fourth && !(it & 1)) lat.x2[it >> 1][ry >> 2] = (u8)d[it].x;
+			}
+			if (lattices && even) {
+				*(uint2*)&lat.p1[it][ry >> 1][bxl * 8] = make_uint2(__builtin_amdgcn_perm(d[it].y, d[it].x, 0x06040200u), __builtin_amdgcn_perm(d[it].w, d[it].z, 0x06040200u));
+				if (fourth && !(it & 1)) *(u32*)&lat.p2[it >> 1][ry >> 2][bxl * 4] = __builtin_amdgcn_perm(d[it].y, d[it].x, 0x0C0C0400u) | __builtin_amdgcn_perm(d[it].w, d[it].z, 0x04000C0Cu);
+				if (!(ry & 7) && !(it & 3)) *(u16*)&lat.p3[it >> 2][ry >> 3][bxl * 2] = (u16)((d[it].x & 0xFFu) | ((d[it].z & 0xFFu) << 8));
+			}
+			if (bx + 1 == nb) lattice_far_x(X, g.n, gy, gz0 + 2 * it, d[it].w >> 24);
 		}
-		atomicOr(&blockSigns[tid & 7], signs);
-	} else if (bx < nb) {
+		if (lattices && !(ry | rz)) pyramid_write_segment<4, false>(X.pyr, g.n, bx * 16, gy, gz0, d[0]); // (levels >= 4: the block's first row)
+		atomicOr(&blockSigns[bxl], signs);
+		__syncthreads();
+		if (lattices) {
+			// level 1: 8 x 8 rows of 64 samples = 256 pieces of 16 bytes (a lattice row inside its brick), lanes ordered so that 8
+			// consecutive ones write one 128-byte tile when the rank's lattice origin is tile-aligned
+			const int seg = (tid >> 3) & 3, y1 = (tid & 3) | ((tid >> 5) & 1) << 2, z1 = ((tid >> 2) & 1) | (tid >> 6) << 1;
+			*(uint4*)(X.pyr[1].data + pyramid_offset(X.pyr[1], (gx * 4 + seg) * 16, by * 8 + y1, bz * 8 + z1)) = *(const uint4*)&lat.p1[z1][y1][seg * 16];
+			if (tid < 32 && X.pyr[2].data) {
+				const int s2 = tid & 1, y2 = (tid >> 1) & 3, z2 = tid >> 3;
+				*(uint4*)(X.pyr[2].data + pyramid_offset(X.pyr[2], (gx * 2 + s2) * 16, by * 4 + y2, bz * 4 + z2)) = *(const uint4*)&lat.p2[z2][y2][s2 * 16];
+			}
+		}
+		if (tid >= 64 && tid < 128 && X.xp[0].data) {
+			const int k = (tid >> 4) & 3, z = tid & 15;
+			*(uint4*)(X.xp[0].data + xplane_offset(X.xp[0], (u32)(gx * 4 + k), (u32)(bz * 16 + z), (u32)(by * 16))) = *(const uint4*)&lat.x0[k][z][0];
+		}
+		if (tid >= 128 && tid < 144 && X.xp[1].data) {
+			const int k = (tid >> 3) & 1, z = tid & 7;
+			*(uint2*)(X.xp[1].data + xplane_offset(X.xp[1], (u32)(gx * 2 + k), (u32)(bz * 8 + z), (u32)(by * 8))) = *(const uint2*)&lat.x1[k][z][0];
+		}
+		if (tid >= 192 && tid < 196) {
+			const int a = tid & 1, b = (tid >> 1) & 1;
+			if (lattices && X.pyr[3].data) *(uint4*)(X.pyr[3].data + pyramid_offset(X.pyr[3], gx * 16, by * 2 + a, bz * 2 + b)) = *(const uint4*)&lat.p3[b][a][0];
+			if (X.xp[2].data) *(u32*)(X.xp[2].data + xplane_offset(X.xp[2], (u32)gx, (u32)(bz * 4 + (tid & 3)), (u32)(by * 4))) = *(const u32*)&lat.x2[tid & 3][0];
+		}
+	} else {
+		if (bx < nb) {
 #pragma unroll 1
-		for (int it = 0; it < 8; ++it) signs |= rebrick_row(g, r, X, bx, gy, gz0 + 2 * it);
-		atomicOr(&blockSigns[tid & 7], signs);
+			for (int it = 0; it < 8; ++it) signs |= rebrick_row(g, r, X, bx, gy, gz0 + 2 * it);
+			atomicOr(&blockSigns[bxl], signs);
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	if (tid < 8 && gx * 8 + tid < nb && X.blockSign)
 		X.blockSign[block_coord_id((u32)(gx * 8 + tid), (u32)by, (u32)bz, (u32)nb)] = block_sign_word(blockSigns[tid]);
 }
