@@ -231,12 +231,12 @@ __device__ __forceinline__ bool f0_next(const ExecParamsDev& p, const LevelDesc&
 // The blocks of one walk, software-pipelined: `cur` has its inputs requested, `nxt` is accepted and gets them requested while
 // `cur` writes its output.  Leaves the LDS state free behind a barrier-less tail (callers meet before they reuse it).
 template <int CAP, bool REMAP, bool SELF = false>
-__device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& T, Fast0State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
+__device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables& T, Fast0State<CAP>& st, u32* wgStats, u32* zeroFlag, u32& parity,
                                         u32 total, u32 lo, u32 first, u32 stride, u32 limit, const int tid)
 {
 	typedef R0<CAP> K;
-	const LevelDesc& L = p.levels[0];
-	const GridView& g = p.G.grid;
+#define F0_PARAMS() const ExecParamsDev& p = (VX_FRESH & 1) ? kernarg_params() : pIn; const LevelDesc& L = p.levels[0]; const GridView& g = p.G.grid; (void)L; (void)g
+	F0_PARAMS();
 	u32 it = first;
 	R0Block cur, nxt;
 	F0Prefetch pf;
@@ -249,6 +249,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& p, const F0Tables& 
 	unsigned long long f0Tick = __builtin_readcyclecounter();
 #endif
 	while (have) {
+		F0_PARAMS();
 		const u32 candIt = it + stride;
 		R0Candidate cand;
 		F0_TICK(0); // (between blocks: next-item bookkeeping)

@@ -95,6 +95,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	bitsWord = TV_LOAD_THROUGH(&L.ntBits[(size_t)slot * 128 + (tid & 127)]);
 	c0 = load16_through(csrc, (u32)tid * 16u); c1 = load16_through(csrc, (u32)(tid + WG) * 16u);
 
+	TRACE_MARK(0);
 	// ---- stage: bitmap, material cache block, 17 x 17 rows of 17 lattice samples; any zero among them? -------------
 	{
 		u32 zero = 0;
@@ -117,6 +118,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 		if (tid == 0) zeroFlag[parity ^ 1u] = 0; // last read behind the previous block's second barrier
 	}
 	__syncthreads();
+	TRACE_MARK(1);
 	const bool clean = r0_uniform(zeroFlag[parity]) == 0;
 	parity ^= 1u;
 	if (VX_ABL & 8192) return;
@@ -152,6 +154,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	}
 	__syncthreads();
 
+	TRACE_MARK(2);
 	// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
 	const u32 nt = r0_uniform(st.wordPrefix[128]);
 	const u32 Q = ((nt + WG - 1) / WG) * 64u;
@@ -174,6 +177,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 		if (lane == 0) st.waveTot[wave] = carry;
 	}
 	__syncthreads();
+	TRACE_MARK(3);
 	{
 		u32 waveBase = 0, tot = 0;
 #pragma unroll
@@ -198,6 +202,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 	}
 	__syncthreads();
 
+	TRACE_MARK(4);
 	const u32 vTotalU = r0_uniform(st.vTotal), tTotalU = r0_uniform(st.tTotal);
 	const bool room = r0_uniform(st.vOff) + vTotalU <= p.P.vertCap && r0_uniform(st.iOff) + tTotalU * 3u <= p.P.idxCap;
 	const int ox = (int)(bx * 16 * L.mult), oy = (int)(by * 16 * L.mult), oz = (int)(bz * 16 * L.mult);
@@ -231,6 +236,7 @@ __device__ __forceinline__ void f1_block(const ExecParamsDev& p, const F0Tables&
 		}
 		if (__ballot(notInterior != 0) && lane == 0) st.suspect = 1;
 	}
+	TRACE_MARK(5);
 	__syncthreads();
 	if (tid == 0) {
 		if (st.suspect) {

@@ -62,6 +62,22 @@ struct ExecParamsDev {
 	const u8* tables;
 };
 
+// The kernel's first argument read afresh through the kernarg segment: a pointer the compiler cannot see through, so nothing
+// loaded from the parameters BEFORE this point is kept alive across it (a persistent kernel otherwise holds every pointer it
+// ever uses in scalar registers for its whole life - 250 of them spilled to vector lanes and read back with v_readlane in
+// k_main) and everything behind it is loaded again, 16 dwords per s_load.  Only inside kernels whose first parameter is the
+// ExecParamsDev.
+#if !defined(VX_FRESH)
+#define VX_FRESH 3   // bit 0: per level-0 block (f0_walk), bit 1: per item of k_main (round 6: 963 -> 375 v_readlane in k_main, 1024^3 step -1.3 %; 0 = the parameters as the compiler keeps them)
+#endif
+__device__ __forceinline__ const ExecParamsDev& kernarg_params()
+{
+	typedef const __attribute__((address_space(4))) ExecParamsDev* KP;
+	KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(kp));
+	return *(const ExecParamsDev*)kp;
+}
+
 // tools builds (tools/ab_build.py x=-DVX_ABL=<bits>): parts of the work switched off to see what they cost in time and
 // instructions (tools/exp/r06_ablate.sh); the results of such a build are wrong by construction.  0 in the product.
 #if !defined(VX_MAIN_WAVES)
@@ -162,6 +178,17 @@ __device__ __forceinline__ void publish_done_through(unsigned long long* flag, u
 
 enum { WAIT_SPINS = 1u << 17 }; // x ~1 us per poll: a tenth of a second, against runs of a millisecond
 
+#if defined(VX_MAIN_TRACE)
+// tools builds: a timeline of k_main's items (100 MHz clock) - per item {kind << 28 | level << 24 | slot, workgroup, ticket drawn,
+// started, last wait over, done}; printed by vx_polygonize after the run (small grids)
+__device__ unsigned long long g_mainTrace[18 * 8192];
+__device__ u32 g_mainTraceN;
+__device__ unsigned long long g_waitEnd[4096];
+__device__ unsigned long long g_marks[4096 * 12];
+#define TRACE_MARK(i) do { if (threadIdx.x == 0) g_marks[(blockIdx.x & 4095u) * 12u + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TRACE_MARK(i) do { } while (0)
+#endif
 // one lane: poll until the word carries this run's tag; returns its payload (0 after giving up).  Once one wait has given
 // up every other one does so at its next look (the run is lost; it must end, not hang the device).
 __device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epoch, u32* giveUp)
@@ -171,6 +198,9 @@ __device__ __forceinline__ u32 wait_done(const unsigned long long* flag, u32 epo
 		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 #else
 		const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#if defined(VX_MAIN_TRACE)
+		if ((u32)(v >> 32) == epoch) { g_waitEnd[blockIdx.x & 4095u] = __builtin_amdgcn_s_memrealtime(); return (u32)v; }
 #endif
 		if ((u32)(v >> 32) == epoch) return (u32)v;
 		if (spins > (u32)WAIT_SPINS || ((spins & 255u) == 255u && __hip_atomic_load(giveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { atomicOr(giveUp, 1u); return 0u; }
@@ -1531,6 +1561,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	const bool defineAll = !p.G.dirty || slot >= p.G.prevActive[level];
 	u16* cacheOut = L.cache + (size_t)slot * BLOCK_CELLS;
 	__syncthreads(); // the previous block of this workgroup is done with the LDS state
+	TRACE_MARK(0);
 
 	// ---- requests: child slots, old cache contents (incremental runs), samples ----------------------
 	int cs = -1;
@@ -1554,6 +1585,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 	}
 	((uint4*)st.out)[tid] = old0; ((uint4*)st.out)[tid + WG] = old1;
 	__syncthreads();
+	TRACE_MARK(1);
 	if (lattice) {
 		// the level's lattice copy (complete: it is kept with the grid's mirrors): one 16-byte load + one byte per sample row
 		for (int r = tid; r < 289; r += WG) {
@@ -1580,6 +1612,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 			if (sIdx < SAMPLES) atomicOr(&st.rowMask[sIdx / 17], (((u32)(v[q] >> 7)) & 1u) << (sIdx % 17));
 		}
 	}
+	TRACE_MARK(2);
 	// ---- child bitmaps (level 1) requested while the rows are classified -----------------------------
 	u32 cb4[4] = { 0, 0, 0, 0 };
 	if (level == 1 && selfChild) {
@@ -1662,6 +1695,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		}
 	}
 	__syncthreads();
+	TRACE_MARK(3);
 	const int y = tid & 15, z = tid >> 4;
 	u32 nt;
 	{
@@ -1700,6 +1734,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		for (int q = 0; q < 4; ++q) { const int w = tid + q * WG; st.childBits[w >> 7][w & 127] = cb4[q]; }
 	}
 	__syncthreads();
+	TRACE_MARK(4);
 	if (PARTIAL && level == 1u && selfChild) {
 		// (what f0_self_bits / f0_next<SELF> leave behind a level-0 block: here for all eight children at once)
 #pragma unroll
@@ -1778,6 +1813,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		}
 	}
 	__syncthreads();
+	TRACE_MARK(5);
 	if (GATED && level >= 2u) {
 		// the children's cache blocks are written by other workgroups of this launch (the level below comes first in the queue)
 		if (tid < 8) {
@@ -1791,6 +1827,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		}
 		acquire_and_meet(tid < 64);
 	}
+	TRACE_MARK(6);
 	// ---- vote.  A lane takes VB cells per trip and requests ALL their child entries before it looks at any: children
 	//      that are neighbours along x come in one load (two u16 entries / two material bytes), and no load is
 	//      conditional (a load with a default value is waited for on the spot) — the children of a cell are always
@@ -1866,6 +1903,7 @@ __device__ __forceinline__ void mat_block(const ExecParamsDev& p, u32 level, u32
 		}
 	}
 	__syncthreads();
+	TRACE_MARK(7);
 	if (THROUGH) {
 		store16_through(cacheOut, (u32)tid * 16u, ((const uint4*)st.out)[tid]);
 		store16_through(cacheOut, (u32)(tid + WG) * 16u, ((const uint4*)st.out)[tid + WG]);

@@ -1560,6 +1560,28 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 		for (int i = 0; i < 7; ++i) fprintf(stderr, "[main profile] %-28s %10u x64 cycles  %5.1f %%\n", names[i], c->hdr[HDR_LARGE + 4 + i], 100.0 * c->hdr[HDR_LARGE + 4 + i] / (double)(sum ? sum : 1));
 	}
 #endif
+#if defined(VX_MAIN_TRACE)
+	{
+		u32 cnt = 0;
+		if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_mainTraceN), sizeof(cnt)) == hipSuccess && cnt && cnt <= 4096u) {
+			std::vector<unsigned long long> v((size_t)cnt * 18);
+			if (hipMemcpyFromSymbol(v.data(), HIP_SYMBOL(g_mainTrace), v.size() * 8) == hipSuccess) {
+				unsigned long long t0 = ~0ull;
+				for (u32 i = 0; i < cnt; ++i) t0 = std::min(t0, v[18 * i + 2]);
+				static const char* kinds[4] = { "level0", "mat", "reg", "tr" };
+				for (u32 i = 0; i < cnt; ++i) {
+					const unsigned long long* e = &v[18 * i];
+					const u32 what = (u32)e[0];
+					fprintf(stderr, "[main trace] %-6s L%u slot %5u wg %4u  ticket %7.2f  start %7.2f  waited %7.2f  end %7.2f us\n", kinds[what >> 28], (what >> 24) & 15u, what & 0xFFFFFFu, (u32)e[1],
+					        (e[2] - t0) * 0.01, (e[3] - t0) * 0.01, e[4] ? (double)(long long)(e[4] - t0) * 0.01 : 0.0, (e[5] - t0) * 0.01);
+					if ((what >> 28) >= 1u) { fprintf(stderr, "             marks:"); for (int m = 0; m < 12; ++m) if (e[6 + m]) fprintf(stderr, " %d:%.2f", m, (double)(long long)(e[6 + m] - t0) * 0.01); fprintf(stderr, "\n"); }
+				}
+			}
+		}
+		cnt = 0;
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_mainTraceN), &cnt, sizeof(cnt));
+	}
+#endif
 #if defined(VX_F0_PROFILE)
 	{
 		static const char* names[9] = { "between blocks", "top barrier", "deposit + barrier", "own bitmap + barrier", "prefix + list + barrier", "cells + barrier", "bases + reserve + describe + barrier", "vertices + triangles", "record" };

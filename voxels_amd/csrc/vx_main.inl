@@ -62,8 +62,10 @@ struct MainPlan {
 // material blocks run as always - the caches a later Modification continues from - and the level-1 material blocks also
 // write the bitmaps of their level-0 children, which no level-0 walk forms in such a run.
 template <bool DIRTY, bool PARTIAL = false>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVES))) void k_main(ExecParamsDev p, MainPlan plan)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVES))) void k_main(ExecParamsDev pArg, MainPlan plan)
 {
+#define MAIN_PARAMS() const ExecParamsDev& p = (VX_FRESH & 2) ? kernarg_params() : pArg
+	MAIN_PARAMS();
 	u8* tab = smem;
 	u8* state = smem + UP_TAB_LDS;
 	// (one 16-byte aligned block of statics in front of the dynamic region: its base stays aligned for the 16-byte LDS accesses)
@@ -97,8 +99,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 	const u32 upperTotal = matTotal + regTotal + trTotal;
 	const u32 total0 = (plan.level0 && !(VX_ABL & 128)) ? r0_uniform(DIRTY ? p.G.workCount[0] : p.G.slotCounts[0]) : 0u;
 
-	const GridView& g = p.G.grid;
-	const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
 	u32 tabKind = 0;          // which table image the LDS holds: 0 none, 1 regular (F0), 2 transition
 	F0Tables FT = {};
 	Tables TT = {};
@@ -119,7 +119,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 #else
 #define MAIN_TICK(i) do { } while (0)
 #endif
+#if defined(VX_MAIN_TRACE)
+	unsigned long long trT0 = 0, trT1 = 0; u32 trWhat = 0;
+#define MAIN_TRACE_END() do { if (tid0 == 0) { const u32 at_ = atomicAdd(&g_mainTraceN, 1u); if (at_ < 8192u) { unsigned long long* e_ = g_mainTrace + 18u * at_; for (u32 m_ = 0; m_ < 12u; ++m_) { e_[6u + m_] = g_marks[(blockIdx.x & 4095u) * 12u + m_]; g_marks[(blockIdx.x & 4095u) * 12u + m_] = 0; } e_[0] = trWhat; e_[1] = blockIdx.x; e_[2] = trT0; e_[3] = trT1; e_[4] = g_waitEnd[blockIdx.x & 4095u]; e_[5] = __builtin_amdgcn_s_memrealtime(); } } } while (0)
+#else
+#define MAIN_TRACE_END() do { } while (0)
+#endif
 	while (upperLeft || level0Left) {
+		MAIN_PARAMS();
+#if defined(VX_MAIN_TRACE)
+		trT0 = __builtin_amdgcn_s_memrealtime();
+#endif
 		int tid = tid0;
 		asm volatile("" : "+v"(tid)); // (per item: what a lane derives from its index alone is not hoisted out of the loop and kept in registers)
 		const bool takeUpper = upperLeft && (preferUpper || !level0Left);
@@ -133,8 +143,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 			if (first >= total0) { level0Left = false; continue; }
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (visible after the walk's first barrier)
 			MAIN_TICK(1);
+#if defined(VX_MAIN_TRACE)
+			trT1 = __builtin_amdgcn_s_memrealtime(); trWhat = first; if (tid0 == 0) g_waitEnd[blockIdx.x & 4095u] = 0;
+#endif
 			f0_walk<REG_CAP_SMALL, false, !DIRTY>(p, FT, *(Fast0State<REG_CAP_SMALL>*)state, wgStats, sh.zeroFlag0, parity0, total0, 0u, first, 1u, min(first + plan.batch, total0), tid);
 			MAIN_TICK(2);
+			MAIN_TRACE_END();
 			continue;
 		}
 		// ---- one item of the upper queue (a few thousand items per run) ---------------------------------------------------
@@ -149,6 +163,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 		for (u32 l = 1; l + 1 < MAX_LEVELS; ++l) if (f >= matEnd[l]) { level = l + 1; base = matEnd[l]; }
 		u32 slot = f - base;
 		if (DIRTY) slot = r0_uniform(p.G.workItems[level][slot]);
+#if defined(VX_MAIN_TRACE)
+		trT1 = __builtin_amdgcn_s_memrealtime(); trWhat = ((isMat ? 1u : (isReg ? 2u : 3u)) << 28) | (level << 24) | slot; if (tid0 == 0) g_waitEnd[blockIdx.x & 4095u] = 0;
+#endif
 		if (isMat) {
 			if (DIRTY) {
 				mat_block<true>(p, level, slot, *(MatLds*)state, tid, false, plan.boxLo[level - 1u], plan.boxHi[level - 1u]);
@@ -159,10 +176,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 			else
 				mat_block<true>(p, level, slot, *(MatLds*)state, tid, (VX_ABL & 256) ? false : plan.level0 != 0u);
 			MAIN_TICK(3);
+			MAIN_TRACE_END();
 			continue;
 		}
 		const LevelDesc& L = p.levels[level];
 		const u32 coord = r0_uniform(L.slotCoord[slot]);
+		const GridView& g = p.G.grid;
+		const F1BrickSampler smp = { g.bDist, g.bMat, g.bBlend, g.n - 1, (u32)g.n >> 4, (u32)g.bRowsY, g.bYb0, g.bZb0 };
 		if (isReg) {
 			if (tabKind != 1u) { FT = f0_stage_tables(tab, p.tables, (u32)tid); tabKind = 1u; } // (behind the barriers of the dequeue; visible after the block's first barrier)
 			f1_block<REG_CAP_SMALL, true>(p, FT, smp, *(Fast1State<REG_CAP_SMALL>*)state, wgStats, zeroFlag, parity, level, slot, coord, 0u, 0u, tid);
@@ -174,6 +194,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVE
 			tr_block<false, true>(p, b, coord, *(TrState*)state, TT, scanScratch, quietFaces, quietParity, smp, tid, false);
 			MAIN_TICK(5);
 		}
+		MAIN_TRACE_END();
 	}
 	__syncthreads();
 	{
