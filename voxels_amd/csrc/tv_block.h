@@ -1282,21 +1282,28 @@ TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G
 		const u32 c = st.cellOf[k];
 		const int f = (int)(c >> 8), row = (int)((c >> 4) & 15), col = (int)(c & 15);
 		const FaceGeom fg = face_geom(f);
-		i8 v9[9], v[13];
-		tr_cell_values(st, f, row, col, v9);
-		tr_expand_values(v9, v);
-		const u32 w = T.trVert(tr_case_code(v9), vi);
+		// case code and zero mask are the classification's (cellBits); of the cell's samples the vertex needs its two end points:
+		// expanded sample i sits at plane offset (dv, du) = (i / 3, i % 3) for i < 9, the low-resolution corners 9..12 are the
+		// plane's corners 0, 2, 6, 8
+		const u32 bits = st.cellBits[k];
+		const u32 w = T.trVert(bits & 0x1FFu, vi);
 		TrResolution r;
 		int corner; u32 dir, slot; bool endpoint;
-		tr_vertex_dir_slot(T, v, w, r.t, dir, slot, endpoint, corner);
+		tr_vertex_dir_slot_z(T, bits >> 9, w, r.t, dir, slot, endpoint, corner);
 		r.endpoint = endpoint ? 1 : 0; r.dir = (u8)dir; r.slot = (u8)slot; r.kind = RK_NEW_EDGE; r.store = NO_SLOT;
+		const i8* cellSamples = st.plane[f] + (row * 2) * TR_PROW + col * 2;
+		const u32 e0 = (w >> 4) & 15u, e1 = w & 15u;
+		// small tables in constants: plane sample g (0..8) of expanded sample i (nibbles); row g / 3 and column g % 3 (2 bits each)
+		const u32 g0 = (u32)(0x8620876543210ull >> (4u * e0)) & 15u, g1 = (u32)(0x8620876543210ull >> (4u * e1)) & 15u;
+		const int p0 = cellSamples[((0x2A540u >> (2u * g0)) & 3u) * TR_PROW + ((0x24924u >> (2u * g0)) & 3u)];
+		const int p1 = cellSamples[((0x2A540u >> (2u * g1)) & 3u) * TR_PROW + ((0x24924u >> (2u * g1)) & 3u)];
 		TrCellGeom geo;
 		tr_cell_geom(fg, b, row, col, geo);
 		// the vertex's material id is the low-res cell's whatever the end points hold (tr_new_vertex), so its row of the
 		// material table is requested before the voxel fetches instead of behind them (one round trip less)
 		const unsigned long long lut = lut_row(G.lut, st.cellMat[k]);
 		RawVertex rv;
-		tr_new_vertex(smp, fg, geo, v, w, r, st.cellMat[k], rv);
+		tr_new_vertex(smp, fg, geo, p0, p1, w, r, st.cellMat[k], rv);
 		pack_vertex_row(rv, lut, P.verts + st.vOff + chunkBase + j);
 	}
 }

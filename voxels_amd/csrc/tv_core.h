@@ -901,8 +901,10 @@ TV_HD void tr_sample_pos(const FaceGeom& fg, const TrCellGeom& c, int k, int P[3
 // `smp` addresses voxels as sums of one term per axis (tv_fast1.h: F1HostSampler for the dense fields, the kernels'
 // F1BrickSampler for the brick mirrors): every edge of a transition cell runs along one axis, so the LOD chain and the two
 // stencils need a handful of terms instead of a full address computation per fetch.
+// p0, p1: the samples at the vertex's end points v0 = (w >> 4) & 15, v1 = w & 15 (expanded sample numbering 0..12; the caller
+// reads the two out of the staged plane: of the cell's 13 samples a new vertex needs no other)
 template <typename SMP>
-TV_HD void tr_new_vertex(const SMP& smp, const FaceGeom& fg, const TrCellGeom& c, const i8 v[13], u32 w,
+TV_HD void tr_new_vertex(const SMP& smp, const FaceGeom& fg, const TrCellGeom& c, int p0, int p1, u32 w,
                          const TrResolution& r, u32 lowMat, RawVertex& o)
 {
 	typedef typename SMP::Off Off;
@@ -913,18 +915,6 @@ TV_HD void tr_new_vertex(const SMP& smp, const FaceGeom& fg, const TrCellGeom& c
 	float N0[3] = { 0.f, 0.f, 0.f }, N1[3] = { 0.f, 0.f, 0.f };
 	int t = r.t, u = 0;
 	u32 adjacency = 0;
-	// v[v0], v[v1] without indexing the array by a run-time value (an array indexed that way lives in scratch memory on
-	// the device): the 13 samples packed into four words with compile-time indices, the word picked by comparisons
-	int p0, p1;
-	{
-		u32 pk[4] = { 0, 0, 0, 0 };
-#pragma unroll
-		for (int i = 0; i < 13; ++i) pk[i >> 2] |= ((u32)v[i] & 0xFFu) << ((i & 3) * 8);
-		const u32 w0 = v0 < 4 ? pk[0] : (v0 < 8 ? pk[1] : (v0 < 12 ? pk[2] : pk[3]));
-		const u32 w1 = v1 < 4 ? pk[0] : (v1 < 8 ? pk[1] : (v1 < 12 ? pk[2] : pk[3]));
-		p0 = (int)(i8)((w0 >> ((v0 & 3) * 8)) & 0xFFu);
-		p1 = (int)(i8)((w1 >> ((v1 & 3) * 8)) & 0xFFu);
-	}
 	if (!r.endpoint) {
 		// FindBestVertexInLODChain (:1484-1509): the end points differ along one axis by a power of two; every step
 		// halves the (signed) distance, keeping the half that holds the sign change (one fetch per step)
@@ -972,7 +962,7 @@ TV_HD void tr_new_vertex(const SMP& smp, const FaceGeom& fg, const TrCellGeom& c
 			if (v0 >= 9) { const int cid = low_corner_id(fg, v0 - 9); adjacency = boundary_mask(c.local[0], c.local[1], c.local[2], c.mult, cid, cid); }
 		}
 	} else {
-		t = (p0 != p1) ? edge_t(p0, p1) : 0;
+		t = (p0 != p1) ? edge_t_crossing(p0, p1) : 0; // (the chain keeps p0 * p1 <= 0)
 		u = 256 - t;
 		gradient_from(a, N0);
 		gradient_from(bb, N1);

@@ -99,7 +99,7 @@ TV_HD bool f1_vertex(const ST& st, const F0Tables& T, const SMP& smp, const u16*
 	const u32 M0 = smp.mat(tx0 + yz0, x0, y0, z0), M1 = smp.mat(tx1 + yz1, x0 + ax, y0 + ay, z0 + az);
 	const u32 cellMat = TV_LOAD_THROUGH(&blockCache[c]); // (requested with the fetches above; past the L1: another workgroup of the launch wrote it)
 	const bool interior = p0 * p1 < 0; // samples of strictly opposite sign: 0 < t < 256, vertex strictly inside its edge
-	const int t = (p0 != p1) ? edge_t(p0, p1) : 0, u = 256 - t; // (:1671-1678)
+	const int t = (p0 != p1) ? edge_t_crossing(p0, p1) : 0, u = 256 - t; // (:1671-1678; the chain keeps p0 * p1 <= 0)
 	const u32 uu = (u32)u & 0x1FFu;
 	RawVertex rv;
 	// x256 position t * P0 + u * P1 = 256 * P0 + u * unit(axis): integers below 2^24, the reference's fp32 expression is exact

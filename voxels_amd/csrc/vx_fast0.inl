@@ -265,8 +265,8 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
 		const bool clean = r0_uniform(zeroFlag[parity]) == 0;
 		parity ^= 1u;
 		bool requested = false;
-		bool mine = true; // (SELF: the block turns out to have geometry, and no more cells than this capacity class holds)
-		if (SELF) {
+		bool mine = !(VX_ABL & 65536); // (SELF: the block turns out to have geometry, and no more cells than this capacity class holds; tools: 65536 = stop behind the deposit)
+		if (SELF && mine) {
 			f0_self_bits(st, L, cur, tid);
 			__syncthreads();
 			const u32 cells = r0_uniform(st.zero);
@@ -275,7 +275,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
 				if (cells == 0) reg_write_empty_record(L, cur.slot);
 				if (cells > (u32)LARGE_THRESHOLD) atomicAdd(p.G.largeBlocks, 1u); // (the host repeats the run with the upper classes)
 			}
-			mine = cells != 0 && cells <= (u32)CAP;
+			mine = cells != 0 && cells <= (u32)CAP && !(VX_ABL & 131072); // (tools: 131072 = stop behind the own bitmap)
 			F0_TICK(3); // own bitmap + barrier
 		}
 		if (mine && clean) {
@@ -308,6 +308,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
 			}
 			__syncthreads();
 			F0_TICK(4); // prefix + compact list + barrier
+			if (!(VX_ABL & 262144)) { // (tools: stop behind the compact list)
 
 			// ---- cells: wave w owns the compact cells [w * Q, w * Q + Q), Q a multiple of 64; local scan per wave -----------
 			const u32 nt = r0_uniform(st.wordPrefix[128]);
@@ -333,6 +334,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
 			}
 			__syncthreads();
 			F0_TICK(5); // cells + barrier
+			if (!(VX_ABL & 524288)) { // (tools: stop behind the cells)
 			{
 				u32 waveBase = 0, tot = 0;
 #pragma unroll
@@ -409,6 +411,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
 				wgStats[0] += nt;
 			}
 			F0_TICK(8); // record
+			} }
 		} else if (mine && tid == 0) {
 			// a zero sample: the general pass takes the block
 			p.G.slowItems[0][atomicAdd(&p.G.slowCount[0], 1u)] = cur.slot;
