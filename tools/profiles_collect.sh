@@ -8,7 +8,7 @@ cp $d/gputests.log profiles/${l}_gputests.log
 cp $d/selftest.txt profiles/${l}_selftest.txt
 cp $d/bench_default.json profiles/${l}_bench_default.json
 cp $d/ks/kernel_stats_serialized.txt profiles/${l}_kernel_stats_serialized.txt
-for i in 1 2; do cp $d/ks/pmc_pass$i.txt profiles/${l}_sq_pass$i.txt; done
+for i in 1 2 3; do [ -f $d/ks/pmc_pass$i.txt ] && cp $d/ks/pmc_pass$i.txt profiles/${l}_sq_pass$i.txt; done
 for i in 1 2 3; do cp $d/pmc/pass$i.txt profiles/${l}_pmc_pass$i.txt; done
 for i in 1 2; do cp $d/pmc_caves/pass$i.txt profiles/${l}_pmc_caves_pass$i.txt; done
 cp $d/tl/timeline_overlapped.txt profiles/${l}_timeline_1024.txt
@@ -17,6 +17,8 @@ grep -v "^W2026\|simple_timer" $d/tlslab.log > profiles/${l}_timeline_slab_8_3.t
 cp $d/tlc/timeline_caves.txt profiles/${l}_timeline_caves.txt
 cp $d/slab_time_y.txt profiles/${l}_slab_time_y.txt
 cp $d/quick_times.txt profiles/${l}_quick_times.txt
+[ -f $d/rebrick_time.txt ] && cp $d/rebrick_time.txt profiles/${l}_rebrick_time.txt
+[ -s $d/main_trace_128.txt ] && cp $d/main_trace_128.txt profiles/${l}_main_trace_128.txt
 cp $d/stress.txt profiles/${l}_stress.txt
 cp $d/decode_kernel_stats.txt profiles/${l}_decode_kernel_stats.txt
 cp $d/tle/timeline_edit_fused.txt profiles/${l}_timeline_edit_fused.txt

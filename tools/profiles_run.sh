@@ -10,7 +10,7 @@ mkdir -p $out
 python -c "from voxels_amd import Polygonizer; p = Polygonizer(); print('selftest', p.selftest().tolist())" > $out/selftest.txt 2>&1
 timeout 1200 python -m pytest tests -m gpu -q > $out/gputests.log 2>&1; echo "pytest rc $?" >> $out/gputests.log
 timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err
-timeout 600 bash tools/kstats.sh $out/ks "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" > $out/ks.log 2>&1
+timeout 600 bash tools/kstats.sh $out/ks "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" > $out/ks.log 2>&1
 timeout 600 bash tools/pmc_run.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" > $out/pmc.log 2>&1
 PMC_CMD="python tools/caves_run.py 1024 4 3" timeout 600 bash tools/pmc_run.sh $out/pmc_caves "FETCH_SIZE" "WRITE_SIZE" > $out/pmc_caves.log 2>&1
 timeout 300 bash tools/timeline.sh $out/tl > $out/tl.log 2>&1
@@ -21,6 +21,8 @@ timeout 400 bash tools/timeline_edit.sh $out/tle 512 0 > $out/tle.log 2>&1
 timeout 400 python tools/bench_edit.py 512 2>&1 | grep -v amdgpu.ids > $out/bench_edit.txt
 timeout 600 python tools/slab_time.py y > $out/slab_time_y.txt 2>&1
 timeout 300 python tools/quick_times.py > $out/quick_times.txt 2>&1
+timeout 300 python tools/rebrick_time.py 1024 8 2>&1 | grep -v amdgpu.ids > $out/rebrick_time.txt
+[ -f tools/ab/trace.so ] && VOXELS_HIP_LIBRARY=tools/ab/trace.so timeout 300 python tools/prof_once.py 128 4 2>&1 > /dev/null | awk '/==== last run ====/{on=1} on' | grep -v amdgpu > $out/main_trace_128.txt
 timeout 300 python tools/stress_runs.py 40000 4000 2>&1 | grep -v amdgpu.ids > $out/stress.txt
 (cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 300 rocprofv3 --kernel-trace --stats -d $out/dec -o k -- python tools/decode_only.py > $out/dec.log 2>&1; python tools/rocpd_summary.py "$(find $out/dec -name '*.db' | head -1)" $out/decode_kernel_stats_full.txt > /dev/null 2>&1; grep -v "^W2026\|simple_timer" $out/decode_kernel_stats_full.txt | cut -c1-150 | head -8 > $out/decode_kernel_stats.txt; rm -rf $out/dec)
 tail -3 $out/gputests.log; cat $out/selftest.txt; head -c 400 $out/bench_default.json; echo; head -12 $out/ks.log; tail -4 $out/slab_time_y.txt; tail -1 $out/quick_times.txt
