@@ -232,6 +232,22 @@ typedef struct vx_block_ranges {
 } vx_block_ranges;
 int vx_device_meshes(vx_ctx* ctx, const vx_vertex** d_verts, const uint32_t** d_indices, uint64_t* n_verts, uint64_t* n_indices);
 int vx_level_ranges(vx_ctx* ctx, uint32_t level, vx_block_ranges* ranges /* one per block, vx_download_level order */);
+/* The same two pools for a renderer in ANOTHER process (or behind another API's external-memory import): inter-process
+ * handles of the two device allocations (hipIpcGetMemHandle; on this platform dmabuf-backed, HSA_ENABLE_IPC_MODE_LEGACY=0).
+ * The importer maps them with hipIpcOpenMemHandle and reads n_verts vertices / n_indices indices from the mapping's start;
+ * vx_level_ranges / vx_device_block_table (copied over by the application) say which ranges are which block's.  The reference
+ * hands out per-block host arrays (include/Polygonizer.h:72-99); this is their device-resident, cross-process form.
+ * `generation` changes whenever the pools were rewritten or replaced (every full run; an incremental run that had to pack
+ * or grow them): an importer holding a mapping of an older generation must drop it and ask again.  Appending incremental
+ * runs keep the generation and only raise the counts.  Exporter and importer must run on the same HIP runtime (a handle of
+ * ROCm 7.0's runtime is not accepted by 7.2's hipIpcOpenMemHandle: tests/ipc_reader.py). */
+typedef struct vx_ipc_meshes {
+	uint8_t verts_handle[64], indices_handle[64]; /* hipIpcMemHandle_t, bytewise */
+	uint64_t n_verts, n_indices;
+	uint64_t verts_capacity, indices_capacity;    /* elements the allocations hold (what an appending run may still fill) */
+	uint64_t generation;
+} vx_ipc_meshes;
+int vx_export_meshes(vx_ctx* ctx, vx_ipc_meshes* out);
 /* Host copy of both pools in ONE step (what BlockPolygons::GetVertices / GetIndices, include/Voxels.h:210-231, hand out —
  * per-block arrays — as views: block k of a level owns verts[ranges[k].v_off ..] etc., with vx_level_ranges /
  * vx_download_level(infos only) giving offsets and counts).  The copy lands in page-locked memory at DMA speed and is

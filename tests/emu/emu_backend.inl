@@ -28,6 +28,7 @@ struct Backend {
 		return p;
 	}
 	void free(void* p) { ::free(p); }
+	bool ipc_handle(void*, unsigned char*) { lastError = "the emulation has no device allocations to export"; return false; }
 	bool fill(void* p, int v, size_t bytes) { memset(p, v, bytes); return true; }
 	bool h2d(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }
 	bool d2h(void* d, const void* s, size_t bytes) { memcpy(d, s, bytes); return true; }

@@ -6,6 +6,7 @@
 Bar: indices, block infos, positions, secondary positions, texture bytes and statistics bit-exact; normals within
 1e-5 (fp32)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -905,6 +906,37 @@ def check_packed_hip(poly, port, d, m, b, label):
     ok, msg = fields.surface_equal(poly.all_levels(), s.all_levels(), nrm_tol=NRM_TOL)
     assert ok, label + ": " + msg
     assert np.array_equal(poly.stats(), s.stats()), label
+
+
+@pytest.mark.gpu
+def test_hip_meshes_exported_to_another_process(poly):
+    """§8(f) row 4 (interop): vx_export_meshes hands out inter-process handles of the two pools; a process that knows nothing
+    of the library (tests/ipc_reader.py: hipIpcOpenMemHandle + hipMemcpy) reads exactly the bytes vx_device_meshes points at.
+    An appending incremental run keeps the generation, a full run changes it."""
+    import ctypes as C
+    import hashlib
+    import subprocess
+    gold = Golden("noise64_fullrange_mat")
+    poly.upload(gold.dist, gold.mat, gold.blend, gold.flags)
+    poly.execute()
+    dv, di, nv, ni = poly.device_meshes()
+    ex = poly.export_meshes()
+    assert ex["n_verts"] == nv and ex["n_indices"] == ni and ex["verts_capacity"] >= nv and ex["indices_capacity"] >= ni
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    verts = np.zeros(nv * 48, np.uint8)
+    idx = np.zeros(ni, np.uint32)
+    assert hip.hipMemcpy(verts.ctypes.data_as(C.c_void_p), C.c_void_p(dv), nv * 48, 2) == 0
+    assert hip.hipMemcpy(idx.ctypes.data_as(C.c_void_p), C.c_void_p(di), ni * 4, 2) == 0
+    want = "ipc digest %s %s" % (hashlib.sha256(verts.tobytes()).hexdigest(), hashlib.sha256(idx.tobytes()).hexdigest())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ipc_reader.py"), ex["verts_handle"].hex(), ex["indices_handle"].hex(), str(nv), str(ni)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert want in r.stdout, (want, r.stdout[-500:])
+    # a full run rewrites the pools: another generation
+    poly.execute()
+    assert poly.export_meshes()["generation"] != ex["generation"]
 
 
 @pytest.mark.gpu

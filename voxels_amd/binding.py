@@ -98,6 +98,7 @@ class HipLibrary:
         lib.vx_grid_upload_packed.argtypes = [vp, vp, C.c_uint64]
         lib.vx_grid_attach_y.argtypes = [vp, u32, u32, u32, vp, C.c_int32, u32, vp, vp, C.c_int32, u32, vp]
         lib.vx_device_meshes.argtypes = [vp, vp, vp, vp, vp]
+        lib.vx_export_meshes.argtypes = [vp, vp]
         lib.vx_compact_pools.argtypes = [vp]
         lib.vx_grid_pack.argtypes = [vp, vp, C.c_uint64, vp]
         lib.vx_grid_create_heightmap.argtypes = [vp, u32, vp]
@@ -256,6 +257,17 @@ class Polygonizer:
         nv, ni = C.c_uint64(), C.c_uint64()
         self._check(self._lib.vx_device_meshes(self._h, C.byref(dv), C.byref(di), C.byref(nv), C.byref(ni)), "vx_device_meshes")
         return dv.value, di.value, nv.value, ni.value
+
+    def export_meshes(self):
+        """Inter-process handles of the two pools (vx_export_meshes): dict with the two 64-byte handles, the counts, the
+        capacities and the pools' generation."""
+        class IpcMeshes(C.Structure):
+            _fields_ = [("verts_handle", C.c_uint8 * 64), ("indices_handle", C.c_uint8 * 64), ("n_verts", C.c_uint64), ("n_indices", C.c_uint64),
+                        ("verts_capacity", C.c_uint64), ("indices_capacity", C.c_uint64), ("generation", C.c_uint64)]
+        m = IpcMeshes()
+        self._check(self._lib.vx_export_meshes(self._h, C.byref(m)), "vx_export_meshes")
+        return {"verts_handle": bytes(m.verts_handle), "indices_handle": bytes(m.indices_handle), "n_verts": int(m.n_verts), "n_indices": int(m.n_indices),
+                "verts_capacity": int(m.verts_capacity), "indices_capacity": int(m.indices_capacity), "generation": int(m.generation)}
 
     def create_terrain(self, n, seed=1337, style=0):
         """The synthetic noise terrain (voxels_amd.synth.terrain) generated on the device into a grid the context owns."""

@@ -3312,6 +3312,15 @@ struct Backend {
 		return p;
 	}
 	void free(void* p) { if (p) (void)hipFree(p); }
+	// inter-process handle of a device allocation (its base pointer): what a renderer in another process opens with hipIpcOpenMemHandle
+	bool ipc_handle(void* p, unsigned char out[64])
+	{
+		static_assert(sizeof(hipIpcMemHandle_t) == 64, "vx_ipc_meshes carries hipIpcMemHandle_t bytewise");
+		hipIpcMemHandle_t h;
+		if (!p || !check(hipIpcGetMemHandle(&h, p), "hipIpcGetMemHandle")) return false;
+		memcpy(out, &h, 64);
+		return true;
+	}
 	bool fill(void* p, int v, size_t bytes) { return check(hipMemsetAsync(p, v, bytes, stream), "hipMemsetAsync"); }
 	bool h2d(void* d, const void* s, size_t bytes)
 	{

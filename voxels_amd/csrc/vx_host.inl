@@ -2154,6 +2154,20 @@ int vx_device_meshes(vx_ctx* c, const vx_vertex** dVerts, const uint32_t** dIdx,
 	return VX_OK;
 }
 
+int vx_export_meshes(vx_ctx* c, vx_ipc_meshes* out)
+{
+	VX_ENTER(c);
+	if (!c || !c->haveSurface || !out) return fail(c, VX_ERR_INVALID, "vx_export_meshes: no surface");
+	memset(out, 0, sizeof(*out));
+	static_assert(sizeof(out->verts_handle) == 64 && sizeof(out->indices_handle) == 64, "hipIpcMemHandle_t is 64 bytes");
+	if (!c->be.ipc_handle(c->dVerts, out->verts_handle) || !c->be.ipc_handle(c->dIdx, out->indices_handle))
+		return fail(c, VX_ERR_DEVICE, "vx_export_meshes: " + c->be.error());
+	out->n_verts = c->poolVerts; out->n_indices = c->poolIdx;
+	out->verts_capacity = c->vertCap; out->indices_capacity = c->idxCap;
+	out->generation = c->poolLineage;
+	return VX_OK;
+}
+
 int vx_host_meshes_acquire(vx_ctx* c, vx_host_meshes* m)
 {
 	VX_ENTER(c);
