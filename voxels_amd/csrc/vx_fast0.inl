@@ -235,7 +235,7 @@ __device__ __forceinline__ void f0_walk(const ExecParamsDev& pIn, const F0Tables
                                         u32 total, u32 lo, u32 first, u32 stride, u32 limit, const int tid)
 {
 	typedef R0<CAP> K;
-#define F0_PARAMS() const ExecParamsDev& p = (VX_FRESH & 1) ? kernarg_params() : pIn; const LevelDesc& L = p.levels[0]; const GridView& g = p.G.grid; (void)L; (void)g
+#define F0_PARAMS() (void)pIn; const ExecParamsDev& p = kernarg_params(); const LevelDesc& L = p.levels[0]; const GridView& g = p.G.grid; (void)L; (void)g
 	F0_PARAMS();
 	u32 it = first;
 	R0Block cur, nxt;

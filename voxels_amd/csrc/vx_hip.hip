@@ -65,11 +65,9 @@ struct ExecParamsDev {
 // The kernel's first argument read afresh through the kernarg segment: a pointer the compiler cannot see through, so nothing
 // loaded from the parameters BEFORE this point is kept alive across it (a persistent kernel otherwise holds every pointer it
 // ever uses in scalar registers for its whole life - 250 of them spilled to vector lanes and read back with v_readlane in
-// k_main) and everything behind it is loaded again, 16 dwords per s_load.  Only inside kernels whose first parameter is the
-// ExecParamsDev.
-#if !defined(VX_FRESH)
-#define VX_FRESH 3   // bit 0: per level-0 block (f0_walk), bit 1: per item of k_main (round 6: 963 -> 375 v_readlane in k_main, 1024^3 step -1.3 %; 0 = the parameters as the compiler keeps them)
-#endif
+// k_main) and everything behind it is loaded again, 16 dwords per s_load.  Only inside kernels whose FIRST parameter is the
+// ExecParamsDev (k_main, k_regular0_fast, k_dirty_regular0_fast: the callers of f0_walk).  Round 6: 963 -> 375 v_readlane in
+// k_main, 126.2M -> 120.8M vector instructions per launch at 1024^3, the step -1.3 %.
 __device__ __forceinline__ const ExecParamsDev& kernarg_params()
 {
 	typedef const __attribute__((address_space(4))) ExecParamsDev* KP;
@@ -80,9 +78,6 @@ __device__ __forceinline__ const ExecParamsDev& kernarg_params()
 
 // tools builds (tools/ab_build.py x=-DVX_ABL=<bits>): parts of the work switched off to see what they cost in time and
 // instructions (tools/exp/r06_ablate.sh); the results of such a build are wrong by construction.  0 in the product.
-#if !defined(VX_MAIN_WAVES)
-#define VX_MAIN_WAVES 4   // waves per SIMD k_main is compiled for (4: 128 VGPRs)
-#endif
 #if !defined(VX_ABL)
 #define VX_ABL 0
 #endif
@@ -885,10 +880,7 @@ __device__ __forceinline__ u16 block_sign_word(u32 collected)
 	return (u16)w;
 }
 
-#if !defined(VX_RB_WAVES)
-#define VX_RB_WAVES 4
-#endif
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_RB_WAVES))) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_rebrick(GridView g, RebrickRanges r, MirrorState X, int yb0, int ybCount, int zb0, const u32* ids)
 {
 	__shared__ u32 blockSigns[8];
 	// what the workgroup's rows contribute to the finest lattice copies and x-plane copies, collected here and written in whole

@@ -62,9 +62,9 @@ struct MainPlan {
 // material blocks run as always - the caches a later Modification continues from - and the level-1 material blocks also
 // write the bitmaps of their level-0 children, which no level-0 walk forms in such a run.
 template <bool DIRTY, bool PARTIAL = false>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(VX_MAIN_WAVES))) void k_main(ExecParamsDev pArg, MainPlan plan)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4))) void k_main(ExecParamsDev pArg, MainPlan plan)
 {
-#define MAIN_PARAMS() const ExecParamsDev& p = (VX_FRESH & 2) ? kernarg_params() : pArg
+#define MAIN_PARAMS() (void)pArg; const ExecParamsDev& p = kernarg_params() // (vx_hip.hip: read afresh, per item)
 	MAIN_PARAMS();
 	u8* tab = smem;
 	u8* state = smem + UP_TAB_LDS;
