@@ -427,7 +427,7 @@ struct Backend {
 							tr_phase_describe(*st, chunk, 0, 1);
 							tr_phase_emit_vertices(*st, T, p.G, F1HostSampler{ &p.G.grid }, p.P, b, chunk, 0, 1);
 						}
-						for (u32 chunk = 0; chunk < st->iTotal; chunk += VDESC_CAP) {
+						for (u32 chunk = 0; chunk < st->iTotal; chunk += TR_INDEX_CHUNK) {
 							tr_phase_stage_indices(*st, T, chunk, 0, 1);
 							tr_phase_flush_indices(*st, T, p.P, chunk, 0, 1);
 						}

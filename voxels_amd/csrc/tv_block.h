@@ -1308,52 +1308,58 @@ TV_HD void tr_phase_emit_vertices(TrState& st, const Tables& T, const Globals& G
 	}
 }
 
-// Index lists of the batch's faces, one lane per index (same scheme as the regular pass).  Phase 1, per cell: a
-// descriptor for every triangle corner of the chunk at its position in the flat index list: compact cell | corner << 9.
+// Index lists of the batch's faces, one lane per TRIANGLE (its three indices share every look-up of their cell).  A chunk is
+// VDESC_CAP triangles = TR_INDEX_CHUNK indices; chunkBase counts indices.  Phase 1, per cell: a descriptor for every triangle
+// of the chunk at its position in the flat triangle list: compact cell | triangle << 9.
+enum { TR_INDEX_CHUNK = 3 * VDESC_CAP };
 TV_HD void tr_phase_stage_indices(TrState& st, const Tables& T, u32 chunkBase, int tid, int nth)
 {
 	const int nt = st.wordPrefix[48];
+	const u32 chunkTri = chunkBase / 3u;
 	for (int k = tid; k < nt; k += nth) {
-		const u32 first = st.ibase[k];
-		const u32 count = 3u * ((u32)T.trCell(T.trClass(st.cellBits[k] & 0x1FFu) & 0x7F)[0] & 15u);
-		if (first >= chunkBase + VDESC_CAP || first + count <= chunkBase) continue;
-		for (u32 i = 0; i < count; ++i) {
-			const u32 pos = first + i;
-			if (pos >= chunkBase && pos < chunkBase + VDESC_CAP) st.vdesc[pos - chunkBase] = (u16)((u32)k | (i << 9));
+		const u32 first = (u32)st.ibase[k] / 3u; // (index counts are multiples of three, and so are their prefix sums)
+		const u32 count = (u32)T.trCell(T.trClass(st.cellBits[k] & 0x1FFu) & 0x7F)[0] & 15u;
+		if (first >= chunkTri + VDESC_CAP || first + count <= chunkTri) continue;
+		for (u32 tr = 0; tr < count; ++tr) {
+			const u32 pos = first + tr;
+			if (pos >= chunkTri && pos < chunkTri + VDESC_CAP) st.vdesc[pos - chunkTri] = (u16)((u32)k | (tr << 9));
 		}
 	}
 }
 
-// Phase 2: each lane resolves and stores its index (relative to its face's first vertex; winding flipped per class/face)
+// Phase 2: each lane resolves and stores its triangle's three indices (relative to its face's first vertex; winding flipped per class/face)
 TV_HD void tr_phase_flush_indices(const TrState& st, const Tables& T, const Pools& P, u32 chunkBase, int tid, int nth)
 {
 	if (st.vOff + st.vTotal > P.vertCap || st.iOff + st.iTotal > P.idxCap) return;
-	const u32 end = (st.iTotal - chunkBase < (u32)VDESC_CAP) ? st.iTotal - chunkBase : (u32)VDESC_CAP;
+	const u32 left = (st.iTotal - chunkBase) / 3u;
+	const u32 end = left < (u32)VDESC_CAP ? left : (u32)VDESC_CAP;
 	u32* out = P.idx + st.iOff + chunkBase;
 	for (u32 j = (u32)tid; j < end; j += (u32)nth) {
 		const u32 desc = st.vdesc[j];
-		const u32 k = desc & 0x1FFu, i = desc >> 9;
+		const u32 k = desc & 0x1FFu, tr = desc >> 9;
 		const u32 c = st.cellOf[k];
 		const u32 f = c >> 8;
 		const u32 bits = st.cellBits[k], code = bits & 0x1FFu;
 		const u32 cls = T.trClass(code);
 		const u8* cd = T.trCell(cls & 0x7F);
 		const bool flip = ((cls >> 7) ^ (f & 1u)) != 0; // reverseWinding = {0,1,0,1,0,1}
-		const u32 tr = i / 3, e = i - tr * 3;
-		const u32 vi = cd[1 + tr * 3 + ((flip && e) ? 3 - e : e)];
 		const u32 faceVBase = st.vbase[st.wordPrefix[f * 8]]; // the face's first cell exists: cell k is in it
-		const u32 newMask = st.newMask[k];
-		u32 id;
-		if ((newMask >> vi) & 1u) {
-			id = (u32)st.vbase[k] - faceVBase + (u32)TV_POPC(newMask & ((1u << vi) - 1u));
-		} else {
-			int t, corner; u32 dir, slot; bool endpoint;
-			tr_vertex_dir_slot_z(T, bits >> 9, T.trVert(code, vi), t, dir, slot, endpoint, corner);
-			const u32 c2 = c - ((dir & 1u) + (((dir >> 1) & 1u) << 4));
-			const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
-			id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
+		const u32 newMask = st.newMask[k], own = (u32)st.vbase[k] - faceVBase;
+#pragma unroll
+		for (u32 e = 0; e < 3; ++e) {
+			const u32 vi = cd[1 + tr * 3 + ((flip && e) ? 3 - e : e)];
+			u32 id;
+			if ((newMask >> vi) & 1u) {
+				id = own + (u32)TV_POPC(newMask & ((1u << vi) - 1u));
+			} else {
+				int t, corner; u32 dir, slot; bool endpoint;
+				tr_vertex_dir_slot_z(T, bits >> 9, T.trVert(code, vi), t, dir, slot, endpoint, corner);
+				const u32 c2 = c - ((dir & 1u) + (((dir >> 1) & 1u) << 4));
+				const u32 k2 = bit_rank(st.ntBits, st.wordPrefix, c2);
+				id = (u32)st.vbase[k2] - faceVBase + ((u32)(st.ords[k2] >> (slot * 4)) & 0xFu);
+			}
+			TV_STREAM_STORE(&out[j * 3u + e], id);
 		}
-		TV_STREAM_STORE(&out[j], id);
 	}
 }
 

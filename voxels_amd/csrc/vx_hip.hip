@@ -2446,7 +2446,7 @@ __device__ __forceinline__ void tr_block(const ExecParamsDev& p, RegBlockCtx b, 
 				if (!(VX_ABL & 512)) tr_phase_emit_vertices(st, T, p.G, smp, p.P, b, chunk, tid, WG);
 			}
 			TRB_TICK(9);
-			for (u32 chunk = 0; chunk < ((VX_ABL & 1024) ? 0u : st.iTotal); chunk += VDESC_CAP) {
+			for (u32 chunk = 0; chunk < ((VX_ABL & 1024) ? 0u : st.iTotal); chunk += TR_INDEX_CHUNK) {
 				__syncthreads();
 				tr_phase_stage_indices(st, T, chunk, tid, WG);
 				__syncthreads();
