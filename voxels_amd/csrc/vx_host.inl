@@ -117,6 +117,9 @@ struct vx_ctx {
 	HostArena* hostArena = nullptr; // page-locked host copy of the pools (vx_download_level; handed out by vx_host_meshes_acquire)
 	uint64_t poolLineage = 0;             // changes whenever the pools are rewritten (a host copy of another lineage is useless)
 	bool listsReady = false;
+	bool liveKnown = false; uint64_t liveVerts = 0, liveIdx = 0; // what the block lists sum up to (live_totals), kept across incremental runs
+	std::vector<unsigned char> blockDead[MAX_LEVELS]; // per level: empty, or one flag per list entry - blocks an incremental run dropped and nobody has asked for the lists since
+	u32 deadBlocks = 0;                               // (the entries leave when the lists are next read: erasing from the middle of a list moved 400 KB per edit at 512^3)
 	u32 poolVerts = 0, poolIdx = 0;
 	u32 stats[20];
 	u32 hdr[HDR_WORDS];
@@ -654,9 +657,28 @@ bool grow_pools_keeping(vx_ctx* c, u32 needVerts, u32 needIdx)
 // Host copy of the block lists of a full run (every block with at least one regular vertex, in coordinate order; ids
 // number ALL blocks of all levels in level-major order, TransVoxelImpl.cpp:395-401).  The lists themselves are part of
 // the device run; this is only their download, done on first access.
-int ensure_lists(vx_ctx* c)
+// the blocks incremental runs dropped leave the lists (order kept: what the reference's erase leaves, TransVoxelImpl.cpp:443-450)
+void purge_dead_blocks(vx_ctx* c)
 {
-	if (c->listsReady) return VX_OK;
+	if (!c->deadBlocks) return;
+	for (u32 L = 0; L < MAX_LEVELS; ++L) {
+		std::vector<unsigned char>& dead = c->blockDead[L];
+		if (dead.empty()) continue;
+		std::vector<EmittedBlock>& list = c->blocks[L];
+		size_t keep = 0;
+		for (size_t i = 0; i < list.size(); ++i) if (!dead[i]) { if (keep != i) list[keep] = list[i]; ++keep; }
+		list.resize(keep);
+		dead.clear();
+	}
+	c->deadBlocks = 0;
+}
+
+// purge = false: the caller (an incremental run) only appends and marks; every reader of the lists takes them purged
+int ensure_lists(vx_ctx* c, bool purge = true)
+{
+	if (c->listsReady) { if (purge) purge_dead_blocks(c); return VX_OK; }
+	for (u32 L = 0; L < MAX_LEVELS; ++L) c->blockDead[L].clear();
+	c->deadBlocks = 0;
 	// the tables were written by the run itself (k_list_write): one copy per level, nothing to sort
 	for (u32 L = 0; L < c->levelsRun; ++L) {
 		const u32 count = c->hdr[HDR_LISTS + L];
@@ -1541,6 +1563,7 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 	c->haveSurface = true;
 	c->editRoomFailed = false; // (a new surface: its first incremental run asks for room again)
 	c->listsReady = false; // the host copy of the block lists is fetched on first access
+	c->liveKnown = false;
 	c->deviceLists = true;
 	u32 idBase = 0;
 	u32 blocksCalculated = 0, trivial = 0;
@@ -1658,13 +1681,22 @@ int vx_polygonize_from(vx_ctx* c, uint32_t num_levels, uint32_t first_meshed_lev
 namespace {
 
 // live vertices / indices according to the block lists
-void live_totals(const vx_ctx* c, uint64_t& verts, uint64_t& idx)
+void add_block_totals(const EmittedBlock& e, uint64_t& verts, uint64_t& idx)
 {
-	verts = idx = 0;
-	for (u32 L = 0; L < c->levelsRun; ++L) for (const EmittedBlock& e : c->blocks[L]) {
-		verts += e.rec.vCount; idx += e.rec.iCount;
-		for (int f = 0; f < 6; ++f) { verts += e.rec.tvCount[f]; idx += e.rec.tiCount[f]; }
+	verts += e.rec.vCount; idx += e.rec.iCount;
+	for (int f = 0; f < 6; ++f) { verts += e.rec.tvCount[f]; idx += e.rec.tiCount[f]; }
+}
+
+// (summed once per surface; an incremental run then subtracts what it drops and adds what it appends - a walk over every block
+// of every level per edit was a third of the call's host time at 512^3)
+void live_totals(vx_ctx* c, uint64_t& verts, uint64_t& idx)
+{
+	if (!c->liveKnown) {
+		c->liveVerts = c->liveIdx = 0;
+		for (u32 L = 0; L < c->levelsRun; ++L) for (size_t i = 0; i < c->blocks[L].size(); ++i) if (c->blockDead[L].empty() || !c->blockDead[L][i]) add_block_totals(c->blocks[L][i], c->liveVerts, c->liveIdx);
+		c->liveKnown = true;
 	}
+	verts = c->liveVerts; idx = c->liveIdx;
 }
 
 // the second pair of pools vx_compact_pools packs into: at least `needV` vertices / `needI` indices, allocated with the pools'
@@ -1780,7 +1812,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 	auto tUs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
 	const auto t0 = tNow(); // (VX_HOST_TIMING: where the call's host time goes)
 	auto t1 = t0, t2 = t0, t3 = t0, t4 = t0;
-	if (ensure_lists(c) != VX_OK) return VX_ERR_DEVICE;
+	if (ensure_lists(c, false) != VX_OK) return VX_ERR_DEVICE;
 	if (!ensure_bricks(c)) return fail(c, VX_ERR_DEVICE, "vx_polygonize_dirty: brick mirror allocation failed: " + c->be.error());
 	// the new blocks' meshes are appended behind what the pools already hold: every kept block stays where it is;
 	// once more than half of the pools is dead they are packed first (into the spare pair, which the first incremental run of
@@ -1999,6 +2031,7 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			std::sort(byCoord.begin(), byCoord.end());
 		}
 		u32 w = 0;
+		fresh[L].reserve(nWork);
 		for (u32 k = 0; k < cnt[L]; ++k) {
 			const u32 coord = coords[start[L] + k];
 			const BlockRecord* rp = nullptr;
@@ -2011,11 +2044,11 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 			if (!rp) continue; // no surface in this block
 			const BlockRecord& r = *rp;
 			if (!r.vCount) continue;
-			EmittedBlock e;
+			fresh[L].emplace_back();
+			EmittedBlock& e = fresh[L].back();
 			e.rec = r;
 			e.id = ids[start[L] + k];
 			block_corners(d, coord, e.minc, e.maxc);
-			fresh[L].push_back(std::move(e));
 		}
 		//  records that do not follow the box's coordinate order are looked up by coordinate, like the chain's: nothing
 		// of the context has been committed yet, and nothing fails here
@@ -2030,9 +2063,23 @@ int vx_polygonize_dirty(vx_ctx* c, const float min_corner[3], const float max_co
 		std::vector<EmittedBlock>& list = c->blocks[L];
 		const float* lo = dropLo[L];
 		const float* hi = dropHi[L];
-		list.erase(std::remove_if(list.begin(), list.end(), [lo, hi](const EmittedBlock& e) {
-			return e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2]; }), list.end());
+		uint64_t goneV = 0, goneI = 0;
+		std::vector<unsigned char>& dead = c->blockDead[L];
+		for (size_t i = 0; i < list.size(); ++i) {
+			const EmittedBlock& e = list[i];
+			if (!dead.empty() && dead[i]) continue;
+			if (e.minc[0] >= lo[0] && e.minc[1] >= lo[1] && e.minc[2] >= lo[2] && e.minc[0] < hi[0] && e.minc[1] < hi[1] && e.minc[2] < hi[2]) {
+				if (dead.empty()) dead.assign(list.size(), 0);
+				dead[i] = 1; ++c->deadBlocks;
+				add_block_totals(e, goneV, goneI);
+			}
+		}
 		list.insert(list.end(), fresh[L].begin(), fresh[L].end());
+		if (!dead.empty()) dead.resize(list.size(), 0);
+		if (c->liveKnown) {
+			c->liveVerts -= goneV; c->liveIdx -= goneI;
+			for (const EmittedBlock& e : fresh[L]) add_block_totals(e, c->liveVerts, c->liveIdx);
+		}
 	}
 	t4 = tNow();
 	if (c->hostTiming) fprintf(stderr, "[vx host, dirty] lists + box %.0f us, enqueue %.0f us, wait %.0f us, records + lists %.0f us, device %.0f us, stream idle before the run %.0f us\n", tUs(t0, t1), tUs(t1, t2), tUs(t2, t3), tUs(t3, t4), ms * 1e3, (double)c->be.idle_before_ms() * 1e3);
