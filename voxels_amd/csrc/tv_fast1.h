@@ -19,7 +19,7 @@
 
 namespace tv {
 
-enum { F1_VDESC = 768, F1_TDESC = 768 };
+enum { F1_VDESC = 1024, F1_TDESC = 1024 }; // (one chunk for an ordinary block of a level >= 1 - ~700 vertices, as many triangles; the state has the room: the transition state is larger)
 
 template <int CAP>
 struct Fast1State {
